@@ -1,0 +1,99 @@
+"""ctypes binding of libciao_hip.so -- the same symbols a Julia `ccall` binds (include/ciao_hip.h).
+
+There is NO CPU fallback: if the shared library is missing this module raises at import of the first symbol, and
+if there is no GPU `ciao_ctx_create` fails with CIAO_ERR_HIP.  The CPU oracle lives in /oracle and is never imported
+from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libciao_hip.so")
+
+OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_ALLOC, ERR_HOOK = 0, -1, -2, -3, -4, -5
+F32, F64 = 0, 1
+LOSS_LS, LOSS_LOGISTIC, LOSS_ZERO = 0, 1, 2
+PROX_ZERO, PROX_L1, PROX_BOX = 0, 1, 2
+
+
+class CiaoError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"libciao_hip status {status}: {msg}")
+        self.status = status
+
+
+class Problem(C.Structure):
+    """ciao_problem"""
+    _fields_ = [("loss", C.c_int32), ("dtype", C.c_int32), ("N", C.c_int64), ("d", C.c_int64), ("ld", C.c_int64),
+                ("N_total", C.c_int64), ("A", C.c_void_p), ("b", C.c_void_p), ("lam", C.c_double)]
+
+
+class ProxDesc(C.Structure):
+    """ciao_prox_desc"""
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("lam", C.c_double), ("lo", C.c_double), ("hi", C.c_double),
+                ("lo_vec", C.c_void_p), ("hi_vec", C.c_void_p)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+
+_vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+_PP, _GP = C.POINTER(Problem), C.POINTER(ProxDesc)
+
+# name -> (restype, argtypes): one row per declaration in include/ciao_hip.h
+SIGNATURES = {
+    "ciao_abi_version": (_i32, []),
+    "ciao_last_error": (C.c_char_p, []),
+    "ciao_ctx_create": (_i32, [_i32, _vp, C.POINTER(_vp)]),
+    "ciao_ctx_destroy": (_i32, [_vp]),
+    "ciao_ctx_set_stream": (_i32, [_vp, _vp]),
+    "ciao_ctx_synchronize": (_i32, [_vp]),
+    "ciao_ctx_set_allreduce": (_i32, [_vp, ALLREDUCE_FN, _vp]),
+    "ciao_ctx_set_option": (_i32, [_vp, C.c_char_p, _i64]),
+    "ciao_ctx_timing_enable": (_i32, [_vp, _i32]),
+    "ciao_ctx_timing_read": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i64)]),
+    "ciao_ctx_last_kernel": (C.c_char_p, [_vp]),
+    "ciao_gradient": (_i32, [_vp, _PP, _i64, _vp, _vp, _vp]),
+    "ciao_prox": (_i32, [_vp, _i32, _i64, _GP, _vp, _f64, _vp]),
+    "ciao_full_gradient": (_i32, [_vp, _PP, _vp, _vp]),
+    "ciao_proxgrad_step": (_i32, [_vp, _PP, _GP, _f64, _vp, _vp, _vp]),
+    "ciao_objective": (_i32, [_vp, _PP, _GP, _vp, C.POINTER(_f64)]),
+    "ciao_svrg_init": (_i32, [_vp, _PP, _vp, _vp, _vp, _vp, _vp]),
+    "ciao_svrg_inner": (_i32, [_vp, _PP, _GP, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ciao_svrg_iterate": (_i32, [_vp, _PP, _GP, _f64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "ciao_saga_init": (_i32, [_vp, _PP, _GP, _f64, _vp, _vp, _vp, _vp]),
+    "ciao_saga_steps": (_i32, [_vp, _PP, _GP, _f64, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "ciao_hat_gamma": (_i32, [_vp, _i32, _i64, _vp, C.POINTER(_f64)]),
+    "ciao_finito_init": (_i32, [_vp, _PP, _GP, _vp, _f64, _vp, _vp, _vp, _vp]),
+    "ciao_finito_steps": (_i32, [_vp, _PP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ciao_lfinito_init": (_i32, [_vp, _PP, _f64, _vp, _vp, _vp, _vp]),
+    "ciao_lfinito_iterate": (_i32, [_vp, _PP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ciao_synth_normal": (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _i64, C.c_uint64, _f64]),
+    "ciao_synth_targets": (_i32, [_vp, _PP, _vp, _f64, _i32, _i64, C.c_uint64, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libciao_hip.so and declare every prototype.  Raises (loudly) when the extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built.  Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C ciaoalgorithms.jl_amd/csrc`).  There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != OK:
+        raise CiaoError(status, load().ciao_last_error().decode("utf-8", "replace"))

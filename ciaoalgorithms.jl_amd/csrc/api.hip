@@ -1,0 +1,777 @@
+// api.hip -- the extern "C" entry points of libciao_hip.so (declared in include/ciao_hip.h).
+//
+// Each entry point validates its arguments on the host (shapes must match what the kernels and their grids assume
+// BEFORE anything is launched), builds the kernel argument structs and enqueues the kernels on the ctx's stream.
+// Nothing here computes on the CPU: if the HIP runtime or the device is missing the calls fail with CIAO_ERR_HIP.
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "ciao_ctx.h"
+#include "launch.h"
+
+namespace ciao {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int32_t hip_fail(hipError_t e, const char *what)
+{
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return CIAO_ERR_HIP;
+}
+
+int32_t ensure(ciao_ctx *ctx, void **buf, size_t *have, size_t need)
+{
+    if (*have >= need) return CIAO_OK;
+    // growing a workspace buffer: wait for work that may still read the old one, then reallocate
+    CIAO_HIP(hipStreamSynchronize(ctx->stream));
+    if (*buf) CIAO_HIP(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    size_t cap = need + need / 4 + 256;
+    hipError_t e = hipMalloc(buf, cap);
+    if (e != hipSuccess) {
+        set_error("workspace allocation of %zu bytes failed: %s", cap, hipGetErrorString(e));
+        return CIAO_ERR_ALLOC;
+    }
+    *have = cap;
+    return CIAO_OK;
+}
+
+// ---- synthetic data -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+// standard normal keyed by (seed, row, col): Box-Muller on two 32-bit uniforms of one 64-bit hash
+__device__ __forceinline__ float normal_at(uint64_t seed, uint64_t row, uint64_t col)
+{
+    uint64_t h = mix64(seed + 0x9E3779B97F4A7C15ULL * (row * 0x100000001B3ULL + col + 1));
+    h = mix64(h ^ (row << 1) ^ 0xD1B54A32D192ED03ULL);
+    const float u1 = ((float)(uint32_t)(h >> 32) + 1.0f) * (1.0f / 4294967296.0f);   // (0,1]
+    const float u2 = (float)(uint32_t)h * (1.0f / 4294967296.0f);                    // [0,1)
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    synth_normal_kernel(T *out, int64_t nrows, int64_t d, int64_t ld, int64_t row0, uint64_t seed, T scale)
+{
+    const int64_t total = nrows * d;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t r = t / d, c = t - r * d;
+        out[r * ld + c] = scale * (T)normal_at(seed, (uint64_t)(row0 + r), (uint64_t)c);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) synth_targets_kernel(const T *A, int64_t N, int64_t d, int64_t ld, const T *x_true,
+                                                           T noise, int labels, int64_t row0, uint64_t seed, T *b)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < N; i += nw) {
+        const T *ap = A + i * ld;
+        T dot = T(0);
+        for (int64_t e = lane; e < d; e += WAVE) dot += ap[e] * x_true[e];
+        dot = wave_allsum(dot);
+        T v = dot + noise * (T)normal_at(seed ^ 0xABCDEF0123456789ULL, (uint64_t)(row0 + i), 0xFFFFFFFFULL);
+        if (labels) v = v >= T(0) ? T(1) : T(-1);
+        if (lane == 0) b[i] = v;
+    }
+}
+
+// ---- helpers ----------------------------------------------------------------------------------------------------------
+static int32_t check_problem(const ciao_ctx *ctx, const ciao_problem *p)
+{
+    CIAO_REQUIRE(ctx, "ctx is NULL");
+    CIAO_REQUIRE(p, "problem is NULL");
+    CIAO_REQUIRE(p->dtype == CIAO_F32 || p->dtype == CIAO_F64, "problem.dtype must be CIAO_F32 or CIAO_F64 (got %d)", p->dtype);
+    CIAO_REQUIRE(p->loss >= CIAO_LOSS_LS && p->loss <= CIAO_LOSS_ZERO, "unknown loss kind %d", p->loss);
+    CIAO_REQUIRE(p->N >= 0 && p->d >= 1, "need N >= 0 and d >= 1 (got N=%lld d=%lld)", (long long)p->N, (long long)p->d);
+    CIAO_REQUIRE(p->ld >= p->d, "row stride ld=%lld < d=%lld", (long long)p->ld, (long long)p->d);
+    CIAO_REQUIRE(p->N_total >= p->N && p->N_total >= 1, "N_total=%lld must be >= max(N,1)", (long long)p->N_total);
+    if (p->N > 0) {
+        CIAO_REQUIRE(p->A, "problem.A is NULL");
+        CIAO_REQUIRE(p->loss == CIAO_LOSS_ZERO || p->b, "problem.b is NULL");
+    }
+    return CIAO_OK;
+}
+
+static int32_t check_prox(const ciao_prox_desc *g)
+{
+    if (!g) return CIAO_OK;
+    CIAO_REQUIRE(g->kind >= CIAO_PROX_ZERO && g->kind <= CIAO_PROX_BOX, "unknown prox kind %d", g->kind);
+    if (g->kind == CIAO_PROX_L1) CIAO_REQUIRE(g->lam >= 0.0, "NormL1 lambda must be >= 0");
+    return CIAO_OK;
+}
+
+template <typename T>
+static RowsArgs<T> rows_args(const ciao_problem *p)
+{
+    RowsArgs<T> a{};
+    a.A = (const T *)p->A;
+    a.b = (p->loss == CIAO_LOSS_ZERO) ? nullptr : (const T *)p->b;
+    a.ld = p->ld;
+    a.d = p->d;
+    a.loss = p->loss;
+    a.lam = (T)p->lam;
+    a.row0 = 0;
+    a.nrows = p->N;
+    a.idx = nullptr;
+    a.invN = T(1) / (T)p->N_total;
+    a.N = p->N;
+    a.gam_uniform = T(1);
+    a.hat_gamma = T(0);
+    return a;
+}
+
+template <typename T>
+static ChainArgs<T> chain_args(const ciao_problem *p, const ciao_prox_desc *g)
+{
+    ChainArgs<T> a{};
+    a.A = (const T *)p->A;
+    a.b = (p->loss == CIAO_LOSS_ZERO) ? nullptr : (const T *)p->b;
+    a.ld = p->ld;
+    a.d = p->d;
+    a.loss = p->loss;
+    a.lam = (T)p->lam;
+    a.batch = 1;
+    a.invN = T(1) / (T)p->N_total;
+    a.gam_uniform = T(1);
+    a.g = make_prox<T>(g);
+    a.N = p->N;
+    return a;
+}
+
+template <typename T>
+static Epilogue<T> epi_zero()
+{
+    Epilogue<T> e{};
+    e.p0 = T(1);
+    return e;
+}
+
+template <typename T>
+static int32_t prox_launch(ciao_ctx *ctx, int64_t d, const ciao_prox_desc *g, const T *x, T gamma, T scale, T *y)
+{
+    hipLaunchKernelGGL((prox_kernel<T>), dim3((unsigned)((d + 255) / 256)), dim3(256), 0, ctx->stream, d, make_prox<T>(g), x,
+                       gamma, scale, y);
+    CIAO_HIP(hipGetLastError());
+    return CIAO_OK;
+}
+
+// ---- typed implementations -------------------------------------------------------------------------------------------
+template <typename T>
+static int32_t full_gradient_t(ciao_ctx *ctx, const ciao_problem *p, const void *x, void *av)
+{
+    RowsArgs<T> a = rows_args<T>(p);
+    a.x1 = (const T *)x;
+    Epilogue<T> e = epi_zero<T>();
+    e.c_sum = a.invN;   // av = sum / N
+    e.av_out = (T *)av;
+    return launch_rows<T>(ctx, RM_GRAD, a, e);
+}
+
+template <typename T>
+static int32_t proxgrad_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, const void *x, void *av,
+                          void *y)
+{
+    RowsArgs<T> a = rows_args<T>(p);
+    a.x1 = (const T *)x;
+    Epilogue<T> e = epi_zero<T>();
+    e.c_sum = a.invN;
+    e.av_out = (T *)av;
+    e.z_out = (T *)y;   // y = prox_{gamma g}(x - gamma*av)
+    e.tau = (T)gamma;
+    e.p0 = -(T)gamma;
+    e.p1 = T(1);
+    e.pw = (const T *)x;
+    e.g = make_prox<T>(g);
+    return launch_rows<T>(ctx, RM_GRAD, a, e);
+}
+
+template <typename T>
+static int32_t svrg_inner_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
+                            const int64_t *idx, const void *av, void *z, const void *z_full, void *w)
+{
+    ChainArgs<T> a = chain_args<T>(p, g);
+    a.nsteps = m;
+    a.idx = idx;
+    a.gamma = (T)gamma;
+    a.av = (T *)av;   // read-only for SVRG
+    a.z = (T *)z;
+    a.zf = (T *)z_full;
+    a.w = (T *)w;
+    return launch_chain<T>(ctx, CA_SVRG, a);
+}
+
+template <typename T>
+static int32_t svrg_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
+                              const int64_t *idx, int32_t plus, void *av, void *z, void *z_full, void *w)
+{
+    CIAO_TRY(svrg_inner_t<T>(ctx, p, g, gamma, m, idx, av, z, z_full, w));
+    hipLaunchKernelGGL((svrg_tail_kernel<T>), dim3((unsigned)((p->d + 255) / 256)), dim3(256), 0, ctx->stream, p->d, (T)m,
+                       (int)plus, (T *)z, (T *)z_full, (T *)w);
+    CIAO_HIP(hipGetLastError());
+    return full_gradient_t<T>(ctx, p, z_full, av);
+}
+
+template <typename T>
+static int32_t saga_init_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, const void *x0,
+                           void *table, void *av, void *z)
+{
+    RowsArgs<T> a = rows_args<T>(p);
+    a.x1 = (const T *)x0;
+    a.table = (T *)table;
+    Epilogue<T> e = epi_zero<T>();
+    e.c_sum = a.invN;
+    e.av_out = (T *)av;
+    CIAO_TRY(launch_rows<T>(ctx, RM_SAGA_INIT, a, e));
+    // z = prox_{gamma g}((1 - gamma) x0)      SAGA_basic.jl:48
+    return prox_launch<T>(ctx, p->d, g, (const T *)x0, (T)gamma, T(1) - (T)gamma, (T *)z);
+}
+
+template <typename T>
+static int32_t saga_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int32_t sag,
+                            int64_t nsteps, const int64_t *idx, void *table, void *av, void *z)
+{
+    ChainArgs<T> a = chain_args<T>(p, g);
+    a.nsteps = nsteps;
+    a.idx = idx;
+    a.gamma = (T)gamma;
+    a.sag = sag;
+    a.table = (T *)table;
+    a.av = (T *)av;
+    a.z = (T *)z;
+    return launch_chain<T>(ctx, CA_SAGA, a);
+}
+
+template <typename T>
+static int32_t finito_init_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
+                             const void *x0, void *table, void *av, void *z)
+{
+    RowsArgs<T> a = rows_args<T>(p);
+    a.x1 = (const T *)x0;
+    a.table = (T *)table;
+    a.gam = (const T *)gam;
+    a.hat_gamma = (T)hat_gamma;
+    Epilogue<T> e = epi_zero<T>();
+    e.c_sum = (T)hat_gamma;   // av = hat_gamma * sum_i s_i/gam_i
+    e.av_out = (T *)av;
+    e.z_out = (T *)z;         // z = prox_{hat_gamma g}(av)
+    e.tau = (T)hat_gamma;
+    e.g = make_prox<T>(g);
+    return launch_rows<T>(ctx, RM_FINITO_INIT, a, e);
+}
+
+template <typename T>
+static int32_t finito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
+                              int64_t nit, const int64_t *bptr, const int64_t *bidx, void *table, void *av, void *z)
+{
+    int64_t t = 0;
+    while (t < nit) {
+        const int64_t r = bptr[t + 1] - bptr[t];
+        CIAO_REQUIRE(r >= 1, "Finito batch %lld is empty", (long long)t);
+        // a run of consecutive batches of the same size
+        int64_t t1 = t + 1;
+        while (t1 < nit && bptr[t1 + 1] - bptr[t1] == r) ++t1;
+        if (!ctx->hook && r <= ctx->chain_max_batch) {
+            ChainArgs<T> a = chain_args<T>(p, g);
+            a.nsteps = (t1 - t) * r;
+            a.idx = bidx + bptr[t];
+            a.batch = r;
+            a.gam = (const T *)gam;
+            a.hat_gamma = (T)hat_gamma;
+            a.table = (T *)table;
+            a.av = (T *)av;
+            a.z = (T *)z;
+            CIAO_TRY(launch_chain<T>(ctx, CA_FINITO, a));
+        } else {
+            for (int64_t tt = t; tt < t1; ++tt) {
+                RowsArgs<T> a = rows_args<T>(p);
+                a.nrows = r;
+                a.idx = bidx + bptr[tt];
+                a.x1 = (const T *)z;
+                a.table = (T *)table;
+                a.gam = (const T *)gam;
+                a.hat_gamma = (T)hat_gamma;
+                Epilogue<T> e = epi_zero<T>();
+                e.c_acc = T(1);   // av += sum_i (t_i - s_i) hat_gamma/gam_i
+                e.acc_in = (const T *)av;
+                e.c_sum = T(1);
+                e.av_out = (T *)av;
+                e.z_out = (T *)z;   // z = prox_{hat_gamma g}(av)
+                e.tau = (T)hat_gamma;
+                e.g = make_prox<T>(g);
+                CIAO_TRY(launch_rows<T>(ctx, RM_FINITO_BATCH, a, e));
+            }
+        }
+        t = t1;
+    }
+    return CIAO_OK;
+}
+
+template <typename T>
+static int32_t lfinito_init_t(ciao_ctx *ctx, const ciao_problem *p, double hat_gamma, const void *x0, void *av, void *z,
+                              void *z_full)
+{
+    RowsArgs<T> a = rows_args<T>(p);
+    a.x1 = (const T *)x0;
+    Epilogue<T> e = epi_zero<T>();
+    e.c_sum = -((T)hat_gamma * a.invN);   // av = x0 - (hat_gamma/N) sum grad f_i(x0)
+    e.c_u = T(1);
+    e.u = (const T *)x0;
+    e.av_out = (T *)av;
+    CIAO_TRY(launch_rows<T>(ctx, RM_GRAD, a, e));
+    const size_t bytes = (size_t)p->d * sizeof(T);
+    CIAO_HIP(hipMemcpyAsync(z, av, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    CIAO_HIP(hipMemcpyAsync(z_full, av, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return CIAO_OK;
+}
+
+template <typename T>
+static int32_t lfinito_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam,
+                                 double hat_gamma, int64_t nb, const int64_t *bptr, const int64_t *bidx, void *av, void *z,
+                                 void *z_full)
+{
+    const T hg = (T)hat_gamma;
+    // z_full = prox_{hg g}(av)                                   Finito_LFinito.jl:83
+    CIAO_TRY(prox_launch<T>(ctx, p->d, g, (const T *)av, hg, T(1), (T *)z_full));
+    {   // av = z_full - (hg/N) sum_i grad f_i(z_full)            :84-88
+        RowsArgs<T> a = rows_args<T>(p);
+        a.x1 = (const T *)z_full;
+        Epilogue<T> e = epi_zero<T>();
+        e.c_sum = -(hg * a.invN);
+        e.c_u = T(1);
+        e.u = (const T *)z_full;
+        e.av_out = (T *)av;
+        CIAO_TRY(launch_rows<T>(ctx, RM_GRAD, a, e));
+    }
+    int64_t t = 0;
+    while (t < nb) {
+        const int64_t r = bptr[t + 1] - bptr[t];
+        CIAO_REQUIRE(r >= 1, "LFinito batch %lld is empty", (long long)t);
+        int64_t t1 = t + 1;
+        while (t1 < nb && bptr[t1 + 1] - bptr[t1] == r) ++t1;
+        if (!ctx->hook && r <= ctx->chain_max_batch) {
+            ChainArgs<T> a = chain_args<T>(p, g);
+            a.nsteps = (t1 - t) * r;
+            a.idx = bidx + bptr[t];
+            a.batch = r;
+            a.gam = (const T *)gam;
+            a.hat_gamma = hg;
+            a.av = (T *)av;
+            a.z = (T *)z;
+            a.zf = (T *)z_full;
+            CIAO_TRY(launch_chain<T>(ctx, CA_LFINITO, a));
+        } else {
+            for (int64_t tt = t; tt < t1; ++tt) {
+                CIAO_TRY(prox_launch<T>(ctx, p->d, g, (const T *)av, hg, T(1), (T *)z));   // :92
+                RowsArgs<T> a = rows_args<T>(p);
+                a.nrows = r;
+                a.idx = bidx + bptr[tt];
+                a.x1 = (const T *)z_full;   // acc += (coef(z_full) - coef(z)) a_i
+                a.x2 = (const T *)z;
+                a.gam = (const T *)gam;
+                a.hat_gamma = hg;
+                Epilogue<T> e = epi_zero<T>();
+                e.c_acc = T(1);
+                e.acc_in = (const T *)av;
+                e.c_sum = hg * a.invN;
+                e.uv_extra = 1;   // + (sum_i hg/gam_i) * (z - z_full)
+                e.c_u = T(1);
+                e.u = (const T *)z;
+                e.c_v = T(-1);
+                e.v = (const T *)z_full;
+                e.av_out = (T *)av;
+                CIAO_TRY(launch_rows<T>(ctx, RM_GRAD2, a, e));
+            }
+        }
+        t = t1;
+    }
+    return CIAO_OK;
+}
+
+template <typename T>
+static int32_t objective_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *x, double *obj)
+{
+    RowsArgs<T> a = rows_args<T>(p);
+    a.x1 = (const T *)x;
+    a.want_fval = 1;
+    CIAO_TRY(launch_rows_raw<T>(ctx, RM_GRAD, a));
+    hipLaunchKernelGGL((gvalue_kernel<T>), dim3(1), dim3(256), 0, ctx->stream, p->d, make_prox<T>(g), (const T *)x, ctx->scal);
+    CIAO_HIP(hipGetLastError());
+    T fsum;
+    double gval;
+    CIAO_HIP(hipMemcpyAsync(&fsum, (const T *)ctx->sumbuf + p->d, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    CIAO_HIP(hipMemcpyAsync(&gval, ctx->scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CIAO_HIP(hipStreamSynchronize(ctx->stream));
+    *obj = (double)fsum / (double)p->N_total + gval;
+    return CIAO_OK;
+}
+
+}  // namespace ciao
+
+using namespace ciao;
+
+#define DISPATCH(dtype, fn, ...) ((dtype) == CIAO_F64 ? fn<double>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
+
+extern "C" {
+
+int32_t ciao_abi_version(void) { return CIAO_ABI_VERSION; }
+
+const char *ciao_last_error(void) { return g_err; }
+
+int32_t ciao_ctx_create(int32_t device, void *stream, ciao_ctx **out)
+{
+    CIAO_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    CIAO_HIP(hipGetDeviceCount(&ndev));
+    CIAO_REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+    CIAO_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CIAO_HIP(hipGetDeviceProperties(&prop, device));
+    ciao_ctx *ctx = new ciao_ctx();
+    ctx->device = device;
+    ctx->stream = (hipStream_t)stream;
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipMalloc((void **)&ctx->scal, 4096 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->errflag, sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->errflag, 0, sizeof(int), ctx->stream);
+    if (e != hipSuccess) {
+        delete ctx;
+        return hip_fail(e, "ctx scratch allocation");
+    }
+    *out = ctx;
+    return CIAO_OK;
+}
+
+int32_t ciao_ctx_destroy(ciao_ctx *ctx)
+{
+    if (!ctx) return CIAO_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->partial) (void)hipFree(ctx->partial);
+    if (ctx->pextra) (void)hipFree(ctx->pextra);
+    if (ctx->sumbuf) (void)hipFree(ctx->sumbuf);
+    if (ctx->scal) (void)hipFree(ctx->scal);
+    if (ctx->errflag) (void)hipFree(ctx->errflag);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    delete ctx;
+    return CIAO_OK;
+}
+
+int32_t ciao_ctx_set_stream(ciao_ctx *ctx, void *stream)
+{
+    CIAO_REQUIRE(ctx, "ctx is NULL");
+    ctx->stream = (hipStream_t)stream;
+    return CIAO_OK;
+}
+
+int32_t ciao_ctx_synchronize(ciao_ctx *ctx)
+{
+    CIAO_REQUIRE(ctx, "ctx is NULL");
+    int flag = 0;
+    CIAO_HIP(hipMemcpyAsync(&flag, ctx->errflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CIAO_HIP(hipStreamSynchronize(ctx->stream));
+    if (flag) {
+        CIAO_HIP(hipMemsetAsync(ctx->errflag, 0, sizeof(int), ctx->stream));
+        set_error("a sample index was outside [0, N): results since the last synchronize are invalid");
+        return CIAO_ERR_ARG;
+    }
+    return CIAO_OK;
+}
+
+int32_t ciao_ctx_set_allreduce(ciao_ctx *ctx, ciao_allreduce_fn fn, void *user)
+{
+    CIAO_REQUIRE(ctx, "ctx is NULL");
+    ctx->hook = fn;
+    ctx->hook_user = user;
+    return CIAO_OK;
+}
+
+int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
+{
+    CIAO_REQUIRE(ctx && key, "ctx or key is NULL");
+    if (!strcmp(key, "sweep_blocks_per_cu")) {
+        CIAO_REQUIRE(value >= 1 && value <= 16, "sweep_blocks_per_cu must be in 1..16");
+        ctx->sweep_blocks_per_cu = value;
+    } else if (!strcmp(key, "sweep_prefetch")) {
+        ctx->sweep_prefetch = value != 0;
+    } else if (!strcmp(key, "chain_max_batch")) {
+        CIAO_REQUIRE(value >= 0, "chain_max_batch must be >= 0");
+        ctx->chain_max_batch = value;
+    } else if (!strcmp(key, "force_generic")) {
+        ctx->force_generic = value != 0;
+    } else {
+        set_error("unknown option '%s'", key);
+        return CIAO_ERR_ARG;
+    }
+    return CIAO_OK;
+}
+
+int32_t ciao_ctx_timing_enable(ciao_ctx *ctx, int32_t enable)
+{
+    CIAO_REQUIRE(ctx, "ctx is NULL");
+    ctx->timing = enable != 0;
+    return CIAO_OK;
+}
+
+int32_t ciao_ctx_timing_read(ciao_ctx *ctx, double *total_ms_host, int64_t *launches_host)
+{
+    CIAO_REQUIRE(ctx && total_ms_host && launches_host, "NULL argument");
+    CIAO_HIP(hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float ms = 0.f;
+        CIAO_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
+        tot += ms;
+    }
+    *total_ms_host = tot;
+    *launches_host = (int64_t)(ctx->ev_used / 2);
+    ctx->ev_used = 0;
+    return CIAO_OK;
+}
+
+const char *ciao_ctx_last_kernel(ciao_ctx *ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
+
+int32_t ciao_gradient(ciao_ctx *ctx, const ciao_problem *p, int64_t i, const void *x, void *y, void *fval)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_REQUIRE(x && y, "x or y is NULL");
+    CIAO_REQUIRE(i >= 0 && i < p->N, "sample index %lld outside [0, %lld)", (long long)i, (long long)p->N);
+    if (p->dtype == CIAO_F64)
+        hipLaunchKernelGGL((gradient_kernel<double>), dim3(1), dim3(WAVE), 0, ctx->stream, (const double *)p->A,
+                           p->loss == CIAO_LOSS_ZERO ? nullptr : (const double *)p->b, p->ld, p->d, p->loss, (double)p->lam, i,
+                           (const double *)x, (double *)y, (double *)fval);
+    else
+        hipLaunchKernelGGL((gradient_kernel<float>), dim3(1), dim3(WAVE), 0, ctx->stream, (const float *)p->A,
+                           p->loss == CIAO_LOSS_ZERO ? nullptr : (const float *)p->b, p->ld, p->d, p->loss, (float)p->lam, i,
+                           (const float *)x, (float *)y, (float *)fval);
+    CIAO_HIP(hipGetLastError());
+    return CIAO_OK;
+}
+
+int32_t ciao_prox(ciao_ctx *ctx, int32_t dtype, int64_t d, const ciao_prox_desc *g, const void *x, double gamma, void *y)
+{
+    CIAO_REQUIRE(ctx, "ctx is NULL");
+    CIAO_REQUIRE(dtype == CIAO_F32 || dtype == CIAO_F64, "bad dtype %d", dtype);
+    CIAO_REQUIRE(d >= 0 && (d == 0 || (x && y)), "bad d or NULL vector");
+    CIAO_TRY(check_prox(g));
+    if (d == 0) return CIAO_OK;
+    if (dtype == CIAO_F64) return prox_launch<double>(ctx, d, g, (const double *)x, gamma, 1.0, (double *)y);
+    return prox_launch<float>(ctx, d, g, (const float *)x, (float)gamma, 1.0f, (float *)y);
+}
+
+int32_t ciao_full_gradient(ciao_ctx *ctx, const ciao_problem *p, const void *x, void *av)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_REQUIRE(x && av, "x or av is NULL");
+    return DISPATCH(p->dtype, full_gradient_t, ctx, p, x, av);
+}
+
+int32_t ciao_proxgrad_step(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, const void *x,
+                           void *av, void *y)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(x && av && y, "x, av or y is NULL");
+    CIAO_REQUIRE(gamma > 0, "gamma must be > 0");
+    return DISPATCH(p->dtype, proxgrad_t, ctx, p, g, gamma, x, av, y);
+}
+
+int32_t ciao_objective(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *x, double *obj_host)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(x && obj_host, "x or obj_host is NULL");
+    return DISPATCH(p->dtype, objective_t, ctx, p, g, x, obj_host);
+}
+
+int32_t ciao_svrg_init(ciao_ctx *ctx, const ciao_problem *p, const void *x0, void *av, void *z, void *z_full, void *w)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_REQUIRE(x0 && av && z && z_full && w, "NULL state vector");
+    const size_t bytes = (size_t)p->d * (p->dtype == CIAO_F64 ? 8 : 4);
+    CIAO_TRY(DISPATCH(p->dtype, full_gradient_t, ctx, p, x0, av));
+    if (z_full != x0) CIAO_HIP(hipMemcpyAsync(z_full, x0, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (w != x0) CIAO_HIP(hipMemcpyAsync(w, x0, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    CIAO_HIP(hipMemsetAsync(z, 0, bytes, ctx->stream));
+    return CIAO_OK;
+}
+
+int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
+                        const int64_t *idx, const void *av, void *z, const void *z_full, void *w)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(m >= 0 && (m == 0 || idx), "m < 0 or idx is NULL");
+    CIAO_REQUIRE(m == 0 || p->N > 0, "cannot sample from an empty problem");
+    CIAO_REQUIRE(av && z && z_full && w, "NULL state vector");
+    CIAO_REQUIRE(gamma > 0, "gamma must be > 0");
+    CIAO_REQUIRE(!ctx->hook, "the SVRG inner cycle is a sequential chain: replicas only, not valid on a row-sharded problem");
+    return DISPATCH(p->dtype, svrg_inner_t, ctx, p, g, gamma, m, idx, av, z, z_full, w);
+}
+
+int32_t ciao_svrg_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
+                          const int64_t *idx, int32_t plus, void *av, void *z, void *z_full, void *w)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(m >= 1 && idx, "m < 1 or idx is NULL");
+    CIAO_REQUIRE(p->N > 0, "cannot sample from an empty problem");
+    CIAO_REQUIRE(av && z && z_full && w, "NULL state vector");
+    CIAO_REQUIRE(gamma > 0, "gamma must be > 0");
+    CIAO_REQUIRE(!ctx->hook, "the SVRG inner cycle is a sequential chain: replicas only, not valid on a row-sharded problem");
+    return DISPATCH(p->dtype, svrg_iterate_t, ctx, p, g, gamma, m, idx, plus, av, z, z_full, w);
+}
+
+int32_t ciao_saga_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, const void *x0,
+                       void *table, void *av, void *z)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(x0 && av && z && (table || p->N == 0), "NULL state vector / table");
+    CIAO_REQUIRE(gamma > 0, "gamma must be > 0");
+    return DISPATCH(p->dtype, saga_init_t, ctx, p, g, gamma, x0, table, av, z);
+}
+
+int32_t ciao_saga_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int32_t sag,
+                        int64_t nsteps, const int64_t *idx, void *table, void *av, void *z)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(nsteps >= 0 && (nsteps == 0 || idx), "nsteps < 0 or idx is NULL");
+    CIAO_REQUIRE(nsteps == 0 || p->N > 0, "cannot sample from an empty problem");
+    CIAO_REQUIRE(table && av && z, "NULL state vector / table");
+    CIAO_REQUIRE(gamma > 0, "gamma must be > 0");
+    CIAO_REQUIRE(!ctx->hook, "SAGA steps are a sequential chain: replicas only, not valid on a row-sharded problem");
+    return DISPATCH(p->dtype, saga_steps_t, ctx, p, g, gamma, sag, nsteps, idx, table, av, z);
+}
+
+int32_t ciao_hat_gamma(ciao_ctx *ctx, int32_t dtype, int64_t N, const void *gam, double *hat_gamma_host)
+{
+    CIAO_REQUIRE(ctx && hat_gamma_host, "ctx or output is NULL");
+    CIAO_REQUIRE(dtype == CIAO_F32 || dtype == CIAO_F64, "bad dtype %d", dtype);
+    CIAO_REQUIRE(N >= 0 && (N == 0 || gam), "N < 0 or gam is NULL");
+    const int nb = 256;
+    if (dtype == CIAO_F64)
+        hipLaunchKernelGGL((invsum_kernel<double>), dim3(nb), dim3(256), 0, ctx->stream, N, (const double *)gam, ctx->scal);
+    else
+        hipLaunchKernelGGL((invsum_kernel<float>), dim3(nb), dim3(256), 0, ctx->stream, N, (const float *)gam, ctx->scal);
+    CIAO_HIP(hipGetLastError());
+    std::vector<double> part(nb);
+    CIAO_HIP(hipMemcpyAsync(part.data(), ctx->scal, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CIAO_HIP(hipStreamSynchronize(ctx->stream));
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += part[i];
+    if (ctx->hook) {
+        CIAO_HIP(hipMemcpyAsync(ctx->scal, &s, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        const int32_t hs = ctx->hook(ctx->hook_user, ctx->scal, 1, CIAO_F64, (void *)ctx->stream);
+        if (hs != 0) {
+            set_error("all-reduce hook failed with status %d", hs);
+            return CIAO_ERR_HOOK;
+        }
+        CIAO_HIP(hipMemcpyAsync(&s, ctx->scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        CIAO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *hat_gamma_host = 1.0 / s;
+    return CIAO_OK;
+}
+
+int32_t ciao_finito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
+                         const void *x0, void *table, void *av, void *z)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(x0 && av && z && ((table && gam) || p->N == 0), "NULL state vector / table / gam");
+    CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
+    return DISPATCH(p->dtype, finito_init_t, ctx, p, g, gam, hat_gamma, x0, table, av, z);
+}
+
+int32_t ciao_finito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
+                          int64_t nit, const int64_t *bptr_host, const int64_t *bidx, void *table, void *av, void *z)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(nit >= 0 && (nit == 0 || (bptr_host && bidx)), "nit < 0 or NULL batch arrays");
+    CIAO_REQUIRE(nit == 0 || p->N > 0, "cannot sample from an empty problem");
+    CIAO_REQUIRE(table && av && z && gam, "NULL state vector / table / gam");
+    CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
+    return DISPATCH(p->dtype, finito_steps_t, ctx, p, g, gam, hat_gamma, nit, bptr_host, bidx, table, av, z);
+}
+
+int32_t ciao_lfinito_init(ciao_ctx *ctx, const ciao_problem *p, double hat_gamma, const void *x0, void *av, void *z,
+                          void *z_full)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_REQUIRE(x0 && av && z && z_full, "NULL state vector");
+    CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
+    return DISPATCH(p->dtype, lfinito_init_t, ctx, p, hat_gamma, x0, av, z, z_full);
+}
+
+int32_t ciao_lfinito_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
+                             int64_t nb, const int64_t *bptr_host, const int64_t *bidx, void *av, void *z, void *z_full)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(nb >= 0 && (nb == 0 || (bptr_host && bidx)), "nb < 0 or NULL batch arrays");
+    CIAO_REQUIRE(av && z && z_full && gam, "NULL state vector / gam");
+    CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
+    return DISPATCH(p->dtype, lfinito_iterate_t, ctx, p, g, gam, hat_gamma, nb, bptr_host, bidx, av, z, z_full);
+}
+
+int32_t ciao_synth_normal(ciao_ctx *ctx, int32_t dtype, void *out, int64_t nrows, int64_t d, int64_t ld, int64_t row0,
+                          uint64_t seed, double scale)
+{
+    CIAO_REQUIRE(ctx && (out || nrows == 0), "ctx or out is NULL");
+    CIAO_REQUIRE(dtype == CIAO_F32 || dtype == CIAO_F64, "bad dtype %d", dtype);
+    CIAO_REQUIRE(nrows >= 0 && d >= 1 && ld >= d, "bad shape");
+    if (nrows == 0) return CIAO_OK;
+    const int64_t total = nrows * d;
+    int64_t grid = (total + 255) / 256;
+    if (grid > (int64_t)ctx->num_cu * 32) grid = (int64_t)ctx->num_cu * 32;
+    if (dtype == CIAO_F64)
+        hipLaunchKernelGGL((synth_normal_kernel<double>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (double *)out, nrows, d,
+                           ld, row0, seed, scale);
+    else
+        hipLaunchKernelGGL((synth_normal_kernel<float>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (float *)out, nrows, d,
+                           ld, row0, seed, (float)scale);
+    CIAO_HIP(hipGetLastError());
+    return CIAO_OK;
+}
+
+int32_t ciao_synth_targets(ciao_ctx *ctx, const ciao_problem *p, const void *x_true, double noise, int32_t labels,
+                           int64_t row0, uint64_t seed, void *b_out)
+{
+    CIAO_REQUIRE(ctx && p && x_true && (b_out || p->N == 0), "NULL argument");
+    CIAO_REQUIRE(p->dtype == CIAO_F32 || p->dtype == CIAO_F64, "bad dtype");
+    CIAO_REQUIRE(p->N >= 0 && p->d >= 1 && p->ld >= p->d && (p->A || p->N == 0), "bad problem shape");
+    if (p->N == 0) return CIAO_OK;
+    int64_t grid = (p->N + 3) / 4;
+    if (grid > (int64_t)ctx->num_cu * 8) grid = (int64_t)ctx->num_cu * 8;
+    if (p->dtype == CIAO_F64)
+        hipLaunchKernelGGL((synth_targets_kernel<double>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const double *)p->A,
+                           p->N, p->d, p->ld, (const double *)x_true, noise, (int)labels, row0, seed, (double *)b_out);
+    else
+        hipLaunchKernelGGL((synth_targets_kernel<float>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const float *)p->A,
+                           p->N, p->d, p->ld, (const float *)x_true, (float)noise, (int)labels, row0, seed, (float *)b_out);
+    CIAO_HIP(hipGetLastError());
+    return CIAO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+// ciao_common.h -- shared device helpers for the gfx950 kernels of libciao_hip.so.
+//
+// CDNA4 facts this code is written against (MI355X_MICROARCH.md): 64-lane waves on SIMD-32 units, 256 CUs in 8 XCDs,
+// 160 KiB LDS per CU, 16 B per lane = 1 KiB per wave-instruction is the widest coalesced access, HBM3E 8 TB/s spec
+// (about 6.3 TB/s measured for streaming), per-XCD L2s that are not coherent with each other (so every cross-workgroup
+// hand-off here is a kernel boundary, never an in-kernel flag).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ciao_hip.h"
+
+namespace ciao {
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------------------------------------------------------
+// DPP cross-lane moves (32-bit halves; 64-bit values move as two halves).  Controls used:
+//   quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140.
+// After the four steps every lane of a 16-lane row holds the row's sum; the four row sums are then combined through
+// v_readlane (SGPRs), in a fixed order, so all 64 lanes end with the bitwise-identical total.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xFFFFFFFFLL), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float readlane(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ double readlane(double v, int l)
+{
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), l);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Sum over the 64 lanes of a wave; result identical (bitwise) in every lane.  Requires all 64 lanes active.
+template <typename T>
+__device__ __forceinline__ T wave_allsum(T v)
+{
+    v += dpp_mov<0xB1>(v);   // xor 1
+    v += dpp_mov<0x4E>(v);   // xor 2
+    v += dpp_mov<0x141>(v);  // row_half_mirror: quads 0<->1, 2<->3 within a row of 16
+    v += dpp_mov<0x140>(v);  // row_mirror: halves of the row
+    T r0 = readlane(v, 0), r1 = readlane(v, 16), r2 = readlane(v, 32), r3 = readlane(v, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Operators (ProximalOperators.jl 0.14 formulas)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fexp(float x) { return expf(x); }
+__device__ __forceinline__ double fexp(double x) { return exp(x); }
+__device__ __forceinline__ float flog(float x) { return logf(x); }
+__device__ __forceinline__ double flog(double x) { return log(x); }
+
+// The per-sample gradient is grad f_i(x)_k = (a_k * s1) * s2 with
+//   LS:        s1 = a'x - b_i,                 s2 = lam        (mul!(y, A', res); y .*= lam)
+//   logistic:  s1 = -y_i / (1 + exp(y_i a'x)), s2 = 1
+//   zero:      s1 = 0,                         s2 = 0
+// so that one code path serves the three families.  `coef` = s1*s2 is the rank-1 coefficient of the row.
+template <typename T>
+struct GradCoef {
+    T s1, s2;
+    __device__ __forceinline__ T coef() const { return s1 * s2; }
+    __device__ __forceinline__ T elem(T a) const { return (a * s1) * s2; }
+};
+
+template <typename T>
+__device__ __forceinline__ GradCoef<T> grad_coef(int loss, T dot, T bi, T lam)
+{
+    GradCoef<T> g;
+    if (loss == CIAO_LOSS_LS) {
+        g.s1 = dot - bi;
+        g.s2 = lam;
+    } else if (loss == CIAO_LOSS_LOGISTIC) {
+        g.s1 = -bi / (T(1) + fexp(bi * dot));
+        g.s2 = T(1);
+    } else {
+        g.s1 = T(0);
+        g.s2 = T(0);
+    }
+    return g;
+}
+
+// f_i(x) given the same scalars (the value gradient! returns).
+template <typename T>
+__device__ __forceinline__ T loss_value(int loss, T dot, T bi, T lam)
+{
+    if (loss == CIAO_LOSS_LS) {
+        T r = dot - bi;
+        return (lam / T(2)) * r * r;
+    } else if (loss == CIAO_LOSS_LOGISTIC) {
+        // log(1 + exp(-y t)), evaluated stably on either side
+        T u = -bi * dot;
+        return u > T(0) ? u + flog(T(1) + fexp(-u)) : flog(T(1) + fexp(u));
+    }
+    return T(0);
+}
+
+template <typename T>
+struct ProxD {
+    int kind;
+    T lam, lo, hi;
+    const T *lo_vec, *hi_vec;
+};
+
+template <typename T>
+__host__ inline ProxD<T> make_prox(const ciao_prox_desc *g)
+{
+    ProxD<T> p;
+    if (!g) {
+        p.kind = CIAO_PROX_ZERO;
+        p.lam = p.lo = p.hi = T(0);
+        p.lo_vec = p.hi_vec = nullptr;
+        return p;
+    }
+    p.kind = g->kind;
+    p.lam = (T)g->lam;
+    p.lo = (T)g->lo;
+    p.hi = (T)g->hi;
+    p.lo_vec = (const T *)g->lo_vec;
+    p.hi_vec = (const T *)g->hi_vec;
+    return p;
+}
+
+// prox_{gamma g}(v) for coordinate k.
+template <typename T>
+__device__ __forceinline__ T prox_elem(const ProxD<T> &g, T v, T gamma, int64_t k)
+{
+    if (g.kind == CIAO_PROX_L1) {
+        T gl = gamma * g.lam;
+        return v + (v <= -gl ? gl : (v >= gl ? -gl : -v));
+    } else if (g.kind == CIAO_PROX_BOX) {
+        T l = g.lo_vec ? g.lo_vec[k] : g.lo, h = g.hi_vec ? g.hi_vec[k] : g.hi;
+        return v < l ? l : (v > h ? h : v);
+    }
+    return v;
+}
+
+// g(x) contribution of coordinate k (0 for Zero and for a feasible Box point).
+template <typename T>
+__device__ __forceinline__ T prox_value_elem(const ProxD<T> &g, T v)
+{
+    return g.kind == CIAO_PROX_L1 ? g.lam * (v < T(0) ? -v : v) : T(0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Epilogue applied to a reduced d-vector `sum` (+ one extra reduced scalar), per coordinate k:
+//     a = c_acc*acc_in[k] + c_sum*sum[k] + cu*u[k] + cv*v[k]           (cu,cv = c_u,c_v, or +/- extra if uv_extra)
+//     av_out[k] = a
+//     z_out[k]  = prox_{tau g}(p0*a + p1*pw[k])                         (if z_out)
+// Covers: SVRG av = sum/N; LFinito av = z_full - (hg/N) sum; Finito av += sum, z = prox(av); SAGA/Finito init;
+// proximal-gradient step y = prox(x - gamma*av).
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct Epilogue {
+    T c_acc, c_sum, c_u, c_v;
+    const T *acc_in, *u, *v;
+    T *av_out;
+    int uv_extra;  // cu = +extra*c_u, cv = -extra*c_u ... see apply()
+    T *z_out;
+    T tau, p0, p1;
+    const T *pw;
+    ProxD<T> g;
+};
+
+template <typename T>
+__device__ __forceinline__ void epilogue_apply(const Epilogue<T> &e, int64_t k, T sum, T extra)
+{
+    T a = e.c_sum * sum;
+    if (e.acc_in) a += e.c_acc * e.acc_in[k];
+    T cu = e.uv_extra ? e.c_u * extra : e.c_u;
+    T cv = e.uv_extra ? e.c_v * extra : e.c_v;
+    if (e.u) a += cu * e.u[k];
+    if (e.v) a += cv * e.v[k];
+    if (e.av_out) e.av_out[k] = a;
+    if (e.z_out) {
+        T t = e.p0 * a;
+        if (e.pw) t += e.p1 * e.pw[k];
+        e.z_out[k] = prox_elem(e.g, t, e.tau, k);
+    }
+}
+
+}  // namespace ciao

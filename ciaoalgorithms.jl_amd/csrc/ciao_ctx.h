@@ -1,0 +1,72 @@
+// ciao_ctx.h -- host-side context of libciao_hip.so (private; the public view is include/ciao_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ciao_hip.h"
+
+struct ciao_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cu = 256;
+
+    // all-reduce hook (multi-GPU); nullptr = single device
+    ciao_allreduce_fn hook = nullptr;
+    void *hook_user = nullptr;
+
+    // private workspace (grown on demand, never inside a timed region after the first call of a given shape)
+    void *partial = nullptr;   // per-block partial d-vectors
+    size_t partial_bytes = 0;
+    void *pextra = nullptr;    // per-block extra scalars
+    size_t pextra_bytes = 0;
+    void *sumbuf = nullptr;    // raw reduced sum (d + 1 elements) handed to the all-reduce hook
+    size_t sumbuf_bytes = 0;
+    double *scal = nullptr;    // small device scratch for scalar reductions (4096 doubles)
+    int *errflag = nullptr;    // sticky device error word (out-of-range index)
+
+    // tuning
+    int64_t sweep_blocks_per_cu = 4;
+    int64_t sweep_prefetch = 1;     // gradient sweeps: 1 = two-deep register pipeline, 0 = occupancy only
+    int64_t chain_max_batch = 64;   // Finito/LFinito batches up to this size run as a sequential chain
+    int64_t force_generic = 0;      // testing: route every rows launch through the generic kernel
+
+    std::string last_kernel;
+
+    // optional HIP-event timing of the dominant kernel (bench.py roofline)
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;   // pairs (start, stop), reused after every read
+    size_t ev_used = 0;
+};
+
+namespace ciao {
+
+void set_error(const char *fmt, ...);
+int32_t hip_fail(hipError_t e, const char *what);
+
+#define CIAO_HIP(call)                                                  \
+    do {                                                                \
+        hipError_t _e = (call);                                         \
+        if (_e != hipSuccess) return ::ciao::hip_fail(_e, #call);       \
+    } while (0)
+
+#define CIAO_REQUIRE(cond, ...)                                         \
+    do {                                                                \
+        if (!(cond)) {                                                  \
+            ::ciao::set_error(__VA_ARGS__);                             \
+            return CIAO_ERR_ARG;                                        \
+        }                                                               \
+    } while (0)
+
+#define CIAO_TRY(expr)                                                  \
+    do {                                                                \
+        int32_t _s = (expr);                                            \
+        if (_s != CIAO_OK) return _s;                                   \
+    } while (0)
+
+int32_t ensure(ciao_ctx *ctx, void **buf, size_t *have, size_t need);
+
+}  // namespace ciao

@@ -1,0 +1,20 @@
+// launch.h -- host dispatch entry points shared by api.hip and the per-type instantiation units.
+#pragma once
+
+#include "chain_kernels.h"
+#include "ciao_ctx.h"
+#include "rows_kernels.h"
+
+namespace ciao {
+
+// rows kernel + finalize (+ all-reduce hook) + epilogue.  Specialised in rows_f32.hip / rows_f64.hip.
+template <typename T>
+int32_t launch_rows(ciao_ctx *ctx, int mode, RowsArgs<T> &a, const Epilogue<T> &ep);
+// same, but leaves the reduced sum in ctx->sumbuf[0..d) and the extra scalar in ctx->sumbuf[d]; no epilogue.
+template <typename T>
+int32_t launch_rows_raw(ciao_ctx *ctx, int mode, RowsArgs<T> &a);
+// persistent single-workgroup chain.  Specialised in chain_f32.hip / chain_f64.hip.
+template <typename T>
+int32_t launch_chain(ciao_ctx *ctx, int alg, ChainArgs<T> &a);
+
+}  // namespace ciao

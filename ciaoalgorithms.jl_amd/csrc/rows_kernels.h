@@ -1,0 +1,412 @@
+// rows_kernels.h -- the batch-parallel "one wave per data row" kernels (SURVEY.md section 8a rows S2, S4, G2, F2, F3,
+// F4): every row a_i of the row-major N x d matrix is read from HBM exactly once, its dot product(s) with the
+// iterate(s) are reduced inside one 64-lane wave (DPP + readlane, no LDS, no barrier), the scalar link function gives
+// the rank-1 coefficient, and the row -- still in registers -- is accumulated into per-wave register accumulators.
+// The waves of a block are then summed through LDS in a fixed order, each block writes one partial d-vector, and
+// finalize_kernel sums the partials in a fixed order (bitwise run-to-run determinism; no float atomics) with the
+// algorithm's epilogue (scale / axpy / prox) fused in.
+//
+// Roofline: HBM-bound.  Algorithmic bytes per row: d*s + s (row + b_i) for the gradient modes, 3*d*s + 2*s + 8 for
+// the Finito batch (row, table row read+write, b_i, gamma_i, index).  Arithmetic intensity 0.5-1 flop/B: far below
+// the vector-FMA ridge, and there is no reuse of A, so MFMA does not apply (one right-hand side = GEMV shape).
+#pragma once
+
+#include "ciao_common.h"
+
+namespace ciao {
+
+enum RowMode {
+    RM_GRAD = 0,         // acc += coef(a'x1) * a                                   (+ extra = sum f_i(x1) if want_fval)
+    RM_GRAD2 = 1,        // acc += (coef(a'x1) - coef(a'x2)) * a ; extra += hg/gam_i  (LFinito batch, Finito_LFinito.jl:93-98)
+    RM_SAGA_INIT = 2,    // table_i = grad f_i(x1) ; acc += table_i                   (SAGA_basic.jl:42-47)
+    RM_FINITO_INIT = 3,  // table_i = x1 - (gam_i/N) grad f_i(x1) ; acc += table_i/gam_i   (Finito_basic.jl:77-83)
+    RM_FINITO_BATCH = 4  // t = x1 - (gam_i/N) grad f_i(x1) ; acc += (t - table_i)*(hg/gam_i) ; table_i = t  (:110-117)
+};
+
+template <typename T>
+struct RowsArgs {
+    const T *A;
+    const T *b;
+    int64_t ld, d;
+    int loss;
+    T lam;
+    int64_t row0, nrows;   // rows row0 .. row0+nrows (idx == nullptr) or idx[0..nrows)
+    const int64_t *idx;
+    const T *x1, *x2;
+    T *table;              // N x d, stride d
+    const T *gam;          // per-sample stepsizes (or nullptr -> gam_uniform)
+    T gam_uniform;
+    T invN;                // 1 / N_total
+    T hat_gamma;
+    int want_fval;
+    T *partial;            // [gridDim.x][pstride]
+    int64_t pstride;
+    T *pextra;             // [gridDim.x]
+    int64_t N;             // local rows (index validation)
+    int *errflag;          // device word set to 1 on an out-of-range index
+};
+
+template <typename T>
+struct VecOf;
+template <>
+struct VecOf<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+    static constexpr int N = 4;
+};
+template <>
+struct VecOf<double> {
+    typedef double type __attribute__((ext_vector_type(2)));
+    static constexpr int N = 2;
+};
+
+constexpr int ROWS_BLOCK = 256;
+constexpr int ROWS_WAVES = ROWS_BLOCK / WAVE;
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fast path: d == K * 64 * VEC exactly, rows 16-byte aligned.  Lane l owns the 16-byte chunks (k*64 + l), k < K, of
+// every d-vector, so each wave-instruction moves 1 KiB contiguous.
+// ------------------------------------------------------------------------------------------------------------------
+// Register budget -> waves per SIMD requested from the compiler (2nd __launch_bounds__ argument = min waves per SIMD):
+// a row fragment is 4*K 32-bit registers; live at once are the accumulator, the row(s) in flight (+1 when pipelined,
+// +1 for the Finito table row) and ~44 (f32) / ~76 (f64) registers of addressing / dot-product temporaries.
+template <int ES, int K, int MODE, int PF>
+struct RowsWaves {
+    static constexpr int budget = 4 * K * (2 + PF) + (MODE == RM_FINITO_BATCH ? 2 * K + 16 : 0) + (ES == 8 ? 76 : 44);
+    static constexpr int raw = 512 / ((budget + 7) / 8 * 8);
+    static constexpr int value = raw < 1 ? 1 : (raw > 8 ? 8 : raw);
+};
+
+template <typename T, int K, int MODE, int PF>
+__global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>::value)) rows_fast_kernel(RowsArgs<T> a)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int VEC = VecOf<T>::N;
+    constexpr int D = K * WAVE * VEC;
+    constexpr bool TWO = (MODE == RM_GRAD2);
+    constexpr bool TABLE = (MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH);
+
+    // LDS: the iterate(s) during the sweep, then the cross-wave reduction buffer.
+    __shared__ __attribute__((aligned(16))) T lds[(TWO ? 2 : 1) * D];
+    __shared__ T red_extra[ROWS_WAVES];
+
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t nwaves = (int64_t)gridDim.x * ROWS_WAVES;
+    int64_t q = (int64_t)blockIdx.x * ROWS_WAVES + wib;
+
+    for (int e = threadIdx.x; e < D; e += ROWS_BLOCK) {
+        lds[e] = a.x1[e];
+        if (TWO) lds[D + e] = a.x2[e];
+    }
+    __syncthreads();
+
+    V acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = V(T(0));
+    T extra = T(0);
+
+    auto row_of = [&](int64_t qq) -> int64_t {
+        if (!a.idx) return a.row0 + qq;
+        int64_t r = a.idx[qq];
+        if ((uint64_t)r >= (uint64_t)a.N) {   // memory-safe: flag it, use row 0 (results are void once flagged)
+            if (lane == 0) *a.errflag = 1;
+            r = 0;
+        }
+        return r;
+    };
+    auto load_row = [&](V(&r)[K], int64_t row) {
+        const V *ap = reinterpret_cast<const V *>(a.A + row * a.ld);
+#pragma unroll
+        for (int k = 0; k < K; ++k) r[k] = ap[k * WAVE + lane];
+    };
+
+    // one row: dot(s) -> link function -> rank-1 accumulate (+ table update)
+    auto process = [&](V(&cur)[K], int64_t row, T bi) {
+        // The iterate is re-read from LDS for every row (keeps it out of the register budget); the opaque lane offset
+        // stops the compiler from hoisting these loop-invariant reads back into 2*K*VEC registers.
+        int xl = lane;
+        asm volatile("" : "+v"(xl));
+        const V *x1v = reinterpret_cast<const V *>(lds) + xl;
+        const V *x2v = reinterpret_cast<const V *>(lds + D) + xl;
+
+        T *tp = TABLE ? a.table + row * a.d : nullptr;
+
+        T d1 = T(0), d2 = T(0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const V xv = x1v[k * WAVE];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) d1 += cur[k][v] * xv[v];
+            if (TWO) {
+                const V yv = x2v[k * WAVE];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) d2 += cur[k][v] * yv[v];
+            }
+        }
+        d1 = wave_allsum(d1);
+        if (TWO) d2 = wave_allsum(d2);
+
+        const GradCoef<T> g1 = grad_coef(a.loss, d1, bi, a.lam);
+        if (MODE == RM_GRAD) {
+            const T c = g1.coef();
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += c * cur[k];
+            if (a.want_fval) extra += loss_value(a.loss, d1, bi, a.lam);
+        } else if (MODE == RM_GRAD2) {
+            const GradCoef<T> g2 = grad_coef(a.loss, d2, bi, a.lam);
+            const T c = g1.coef() - g2.coef();
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += c * cur[k];
+            const T gi = a.gam ? a.gam[row] : a.gam_uniform;
+            extra += a.hat_gamma / gi;
+        } else if (MODE == RM_SAGA_INIT) {
+            V *sp = reinterpret_cast<V *>(tp);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                V gv;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) gv[v] = g1.elem(cur[k][v]);
+                sp[k * WAVE + lane] = gv;
+                acc[k] += gv;
+            }
+        } else {  // FINITO_INIT / FINITO_BATCH
+            const T gi = a.gam ? a.gam[row] : a.gam_uniform;
+            const T cg = gi * a.invN;   // gam_i / N
+            const T rr = (MODE == RM_FINITO_INIT) ? T(1) / gi : a.hat_gamma / gi;
+            V *sp = reinterpret_cast<V *>(tp);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const V xv = x1v[k * WAVE];
+                V tv;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) tv[v] = xv[v] - cg * g1.elem(cur[k][v]);
+                if (MODE == RM_FINITO_INIT) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[k][v] += tv[v] * rr;   // s_i / gam_i
+                } else {
+                    const V sv = sp[k * WAVE + lane];   // old table row, read in place just before it is replaced
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[k][v] += (tv[v] - sv[v]) * rr;
+                }
+                sp[k * WAVE + lane] = tv;
+                // keep the scheduler from hoisting every x / table fragment read to the top (register pressure)
+                if (K >= 8 && (k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    if (PF) {
+        // explicit two-deep software pipeline (ping-pong register buffers): the next row's loads are in flight while
+        // the current row is reduced.
+        V bufA[K], bufB[K];
+        int64_t rowA = 0, rowB = 0;
+        T bA = T(0), bB = T(0);
+        if (q < a.nrows) {
+            rowA = row_of(q);
+            load_row(bufA, rowA);
+            bA = a.b ? a.b[rowA] : T(0);
+            while (true) {
+                int64_t qn = q + nwaves;
+                bool more = qn < a.nrows;
+                if (more) {
+                    rowB = row_of(qn);
+                    load_row(bufB, rowB);
+                    bB = a.b ? a.b[rowB] : T(0);
+                }
+                process(bufA, rowA, bA);
+                if (!more) break;
+                q = qn;
+                qn = q + nwaves;
+                more = qn < a.nrows;
+                if (more) {
+                    rowA = row_of(qn);
+                    load_row(bufA, rowA);
+                    bA = a.b ? a.b[rowA] : T(0);
+                }
+                process(bufB, rowB, bB);
+                if (!more) break;
+                q = qn;
+            }
+        }
+    } else {
+        // latency hidden by occupancy alone: one row in flight per wave, more waves per SIMD
+        for (; q < a.nrows; q += nwaves) {
+            V cur[K];
+            const int64_t row = row_of(q);
+            load_row(cur, row);
+            const T bi = a.b ? a.b[row] : T(0);
+            process(cur, row, bi);
+        }
+    }
+
+    // cross-wave reduction through LDS in wave order (deterministic), then one partial per block
+    __syncthreads();  // everyone is done reading the iterates
+    V *red = reinterpret_cast<V *>(lds);
+    for (int w = 0; w < ROWS_WAVES; ++w) {
+        if (wib == w) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (w == 0)
+                    red[k * WAVE + lane] = acc[k];
+                else
+                    red[k * WAVE + lane] += acc[k];
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0) red_extra[wib] = extra;   // extra is wave-uniform
+    __syncthreads();
+    T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
+    for (int e = threadIdx.x; e < D; e += ROWS_BLOCK) pout[e] = lds[e];
+    if (threadIdx.x == 0) {
+        T ex = T(0);
+        for (int w = 0; w < ROWS_WAVES; ++w) ex += red_extra[w];
+        a.pextra[blockIdx.x] = ex;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Generic path: any d, any alignment.  Lane l owns elements l, l+64, ...; the per-wave accumulator lives in LDS
+// (wave-private region, so no atomics and no barriers in the loop); the row is read twice (second read is an L1/L2
+// hit).  Correctness path for small / odd shapes (e.g. the reference's own N=6,d=3 and N=8,d=5 tests).
+// Dynamic LDS layout: x1[d] | x2[d] (if TWO) | acc[NW][d]
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int NW, int MODE>
+__global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
+{
+    constexpr bool TWO = (MODE == RM_GRAD2);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *smem = reinterpret_cast<T *>(smem_raw);
+    const int64_t d = a.d;
+    T *x1s = smem;
+    T *x2s = smem + d;
+    T *accs = smem + (TWO ? 2 : 1) * d;
+
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t nwaves = (int64_t)gridDim.x * NW;
+    T *acc = accs + (int64_t)wib * d;
+
+    for (int64_t e = threadIdx.x; e < d; e += NW * WAVE) {
+        x1s[e] = a.x1[e];
+        if (TWO) x2s[e] = a.x2[e];
+    }
+    for (int64_t e = threadIdx.x; e < (int64_t)NW * d; e += NW * WAVE) accs[e] = T(0);
+    __syncthreads();
+
+    T extra = T(0);
+    for (int64_t q = (int64_t)blockIdx.x * NW + wib; q < a.nrows; q += nwaves) {
+        int64_t row = a.idx ? a.idx[q] : a.row0 + q;
+        if ((uint64_t)row >= (uint64_t)a.N) {
+            if (lane == 0) *a.errflag = 1;
+            row = 0;
+        }
+        const T *ap = a.A + row * a.ld;
+        const T bi = a.b ? a.b[row] : T(0);
+        T d1 = T(0), d2 = T(0);
+        for (int64_t e = lane; e < d; e += WAVE) {
+            const T av = ap[e];
+            d1 += av * x1s[e];
+            if (TWO) d2 += av * x2s[e];
+        }
+        d1 = wave_allsum(d1);
+        if (TWO) d2 = wave_allsum(d2);
+        const GradCoef<T> g1 = grad_coef(a.loss, d1, bi, a.lam);
+        T *tp = a.table ? a.table + row * d : nullptr;
+        if (MODE == RM_GRAD) {
+            const T c = g1.coef();
+            for (int64_t e = lane; e < d; e += WAVE) acc[e] += c * ap[e];
+            if (a.want_fval) extra += loss_value(a.loss, d1, bi, a.lam);
+        } else if (MODE == RM_GRAD2) {
+            const GradCoef<T> g2 = grad_coef(a.loss, d2, bi, a.lam);
+            const T c = g1.coef() - g2.coef();
+            for (int64_t e = lane; e < d; e += WAVE) acc[e] += c * ap[e];
+            const T gi = a.gam ? a.gam[row] : a.gam_uniform;
+            extra += a.hat_gamma / gi;
+        } else if (MODE == RM_SAGA_INIT) {
+            for (int64_t e = lane; e < d; e += WAVE) {
+                const T gv = g1.elem(ap[e]);
+                tp[e] = gv;
+                acc[e] += gv;
+            }
+        } else {
+            const T gi = a.gam ? a.gam[row] : a.gam_uniform;
+            const T cg = gi * a.invN;
+            const T rr = (MODE == RM_FINITO_INIT) ? T(1) / gi : a.hat_gamma / gi;
+            for (int64_t e = lane; e < d; e += WAVE) {
+                const T tv = x1s[e] - cg * g1.elem(ap[e]);
+                if (MODE == RM_FINITO_INIT)
+                    acc[e] += tv * rr;
+                else
+                    acc[e] += (tv - tp[e]) * rr;
+                tp[e] = tv;
+            }
+        }
+    }
+
+    __shared__ T red_extra[NW];
+    if (lane == 0) red_extra[wib] = extra;   // extra is wave-uniform
+    __syncthreads();
+    T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
+    for (int64_t e = threadIdx.x; e < d; e += NW * WAVE) {
+        T s = accs[e];
+        for (int w = 1; w < NW; ++w) s += accs[(int64_t)w * d + e];
+        pout[e] = s;
+    }
+    if (threadIdx.x == 0) {
+        T ex = T(0);
+        for (int w = 0; w < NW; ++w) ex += red_extra[w];
+        a.pextra[blockIdx.x] = ex;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// finalize: sum the per-block partials in a fixed order and apply the epilogue.  Block = (64 columns) x (16 slices).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FIN_SLICES = 16;
+
+template <typename T>
+__global__ void __launch_bounds__(WAVE *FIN_SLICES)
+    finalize_kernel(const T *__restrict__ partial, int64_t pstride, int nparts, const T *__restrict__ pextra,
+                    int64_t d, T *raw_out, Epilogue<T> ep)
+{
+    __shared__ T lds[FIN_SLICES][WAVE];
+    __shared__ T lds_extra;
+    const int tx = threadIdx.x & (WAVE - 1);
+    const int ty = threadIdx.x >> 6;
+    const int64_t col = (int64_t)blockIdx.x * WAVE + tx;
+
+    T s = T(0);
+    if (col < d)
+        for (int p = ty; p < nparts; p += FIN_SLICES) s += partial[(int64_t)p * pstride + col];
+    lds[ty][tx] = s;
+    if (ty == 0) {
+        T ex = T(0);
+        for (int p = tx; p < nparts; p += WAVE) ex += pextra[p];
+        ex = wave_allsum(ex);
+        if (tx == 0) lds_extra = ex;
+    }
+    __syncthreads();
+    if (ty == 0 && col < d) {
+        T tot = lds[0][tx];
+#pragma unroll
+        for (int y = 1; y < FIN_SLICES; ++y) tot += lds[y][tx];
+        const T extra = lds_extra;
+        if (raw_out) {
+            raw_out[col] = tot;
+            if (col == 0) raw_out[d] = extra;
+        } else {
+            epilogue_apply(ep, col, tot, extra);
+        }
+    }
+}
+
+// epilogue on an already reduced (and all-reduced) raw sum: raw[0..d) + extra at raw[d]
+template <typename T>
+__global__ void __launch_bounds__(256) epilogue_kernel(const T *__restrict__ raw, int64_t d, Epilogue<T> ep)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < d) epilogue_apply(ep, k, raw[k], raw[d]);
+}
+
+}  // namespace ciao

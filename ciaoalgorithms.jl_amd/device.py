@@ -1,0 +1,285 @@
+"""Device-side plumbing: a `Context` (ciao_ctx handle bound to a torch HIP stream) and typed wrappers that pass torch
+device tensors to the C ABI.  PyTorch is used here only for device memory, streams and (in parallel.py)
+torch.distributed -- all arithmetic happens in libciao_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.F32, torch.float64: L.F64}
+_NP2T = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
+
+
+def torch_dtype(R) -> torch.dtype:
+    """Map the reference's real type parameter `R` (numpy/torch dtype or python float) to a torch dtype."""
+    if isinstance(R, torch.dtype):
+        if R not in _DT:
+            raise TypeError(f"only float32/float64 are supported on the device path, got {R}")
+        return R
+    if R is float:
+        return torch.float64
+    return _NP2T[np.dtype(R)]
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class PackedF:
+    """F = [f_1 .. f_N] packed for the device: row-major A (N x d), b (targets or labels), loss kind, LeastSquares λ.
+
+    Replaces the reference's Vector of N one-row operator objects (test/test_lasso.jl:50-58).  `N_total` is the global
+    sample count when A holds only this rank's row shard (parallel.py); `row0` is the global index of local row 0.
+    """
+
+    def __init__(self, loss: int, A: torch.Tensor | None, b: torch.Tensor | None, lam: float = 1.0, N_total: int | None = None,
+                 row0: int = 0, d: int | None = None, dtype: torch.dtype | None = None, N: int | None = None):
+        self.loss = int(loss)
+        if A is not None:
+            assert A.is_cuda and A.dim() == 2 and A.stride(1) == 1, "A must be a row-major device matrix"
+            assert A.dtype in _DT, f"unsupported dtype {A.dtype}"
+            self.N, self.d = int(A.shape[0]), int(A.shape[1])
+            self.ld = int(A.stride(0)) if self.N > 1 else self.d
+            self.dtype = A.dtype
+            self.device = A.device
+        else:  # F = fill(Zero(), N): no data at all (SVRG.jl:58)
+            assert loss == L.LOSS_ZERO and d is not None and dtype is not None and N is not None
+            self.N, self.d, self.ld, self.dtype = int(N), int(d), int(d), dtype
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if b is not None:
+            assert b.is_cuda and b.dtype == self.dtype and b.is_contiguous() and b.shape == (self.N,)
+        elif loss != L.LOSS_ZERO:
+            raise ValueError("b (targets / labels) is required for LeastSquares and logistic F")
+        self.A, self.b, self.lam = A, b, float(lam)
+        self.N_total = int(N_total) if N_total is not None else self.N
+        self.row0 = int(row0)
+        self._c = L.Problem(self.loss, _DT[self.dtype], self.N, self.d, max(self.ld, self.d), self.N_total,
+                            A.data_ptr() if (A is not None and self.N > 0) else None,
+                            b.data_ptr() if (b is not None and self.N > 0) else None, self.lam)
+
+    @property
+    def ref(self):
+        return C.byref(self._c)
+
+    # reference-style constructors --------------------------------------------------------------------------------
+    @staticmethod
+    def least_squares(A, b, lam=1.0, **kw):
+        """f_i = LeastSquares(A[i:i,:], b[i:i], lam)  (test/test_lasso.jl:52-54)"""
+        return PackedF(L.LOSS_LS, A, b, lam, **kw)
+
+    @staticmethod
+    def logistic(A, y, **kw):
+        """f_i = Precompose(LogisticLoss([y_i], 1.0), A[i:i,:], 1.0)  (test/test_logistic_l1.jl:36)"""
+        return PackedF(L.LOSS_LOGISTIC, A, y, 1.0, **kw)
+
+    @staticmethod
+    def zero(N, d, dtype):
+        return PackedF(L.LOSS_ZERO, None, None, 0.0, d=d, dtype=dtype, N=N)
+
+
+class ProxG:
+    """g packed for the device: Zero / NormL1(λ) / IndBox(lo, hi)."""
+
+    def __init__(self, kind=L.PROX_ZERO, lam=0.0, lo=-float("inf"), hi=float("inf"), lo_vec=None, hi_vec=None):
+        self.kind, self.lam, self.lo, self.hi = int(kind), float(lam), float(lo), float(hi)
+        self.lo_vec, self.hi_vec = lo_vec, hi_vec  # keep the device tensors alive
+        self._c = L.ProxDesc(self.kind, 0, self.lam, self.lo, self.hi,
+                             lo_vec.data_ptr() if lo_vec is not None else None,
+                             hi_vec.data_ptr() if hi_vec is not None else None)
+
+    @property
+    def ref(self):
+        return C.byref(self._c)
+
+
+class Context:
+    """One device + one HIP stream + the library's private workspace (ciao_ctx).  Not thread-safe."""
+
+    def __init__(self, device: int | None = None, stream: "torch.cuda.Stream | None" = None):
+        self.lib = L.load()  # raises if the extension is not built
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self.device = int(device)
+        self._h = C.c_void_p()
+        if stream is None and torch.cuda.is_available():
+            stream = torch.cuda.current_stream(self.device)
+        self.stream = stream
+        handle = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        L.check(self.lib.ciao_ctx_create(self.device, handle, C.byref(self._h)))
+        self._hook_keepalive = None
+
+    # -- lifetime ----------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ciao_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        """Wait for the stream and surface a sticky device-side error (an out-of-range sample index)."""
+        L.check(self.lib.ciao_ctx_synchronize(self._h))
+
+    def set_option(self, key: str, value: int):
+        L.check(self.lib.ciao_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def timing_enable(self, on: bool = True):
+        L.check(self.lib.ciao_ctx_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self) -> tuple[float, int]:
+        """(summed device ms of the dominant-kernel launches since the last read, their count); synchronises."""
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        L.check(self.lib.ciao_ctx_timing_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def last_kernel(self) -> str:
+        return self.lib.ciao_ctx_last_kernel(self._h).decode()
+
+    def set_allreduce(self, fn):
+        """fn(buf_ptr:int, count:int, dtype:int, stream_ptr:int) -> int (0 = ok); None clears the hook."""
+        if fn is None:
+            self._hook_keepalive = None
+            L.check(self.lib.ciao_ctx_set_allreduce(self._h, L.ALLREDUCE_FN(0), None))
+            return
+
+        def _tramp(_user, buf, count, dtype, stream):
+            try:
+                return int(fn(buf, count, dtype, stream))
+            except Exception as e:  # never let a Python exception unwind through C
+                import sys
+                print(f"[ciao] all-reduce hook raised: {e!r}", file=sys.stderr)
+                return 1
+
+        cb = L.ALLREDUCE_FN(_tramp)
+        self._hook_keepalive = cb
+        L.check(self.lib.ciao_ctx_set_allreduce(self._h, cb, None))
+
+    # -- helpers -------------------------------------------------------------------------------------------------------
+    def _vec(self, t: torch.Tensor, p: PackedF, name: str, n: int | None = None):
+        n = p.d if n is None else n
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == p.dtype and t.is_contiguous() and t.numel() == n):
+            raise ValueError(f"{name}: need a contiguous {p.dtype} device vector of length {n}, got "
+                             f"{getattr(t, 'dtype', type(t))} {tuple(getattr(t, 'shape', ()))} on {getattr(t, 'device', '?')}")
+        return _ptr(t)
+
+    def _idx(self, idx) -> torch.Tensor:
+        if isinstance(idx, torch.Tensor):
+            assert idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous()
+            return idx
+        return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(f"cuda:{self.device}", non_blocking=False)
+
+    # -- L1 plugin API ----------------------------------------------------------------------------------------------
+    def gradient(self, p: PackedF, i: int, x, y, fval=None):
+        L.check(self.lib.ciao_gradient(self._h, p.ref, int(i), self._vec(x, p, "x"), self._vec(y, p, "y"), _ptr(fval)))
+
+    def prox(self, g: ProxG, x: torch.Tensor, gamma: float, y: torch.Tensor):
+        assert x.is_cuda and y.is_cuda and x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous()
+        L.check(self.lib.ciao_prox(self._h, _DT[x.dtype], x.numel(), g.ref, _ptr(x), float(gamma), _ptr(y)))
+
+    # -- sweep -------------------------------------------------------------------------------------------------------------
+    def full_gradient(self, p: PackedF, x, av):
+        L.check(self.lib.ciao_full_gradient(self._h, p.ref, self._vec(x, p, "x"), self._vec(av, p, "av")))
+
+    def proxgrad_step(self, p: PackedF, g: ProxG, gamma: float, x, av, y):
+        L.check(self.lib.ciao_proxgrad_step(self._h, p.ref, g.ref, float(gamma), self._vec(x, p, "x"), self._vec(av, p, "av"),
+                                            self._vec(y, p, "y")))
+
+    def objective(self, p: PackedF, g: ProxG, x) -> float:
+        out = C.c_double(0.0)
+        L.check(self.lib.ciao_objective(self._h, p.ref, g.ref, self._vec(x, p, "x"), C.byref(out)))
+        return out.value
+
+    # -- SVRG ------------------------------------------------------------------------------------------------------------
+    def svrg_init(self, p, x0, av, z, z_full, w):
+        L.check(self.lib.ciao_svrg_init(self._h, p.ref, self._vec(x0, p, "x0"), self._vec(av, p, "av"), self._vec(z, p, "z"),
+                                        self._vec(z_full, p, "z_full"), self._vec(w, p, "w")))
+
+    def svrg_inner(self, p, g, gamma, idx, av, z, z_full, w):
+        idx = self._idx(idx)
+        L.check(self.lib.ciao_svrg_inner(self._h, p.ref, g.ref, float(gamma), idx.numel(), _ptr(idx), self._vec(av, p, "av"),
+                                         self._vec(z, p, "z"), self._vec(z_full, p, "z_full"), self._vec(w, p, "w")))
+        return idx
+
+    def svrg_iterate(self, p, g, gamma, idx, plus, av, z, z_full, w):
+        idx = self._idx(idx)
+        L.check(self.lib.ciao_svrg_iterate(self._h, p.ref, g.ref, float(gamma), idx.numel(), _ptr(idx), 1 if plus else 0,
+                                           self._vec(av, p, "av"), self._vec(z, p, "z"), self._vec(z_full, p, "z_full"),
+                                           self._vec(w, p, "w")))
+        return idx
+
+    # -- SAGA / SAG ----------------------------------------------------------------------------------------------------
+    def saga_init(self, p, g, gamma, x0, table, av, z):
+        L.check(self.lib.ciao_saga_init(self._h, p.ref, g.ref, float(gamma), self._vec(x0, p, "x0"),
+                                        self._vec(table, p, "table", p.N * p.d), self._vec(av, p, "av"), self._vec(z, p, "z")))
+
+    def saga_steps(self, p, g, gamma, sag, idx, table, av, z):
+        idx = self._idx(idx)
+        L.check(self.lib.ciao_saga_steps(self._h, p.ref, g.ref, float(gamma), 1 if sag else 0, idx.numel(), _ptr(idx),
+                                         self._vec(table, p, "table", p.N * p.d), self._vec(av, p, "av"), self._vec(z, p, "z")))
+        return idx
+
+    # -- Finito / LFinito -------------------------------------------------------------------------------------------
+    def hat_gamma(self, gam: torch.Tensor) -> float:
+        out = C.c_double(0.0)
+        L.check(self.lib.ciao_hat_gamma(self._h, _DT[gam.dtype], gam.numel(), _ptr(gam), C.byref(out)))
+        return out.value
+
+    def finito_init(self, p, g, gam, hat_gamma, x0, table, av, z):
+        L.check(self.lib.ciao_finito_init(self._h, p.ref, g.ref, self._vec(gam, p, "gam", p.N), float(hat_gamma),
+                                          self._vec(x0, p, "x0"), self._vec(table, p, "table", p.N * p.d),
+                                          self._vec(av, p, "av"), self._vec(z, p, "z")))
+
+    def finito_steps(self, p, g, gam, hat_gamma, bptr: np.ndarray, bidx, table, av, z):
+        bptr = np.ascontiguousarray(bptr, dtype=np.int64)
+        bidx = self._idx(bidx)
+        assert bptr[0] == 0 and bptr[-1] == bidx.numel()
+        L.check(self.lib.ciao_finito_steps(self._h, p.ref, g.ref, self._vec(gam, p, "gam", p.N), float(hat_gamma),
+                                           len(bptr) - 1, C.c_void_p(bptr.ctypes.data), _ptr(bidx),
+                                           self._vec(table, p, "table", p.N * p.d), self._vec(av, p, "av"),
+                                           self._vec(z, p, "z")))
+        return bidx
+
+    def lfinito_init(self, p, hat_gamma, x0, av, z, z_full):
+        L.check(self.lib.ciao_lfinito_init(self._h, p.ref, float(hat_gamma), self._vec(x0, p, "x0"), self._vec(av, p, "av"),
+                                           self._vec(z, p, "z"), self._vec(z_full, p, "z_full")))
+
+    def lfinito_iterate(self, p, g, gam, hat_gamma, bptr: np.ndarray, bidx, av, z, z_full):
+        bptr = np.ascontiguousarray(bptr, dtype=np.int64)
+        bidx = self._idx(bidx)
+        assert bptr[0] == 0 and bptr[-1] == bidx.numel()
+        L.check(self.lib.ciao_lfinito_iterate(self._h, p.ref, g.ref, self._vec(gam, p, "gam", p.N), float(hat_gamma),
+                                              len(bptr) - 1, C.c_void_p(bptr.ctypes.data), _ptr(bidx), self._vec(av, p, "av"),
+                                              self._vec(z, p, "z"), self._vec(z_full, p, "z_full")))
+        return bidx
+
+    # -- synthetic data -------------------------------------------------------------------------------------------------
+    def synth_normal(self, out: torch.Tensor, row0: int, seed: int, scale: float):
+        assert out.is_cuda and out.dim() == 2 and out.stride(1) == 1
+        L.check(self.lib.ciao_synth_normal(self._h, _DT[out.dtype], _ptr(out), out.shape[0], out.shape[1],
+                                           out.stride(0) if out.shape[0] > 1 else out.shape[1], int(row0), int(seed), float(scale)))
+
+    def synth_targets(self, p: PackedF, x_true, noise: float, labels: bool, seed: int, b_out):
+        L.check(self.lib.ciao_synth_targets(self._h, p.ref, self._vec(x_true, p, "x_true"), float(noise), 1 if labels else 0,
+                                            int(p.row0), int(seed), self._vec(b_out, p, "b_out", p.N)))
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context() -> Context:
+    """A per-device Context bound to torch's current stream at first use."""
+    dev = torch.cuda.current_device()
+    ctx = _default_ctx.get(dev)
+    if ctx is None:
+        ctx = Context(dev)
+        _default_ctx[dev] = ctx
+    return ctx

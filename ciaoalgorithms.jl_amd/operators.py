@@ -1,0 +1,156 @@
+"""Operator descriptions in the ProximalOperators.jl vocabulary, and their packing for the device.
+
+The reference accepts any ProximalOperators object for f_i and g and calls `gradient!` / `prox!` on it per sample
+(SVRG_basic.jl:74-80 ...).  A GPU kernel cannot call an opaque host closure per sample, so this path *recognises* the
+families the reference's own tests use and packs them:
+
+    f_i = LeastSquares(A_i (1 x d), b_i (1), λ)                       test/test_lasso.jl:52-54
+    f_i = Precompose(LogisticLoss([y_i], 1.0), a_i' (1 x d), 1.0)     test/test_logistic_l1.jl:36
+    f_i = Zero()                                                      SVRG.jl:58 (default F)
+    g   = NormL1(λ) | Zero() | IndBox(lo, hi)                         test/test_lasso.jl:59, SVRG.jl:49, test_sharing.jl:16
+
+Anything else raises TypeError -- there is no silent host fallback.  These classes only *describe* operators (they hold
+host data and constructor arguments); no arithmetic happens here.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .device import PackedF, ProxG, torch_dtype
+
+
+class Zero:
+    """ProximalOperators.Zero(): f(x) = 0; gradient 0; prox = identity."""
+
+    def __repr__(self):
+        return "Zero()"
+
+
+class NormL1:
+    """ProximalOperators.NormL1(λ): g(x) = λ‖x‖₁ (default λ = 1)."""
+
+    def __init__(self, lam=1.0):
+        if not (np.ndim(lam) == 0 and float(lam) >= 0):
+            raise ValueError("NormL1: λ must be a nonnegative scalar on the device path")
+        self.lam = float(lam)
+
+    def __repr__(self):
+        return f"NormL1({self.lam})"
+
+
+class IndBox:
+    """ProximalOperators.IndBox(lo, hi): indicator of {lo <= x <= hi}; scalar or per-coordinate bounds."""
+
+    def __init__(self, lo, hi):
+        if np.any(np.asarray(lo) > np.asarray(hi)):
+            raise ValueError("IndBox: lo must be <= hi")
+        self.lo, self.hi = lo, hi
+
+    def __repr__(self):
+        return "IndBox(...)"
+
+
+class LeastSquares:
+    """ProximalOperators.LeastSquares(A, b, λ): f(x) = λ/2 ‖A x − b‖² (default λ = 1)."""
+
+    def __init__(self, A, b, lam=1.0):
+        self.A = np.atleast_2d(np.asarray(A))
+        self.b = np.atleast_1d(np.asarray(b))
+        if self.A.shape[0] != self.b.shape[0]:
+            raise ValueError("LeastSquares: A and b have incompatible sizes")
+        if float(lam) < 0:
+            raise ValueError("LeastSquares: λ must be nonnegative")
+        self.lam = float(lam)
+
+
+class LogisticLoss:
+    """ProximalOperators.LogisticLoss(y, μ): f(x) = μ Σ log(1 + exp(−y_i x_i))."""
+
+    def __init__(self, y, mu=1.0):
+        self.y = np.atleast_1d(np.asarray(y))
+        if not np.all(np.abs(self.y) == 1):
+            raise ValueError("LogisticLoss: labels must be ±1")
+        self.mu = float(mu)
+
+
+class Precompose:
+    """ProximalOperators.Precompose(f, L, μ[, b]): x ↦ f(L x + b), with L Lᵀ = μ I claimed by the caller."""
+
+    def __init__(self, f, Lmat, mu=1.0, b=0.0):
+        self.f, self.L, self.mu, self.b = f, np.atleast_2d(np.asarray(Lmat)), float(mu), b
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# packing
+# ------------------------------------------------------------------------------------------------------------------------
+
+def _dev(a: np.ndarray, dtype: torch.dtype, device) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype=dtype, device=device).contiguous()
+
+
+def pack_F(F, N: int, d: int, R, device=None) -> PackedF:
+    """Recognise and pack the finite-sum term.  F is None (Zero()), a PackedF, or a sequence of N one-row operators."""
+    dtype = torch_dtype(R)
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if isinstance(F, PackedF):
+        if F.dtype != dtype:
+            raise TypeError(f"F is packed as {F.dtype} but the solver's real type is {dtype} (no silent promotion)")
+        if F.d != d:
+            raise ValueError(f"F has d={F.d} but x0 has length {d}")
+        return F
+    if F is None:
+        return PackedF.zero(N, d, dtype)
+    F = list(F)
+    if len(F) != N:
+        raise ValueError(f"F has {len(F)} terms but N={N}")
+    if N == 0:
+        return PackedF.zero(0, d, dtype)
+    if all(isinstance(f, Zero) for f in F):
+        return PackedF.zero(N, d, dtype)
+    if all(isinstance(f, LeastSquares) for f in F):
+        lam = F[0].lam
+        if any(f.lam != lam for f in F):
+            raise TypeError("LeastSquares terms with different λ cannot be packed")
+        if any(f.A.shape != (1, d) for f in F):
+            raise TypeError("only one-row LeastSquares terms (A_i of size 1 x d) are packable")
+        if any(np.iscomplexobj(f.A) or np.iscomplexobj(f.b) for f in F):
+            raise TypeError("complex data is outside the device path")
+        A = np.concatenate([f.A for f in F], axis=0)
+        b = np.concatenate([f.b for f in F], axis=0)
+        return PackedF.least_squares(_dev(A, dtype, device), _dev(b, dtype, device), lam)
+    if all(isinstance(f, Precompose) and isinstance(f.f, LogisticLoss) for f in F):
+        for f in F:
+            if f.L.shape != (1, d) or f.f.y.shape != (1,) or f.f.mu != 1.0 or np.any(np.asarray(f.b) != 0):
+                raise TypeError("only Precompose(LogisticLoss([y_i], 1.0), a_i' (1 x d), mu) terms are packable")
+        A = np.concatenate([f.L for f in F], axis=0)
+        y = np.concatenate([f.f.y for f in F], axis=0)
+        return PackedF.logistic(_dev(A, dtype, device), _dev(y, dtype, device))
+    kinds = sorted({type(f).__name__ for f in F})
+    raise TypeError(f"F of kinds {kinds} is not a family the device path can pack (LeastSquares rows, "
+                    f"Precompose(LogisticLoss) rows, Zero); there is no host fallback")
+
+
+def pack_g(g, d: int, R, device=None) -> ProxG:
+    dtype = torch_dtype(R)
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if isinstance(g, ProxG):
+        return g
+    if g is None or isinstance(g, Zero):
+        return ProxG(L.PROX_ZERO)
+    if isinstance(g, NormL1):
+        return ProxG(L.PROX_L1, lam=g.lam)
+    if isinstance(g, IndBox):
+        lo_vec = hi_vec = None
+        lo, hi = -float("inf"), float("inf")
+        if np.ndim(g.lo) > 0:
+            lo_vec = _dev(np.asarray(g.lo, dtype=np.float64).reshape(d), dtype, device)
+        else:
+            lo = float(g.lo)
+        if np.ndim(g.hi) > 0:
+            hi_vec = _dev(np.asarray(g.hi, dtype=np.float64).reshape(d), dtype, device)
+        else:
+            hi = float(g.hi)
+        return ProxG(L.PROX_BOX, lo=lo, hi=hi, lo_vec=lo_vec, hi_vec=hi_vec)
+    raise TypeError(f"g of type {type(g).__name__} is not a family the device path supports (Zero, NormL1, IndBox)")

@@ -1,0 +1,103 @@
+"""Multi-GPU: one process per GPU, rows of the finite sum sharded, one all-reduce of the d-vector per sweep / batch.
+
+What shards: the full-gradient sweeps (SVRG_basic.jl:58-63,:87-92; Finito_LFinito.jl:85-88) and
+the Finito / LFinito batches (Finito_basic.jl:110-117) -- rows are independent, the only coupling is the sum of the
+rank-1 terms into one d-vector.  Rank p owns the contiguous rows [row0, row0 + n_local) of A, b, gam and of the
+SAGA/Finito table; every d-vector (x, z, w, av, z_full) is replicated and stays bitwise identical across ranks because
+every rank applies the same epilogue to the same all-reduced sum.
+
+What does NOT shard: the sequential inner chains (SVRG_basic.jl:73-82, SAGA_basic.jl:53-68): replicas only.
+
+The collective is RCCL (`torch.distributed` backend "nccl" on ROCm) over xGMI.  The message is d+1 scalars (8 KB at
+d=1024 fp64): latency-bound, so it is issued once per sweep on the compute stream, never per row block.
+libciao_hip.so calls back into `AllReduceHook` between its reduce and epilogue kernels (ciao_ctx_set_allreduce).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def shard_rows(N_total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous block partition: returns (row0, n_local); the first N_total % world ranks get one extra row."""
+    assert 0 <= rank < world and N_total >= 0
+    base, rem = divmod(N_total, world)
+    n_local = base + (1 if rank < rem else 0)
+    row0 = rank * base + min(rank, rem)
+    return row0, n_local
+
+
+class _DeviceBuffer:
+    """Zero-copy view of library-owned device memory through the CUDA array interface (HIP pointers on ROCm)."""
+
+    def __init__(self, ptr: int, count: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (int(ptr), False), "version": 2,
+                                         "strides": None}
+
+
+def _wrap(ptr: int, count: int, dtype: int, device: torch.device) -> torch.Tensor:
+    np_dt = np.float64 if dtype == L.F64 else np.float32
+    if device.type == "cpu":
+        ctype = C.c_double if dtype == L.F64 else C.c_float
+        arr = np.ctypeslib.as_array(C.cast(C.c_void_p(ptr), C.POINTER(ctype)), shape=(count,))
+        return torch.from_numpy(arr)
+    return torch.as_tensor(_DeviceBuffer(ptr, count, np.dtype(np_dt).str), device=device)
+
+
+class AllReduceHook:
+    """Callable handed to Context.set_allreduce: sums `count` scalars at `buf` in place over the process group.
+
+    backend "nccl" (= RCCL): the collective is enqueued on RCCL's stream behind the compute stream.
+    backend "gloo" with device tensors (single-box rehearsals): staged through host memory.
+    """
+
+    def __init__(self, device: torch.device | str, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.device = torch.device(device)
+        self.group = group
+        self.calls = 0
+        self.bytes = 0
+
+    def __call__(self, buf: int, count: int, dtype: int, stream: int) -> int:
+        dist = self.dist
+        t = _wrap(buf, count, dtype, self.device)
+        backend = dist.get_backend(self.group)
+        if self.device.type == "cuda" and backend != "nccl":
+            if stream:
+                torch.cuda.ExternalStream(stream, device=self.device).synchronize()
+            else:
+                torch.cuda.current_stream(self.device).synchronize()
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        elif self.device.type == "cuda" and stream and stream != torch.cuda.current_stream(self.device).cuda_stream:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self.calls += 1
+        self.bytes += count * (8 if dtype == L.F64 else 4)
+        return 0
+
+
+def init_process_group_from_env(backend: str | None = None):
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK from the environment)."""
+    import os
+
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local

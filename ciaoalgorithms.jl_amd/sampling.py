@@ -1,0 +1,93 @@
+"""Injected index streams for the finite-sum solvers.
+
+The reference draws every sample from Julia's *global* RNG (`rand(state.ind, m)` SVRG_basic.jl:73, `rand(1:N)`
+SAGA_basic.jl:55, `sample(1:N, r, replace=false)` Finito_basic.jl:97, `randperm(d)` Finito_basic.jl:102 and
+Finito_LFinito.jl:89).  That stream depends on the Julia version and cannot be reproduced outside Julia, so here the
+sampling decisions are an explicit *input*: a counter-based splitmix64 stream whose k-th output depends only on
+(seed, k).  Drawing m indices in one call or one at a time gives the same sequence, which is what lets the device path
+consume indices in large chunks while the CPU oracle consumes them one by one.
+
+All indices are 0-based int64 (the C ABI is 0-based; the Julia wrapper subtracts 1).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def _splitmix64(seed: int, start: int, n: int) -> np.ndarray:
+    """Outputs start .. start+n-1 of the splitmix64 sequence seeded with `seed` (vectorised, wrap-around uint64)."""
+    with np.errstate(over="ignore"):
+        k = np.arange(start + 1, start + n + 1, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + k * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+class IndexStream:
+    """Deterministic, chunking-independent source of the four kinds of random draws the reference makes."""
+
+    def __init__(self, seed: int = 0):
+        self.seed = int(seed)
+        self.pos = 0  # number of 64-bit outputs consumed so far
+
+    def _take(self, n: int) -> np.ndarray:
+        out = _splitmix64(self.seed, self.pos, n)
+        self.pos += n
+        return out
+
+    def rand_indices(self, N: int, m: int) -> np.ndarray:
+        """m i.i.d. uniform draws from 0..N-1 (with replacement); N < 2**32."""
+        assert 0 < N < (1 << 32)
+        u = self._take(m) >> np.uint64(32)
+        return ((u * np.uint64(N)) >> np.uint64(32)).astype(np.int64)
+
+    def randperm(self, n: int) -> np.ndarray:
+        """Uniform random permutation of 0..n-1 (argsort of n stream outputs; ties have probability ~n^2/2^64)."""
+        return np.argsort(self._take(n), kind="stable").astype(np.int64)
+
+    def sample_without_replacement(self, N: int, r: int) -> np.ndarray:
+        """r distinct uniform indices from 0..N-1, in draw order (rejection of repeats)."""
+        assert 0 < r <= N
+        if 2 * r > N:
+            return self.randperm(N)[:r].copy()
+        out = np.empty(0, np.int64)
+        while out.size < r:
+            cand = self.rand_indices(N, max(r - out.size, 1))
+            out = np.concatenate([out, cand])
+            _, first = np.unique(out, return_index=True)
+            out = out[np.sort(first)]
+        return np.ascontiguousarray(out[:r])
+
+
+class FixedStream:
+    """Replays explicit index arrays (for golden-vector tests): rand_indices pops from `indices`, randperm and
+    sample_without_replacement pop whole arrays from their queues."""
+
+    def __init__(self, indices=(), perms=(), samples=()):
+        self._idx = np.asarray(indices, np.int64)
+        self._ipos = 0
+        self._perms = [np.asarray(p, np.int64) for p in perms]
+        self._samples = [np.asarray(s, np.int64) for s in samples]
+
+    def rand_indices(self, N, m):
+        out = self._idx[self._ipos:self._ipos + m]
+        if out.size != m:
+            raise IndexError("FixedStream: index stream exhausted")
+        self._ipos += m
+        assert out.size == 0 or (out.min() >= 0 and out.max() < N)
+        return out.copy()
+
+    def randperm(self, n):
+        p = self._perms.pop(0)
+        assert p.size == n
+        return p
+
+    def sample_without_replacement(self, N, r):
+        s = self._samples.pop(0)
+        assert s.size == r
+        return s

@@ -1,0 +1,452 @@
+"""Host-side mirror of the reference's solver API (L3) and iterables (L2) for the finite-sum hot path.
+
+Same names, keyword arguments, iteration protocol and error behaviour as
+    src/algorithms/SVRG/SVRG.jl, SVRG_basic.jl
+    src/algorithms/SAGA_SAG/SAGA.jl, SAGA_basic.jl
+    src/algorithms/Finito/Finito.jl, Finito_basic.jl, Finito_LFinito.jl
+but every `gradient!` / `prox!` / broadcast of the hot loops runs in libciao_hip.so (HIP, gfx950) through the C ABI.
+Python identifiers may be Greek, so `γ`, `μ`, `α` work as keywords exactly as in Julia; ASCII aliases `gamma`, `mu`,
+`alpha` are accepted too.
+
+Differences forced by the device boundary (documented in DESIGN.md):
+  * the sampling stream is an explicit input (`stream=IndexStream(seed)`), see sampling.py;
+  * F must be one of the packable families (operators.py), or an already packed `PackedF` living on the device;
+  * state vectors are torch device tensors; `solution(state)` returns the state's own tensor (identity, as in
+    test/test_lasso.jl:185), and the solver returns it as a numpy array when x0 was a numpy array;
+  * the adaptive Finito variant (Finito_adaptive.jl) is out of scope for this path.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import torch
+
+from .device import Context, PackedF, default_context, torch_dtype
+from .operators import pack_F, pack_g
+from .sampling import IndexStream
+
+__all__ = ["SVRG", "SAGA", "SAG", "Finito", "iterator", "solution"]
+
+
+def _pick(greek, ascii_, name):
+    if greek is not None and ascii_ is not None:
+        raise TypeError(f"give {name} once")
+    return greek if greek is not None else ascii_
+
+
+def _x0_to_device(x0, dtype):
+    """Return (device vector, was_numpy).  A device tensor of the right dtype is used as is (no copy)."""
+    if isinstance(x0, torch.Tensor):
+        if x0.dtype != dtype:
+            raise TypeError(f"x0 has dtype {x0.dtype} but the solver's real type is {dtype} (no silent promotion)")
+        if x0.is_complex():
+            raise TypeError("complex iterates are outside the device path")
+        t = x0 if x0.is_cuda else x0.cuda()
+        return t.contiguous().view(-1), False
+    a = np.asarray(x0)
+    if np.iscomplexobj(a):
+        raise TypeError("complex iterates are outside the device path")
+    if torch_dtype(a.dtype if a.dtype.kind == "f" else np.float64) != dtype:
+        raise TypeError(f"x0 has dtype {a.dtype} but the solver's real type is {dtype} (no silent promotion)")
+    return torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).cuda(), True
+
+
+def _maxL(Lc):
+    return float(np.max(np.asarray(Lc.detach().cpu() if isinstance(Lc, torch.Tensor) else Lc)))
+
+
+class _Iterable:
+    """Common part of the four iterables: problem packing and the Python iteration protocol."""
+
+    def __init__(self, R, F, g, x0, N, ctx, stream):
+        if N is None:
+            raise TypeError("N (number of terms in the finite sum) is required")
+        self.R = torch_dtype(R)
+        self.x0 = x0  # NOT copied: `iter.x0 === x0` (test/test_lasso.jl:182)
+        self.N = int(N)
+        self._x0_dev, self._numpy = _x0_to_device(x0, self.R)
+        self.d = self._x0_dev.numel()
+        self.ctx = ctx if ctx is not None else default_context()
+        self.F = pack_F(F, self.N, self.d, self.R, self._x0_dev.device)
+        if self.F.N_total != self.N:
+            raise ValueError(f"F holds N_total={self.F.N_total} terms but N={self.N}")
+        self.g = pack_g(g, self.d, self.R, self._x0_dev.device)
+        self.stream = stream if stream is not None else IndexStream(0)
+        self._state = None
+        self._started = False
+
+    def _new(self):
+        return torch.empty(self.d, dtype=self.R, device=self._x0_dev.device)
+
+    # Python iteration protocol = Base.iterate(iter) then Base.iterate(iter, state)
+    def __iter__(self):
+        self._state, self._started = None, False
+        return self
+
+    def __next__(self):
+        if not self._started:
+            self._started = True
+            self._state = self._init()
+            if self._state is None:  # invalid configuration: `return nothing` ends the iteration
+                raise StopIteration
+            return self._state
+        if self._state is None:
+            raise StopIteration
+        self._step(self._state, 1)
+        return self._state
+
+
+# ======================================================================================================================
+# SVRG  (SVRG_basic.jl)
+# ======================================================================================================================
+class SVRG_basic_state:
+    def __init__(self, γ, m, av, z, z_full, w):
+        self.γ, self.m, self.av, self.z, self.z_full, self.w = γ, m, av, z, z_full, w
+
+    gamma = property(lambda self: self.γ)
+
+
+class SVRG_basic_iterable(_Iterable):
+    def __init__(self, R, F, g, x0, N, L, μ, γ, m, plus, ctx=None, stream=None):
+        super().__init__(R, F, g, x0, N, ctx, stream)
+        self.L, self.μ, self.γ, self.m, self.plus = L, μ, γ, m, plus
+        if self.F.row0 != 0 or self.F.N != self.N:
+            raise ValueError("the SVRG inner cycle is a sequential chain: it needs the whole problem on one device")
+
+    def _init(self):                                                       # SVRG_basic.jl:30-69
+        N = self.N
+        m = N if self.m is None else self.m
+        if self.γ is None:
+            if self.plus:
+                warnings.warn("provide a stepsize γ")
+                return None
+            if self.L is None or self.μ is None:
+                warnings.warn("smoothness or convexity parameter absent")
+                return None
+            L_M, μ_M = _maxL(self.L), _maxL(self.μ)
+            γ = 1 / (10 * L_M)
+            rho = (1 + 4 * L_M * γ ** 2 * μ_M * (N + 1)) / (μ_M * γ * N * (1 - 4 * L_M * γ))
+            if rho >= 1:
+                warnings.warn("convergence condition violated...provide a stepsize!")
+        else:
+            γ = self.γ
+        av, z, z_full, w = self._new(), self._new(), self._new(), self._new()
+        self.ctx.svrg_init(self.F, self._x0_dev, av, z, z_full, w)         # :57-66
+        return SVRG_basic_state(float(γ), int(m), av, z, z_full, w)
+
+    def _step(self, st, n):                                                # SVRG_basic.jl:71-96
+        for _ in range(n):
+            idx = self.stream.rand_indices(self.N, st.m)                   # :73
+            self.ctx.svrg_iterate(self.F, self.g, st.γ, idx, self.plus, st.av, st.z, st.z_full, st.w)
+            if self.plus:
+                st.m *= 2                                                  # :93
+
+
+# ======================================================================================================================
+# SAGA / SAG  (SAGA_basic.jl)
+# ======================================================================================================================
+class SAGA_basic_state:
+    def __init__(self, s, γ, av, z):
+        self.s, self.γ, self.av, self.z, self.ind = s, γ, av, z, 0
+
+    gamma = property(lambda self: self.γ)
+
+
+class SAGA_basic_iterable(_Iterable):
+    def __init__(self, R, F, g, x0, N, L, γ, SAG, ctx=None, stream=None):
+        super().__init__(R, F, g, x0, N, ctx, stream)
+        self.L, self.γ, self.SAG = L, γ, SAG
+        if self.F.row0 != 0 or self.F.N != self.N:
+            raise ValueError("SAGA steps are a sequential chain: they need the whole problem on one device")
+
+    def _init(self):                                                       # SAGA_basic.jl:26-51
+        if self.γ is None:
+            if self.L is None:
+                warnings.warn("smoothness parameter absent")
+                return None
+            L_M = _maxL(self.L)
+            γ = 1 / (16 * L_M) if self.SAG else 1 / (3 * L_M)
+        else:
+            γ = self.γ
+        s = torch.empty((self.N, self.d), dtype=self.R, device=self._x0_dev.device)   # N x d table, 288 GB HBM budget
+        av, z = self._new(), self._new()
+        self.ctx.saga_init(self.F, self.g, γ, self._x0_dev, s, av, z)      # :41-48
+        return SAGA_basic_state(s, float(γ), av, z)
+
+    def _step(self, st, n):                                                # SAGA_basic.jl:53-68, n consecutive calls
+        idx = self.stream.rand_indices(self.N, n)                          # :55 (one draw per iteration)
+        self.ctx.saga_steps(self.F, self.g, st.γ, self.SAG, idx, st.s, st.av, st.z)
+        st.ind = int(idx[-1]) + 1 if n > 0 else st.ind                     # 1-based like the reference's state.ind
+
+
+# ======================================================================================================================
+# Finito / MISO  (Finito_basic.jl) and LFinito (Finito_LFinito.jl)
+# ======================================================================================================================
+def _finito_gammas(it):
+    """Finito_basic.jl:61-74 / Finito_LFinito.jl:51-63 -> device N-vector of stepsizes, or None (with the @warn)."""
+    R, N, dev = it.R, it.N, it._x0_dev.device
+    np_R = np.float64 if R == torch.float64 else np.float32
+    if it.γ is None:
+        if it.L is None:
+            warnings.warn("--> smoothness parameter absent")
+            return None
+        if np.ndim(it.L) == 0 and not isinstance(it.L, torch.Tensor):
+            val = np_R(it.α) * np_R(N) / np_R(it.L)
+            return torch.full((it.F.N,), float(val), dtype=R, device=dev)
+        Lh = it.L.to(device=dev, dtype=R) if isinstance(it.L, torch.Tensor) else torch.from_numpy(np.asarray(it.L, dtype=np_R)).to(dev)
+        Lh = Lh[it.F.row0:it.F.row0 + it.F.N] if Lh.numel() == N and it.F.N != N else Lh
+        return ((np_R(it.α) * np_R(N)) / Lh).contiguous()
+    if np.ndim(it.γ) == 0 and not isinstance(it.γ, torch.Tensor):
+        return torch.full((it.F.N,), float(np_R(it.γ)), dtype=R, device=dev)
+    gh = it.γ.to(device=dev, dtype=R) if isinstance(it.γ, torch.Tensor) else torch.from_numpy(np.asarray(it.γ, dtype=np_R)).to(dev)
+    gh = gh[it.F.row0:it.F.row0 + it.F.N] if gh.numel() == N and it.F.N != N else gh
+    return gh.contiguous()
+
+
+def _static_batch(N, r, j):
+    """j-th (0-based) static batch of Finito_basic.jl:52-58: contiguous block of r, the last one may be shorter."""
+    lo = r * j
+    return np.arange(lo, min(lo + r, N), dtype=np.int64)
+
+
+def _localise(it, batch):
+    """Keep the members of a (global-index) batch that this rank owns, as local row indices (parallel.py)."""
+    if it.F.N == it.N:
+        return batch
+    lo, hi = it.F.row0, it.F.row0 + it.F.N
+    sel = batch[(batch >= lo) & (batch < hi)]
+    return sel - lo
+
+
+class FINITO_basic_state:
+    def __init__(self, s, γ, hat_γ, av, z, d):
+        self.s, self.γ, self.hat_γ, self.av, self.z, self.d = s, γ, hat_γ, av, z, d
+        self.ind = None
+        self.idxr, self.idx, self.inds = 1, 0, np.arange(d, dtype=np.int64)   # Finito_basic.jl:37-40 (1-based idxr)
+
+    hat_gamma = property(lambda self: self.hat_γ)
+
+
+class FINITO_basic_iterable(_Iterable):
+    def __init__(self, R, F, g, x0, N, L, γ, sweeping, batch, α, ctx=None, stream=None):
+        super().__init__(R, F, g, x0, N, ctx, stream)
+        self.L, self.γ, self.sweeping, self.batch, self.α = L, γ, int(sweeping), int(batch), α
+        if self.batch < 1:
+            raise ValueError("batch size must be >= 1")
+
+    def _init(self):                                                       # Finito_basic.jl:44-89
+        N, r = self.N, self.batch
+        d_b = -(-N // r) if N > 0 else 0                                   # cld(N, r)  :59
+        gam = _finito_gammas(self)                                         # :61-74
+        if gam is None:
+            return None
+        hat_γ = self.ctx.hat_gamma(gam)                                    # :82
+        s = torch.empty((self.F.N, self.d), dtype=self.R, device=self._x0_dev.device)
+        av, z = self._new(), self._new()
+        self.ctx.finito_init(self.F, self.g, gam, hat_γ, self._x0_dev, s, av, z)   # :76-84
+        return FINITO_basic_state(s, gam, hat_γ, av, z, d_b)
+
+    def _next_batch(self, st):                                             # Finito_basic.jl:95-108
+        N, r = self.N, self.batch
+        if self.sweeping == 1:
+            return self.stream.sample_without_replacement(N, r)           # :97
+        if self.sweeping == 2:
+            st.idxr = st.idxr % st.d + 1                                   # :99  (first step uses batch 2)
+        elif self.sweeping == 3:
+            if st.idx == st.d:                                             # :101-106
+                st.inds = self.stream.randperm(st.d)
+                st.idx = 1
+            else:
+                st.idx += 1
+            st.idxr = int(st.inds[st.idx - 1]) + 1
+        return _static_batch(N, r, st.idxr - 1)
+
+    def _step(self, st, n):                                                # Finito_basic.jl:109-118, n iterations
+        batches = [_localise(self, self._next_batch(st)) for _ in range(n)]
+        bptr = np.zeros(n + 1, np.int64)
+        np.cumsum([len(b) for b in batches], out=bptr[1:])
+        if self.F.N != self.N and any(len(b) == 0 for b in batches):
+            raise ValueError("a Finito batch has no member on this rank: use batches that span all ranks")
+        bidx = np.concatenate(batches) if batches else np.zeros(0, np.int64)
+        self.ctx.finito_steps(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.s, st.av, st.z)
+
+
+class FINITO_LFinito_state:
+    def __init__(self, γ, hat_γ, av, d, z, z_full):
+        self.γ, self.hat_γ, self.av, self.d, self.z, self.z_full = γ, hat_γ, av, d, z, z_full
+        self.inds = np.arange(d, dtype=np.int64)
+
+    hat_gamma = property(lambda self: self.hat_γ)
+
+
+class FINITO_LFinito_iterable(_Iterable):
+    def __init__(self, R, F, g, x0, N, L, γ, sweeping, batch, α, ctx=None, stream=None):
+        super().__init__(R, F, g, x0, N, ctx, stream)
+        self.L, self.γ, self.sweeping, self.batch, self.α = L, γ, int(sweeping), int(batch), α
+        if self.batch < 1:
+            raise ValueError("batch size must be >= 1")
+
+    def _init(self):                                                       # Finito_LFinito.jl:40-76
+        N, r = self.N, self.batch
+        gam = _finito_gammas(self)                                         # :51-63
+        if gam is None:
+            return None
+        hat_γ = self.ctx.hat_gamma(gam)                                    # :66
+        av, z, z_full = self._new(), self._new(), self._new()
+        self.ctx.lfinito_init(self.F, hat_γ, self._x0_dev, av, z, z_full)  # :67-72
+        return FINITO_LFinito_state(gam, hat_γ, av, -(-N // r) if N > 0 else 0, z, z_full)
+
+    def _step(self, st, n):                                                # Finito_LFinito.jl:78-103
+        N, r = self.N, self.batch
+        for _ in range(n):
+            if self.sweeping == 3:
+                st.inds = self.stream.randperm(st.d)                       # :89
+            if r == 1 and self.sweeping != 3 and self.F.N == self.N:
+                bptr = np.arange(N + 1, dtype=np.int64)                    # identity order, one sample per batch
+                bidx = np.arange(N, dtype=np.int64)
+            else:
+                batches = [_localise(self, _static_batch(N, r, int(j))) for j in st.inds]
+                if self.F.N != self.N and any(len(b) == 0 for b in batches):
+                    raise ValueError("an LFinito batch has no member on this rank: use batches that span all ranks")
+                bptr = np.zeros(len(batches) + 1, np.int64)
+                np.cumsum([len(b) for b in batches], out=bptr[1:])
+                bidx = np.concatenate(batches) if batches else np.zeros(0, np.int64)
+            self.ctx.lfinito_iterate(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.av, st.z, st.z_full)
+
+
+# ======================================================================================================================
+# solution(state)   -- SVRG_basic.jl:99, SAGA_basic.jl:71, Finito_basic.jl:123, Finito_LFinito.jl:105
+# ======================================================================================================================
+def solution(state):
+    if state is None:
+        raise TypeError("solution(nothing): no method matching solution(::Nothing) -- the iterable ended before yielding "
+                        "a state (invalid configuration, see the warning above)")
+    return state.z_full if isinstance(state, SVRG_basic_state) else state.z
+
+
+# ======================================================================================================================
+# L3: solver structs + functors + iterator()
+# ======================================================================================================================
+class _Solver:
+    _chunk = 1 << 20   # iterations per device launch in the functor's fast path
+
+    def _drive(self, it, maxit, disp):
+        """The functor's loop (SVRG.jl:69-83): take(iter, maxit), optional printing, return (solution, num_iters).
+
+        Nothing observes the intermediate states unless `verbose`, so iterations that are one device step each
+        (SAGA, Finito) are issued `chunk` at a time; the yielded-state semantics of `iterator(...)` are unchanged.
+        """
+        it_obj = iter(it)
+        num_iters, state = 0, None
+        try:
+            state = next(it_obj)
+            num_iters = 1
+        except StopIteration:
+            pass
+        if state is not None:
+            if self.verbose and num_iters % self.freq == 0:
+                disp(num_iters, state)
+            while num_iters < maxit:
+                n = maxit - num_iters
+                if self.verbose:
+                    n = min(n, self.freq - num_iters % self.freq)
+                n = min(n, self._chunk if it._chunkable else 1)
+                it._step(state, n)
+                num_iters += n
+                if self.verbose and num_iters % self.freq == 0:
+                    disp(num_iters, state)
+            if self.verbose and num_iters % self.freq != 0:
+                disp(num_iters, state)
+        sol = solution(state)
+        it.ctx.synchronize()
+        return (sol.cpu().numpy().reshape(np.shape(it.x0)) if it._numpy else sol), num_iters
+
+
+SVRG_basic_iterable._chunkable = False
+SAGA_basic_iterable._chunkable = True
+FINITO_basic_iterable._chunkable = True
+FINITO_LFinito_iterable._chunkable = False
+
+
+class SVRG(_Solver):
+    """SVRG{R}(; γ, maxit=10000, verbose=false, freq=1000, m=nothing, plus=false)   (SVRG.jl:24-44, :112-113)"""
+
+    def __init__(self, R=np.float64, *, γ=None, gamma=None, maxit=10000, verbose=False, freq=1000, m=None, plus=False):
+        γ = _pick(γ, gamma, "γ")
+        assert γ is None or γ > 0
+        assert maxit > 0
+        assert freq > 0
+        self.R, self.γ, self.maxit, self.verbose, self.freq, self.m, self.plus = R, γ, int(maxit), verbose, int(freq), m, plus
+
+    def _iterable(self, x0, F=None, g=None, L=None, μ=None, mu=None, N=None, ctx=None, stream=None):
+        μ = _pick(μ, mu, "μ")
+        m = self.m if self.m is not None else N                            # SVRG.jl:59
+        return SVRG_basic_iterable(self.R, F, g, x0, N, L, μ, self.γ, m, self.plus, ctx=ctx, stream=stream)
+
+    def __call__(self, x0, **kw):                                          # SVRG.jl:46-84
+        maxit = self.maxit
+        if self.plus and self.maxit > 25:                                  # :61-65
+            maxit = 25
+            warnings.warn("exponential number of inner updates...reverted to 25 maximum iterations")
+        return self._drive(self._iterable(x0, **kw), maxit, lambda it, st: print("%5d | %.3e  " % (it, st.γ)))
+
+
+class SAGA(_Solver):
+    """SAGA{R}(; γ, maxit=10000, verbose=false, freq=1000, SAG_flag=false)   (SAGA.jl:24-42, :108-109)"""
+
+    def __init__(self, R=np.float64, *, γ=None, gamma=None, maxit=10000, verbose=False, freq=1000, SAG_flag=False):
+        γ = _pick(γ, gamma, "γ")
+        assert γ is None or γ > 0
+        assert maxit > 0
+        assert freq > 0
+        self.R, self.γ, self.maxit, self.verbose, self.freq, self.SAG_flag = R, γ, int(maxit), verbose, int(freq), SAG_flag
+
+    def _iterable(self, x0, F=None, g=None, L=None, N=None, ctx=None, stream=None):
+        return SAGA_basic_iterable(self.R, F, g, x0, N, L, self.γ, self.SAG_flag, ctx=ctx, stream=stream)
+
+    def __call__(self, x0, **kw):                                          # SAGA.jl:44-73
+        return self._drive(self._iterable(x0, **kw), self.maxit, lambda it, st: print("%5d | %.3e  " % (it, st.γ)))
+
+
+def SAG(R=np.float64, **kw):
+    """SAG(R; kwargs...) = SAGA{R}(; kwargs..., SAG_flag=true)   (SAGA.jl:190-191)"""
+    return SAGA(R, SAG_flag=True, **kw)
+
+
+class Finito(_Solver):
+    """Finito{R}(; γ, sweeping=1, LFinito=false, adaptive=false, minibatch=(false,1), maxit=10000, verbose=false,
+    freq=10000, α=0.999, tol=1e-8, tol_b=1e-9)   (Finito.jl:32-64, :165-166)"""
+
+    def __init__(self, R=np.float64, *, γ=None, gamma=None, sweeping=1, LFinito=False, adaptive=False, minibatch=(False, 1),
+                 maxit=10000, verbose=False, freq=10000, α=None, alpha=None, tol=1e-8, tol_b=1e-9):
+        γ = _pick(γ, gamma, "γ")
+        α = _pick(α, alpha, "α")
+        α = 0.999 if α is None else α
+        assert γ is None or np.min(np.asarray(γ.cpu() if isinstance(γ, torch.Tensor) else γ)) > 0
+        assert maxit > 0
+        assert tol > 0
+        assert tol_b > 0
+        assert freq > 0
+        self.R, self.γ, self.sweeping, self.LFinito, self.adaptive = R, γ, sweeping, LFinito, adaptive
+        self.minibatch, self.maxit, self.verbose, self.freq, self.α, self.tol, self.tol_b = (
+            tuple(minibatch), int(maxit), verbose, int(freq), α, tol, tol_b)
+
+    def _iterable(self, x0, F=None, g=None, L=None, N=None, ctx=None, stream=None):   # Finito.jl:80-116
+        if self.LFinito:
+            return FINITO_LFinito_iterable(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α,
+                                           ctx=ctx, stream=stream)
+        if self.adaptive:
+            raise NotImplementedError("adaptive Finito (Finito_adaptive.jl) is outside the device hot path "
+                                      "(data-dependent per-sample backtracking; SURVEY.md section 8f)")
+        return FINITO_basic_iterable(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α,
+                                     ctx=ctx, stream=stream)
+
+    def __call__(self, x0, **kw):                                          # Finito.jl:66-133
+        return self._drive(self._iterable(x0, **kw), self.maxit, lambda it, st: print("%5d | %.3e  " % (it, st.hat_γ)))
+
+
+def iterator(solver, x0, **kw):
+    """iterator(solver, x0; F, g, L, [μ], N): the raw iterable; maxit/verbose/freq of the solver are ignored
+    (SVRG.jl:132-147, SAGA.jl:128-142, Finito.jl:186-234)."""
+    return solver._iterable(x0, **kw)

@@ -1,0 +1,203 @@
+/*
+ * ciao_hip.h -- C ABI of libciao_hip.so: the finite-sum hot path of CIAOAlgorithms.jl (SVRG / SAGA+SAG / Finito /
+ * LFinito iterate updates) as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * This is the drop-in boundary.  The reference (pure Julia) has no FFI of its own; the boundary is inserted exactly
+ * where its iterables (L2) call the ProximalOperators.jl plugin API (L1):
+ *      gradient!(y, f_i, x)      prox!(y, g, x, gamma)
+ * and where the solver functors (L3) call Base.iterate on those iterables.  Each entry point below names the
+ * reference lines (relative to /root/reference/src/algorithms/) whose work it performs.  INTEGRATION.md shows the
+ * Julia `ccall` stubs that bind these symbols.
+ *
+ * Conventions
+ *   - extern "C"; plain pointers and sizes; no C++/torch types; no exceptions cross the ABI.
+ *   - every call returns int32 status: 0 = ok, negative = error (ciao_last_error() has the text).
+ *   - all vectors/matrices are DEVICE pointers unless the parameter name ends in `_host`.  The caller owns every
+ *     buffer (AMDGPU.jl ROCArray / torch tensor); the library never frees or reallocates them and only owns the
+ *     private workspace inside ciao_ctx.
+ *   - work is enqueued on the ctx's HIP stream; calls are asynchronous unless they return host data.
+ *   - one ctx = one device + one stream; not thread-safe (the reference is single-threaded with a global RNG).
+ *   - sample indices are int64, 0-BASED (the Julia wrapper subtracts 1).  The reference's RNG draws are an INPUT
+ *     (index arrays), because Julia's stream is not reproducible outside Julia.
+ *   - real type `R` of the reference = `dtype` here (f32 or f64); nothing is silently promoted
+ *     (test/test_lasso.jl:74 asserts eltype).  Scalars cross the ABI as double and are rounded to R once.
+ *   - data layout: A is row-major N x d with row stride `ld` elements (a Julia d x N column-major Matrix is exactly
+ *     this with ld = d); the SAGA/Finito table is row-major N x d, stride d.
+ *   - multi-GPU: rows are sharded; every entry point that sums over samples calls the ctx's all-reduce hook (if set)
+ *     on the raw d-vector sum before its epilogue (see ciao_ctx_set_allreduce).
+ */
+#ifndef CIAO_HIP_H
+#define CIAO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CIAO_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define CIAO_API __attribute__((visibility("default")))
+#else
+#define CIAO_API
+#endif
+
+enum {
+    CIAO_OK = 0,
+    CIAO_ERR_ARG = -1,         /* bad argument (null pointer, negative size, misaligned, index out of range) */
+    CIAO_ERR_HIP = -2,         /* a HIP runtime call failed                                                */
+    CIAO_ERR_UNSUPPORTED = -3, /* shape / operator family outside what the kernels cover                   */
+    CIAO_ERR_ALLOC = -4,       /* workspace allocation failed                                              */
+    CIAO_ERR_HOOK = -5         /* the all-reduce hook returned non-zero                                    */
+};
+
+enum { CIAO_F32 = 0, CIAO_F64 = 1 };
+
+/* f_i families */
+enum {
+    CIAO_LOSS_LS = 0,       /* LeastSquares(a_i' (1 x d), [b_i], lam): f_i(x) = lam/2 (a_i'x - b_i)^2   test/test_lasso.jl:54 */
+    CIAO_LOSS_LOGISTIC = 1, /* Precompose(LogisticLoss([y_i],1), a_i', 1): log(1+exp(-y_i a_i'x))        test/test_logistic_l1.jl:36 */
+    CIAO_LOSS_ZERO = 2      /* Zero(): the default F = fill(Zero(), N)                                   SVRG/SVRG.jl:58 */
+};
+
+/* g families (rows O3, O4) */
+enum {
+    CIAO_PROX_ZERO = 0, /* Zero(): prox = identity                       SVRG/SVRG.jl:49             */
+    CIAO_PROX_L1 = 1,   /* NormL1(lam): soft threshold at gamma*lam      test/test_lasso.jl:59       */
+    CIAO_PROX_BOX = 2   /* IndBox(lo, hi): clamp, scalar or per-coordinate  test/test_sharing.jl:16   */
+};
+
+/* Packed F = [f_1 .. f_N] (replaces the reference's Vector of N one-row operator objects, test/test_lasso.jl:50-58).
+ * N is the number of rows RESIDENT on this device (the local shard); N_total the global count used for the 1/N
+ * factors (== N on one GPU).  Sample indices, `gam` and the SAGA/Finito tables are indexed by LOCAL row. */
+typedef struct {
+    int32_t loss;      /* CIAO_LOSS_*                        */
+    int32_t dtype;     /* CIAO_F32 / CIAO_F64                */
+    int64_t N;         /* local rows                         */
+    int64_t d;         /* features                           */
+    int64_t ld;        /* row stride of A in elements (>= d) */
+    int64_t N_total;   /* global N (for the 1/N factors)     */
+    const void *A;     /* device, N x ld                     */
+    const void *b;     /* device, N: targets b_i (LS) or labels y_i in {-1,+1} (logistic); NULL for ZERO */
+    double lam;        /* LeastSquares lambda (ignored otherwise) */
+} ciao_problem;
+
+typedef struct {
+    int32_t kind;       /* CIAO_PROX_*                                  */
+    int32_t _pad;
+    double lam;         /* NormL1 lambda                                */
+    double lo, hi;      /* IndBox scalar bounds                         */
+    const void *lo_vec; /* device d-vector of lower bounds, or NULL     */
+    const void *hi_vec; /* device d-vector of upper bounds, or NULL     */
+} ciao_prox_desc;
+
+typedef struct ciao_ctx ciao_ctx; /* opaque: device id, stream, private workspace, all-reduce hook */
+
+/* All-reduce hook: sum `count` elements of dtype at device pointer `buf` IN PLACE across all ranks, enqueued on
+ * `stream` (a hipStream_t).  Return 0 on success.  With RCCL: ncclAllReduce(buf, buf, count, type, ncclSum, comm,
+ * stream).  The Python host passes a closure around torch.distributed.all_reduce. */
+typedef int32_t (*ciao_allreduce_fn)(void *user, void *buf, int64_t count, int32_t dtype, void *stream);
+
+/* ---- library / context ------------------------------------------------------------------------------------- */
+CIAO_API int32_t ciao_abi_version(void);
+CIAO_API const char *ciao_last_error(void);
+/* device >= 0; stream = hipStream_t to enqueue on (NULL = the device's default stream). */
+CIAO_API int32_t ciao_ctx_create(int32_t device, void *stream, ciao_ctx **out);
+CIAO_API int32_t ciao_ctx_destroy(ciao_ctx *ctx);
+CIAO_API int32_t ciao_ctx_set_stream(ciao_ctx *ctx, void *stream);
+CIAO_API int32_t ciao_ctx_synchronize(ciao_ctx *ctx);
+CIAO_API int32_t ciao_ctx_set_allreduce(ciao_ctx *ctx, ciao_allreduce_fn fn, void *user); /* fn = NULL: single GPU */
+/* Tuning knobs (performance only, never results-changing beyond summation order): key "sweep_blocks_per_cu",
+ * "chain_prefetch" ... ; returns CIAO_ERR_ARG for unknown keys. */
+CIAO_API int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value);
+/* Kernel timing for bench.py's roofline line: when enabled, every launch of the dominant streaming kernel of an entry
+ * point (rows_fast_kernel / rows_generic_kernel) is bracketed by HIP events on the ctx's stream.  _read synchronises,
+ * returns the summed device time of those launches and their count since the last read, and resets the counters. */
+CIAO_API int32_t ciao_ctx_timing_enable(ciao_ctx *ctx, int32_t enable);
+CIAO_API int32_t ciao_ctx_timing_read(ciao_ctx *ctx, double *total_ms_host, int64_t *launches_host);
+/* Name + grid of the dominant kernel of the last entry point called (for bench.py / rocprof correlation). */
+CIAO_API const char *ciao_ctx_last_kernel(ciao_ctx *ctx);
+
+/* ---- L1 plugin API (ProximalOperators.jl calling convention) ---------------------------------------------- */
+/* gradient!(y, F[i], x): y = grad f_i(x); if fval != NULL also *fval = f_i(x) (device scalar of dtype).
+ * Call sites: SVRG/SVRG_basic.jl:60,74,75,89; SAGA_SAG/SAGA_basic.jl:43,56; Finito/Finito_basic.jl:78,112. */
+CIAO_API int32_t ciao_gradient(ciao_ctx *ctx, const ciao_problem *p, int64_t i, const void *x, void *y, void *fval);
+/* prox!(y, g, x, gamma): y = prox_{gamma g}(x); y may alias x.
+ * Call sites: SVRG_basic.jl:80; SAGA_basic.jl:48,64; Finito_basic.jl:84,118; Finito_LFinito.jl:83,92. */
+CIAO_API int32_t ciao_prox(ciao_ctx *ctx, int32_t dtype, int64_t d, const ciao_prox_desc *g, const void *x, double gamma,
+                  void *y);
+
+/* ---- the roofline sweep ------------------------------------------------------------------------------------ */
+/* av = (1/N_total) sum_i grad f_i(x)       SVRG_basic.jl:58-63 (init) and :87-92 (epoch tail).
+ * Reads every row of A exactly once. */
+CIAO_API int32_t ciao_full_gradient(ciao_ctx *ctx, const ciao_problem *p, const void *x, void *av);
+/* Fused proximal-gradient step on the full gradient (the "full-gradient + prox sweep" of the north star; it is also
+ * LFinito's `prox!` + full pass, Finito_LFinito.jl:83-88, in x-coordinates):
+ *     av = (1/N_total) sum_i grad f_i(x);   y = prox_{gamma g}(x - gamma * av)          (y may alias x) */
+CIAO_API int32_t ciao_proxgrad_step(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma,
+                           const void *x, void *av, void *y);
+/* (1/N_total) sum_i f_i(x) + g(x) on the same sweep (the value `gradient!` returns and the reference discards;
+ * test/test_lasso.jl:45 computes it outside).  *obj_host receives the value (synchronises). */
+CIAO_API int32_t ciao_objective(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *x,
+                       double *obj_host);
+
+/* ---- SVRG / SVRG++  (SVRG/SVRG_basic.jl) -------------------------------------------------------------------- */
+/* Base.iterate(iter), :57-66: av = full gradient at x0; z_full = x0; z = 0; w = x0. */
+CIAO_API int32_t ciao_svrg_init(ciao_ctx *ctx, const ciao_problem *p, const void *x0, void *av, void *z, void *z_full,
+                       void *w);
+/* The inner cycle :73-82 for the m draws idx[0..m) (device int64, 0-based LOCAL rows):
+ *     temp = gamma*(grad f_i(z_full) - grad f_i(w) - av) + w ; w = prox_{gamma g}(temp) ; z += w.
+ * Strictly sequential in w: runs as one persistent workgroup (replicas-only across GPUs). */
+CIAO_API int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
+                        const int64_t *idx, const void *av, void *z, const void *z_full, void *w);
+/* Base.iterate(iter, state), :71-96 = inner cycle + tail (z_full = z/m; basic: w = z_full; z = 0) + full pass.
+ * (`state.m *= 2` of SVRG++ is host bookkeeping; pass the current m.) */
+CIAO_API int32_t ciao_svrg_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
+                          const int64_t *idx, int32_t plus, void *av, void *z, void *z_full, void *w);
+
+/* ---- SAGA / SAG  (SAGA_SAG/SAGA_basic.jl) ------------------------------------------------------------------- */
+/* Base.iterate(iter), :41-48: table[i] = grad f_i(x0); av = sum/N; z = prox_{gamma g}((1-gamma) x0). */
+CIAO_API int32_t ciao_saga_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma,
+                       const void *x0, void *table, void *av, void *z);
+/* nsteps consecutive Base.iterate(iter,state), :53-68, with the draws idx[0..nsteps) (device int64). */
+CIAO_API int32_t ciao_saga_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int32_t sag,
+                        int64_t nsteps, const int64_t *idx, void *table, void *av, void *z);
+
+/* ---- Finito / MISO  (Finito/Finito_basic.jl) ---------------------------------------------------------------- */
+/* hat_gamma = 1 / sum_i (1/gam_i)  over the LOCAL rows then all-reduced (Finito_basic.jl:82). Synchronises. */
+CIAO_API int32_t ciao_hat_gamma(ciao_ctx *ctx, int32_t dtype, int64_t N, const void *gam, double *hat_gamma_host);
+/* Base.iterate(iter), :76-84: table[i] = x0 - (gam_i/N) grad f_i(x0); av = hat_gamma sum_i table[i]/gam_i;
+ * z = prox_{hat_gamma g}(av).  gam: device N-vector of per-sample stepsizes (built by the host from :61-74). */
+CIAO_API int32_t ciao_finito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam,
+                         double hat_gamma, const void *x0, void *table, void *av, void *z);
+/* nit consecutive Base.iterate(iter,state), :109-118.  Iteration t uses the samples
+ * bidx[bptr_host[t] .. bptr_host[t+1]) (bidx: device int64, LOCAL rows; bptr_host: HOST int64[nit+1]); the batch
+ * choice (:95-108) is host logic.  Small batches run as one persistent chain; large ones batch-parallel. */
+CIAO_API int32_t ciao_finito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam,
+                          double hat_gamma, int64_t nit, const int64_t *bptr_host, const int64_t *bidx,
+                          void *table, void *av, void *z);
+
+/* ---- LFinito  (Finito/Finito_LFinito.jl) -------------------------------------------------------------------- */
+/* Base.iterate(iter), :66-72: av = x0 - (hat_gamma/N) sum_i grad f_i(x0); z = z_full = av (state ctor :27-37). */
+CIAO_API int32_t ciao_lfinito_init(ciao_ctx *ctx, const ciao_problem *p, double hat_gamma, const void *x0, void *av,
+                          void *z, void *z_full);
+/* One Base.iterate(iter,state), :82-100: z_full = prox(av); av = z_full - (hat_gamma/N) sum grad f_i(z_full);
+ * then for each of the nb batches, in the order given: z = prox(av); av += sum_{i in batch} [ (hat_gamma/N)
+ * (grad f_i(z_full) - grad f_i(z)) + (hat_gamma/gam_i)(z - z_full) ]. */
+CIAO_API int32_t ciao_lfinito_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam,
+                             double hat_gamma, int64_t nb, const int64_t *bptr_host, const int64_t *bidx,
+                             void *av, void *z, void *z_full);
+
+/* ---- synthetic data (bench / tests): counter-based generator, reproducible per (seed, row, col) ------------- */
+/* out[i*ld + k] = scale * N(0,1) for rows row0 .. row0+nrows, keyed by the GLOBAL (row, col). */
+CIAO_API int32_t ciao_synth_normal(ciao_ctx *ctx, int32_t dtype, void *out, int64_t nrows, int64_t d, int64_t ld,
+                          int64_t row0, uint64_t seed, double scale);
+/* b = A x_true + noise*N(0,1) (LS targets) or sign(...) (logistic labels when `labels` != 0). */
+CIAO_API int32_t ciao_synth_targets(ciao_ctx *ctx, const ciao_problem *p, const void *x_true, double noise, int32_t labels,
+                           int64_t row0, uint64_t seed, void *b_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIAO_HIP_H */

@@ -1,0 +1,83 @@
+/*
+ * ciao_oracle.h -- CPU oracle for the finite-sum hot path of CIAOAlgorithms.jl.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under ciaoalgorithms.jl_amd/ (the product) may include, link, import or
+ * execute anything in this directory; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do,
+ * and only as the checker / the CPU baseline.
+ *
+ * Parity status: PINNED by the reference's own known-answer tests (tests/test_oracle_pins.py):
+ *   - literal l1-logistic fixture + hard-coded x_star     (/root/reference/test/test_logistic_l1.jl:12-29)
+ *   - lasso known-answer generator                        (/root/reference/test/test_lasso.jl:15-47)
+ *   - structural pins: maxit=1 returns the init state     (test_lasso.jl:188-192, :224-228)
+ * The Julia reference cannot run in this container (no julia binary), so there is no oracle/_ref build and no
+ * per-step golden vector produced by the reference itself; per-step vectors under tests/golden/ are produced
+ * by THIS restatement and are labelled so.
+ */
+#ifndef CIAO_ORACLE_H
+#define CIAO_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_LOSS_LS = 0, ORC_LOSS_LOGISTIC = 1, ORC_LOSS_ZERO = 2 };
+enum { ORC_PROX_ZERO = 0, ORC_PROX_L1 = 1, ORC_PROX_BOX = 2 };
+
+/* F = [f_1..f_N] packed: row-major A (N x d), b (N) = targets (LS) or labels (logistic), lam = LeastSquares λ. */
+typedef struct {
+    int32_t loss;
+    int32_t _pad;
+    int64_t N, d;
+    const void *A;
+    const void *b;
+    double lam;
+} orc_problem;
+
+/* g */
+typedef struct {
+    int32_t kind;
+    int32_t _pad;
+    double lam;          /* NormL1(lam)                     */
+    double lo, hi;       /* IndBox scalar bounds            */
+    const void *lo_vec;  /* IndBox per-coordinate (or NULL) */
+    const void *hi_vec;
+} orc_prox_desc;
+
+#define ORC_DECL(R, S)                                                                                          \
+    R orc_gradient_##S(int loss, int64_t d, const R *a, R bi, R lam, const R *x, R *y);                        \
+    void orc_prox_##S(const orc_prox_desc *g, int64_t d, const R *x, R gamma, R *y);                           \
+    void orc_full_pass_##S(const orc_problem *p, const R *x, R *av, R *tmp);                                   \
+    void orc_svrg_init_##S(const orc_problem *p, const R *x0, R *av, R *z, R *z_full, R *w);                   \
+    void orc_svrg_inner_##S(const orc_problem *p, const orc_prox_desc *g, R gamma, int64_t m,                  \
+                            const int64_t *idx, const R *av, R *z, const R *z_full, R *w);                     \
+    void orc_svrg_iterate_##S(const orc_problem *p, const orc_prox_desc *g, R gamma, int64_t m,                \
+                              const int64_t *idx, int plus, R *av, R *z, R *z_full, R *w);                     \
+    void orc_saga_init_##S(const orc_problem *p, const orc_prox_desc *g, R gamma, const R *x0, R *table,       \
+                           R *av, R *z);                                                                       \
+    void orc_saga_steps_##S(const orc_problem *p, const orc_prox_desc *g, R gamma, int sag, int64_t nsteps,    \
+                            const int64_t *idx, R *table, R *av, R *z);                                        \
+    void orc_finito_init_##S(const orc_problem *p, const orc_prox_desc *g, const R *gam, const R *x0,          \
+                             R *table, R *av, R *z, R *hat_gamma);                                             \
+    void orc_finito_steps_##S(const orc_problem *p, const orc_prox_desc *g, const R *gam, R hat_gamma,         \
+                              int64_t nit, const int64_t *bptr, const int64_t *bidx, R *table, R *av, R *z);   \
+    void orc_lfinito_init_##S(const orc_problem *p, const R *gam, const R *x0, R *av, R *z, R *z_full,         \
+                              R *hat_gamma);                                                                   \
+    void orc_lfinito_iterate_##S(const orc_problem *p, const orc_prox_desc *g, const R *gam, R hat_gamma,      \
+                                 int64_t nb, const int64_t *bptr, const int64_t *bidx, R *av, R *z,            \
+                                 R *z_full);                                                                   \
+    double orc_objective_##S(const orc_problem *p, const orc_prox_desc *g, const R *x);
+
+ORC_DECL(double, f64)
+ORC_DECL(float, f32)
+#undef ORC_DECL
+
+/* Multi-threaded best-case CPU sweep (OpenMP) used ONLY as bench.py's "all host cores" baseline:
+ * av = (1/N) sum_i grad f_i(x);  returns the number of threads used. */
+int orc_full_pass_omp_f64(const orc_problem *p, const double *x, double *av);
+int orc_full_pass_omp_f32(const orc_problem *p, const float *x, float *av);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

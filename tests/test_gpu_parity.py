@@ -1,0 +1,480 @@
+"""GPU parity tests proper: every C-ABI entry point of libciao_hip.so against the CPU oracle on the same seeded
+inputs (sizes the oracle finishes in seconds), through the ctypes binding (the same ABI a Julia ccall binds).
+
+Tolerances (stated, per north_star "matching the CPU reference to a stated fp64 tolerance"):
+    fp64: 1e-10 relative to the infinity norm of the reference vector (+1e-12 absolute)
+    fp32: 2e-4  relative (+1e-6 absolute)
+Bitwise equality is not attainable: the reference sums sequentially (SVRG_basic.jl:59-63) while the device sums
+in a fixed tree order; the device result is bitwise reproducible run to run (tested below).
+"""
+import numpy as np
+import pytest
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float64: (1e-10, 1e-12), np.float32: (2e-4, 1e-6)}
+
+
+def close(dev, ref, dtype, scale=1.0, what=""):
+    dev = dev.detach().cpu().numpy() if hasattr(dev, "detach") else np.asarray(dev)
+    ref = np.asarray(ref)
+    rel, ab = TOL[dtype]
+    bound = scale * (rel * max(np.abs(ref).max(initial=0.0), 1e-30) + ab)
+    err = np.abs(dev.astype(np.float64) - ref.astype(np.float64)).max(initial=0.0)
+    assert err <= bound, f"{what}: max abs err {err:.3e} > {bound:.3e}"
+
+
+def make(loss, A, b, lam_f, dtype, pad=0):
+    """(oracle Problem, device PackedF) over the same data; pad > 0 gives the device copy a row stride d+pad."""
+    import torch
+    from oracle import oracle as O
+    from ciaoalgorithms_jl_amd.device import PackedF
+    import ciaoalgorithms_jl_amd._lib as L
+    op = O.Problem(loss, A, b, lam_f)
+    N, d = A.shape
+    tA = torch.from_numpy(A).cuda()
+    if pad:
+        buf = torch.zeros((N, d + pad), dtype=tA.dtype, device="cuda")
+        buf[:, :d] = tA
+        tA = buf[:, :d]
+    tb = torch.from_numpy(b).cuda()
+    kind = {"ls": L.LOSS_LS, "logistic": L.LOSS_LOGISTIC}[loss]
+    return op, PackedF(kind, tA, tb, lam_f)
+
+
+def make_g(kind, dtype, d, lam=0.05):
+    import torch
+    from oracle import oracle as O
+    from ciaoalgorithms_jl_amd.device import ProxG
+    import ciaoalgorithms_jl_amd._lib as L
+    if kind == "zero":
+        return O.Prox("zero"), ProxG(L.PROX_ZERO)
+    if kind == "l1":
+        return O.Prox("l1", lam=lam), ProxG(L.PROX_L1, lam=lam)
+    if kind == "box":
+        return O.Prox("box", lo=-0.2, hi=0.3, dtype=dtype), ProxG(L.PROX_BOX, lo=-0.2, hi=0.3)
+    lo = np.linspace(-0.3, 0.0, d).astype(dtype)
+    hi = np.linspace(0.05, 0.4, d).astype(dtype)
+    return (O.Prox("box", lo=lo, hi=hi, dtype=dtype),
+            ProxG(L.PROX_BOX, lo_vec=torch.from_numpy(lo).cuda(), hi_vec=torch.from_numpy(hi).cuda()))
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+SHAPES = [(1, 1), (6, 3), (8, 5), (37, 50), (200, 64), (129, 128), (300, 256), (64, 1024), (33, 1000), (16, 2048), (5, 4096)]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# L1 plugin API
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("loss", ["ls", "logistic"])
+def test_gradient_single_sample(ctx, dtype, loss):
+    import torch
+    from oracle import oracle as O
+    A, b, x = P.synthetic(loss, 9, 70, dtype)
+    op, dp = make(loss, A, b, 9.0, dtype)
+    y = torch.empty(70, dtype=dev(x).dtype, device="cuda")
+    fv = torch.empty(1, dtype=y.dtype, device="cuda")
+    for i in (0, 4, 8):
+        ctx.gradient(dp, i, dev(x), y, fv)
+        gy, f = O.gradient(op.loss, A[i], b[i], 9.0, x)
+        close(y, gy, dtype, what=f"gradient i={i}")
+        close(fv, [f], dtype, scale=10, what="f_i value")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("gk", ["zero", "l1", "box", "boxvec"])
+def test_prox(ctx, dtype, gk):
+    import torch
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    for d in (1, 5, 257, 1024):
+        x = rng.standard_normal(d).astype(dtype)
+        og, dg = make_g(gk, dtype, d)
+        y = torch.empty(d, dtype=dev(x).dtype, device="cuda")
+        ctx.prox(dg, dev(x), 0.7, y)
+        assert np.array_equal(y.cpu().numpy(), O.prox(og, x, dtype(0.7))), "prox is elementwise: must be bit-exact"
+        xin = dev(x)
+        ctx.prox(dg, xin, 0.7, xin)  # in place
+        assert np.array_equal(xin.cpu().numpy(), O.prox(og, x, dtype(0.7)))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the sweep: S2 / S4 (full gradient), fused prox-gradient step, objective
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("loss", ["ls", "logistic"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_full_gradient(ctx, dtype, loss, shape):
+    import torch
+    from oracle import oracle as O
+    N, d = shape
+    A, b, x = P.synthetic(loss, N, d, dtype, seed=N + d)
+    op, dp = make(loss, A, b, float(N), dtype)
+    av = torch.empty(d, dtype=dev(x).dtype, device="cuda")
+    ctx.full_gradient(dp, dev(x), av)
+    ref = O.full_pass(op, x)
+    ref64 = O.full_pass(O.Problem(loss, A.astype(np.float64), b.astype(np.float64), float(N)), x.astype(np.float64))
+    # judge against the fp64 oracle so that the fp32 oracle's own sequential-sum error does not enter
+    close(av, ref64, dtype, what=f"full_gradient {ctx.last_kernel()}")
+    close(av, ref, dtype, scale=4, what="full_gradient vs same-precision oracle")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_full_gradient_generic_equals_fast(ctx, dtype):
+    """Same rows through the LDS-accumulator generic kernel and through the register fast path."""
+    import torch
+    A, b, x = P.synthetic("ls", 500, 512, dtype)
+    _, dp = make("ls", A, b, 500.0, dtype)
+    av1 = torch.empty(512, dtype=dev(x).dtype, device="cuda")
+    av2 = torch.empty_like(av1)
+    ctx.full_gradient(dp, dev(x), av1)
+    assert "rows_fast_kernel" in ctx.last_kernel()
+    ctx.set_option("force_generic", 1)
+    try:
+        ctx.full_gradient(dp, dev(x), av2)
+        assert "rows_generic_kernel" in ctx.last_kernel()
+    finally:
+        ctx.set_option("force_generic", 0)
+    close(av2, av1.cpu().numpy(), dtype, what="generic vs fast")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_full_gradient_padded_rows_and_prefetch_variants(ctx, dtype):
+    import torch
+    from oracle import oracle as O
+    A, b, x = P.synthetic("logistic", 1000, 256, dtype)
+    op, dp = make("logistic", A, b, 1.0, dtype, pad=64)   # ld = 320: still 16-byte aligned rows -> fast path
+    assert dp.ld == 320
+    ref = O.full_pass(op, x)
+    outs = []
+    for pf in (1, 0):
+        ctx.set_option("sweep_prefetch", pf)
+        av = torch.empty(256, dtype=dev(x).dtype, device="cuda")
+        ctx.full_gradient(dp, dev(x), av)
+        assert "rows_fast_kernel" in ctx.last_kernel()
+        close(av, ref, dtype, scale=4, what=f"padded rows prefetch={pf}")
+        outs.append(av.cpu().numpy())
+    ctx.set_option("sweep_prefetch", 1)
+    # the two pipelining flavours assign the same rows to the same waves: identical summation order
+    assert np.array_equal(outs[0], outs[1])
+    op2, dp2 = make("logistic", A, b, 1.0, dtype, pad=3)    # ld = 259: unaligned rows -> generic path
+    av = torch.empty(256, dtype=dev(x).dtype, device="cuda")
+    ctx.full_gradient(dp2, dev(x), av)
+    assert "rows_generic_kernel" in ctx.last_kernel()
+    close(av, ref, dtype, scale=4, what="unaligned rows")
+
+
+def test_full_gradient_empty_problem(ctx):
+    """N = 0 (empty input): the sum over no samples is the zero vector."""
+    import torch
+    from ciaoalgorithms_jl_amd.device import PackedF
+    import ciaoalgorithms_jl_amd._lib as L
+    A = torch.zeros((0, 16), dtype=torch.float64, device="cuda")
+    b = torch.zeros((0,), dtype=torch.float64, device="cuda")
+    dp = PackedF(L.LOSS_LS, A, b, 1.0, N_total=1)
+    av = torch.full((16,), 7.0, dtype=torch.float64, device="cuda")
+    ctx.full_gradient(dp, torch.ones(16, dtype=torch.float64, device="cuda"), av)
+    assert torch.count_nonzero(av).item() == 0
+
+
+def test_zero_loss(ctx):
+    """F = fill(Zero(), N) (SVRG.jl:58): every gradient is zero, SVRG reduces to repeated prox."""
+    import torch
+    from ciaoalgorithms_jl_amd.device import PackedF
+    dp = PackedF.zero(10, 33, torch.float64)
+    av = torch.full((33,), 7.0, dtype=torch.float64, device="cuda")
+    ctx.full_gradient(dp, torch.ones(33, dtype=torch.float64, device="cuda"), av)
+    assert torch.count_nonzero(av).item() == 0
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("gk", ["zero", "l1", "boxvec"])
+def test_proxgrad_step_and_objective(ctx, dtype, gk):
+    import torch
+    from oracle import oracle as O
+    for loss, (N, d) in (("ls", (300, 1024)), ("logistic", (77, 50))):
+        A, b, x = P.synthetic(loss, N, d, dtype)
+        op, dp = make(loss, A, b, float(N), dtype)
+        og, dg = make_g(gk, dtype, d, lam=0.01)
+        gamma = 0.05
+        av = torch.empty(d, dtype=dev(x).dtype, device="cuda")
+        y = torch.empty_like(av)
+        ctx.proxgrad_step(dp, dg, gamma, dev(x), av, y)
+        rav = O.full_pass(op, x)
+        ry = O.prox(og, (x - dtype(gamma) * rav).astype(dtype), dtype(gamma))
+        close(av, rav, dtype, scale=4, what="proxgrad av")
+        close(y, ry, dtype, scale=8, what="proxgrad y")
+        obj = ctx.objective(dp, dg, dev(x))
+        robj = O.objective(op, og, x)
+        assert abs(obj - robj) <= (1e-9 if dtype == np.float64 else 2e-4) * max(1.0, abs(robj))
+
+
+def test_sweep_is_bitwise_reproducible(ctx):
+    import torch
+    A, b, x = P.synthetic("ls", 5000, 1024, np.float64)
+    _, dp = make("ls", A, b, 5000.0, np.float64)
+    outs = []
+    for _ in range(3):
+        av = torch.empty(1024, dtype=torch.float64, device="cuda")
+        ctx.full_gradient(dp, dev(x), av)
+        outs.append(av.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# SVRG
+# ----------------------------------------------------------------------------------------------------------------------
+CHAIN_SHAPES = [(6, 3), (8, 5), (50, 50), (40, 256), (30, 300), (64, 1024), (20, 1500), (10, 4096)]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("loss", ["ls", "logistic"])
+@pytest.mark.parametrize("shape", CHAIN_SHAPES)
+def test_svrg_epochs(ctx, ciao, dtype, loss, shape):
+    """init + 3 x Base.iterate (inner cycle m = 2N, tail, full pass) vs the oracle, same index stream."""
+    import torch
+    from oracle import oracle as O
+    N, d = shape
+    A, b, x0 = P.synthetic(loss, N, d, dtype, seed=7)
+    lam_f = float(N) if loss == "ls" else 1.0
+    op, dp = make(loss, A, b, lam_f, dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.01)
+    Lmax = (lam_f if loss == "ls" else 0.25) * np.max(np.sum(A.astype(np.float64) ** 2, axis=1))
+    gamma = 1.0 / (7 * Lmax)
+    st = ciao.IndexStream(5)
+    tdt = dev(x0).dtype
+    av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+    ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+    rav, rz, rzf, rw = O.svrg_init(op, x0)
+    close(av, rav, dtype, scale=4, what="svrg_init av")
+    assert np.array_equal(zf.cpu().numpy(), x0) and np.array_equal(w.cpu().numpy(), x0) and not z.any().item()
+    m = 2 * N
+    for ep in range(3):
+        idx = st.rand_indices(N, m)
+        ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w)
+        O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
+        close(zf, rzf, dtype, scale=50, what=f"svrg epoch {ep} z_full ({ctx.last_kernel()})")
+        close(w, rw, dtype, scale=50, what=f"svrg epoch {ep} w")
+        close(av, rav, dtype, scale=50, what=f"svrg epoch {ep} av")
+        assert not z.any().item()
+    ctx.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_svrg_plus_and_inner_only(ctx, ciao, dtype):
+    import torch
+    from oracle import oracle as O
+    N, d = 25, 130
+    A, b, x0 = P.synthetic("logistic", N, d, dtype, seed=2)
+    op, dp = make("logistic", A, b, 1.0, dtype)
+    og, dg = make_g("boxvec", dtype, d)
+    gamma = 0.3
+    tdt = dev(x0).dtype
+    av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+    ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+    rav, rz, rzf, rw = O.svrg_init(op, x0)
+    st = ciao.IndexStream(11)
+    m = 3
+    for ep in range(4):   # SVRG++: w is not reset, m doubles (SVRG_basic.jl:85,93)
+        idx = st.rand_indices(N, m)
+        ctx.svrg_iterate(dp, dg, gamma, idx, True, av, z, zf, w)
+        O.svrg_iterate(op, og, dtype(gamma), idx, True, rav, rz, rzf, rw)
+        m *= 2
+        close(zf, rzf, dtype, scale=50, what=f"svrg++ epoch {ep} z_full")
+        close(w, rw, dtype, scale=50, what=f"svrg++ epoch {ep} w")
+    # inner cycle alone accumulates into z
+    idx = st.rand_indices(N, 17)
+    ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
+    O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
+    close(z, rz, dtype, scale=50, what="svrg_inner z")
+    close(w, rw, dtype, scale=50, what="svrg_inner w")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# SAGA / SAG
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("sag", [False, True])
+@pytest.mark.parametrize("shape", CHAIN_SHAPES)
+def test_saga_steps(ctx, ciao, dtype, sag, shape):
+    """Table init + 4N steps.  Small N makes repeated indices inside the prefetch window the common case, which is
+    exactly the read-after-write hazard of the table-row prefetch."""
+    import torch
+    from oracle import oracle as O
+    N, d = shape
+    loss = "ls" if (N + d) % 2 else "logistic"
+    A, b, x0 = P.synthetic(loss, N, d, dtype, seed=9)
+    lam_f = float(N) if loss == "ls" else 1.0
+    op, dp = make(loss, A, b, lam_f, dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.02)
+    Lmax = (lam_f if loss == "ls" else 0.25) * np.max(np.sum(A.astype(np.float64) ** 2, axis=1))
+    gamma = 1.0 / ((16 if sag else 3) * Lmax)
+    tdt = dev(x0).dtype
+    table = torch.empty((N, d), dtype=tdt, device="cuda")
+    av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+    ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
+    rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
+    close(table, rt, dtype, scale=4, what="saga_init table")
+    close(av, rav, dtype, scale=4, what="saga_init av")
+    close(z, rz, dtype, scale=4, what="saga_init z  (= prox((1-gamma) x0))")
+    st = ciao.IndexStream(21)
+    for chunk in (1, 2, 4 * N, 7):
+        idx = st.rand_indices(N, chunk)
+        if chunk == 7:
+            idx[:] = idx[0]   # the same row seven times in a row
+        ctx.saga_steps(dp, dg, gamma, sag, idx, table, av, z)
+        O.saga_steps(op, og, dtype(gamma), sag, idx, rt, rav, rz)
+        close(z, rz, dtype, scale=100, what=f"saga z after chunk {chunk} ({ctx.last_kernel()})")
+        close(av, rav, dtype, scale=100, what=f"saga av after chunk {chunk}")
+        close(table, rt, dtype, scale=100, what=f"saga table after chunk {chunk}")
+    # invariant av == (1/N) sum_i s_i  
+    close(av, table.double().mean(dim=0).cpu().numpy(), dtype, scale=100, what="av invariant")
+    ctx.synchronize()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Finito / LFinito
+# ----------------------------------------------------------------------------------------------------------------------
+def _batches(stream, N, r, nit, mode):
+    out = []
+    for t in range(nit):
+        if mode == "random":
+            out.append(stream.sample_without_replacement(N, r))
+        else:
+            nb = -(-N // r)
+            j = (t + 1) % nb
+            out.append(np.arange(r * j, min(r * j + r, N), dtype=np.int64))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape,r", [((6, 3), 1), ((8, 5), 2), ((8, 5), 3), ((50, 50), 7), ((40, 256), 1), ((64, 1024), 16),
+                                     ((300, 64), 100), ((20, 1500), 4), ((10, 4096), 3)])
+@pytest.mark.parametrize("chain_max", [64, 0])
+def test_finito_steps(ctx, ciao, dtype, shape, r, chain_max):
+    """chain_max=64: batches run in the sequential chain kernel; chain_max=0: every batch goes batch-parallel."""
+    import torch
+    from oracle import oracle as O
+    N, d = shape
+    loss = "logistic" if (N + d) % 2 else "ls"
+    A, b, x0 = P.synthetic(loss, N, d, dtype, seed=4)
+    lam_f = float(N) if loss == "ls" else 1.0
+    op, dp = make(loss, A, b, lam_f, dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.02)
+    Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1)
+    gam = (0.999 * N / Li).astype(dtype)
+    tdt = dev(x0).dtype
+    table = torch.empty((N, d), dtype=tdt, device="cuda")
+    av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+    dgam = dev(gam)
+    hg = ctx.hat_gamma(dgam)
+    rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
+    assert abs(hg - float(rhg)) <= (1e-12 if dtype == np.float64 else 1e-5) * abs(float(rhg))
+    ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
+    close(table, rt, dtype, scale=4, what="finito_init table")
+    close(av, rav, dtype, scale=20, what="finito_init av")
+    close(z, rz, dtype, scale=20, what="finito_init z")
+    ctx.set_option("chain_max_batch", chain_max)
+    try:
+        st = ciao.IndexStream(33)
+        for mode, nit in (("random", 5), ("cyclic", 2 * (-(-N // r)) + 1)):
+            batches = _batches(st, N, r, nit, mode)
+            bptr = np.zeros(nit + 1, np.int64)
+            np.cumsum([len(x) for x in batches], out=bptr[1:])
+            ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(batches), table, av, z)
+            O.finito_steps(op, og, gam, rhg, batches, rt, rav, rz)
+            close(z, rz, dtype, scale=200, what=f"finito z {mode} ({ctx.last_kernel()})")
+            close(av, rav, dtype, scale=200, what=f"finito av {mode}")
+            close(table, rt, dtype, scale=200, what=f"finito table {mode}")
+    finally:
+        ctx.set_option("chain_max_batch", 64)
+    # invariant av == hat_gamma * sum_i s_i / gamma_i   (row F3)
+    inv = (table.double() / dgam.double()[:, None]).sum(dim=0).cpu().numpy() * hg
+    close(av, inv, dtype, scale=200, what="finito av invariant")
+    ctx.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape,r", [((6, 3), 1), ((8, 5), 2), ((8, 5), 3), ((50, 50), 7), ((64, 1024), 16), ((300, 64), 100),
+                                     ((20, 1500), 1)])
+@pytest.mark.parametrize("chain_max", [64, 0])
+def test_lfinito_iterations(ctx, ciao, dtype, shape, r, chain_max):
+    import torch
+    from oracle import oracle as O
+    N, d = shape
+    loss = "logistic" if (N + d) % 2 else "ls"
+    A, b, x0 = P.synthetic(loss, N, d, dtype, seed=6)
+    lam_f = float(N) if loss == "ls" else 1.0
+    op, dp = make(loss, A, b, lam_f, dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.02)
+    Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1)
+    gam = (0.999 * N / Li).astype(dtype)
+    tdt = dev(x0).dtype
+    av, z, zf = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(3))
+    dgam = dev(gam)
+    hg = ctx.hat_gamma(dgam)
+    rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
+    ctx.lfinito_init(dp, hg, dev(x0), av, z, zf)
+    close(av, rav, dtype, scale=20, what="lfinito_init av")
+    assert torch.equal(z, av) and torch.equal(zf, av)
+    nb = -(-N // r)
+    static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in range(nb)]
+    ctx.set_option("chain_max_batch", chain_max)
+    try:
+        st = ciao.IndexStream(8)
+        for it in range(3):
+            order = np.arange(nb) if it == 0 else st.randperm(nb)
+            batches = [static[j] for j in order]
+            bptr = np.zeros(nb + 1, np.int64)
+            np.cumsum([len(x) for x in batches], out=bptr[1:])
+            ctx.lfinito_iterate(dp, dg, dgam, hg, bptr, np.concatenate(batches), av, z, zf)
+            O.lfinito_iterate(op, og, gam, rhg, batches, rav, rz, rzf)
+            close(zf, rzf, dtype, scale=200, what=f"lfinito z_full it {it}")
+            close(z, rz, dtype, scale=200, what=f"lfinito z it {it} ({ctx.last_kernel()})")
+            close(av, rav, dtype, scale=200, what=f"lfinito av it {it}")
+    finally:
+        ctx.set_option("chain_max_batch", 64)
+    ctx.synchronize()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# error behaviour at the boundary
+# ----------------------------------------------------------------------------------------------------------------------
+def test_out_of_range_index_is_reported_not_faulted(ctx, ciao):
+    import torch
+    from ciaoalgorithms_jl_amd._lib import CiaoError
+    A, b, x0 = P.synthetic("ls", 10, 8, np.float64)
+    _, dp = make("ls", A, b, 10.0, np.float64)
+    _, dg = make_g("zero", np.float64, 8)
+    av, z, zf, w = (torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(4))
+    ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+    ctx.svrg_inner(dp, dg, 0.1, np.array([1, 2, 10, 3], np.int64), av, z, zf, w)   # 10 is out of range
+    with pytest.raises(CiaoError):
+        ctx.synchronize()
+    ctx.synchronize()   # the sticky flag is cleared once reported
+
+
+def test_argument_validation(ctx):
+    import torch
+    from ciaoalgorithms_jl_amd._lib import CiaoError
+    A, b, x0 = P.synthetic("ls", 10, 8, np.float64)
+    _, dp = make("ls", A, b, 10.0, np.float64)
+    _, dg = make_g("zero", np.float64, 8)
+    av = torch.zeros(8, dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError):
+        ctx.full_gradient(dp, torch.zeros(7, dtype=torch.float64, device="cuda"), av)      # wrong length
+    with pytest.raises(ValueError):
+        ctx.full_gradient(dp, torch.zeros(8, dtype=torch.float32, device="cuda"), av)      # silent promotion refused
+    with pytest.raises(CiaoError):
+        ctx.proxgrad_step(dp, dg, -1.0, dev(x0), av, av)                                   # gamma <= 0
+    with pytest.raises(CiaoError):
+        ctx.gradient(dp, 10, dev(x0), av)                                                  # sample index out of range
+    with pytest.raises(CiaoError):
+        ctx.set_option("no_such_option", 1)
