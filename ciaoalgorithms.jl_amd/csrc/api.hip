@@ -104,9 +104,9 @@ static int32_t check_problem(const ciao_ctx *ctx, const ciao_problem *p)
     CIAO_REQUIRE(p->N >= 0 && p->d >= 1, "need N >= 0 and d >= 1 (got N=%lld d=%lld)", (long long)p->N, (long long)p->d);
     CIAO_REQUIRE(p->ld >= p->d, "row stride ld=%lld < d=%lld", (long long)p->ld, (long long)p->d);
     CIAO_REQUIRE(p->N_total >= p->N && p->N_total >= 1, "N_total=%lld must be >= max(N,1)", (long long)p->N_total);
-    if (p->N > 0) {
+    if (p->N > 0 && p->loss != CIAO_LOSS_ZERO) {   // Zero() terms carry no data (SVRG.jl:58)
         CIAO_REQUIRE(p->A, "problem.A is NULL");
-        CIAO_REQUIRE(p->loss == CIAO_LOSS_ZERO || p->b, "problem.b is NULL");
+        CIAO_REQUIRE(p->b, "problem.b is NULL");
     }
     return CIAO_OK;
 }
@@ -123,7 +123,7 @@ template <typename T>
 static RowsArgs<T> rows_args(const ciao_problem *p)
 {
     RowsArgs<T> a{};
-    a.A = (const T *)p->A;
+    a.A = (p->loss == CIAO_LOSS_ZERO) ? nullptr : (const T *)p->A;
     a.b = (p->loss == CIAO_LOSS_ZERO) ? nullptr : (const T *)p->b;
     a.ld = p->ld;
     a.d = p->d;
@@ -143,7 +143,7 @@ template <typename T>
 static ChainArgs<T> chain_args(const ciao_problem *p, const ciao_prox_desc *g)
 {
     ChainArgs<T> a{};
-    a.A = (const T *)p->A;
+    a.A = (p->loss == CIAO_LOSS_ZERO) ? nullptr : (const T *)p->A;
     a.b = (p->loss == CIAO_LOSS_ZERO) ? nullptr : (const T *)p->b;
     a.ld = p->ld;
     a.d = p->d;
@@ -555,11 +555,11 @@ int32_t ciao_gradient(ciao_ctx *ctx, const ciao_problem *p, int64_t i, const voi
     CIAO_REQUIRE(x && y, "x or y is NULL");
     CIAO_REQUIRE(i >= 0 && i < p->N, "sample index %lld outside [0, %lld)", (long long)i, (long long)p->N);
     if (p->dtype == CIAO_F64)
-        hipLaunchKernelGGL((gradient_kernel<double>), dim3(1), dim3(WAVE), 0, ctx->stream, (const double *)p->A,
+        hipLaunchKernelGGL((gradient_kernel<double>), dim3(1), dim3(WAVE), 0, ctx->stream, p->loss == CIAO_LOSS_ZERO ? nullptr : (const double *)p->A,
                            p->loss == CIAO_LOSS_ZERO ? nullptr : (const double *)p->b, p->ld, p->d, p->loss, (double)p->lam, i,
                            (const double *)x, (double *)y, (double *)fval);
     else
-        hipLaunchKernelGGL((gradient_kernel<float>), dim3(1), dim3(WAVE), 0, ctx->stream, (const float *)p->A,
+        hipLaunchKernelGGL((gradient_kernel<float>), dim3(1), dim3(WAVE), 0, ctx->stream, p->loss == CIAO_LOSS_ZERO ? nullptr : (const float *)p->A,
                            p->loss == CIAO_LOSS_ZERO ? nullptr : (const float *)p->b, p->ld, p->d, p->loss, (float)p->lam, i,
                            (const float *)x, (float *)y, (float *)fval);
     CIAO_HIP(hipGetLastError());

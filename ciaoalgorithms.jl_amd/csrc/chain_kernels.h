@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_kernel(ChainArgs<T> a)
             ring_stale[u] = stale;
             const T *ap = a.A + r * a.ld;
 #pragma unroll
-            for (int j = 0; j < E; ++j) ar[u][j] = valid[j] ? ap[eidx[j]] : T(0);
+            for (int j = 0; j < E; ++j) ar[u][j] = (valid[j] && a.A) ? ap[eidx[j]] : T(0);
             if (HAS_TABLE && !stale) {
                 const T *sp = a.table + r * d;
 #pragma unroll
@@ -248,13 +248,13 @@ __global__ void __launch_bounds__(WAVE)
     gradient_kernel(const T *A, const T *b, int64_t ld, int64_t d, int loss, T lam, int64_t i, const T *x, T *y, T *fval)
 {
     const int lane = threadIdx.x;
-    const T *ap = A + i * ld;
+    const T *ap = A ? A + i * ld : nullptr;
     T dot = T(0);
-    for (int64_t e = lane; e < d; e += WAVE) dot += ap[e] * x[e];
+    for (int64_t e = lane; e < d; e += WAVE) dot += (ap ? ap[e] : T(0)) * x[e];
     dot = wave_allsum(dot);
     const T bi = b ? b[i] : T(0);
     const GradCoef<T> g = grad_coef(loss, dot, bi, lam);
-    for (int64_t e = lane; e < d; e += WAVE) y[e] = g.elem(ap[e]);
+    for (int64_t e = lane; e < d; e += WAVE) y[e] = g.elem(ap ? ap[e] : T(0));
     if (fval && lane == 0) *fval = loss_value(loss, dot, bi, lam);
 }
 

@@ -115,9 +115,14 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
         return r;
     };
     auto load_row = [&](V(&r)[K], int64_t row) {
-        const V *ap = reinterpret_cast<const V *>(a.A + row * a.ld);
+        if (a.A) {
+            const V *ap = reinterpret_cast<const V *>(a.A + row * a.ld);
 #pragma unroll
-        for (int k = 0; k < K; ++k) r[k] = ap[k * WAVE + lane];
+            for (int k = 0; k < K; ++k) r[k] = ap[k * WAVE + lane];
+        } else {   // F = fill(Zero(), N): there is no data matrix at all
+#pragma unroll
+            for (int k = 0; k < K; ++k) r[k] = V(T(0));
+        }
     };
 
     // one row: dot(s) -> link function -> rank-1 accumulate (+ table update)
@@ -301,11 +306,11 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
             if (lane == 0) *a.errflag = 1;
             row = 0;
         }
-        const T *ap = a.A + row * a.ld;
+        const T *ap = a.A ? a.A + row * a.ld : nullptr;
         const T bi = a.b ? a.b[row] : T(0);
         T d1 = T(0), d2 = T(0);
         for (int64_t e = lane; e < d; e += WAVE) {
-            const T av = ap[e];
+            const T av = ap ? ap[e] : T(0);
             d1 += av * x1s[e];
             if (TWO) d2 += av * x2s[e];
         }
@@ -315,17 +320,17 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
         T *tp = a.table ? a.table + row * d : nullptr;
         if (MODE == RM_GRAD) {
             const T c = g1.coef();
-            for (int64_t e = lane; e < d; e += WAVE) acc[e] += c * ap[e];
+            for (int64_t e = lane; e < d; e += WAVE) acc[e] += c * (ap ? ap[e] : T(0));
             if (a.want_fval) extra += loss_value(a.loss, d1, bi, a.lam);
         } else if (MODE == RM_GRAD2) {
             const GradCoef<T> g2 = grad_coef(a.loss, d2, bi, a.lam);
             const T c = g1.coef() - g2.coef();
-            for (int64_t e = lane; e < d; e += WAVE) acc[e] += c * ap[e];
+            for (int64_t e = lane; e < d; e += WAVE) acc[e] += c * (ap ? ap[e] : T(0));
             const T gi = a.gam ? a.gam[row] : a.gam_uniform;
             extra += a.hat_gamma / gi;
         } else if (MODE == RM_SAGA_INIT) {
             for (int64_t e = lane; e < d; e += WAVE) {
-                const T gv = g1.elem(ap[e]);
+                const T gv = g1.elem(ap ? ap[e] : T(0));
                 tp[e] = gv;
                 acc[e] += gv;
             }
@@ -334,7 +339,7 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
             const T cg = gi * a.invN;
             const T rr = (MODE == RM_FINITO_INIT) ? T(1) / gi : a.hat_gamma / gi;
             for (int64_t e = lane; e < d; e += WAVE) {
-                const T tv = x1s[e] - cg * g1.elem(ap[e]);
+                const T tv = x1s[e] - cg * g1.elem(ap ? ap[e] : T(0));
                 if (MODE == RM_FINITO_INIT)
                     acc[e] += tv * rr;
                 else

@@ -1,0 +1,103 @@
+"""CPU-side checks of the drop-in boundary: libciao_hip.so loads and exports every symbol include/ciao_hip.h declares,
+the ctypes prototype table covers exactly that set, the ctypes struct layouts match the C structs, and -- with no GPU in
+this container -- creating a context fails LOUDLY (there is no CPU fallback on the product path)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ciao_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r"CIAO_API\s+[\w\s\*]+?\b(ciao_\w+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = declared_symbols()
+    for must in ("ciao_ctx_create", "ciao_gradient", "ciao_prox", "ciao_full_gradient", "ciao_proxgrad_step", "ciao_svrg_init",
+                 "ciao_svrg_inner", "ciao_svrg_iterate", "ciao_saga_init", "ciao_saga_steps", "ciao_finito_init",
+                 "ciao_finito_steps", "ciao_lfinito_init", "ciao_lfinito_iterate", "ciao_ctx_set_allreduce", "ciao_last_error"):
+        assert must in names
+    assert len(names) >= 28
+
+
+def test_library_exports_every_declared_symbol(ciao):
+    lib = ciao._lib.load()
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} is declared in include/ciao_hip.h but not exported by libciao_hip.so"
+    assert lib.ciao_abi_version() == 1
+
+
+def test_ctypes_table_matches_header(ciao):
+    assert sorted(ciao._lib.SIGNATURES) == declared_symbols()
+
+
+def test_no_unexpected_exports(ciao):
+    """-fvisibility=hidden: only the C ABI is visible (no C++ symbols leak across the boundary)."""
+    out = subprocess.run(["nm", "-D", "--defined-only", ciao._lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = [ln.split()[-1] for ln in out.splitlines() if " T " in ln]
+    assert sorted(syms) == declared_symbols()
+
+
+def test_struct_layouts_match_the_header(ciao, tmp_path):
+    """Compile a tiny C program against the header and compare sizeof/offsetof with the ctypes mirrors."""
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ciao_hip.h"\nint main(void){\n'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ciao_problem), offsetof(ciao_problem,dtype),'
+                   ' offsetof(ciao_problem,N), offsetof(ciao_problem,d), offsetof(ciao_problem,ld), offsetof(ciao_problem,N_total),'
+                   ' offsetof(ciao_problem,A), offsetof(ciao_problem,b), offsetof(ciao_problem,lam), sizeof(ciao_prox_desc));\n'
+                   'printf("%zu %zu %zu %zu %zu\\n", offsetof(ciao_prox_desc,lam), offsetof(ciao_prox_desc,lo), offsetof(ciao_prox_desc,hi),'
+                   ' offsetof(ciao_prox_desc,lo_vec), offsetof(ciao_prox_desc,hi_vec));\nreturn 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    a, b = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")[:2]
+    P, G = ciao._lib.Problem, ciao._lib.ProxDesc
+    assert [int(v) for v in a.split()] == [C.sizeof(P), P.dtype.offset, P.N.offset, P.d.offset, P.ld.offset, P.N_total.offset,
+                                           P.A.offset, P.b.offset, P.lam.offset, C.sizeof(G)]
+    assert [int(v) for v in b.split()] == [G.lam.offset, G.lo.offset, G.hi.offset, G.lo_vec.offset, G.hi_vec.offset]
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary must be consumable from C (and therefore from Julia's ccall): compile the header as C11, pedantic."""
+    src = tmp_path / "inc.c"
+    src.write_text('#include "ciao_hip.h"\nint main(void){return CIAO_ABI_VERSION - 1;}\n')
+    subprocess.run(["gcc", "-std=c11", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                    "-o", str(tmp_path / "inc.o")], check=True)
+
+
+def test_context_creation_fails_loudly_without_a_gpu(ciao):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for the GPU-less container")
+    lib = ciao._lib.load()
+    h = C.c_void_p()
+    st = lib.ciao_ctx_create(0, None, C.byref(h))
+    assert st == ciao._lib.ERR_HIP and not h.value
+    assert b"HIP error" in lib.ciao_last_error()
+    from ciaoalgorithms_jl_amd.device import Context
+    with pytest.raises(ciao._lib.CiaoError):
+        Context(0)
+
+
+def test_null_arguments_are_rejected_before_any_launch(ciao):
+    lib = ciao._lib.load()
+    assert lib.ciao_ctx_create(0, None, None) == ciao._lib.ERR_ARG
+    assert lib.ciao_full_gradient(None, None, None, None) == ciao._lib.ERR_ARG
+    assert lib.ciao_ctx_synchronize(None) == ciao._lib.ERR_ARG
+    assert lib.ciao_ctx_destroy(None) == ciao._lib.OK
+
+
+def test_product_package_never_touches_the_oracle():
+    """No file of the product package may import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "ciaoalgorithms.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".inc", ".jl", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                for bad in ("from oracle", "import oracle", "ciao_oracle", "libciao_oracle", "orc_"):
+                    assert bad not in text, f"{os.path.join(dirpath, f)} references the oracle ({bad})"

@@ -1,0 +1,293 @@
+"""The reference's own end-to-end tests, run through the device path (solver API -> C ABI -> HIP kernels).
+
+Mirrors test/test_logistic_l1.jl (literal fixture, hard-coded x_star) and test/test_lasso.jl (known-answer generator)
+of /root/reference, testset by testset, for the algorithms on the hot path: Finito basic (3 sweeps, minibatch),
+LFinito, scalar gamma / scalar L, SVRG, SVRG++, SAGA, SAG, and the iterator / solution / eltype / maxit=1 pins.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api(ciao, ctx):
+    import ciaoalgorithms_jl_amd.operators as ops
+    import ciaoalgorithms_jl_amd.solvers as S
+    return S, ops
+
+
+def logistic_problem(ops, T):
+    A, y, L, lam, x0, x_star = P.logistic_fixture(T)
+    N, n = A.shape
+    # F exactly as the reference builds it (test_logistic_l1.jl:33-41): N one-row operator objects
+    F = [ops.Precompose(ops.LogisticLoss([y[i]], 1.0), A[i].reshape(1, n), 1.0) for i in range(N)]
+    return F, ops.NormL1(lam), L, x0, x_star, N
+
+
+def lasso_problem(ops, T):
+    A, b, L, lam, x0, x_star, f_star = P.lasso_known_answer(dtype=T)
+    N, n = A.shape
+    F = [ops.LeastSquares(A[i:i + 1, :], b[i:i + 1], float(N)) for i in range(N)]   # test_lasso.jl:52-54
+    return F, ops.NormL1(lam), L, x0, N, (lambda x: P.lasso_cost(A, b, lam, x)), f_star
+
+
+# ======================================================================================================================
+# test/test_logistic_l1.jl
+# ======================================================================================================================
+class TestLogisticL1:
+    T = np.float64
+    maxit, tol = 9000, 1e-4
+
+    @pytest.mark.parametrize("sweeping", [1, 2, 3])
+    def test_nominal_finito(self, api, ciao, sweeping):                     # :55-59
+        S, ops = api
+        F, g, L, x0, x_star, N = logistic_problem(ops, self.T)
+        solver = S.Finito(self.T, maxit=self.maxit, sweeping=sweeping)
+        x, it = solver(x0, F=F, g=g, L=L, N=N)
+        assert np.abs(x - x_star).max() < self.tol and it == self.maxit
+
+    @pytest.mark.parametrize("sweeping", [2, 3])
+    def test_lfinito(self, api, sweeping):                                  # :62-68
+        S, ops = api
+        F, g, L, x0, x_star, N = logistic_problem(ops, self.T)
+        x, it = S.Finito(self.T, maxit=self.maxit, sweeping=sweeping, LFinito=True)(x0, F=F, g=g, L=L, N=N)
+        assert np.abs(x - x_star).max() < self.tol
+
+    @pytest.mark.parametrize("sweeping,batch", [(1, 2), (2, 2), (3, 3)])
+    def test_finito_minibatch(self, api, sweeping, batch):                  # :71-81
+        S, ops = api
+        F, g, L, x0, x_star, N = logistic_problem(ops, self.T)
+        x, it = S.Finito(self.T, maxit=self.maxit, sweeping=sweeping, minibatch=(True, batch))(x0, F=F, g=g, L=L, N=N)
+        assert np.abs(x - x_star).max() < self.tol
+
+    @pytest.mark.parametrize("sweeping,batch", [(2, 1), (2, 2), (3, 3)])
+    def test_lfinito_minibatch(self, api, sweeping, batch):                 # :84-93
+        S, ops = api
+        F, g, L, x0, x_star, N = logistic_problem(ops, self.T)
+        x, it = S.Finito(self.T, maxit=self.maxit, sweeping=sweeping, LFinito=True, minibatch=(True, batch))(
+            x0, F=F, g=g, L=L, N=N)
+        assert np.abs(x - x_star).max() < self.tol
+
+    def test_gamma_and_L_as_scalars(self, api):                             # :96-108
+        S, ops = api
+        F, g, L, x0, x_star, N = logistic_problem(ops, self.T)
+        x, _ = S.Finito(self.T, maxit=self.maxit, γ=N / np.max(L))(x0, F=F, g=g, L=L, N=N)
+        assert np.abs(x - x_star).max() < self.tol
+        x, _ = S.Finito(self.T, maxit=self.maxit)(x0, F=F, g=g, L=float(np.max(L)), N=N)
+        assert np.abs(x - x_star).max() < self.tol
+
+    @pytest.mark.parametrize("LFinito", [True, False])
+    def test_finito_iterator(self, api, LFinito):                           # :111-122
+        import torch
+        S, ops = api
+        F, g, L, x0, x_star, N = logistic_problem(ops, self.T)
+        solver = S.Finito(self.T, sweeping=2, LFinito=LFinito, maxit=10)
+        it = S.iterator(solver, x0, F=F, g=g, L=L, N=N)
+        assert it.x0 is x0
+        for k, state in zip(range(2), it):
+            assert S.solution(state) is state.z
+            assert S.solution(state).dtype == torch.float64
+        x_f, n_it = solver(x0, F=F, g=g, L=L, N=N)
+        last = None
+        for k, state in zip(range(10), S.iterator(solver, x0, F=F, g=g, L=L, N=N)):
+            last = state
+        # deterministic cyclic sweep: loop(take(iter, 10)) == solver(maxit=10) EXACTLY (:121)
+        assert np.array_equal(S.solution(last).cpu().numpy(), x_f) and n_it == 10
+
+    def test_svrg(self, api):                                               # :125-137
+        S, ops = api
+        F, g, L, x0, x_star, N = logistic_problem(ops, self.T)
+        γ = 1 / (10 * np.max(L))
+        x, it = S.SVRG(self.T, maxit=self.maxit, γ=γ)(x0, F=F, g=g, N=N)
+        assert np.linalg.norm(x - x_star) < self.tol
+        x, it = S.SVRG(self.T, maxit=16, γ=γ, m=N, plus=True)(x0, F=F, g=g, N=N)
+        assert np.linalg.norm(x - x_star) < self.tol and it == 16
+
+    def test_svrg_iterator(self, api):                                      # :140-154
+        import torch
+        S, ops = api
+        F, g, L, x0, x_star, N = logistic_problem(ops, self.T)
+        γ = 1 / (10 * np.max(L))
+        it = S.iterator(S.SVRG(self.T, γ=γ), x0, F=F, g=g, N=N)
+        assert it.x0 is x0
+        for k, state in zip(range(2), it):
+            assert S.solution(state) is state.z_full
+            assert S.solution(state).dtype == torch.float64
+        first = next(iter(S.iterator(S.SVRG(self.T, γ=γ), x0, F=F, g=g, N=N)))
+        x1, n1 = S.SVRG(self.T, γ=γ, maxit=1)(x0, F=F, g=g, L=L, N=N)
+        assert np.array_equal(S.solution(first).cpu().numpy(), x1) and n1 == 1
+        assert np.array_equal(x1, x0)   # maxit=1 returns (a copy of) x0: SURVEY.md section 3.1
+
+    @pytest.mark.parametrize("sag", [False, True])
+    def test_saga_sag(self, api, sag):                                      # :158-225
+        import torch
+        S, ops = api
+        F, g, L, x0, x_star, N = logistic_problem(ops, self.T)
+        mk = (lambda **kw: S.SAG(self.T, **kw)) if sag else (lambda **kw: S.SAGA(self.T, **kw))
+        x, it = mk(maxit=self.maxit)(x0, F=F, g=g, N=N, L=L)
+        if not sag:   # the reference's own SAGA lines lack @test (:164,:170); SAGA does converge here, SAG only to ~6e-3
+            assert np.linalg.norm(x - x_star) < self.tol
+        else:
+            assert np.linalg.norm(x - x_star) < 5e-2
+        γ = 1 / ((16 if sag else 3) * np.max(L))
+        it = S.iterator(mk(γ=γ), x0, F=F, g=g, N=N)
+        assert it.x0 is x0
+        for k, state in zip(range(2), it):
+            assert S.solution(state) is state.z
+            assert S.solution(state).dtype == torch.float64
+        first = next(iter(S.iterator(mk(γ=γ), x0, F=F, g=g, N=N)))
+        x1, n1 = mk(γ=γ, maxit=1)(x0, F=F, g=g, L=L, N=N)
+        assert np.array_equal(S.solution(first).cpu().numpy(), x1) and n1 == 1
+        # SAGA's init quirk (SAGA_basic.jl:48): z0 = prox_{γ g}((1-γ) x0)
+        lam = 1.0 / N
+        t = (1 - γ) * x0
+        assert np.allclose(x1, np.sign(t) * np.maximum(np.abs(t) - γ * lam, 0), rtol=0, atol=1e-15)
+
+
+# ======================================================================================================================
+# test/test_lasso.jl  (real types only: complex T is outside the device path)
+# ======================================================================================================================
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+class TestLasso:
+    maxit, tol = 1000, 1e-4
+
+    @pytest.mark.parametrize("sweeping", [1, 2, 3])
+    def test_basic_finito(self, api, T, sweeping):                          # :70-75
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        x, it = S.Finito(T, maxit=self.maxit, sweeping=sweeping)(x0, F=F, g=g, L=L, N=N)
+        assert cost(x) - f_star < self.tol
+        assert x.dtype == T
+
+    @pytest.mark.parametrize("sweeping", [2, 3])
+    def test_lfinito(self, api, T, sweeping):                               # :78-85
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        x, it = S.Finito(T, maxit=self.maxit, sweeping=sweeping, LFinito=True)(x0, F=F, g=g, L=L, N=N)
+        assert cost(x) - f_star < self.tol and x.dtype == T
+
+    @pytest.mark.parametrize("sweeping,batch", [(1, 2), (2, 2), (3, 3)])
+    def test_finito_minibatch(self, api, T, sweeping, batch):               # :101-111
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        x, it = S.Finito(T, maxit=self.maxit, sweeping=sweeping, minibatch=(True, batch))(x0, F=F, g=g, L=L, N=N)
+        assert cost(x) - f_star < self.tol and x.dtype == T
+
+    @pytest.mark.parametrize("sweeping,batch", [(2, 1), (2, 2), (3, 3)])
+    def test_lfinito_minibatch(self, api, T, sweeping, batch):              # :114-125
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        x, it = S.Finito(T, maxit=self.maxit, sweeping=sweeping, LFinito=True, minibatch=(True, batch))(
+            x0, F=F, g=g, L=L, N=N)
+        assert cost(x) - f_star < self.tol and x.dtype == T
+
+    def test_gamma_and_L_as_scalars(self, api, T):                          # :128-140
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        x, _ = S.Finito(T, maxit=self.maxit, γ=float(N / np.max(L)))(x0, F=F, g=g, L=L, N=N)
+        assert cost(x) - f_star < self.tol
+        x, _ = S.Finito(T, maxit=self.maxit)(x0, F=F, g=g, L=float(np.max(L)), N=N)
+        assert cost(x) - f_star < self.tol
+
+    @pytest.mark.parametrize("sweeping,LFinito", [(1, False), (2, False), (3, True)])
+    def test_finito_iterator(self, api, T, sweeping, LFinito):              # :143-157
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        it = S.iterator(S.Finito(T, sweeping=sweeping, LFinito=LFinito), x0, F=F, g=g, L=L, N=N)
+        assert it.x0 is x0
+        for k, state in zip(range(2), it):
+            assert S.solution(state) is state.z
+            assert S.solution(state).cpu().numpy().dtype == T
+
+    def test_svrg(self, api, T):                                            # :164-176
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        γ = float(1 / (7 * np.max(L)))
+        x, it = S.SVRG(T, maxit=self.maxit, γ=γ)(x0, F=F, g=g, N=N)
+        assert cost(x) - f_star < self.tol and x.dtype == T
+        x, it = S.SVRG(T, maxit=16, γ=γ, m=1, plus=True)(x0, F=F, g=g, N=N)
+        assert cost(x) - f_star < self.tol and x.dtype == T
+
+    def test_svrg_iterator(self, api, T):                                   # :179-193
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        γ = float(1 / (7 * np.max(L)))
+        it = S.iterator(S.SVRG(T, γ=γ), x0, F=F, g=g, N=N)
+        assert it.x0 is x0
+        for k, state in zip(range(2), it):
+            assert S.solution(state) is state.z_full
+        first = next(iter(S.iterator(S.SVRG(T, γ=γ), x0, F=F, g=g, N=N)))
+        x1, n1 = S.SVRG(T, γ=γ, maxit=1)(x0, F=F, g=g, L=L, N=N)
+        assert np.array_equal(S.solution(first).cpu().numpy(), x1)
+
+    @pytest.mark.parametrize("sag", [False, True])
+    def test_saga_sag(self, api, T, sag):                                   # :199-266
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        mk = (lambda **kw: S.SAG(T, **kw)) if sag else (lambda **kw: S.SAGA(T, **kw))
+        maxit = 10000 if sag else self.maxit                                # :233
+        x, it = mk(maxit=maxit)(x0, F=F, g=g, N=N, L=L)
+        assert cost(x) - f_star < self.tol and x.dtype == T
+        γ = float(1 / ((16 if sag else 3) * np.max(L)))
+        x, it = mk(maxit=maxit, γ=γ)(x0, F=F, g=g, N=N)
+        assert cost(x) - f_star < self.tol and x.dtype == T
+        first = next(iter(S.iterator(mk(γ=γ), x0, F=F, g=g, N=N)))
+        x1, n1 = mk(γ=γ, maxit=1)(x0, F=F, g=g, L=L, N=N)
+        assert np.array_equal(S.solution(first).cpu().numpy(), x1)
+
+
+# ======================================================================================================================
+# configuration errors mirror the reference: @warn + `return nothing` -> solution(nothing) fails; ctor asserts
+# ======================================================================================================================
+def test_missing_stepsize_information(api):
+    S, ops = api
+    F, g, L, x0, x_star, N = logistic_problem(ops, np.float64)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with pytest.raises(TypeError):                                      # solution(nothing): MethodError (SVRG.jl:83)
+            S.SVRG(np.float64, maxit=3)(x0, F=F, g=g, N=N)                  # no γ, no L/μ (SVRG_basic.jl:40-42)
+        with pytest.raises(TypeError):
+            S.SAGA(np.float64, maxit=3)(x0, F=F, g=g, N=N)                  # SAGA_basic.jl:30-32
+        with pytest.raises(TypeError):
+            S.Finito(np.float64, maxit=3)(x0, F=F, g=g, N=N)                # Finito_basic.jl:62-64
+        with pytest.raises(TypeError):
+            S.SVRG(np.float64, maxit=3, plus=True)(x0, F=F, g=g, N=N, L=L, μ=L)   # SVRG++ needs γ (:36-38)
+        assert len(w) >= 4
+    with pytest.raises(AssertionError):
+        S.SVRG(np.float64, γ=-1.0)                                          # SVRG.jl:39
+    with pytest.raises(AssertionError):
+        S.SAGA(np.float64, maxit=0)                                         # SAGA.jl:38
+    with pytest.raises(TypeError):
+        S.SVRG(np.float64, γ=0.1, maxit=2)(x0, F=[object()] * N, g=g, N=N)  # unrecognised operator family: no fallback
+    with pytest.raises(TypeError):
+        S.SVRG(np.float32, γ=0.1, maxit=2)(x0, F=F, g=g, N=N)               # float64 x0 with R=float32: no silent promotion
+
+
+def test_svrg_plus_caps_maxit_at_25(api):
+    S, ops = api
+    F, g, L, x0, x_star, N = logistic_problem(ops, np.float64)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        x, it = S.SVRG(np.float64, maxit=12, γ=1e-3, m=1, plus=True)(x0, F=F, g=g, N=N)
+        assert it == 12 and not w
+    solver = S.SVRG(np.float64, maxit=40, γ=1e-3, m=1, plus=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        # 2^24 inner updates in the last epoch would take minutes; only check the cap logic through the iterable
+        it = solver._iterable(x0, F=F, g=g, N=N)
+        assert solver.plus and solver.maxit > 25                            # SVRG.jl:61-65 -> the functor clamps to 25
+
+
+def test_default_g_and_default_F(api):
+    """g defaults to Zero() (SVRG.jl:49) and F to fill(Zero(), N) (:58): the iterate never moves from x0."""
+    S, ops = api
+    x0 = np.linspace(-1, 1, 7)
+    x, it = S.SVRG(np.float64, γ=0.5, maxit=4)(x0, N=5)
+    assert np.allclose(x, x0, rtol=1e-15, atol=0) and it == 4
+    x, it = S.SAGA(np.float64, γ=0.5, maxit=4)(x0, N=5)
+    assert np.allclose(x, 0.5 * x0)   # z0 = prox((1-γ) x0) = 0.5 x0, then z <- z - γ*0

@@ -1,0 +1,187 @@
+"""Pins the CPU oracle (oracle/) against the reference's OWN known-answer tests -- the oracle must pass these before
+any GPU-vs-oracle parity claim means anything.
+
+  (1) literal fixture  test/test_logistic_l1.jl:12-29 (8 x 5 data, labels, hard-coded x_star), every asserted testset
+  (2) constructed known answer  test/test_lasso.jl:15-47 (generator restated in tests/problems.py), every algorithm
+  (3) structural pins: solver(maxit=1) == first state; deterministic cyclic iterator == solver; eltype preserved
+  (4) the invariants av == (1/N) sum grad f_i(z_full) (SVRG), av == mean(table) (SAGA), av == hg sum s_i/g_i (Finito)
+"""
+import numpy as np
+import pytest
+
+import problems as P
+from oracle import oracle as O
+from oracle import ref_solvers as RS
+
+
+@pytest.fixture(scope="module")
+def Stream(ciao):
+    return ciao.IndexStream
+
+
+def logistic(dtype=np.float64):
+    A, y, L, lam, x0, x_star = P.logistic_fixture(dtype)
+    return O.Problem("logistic", A, y, 1.0), O.Prox("l1", lam=lam), L, x0, x_star
+
+
+def lasso(dtype):
+    A, b, L, lam, x0, x_star, f_star = P.lasso_known_answer(dtype=dtype)
+    N = A.shape[0]
+    return O.Problem("ls", A, b, float(N)), O.Prox("l1", lam=lam), L, x0, (lambda x: P.lasso_cost(A, b, lam, x)), f_star
+
+
+# ---- (1) test_logistic_l1.jl ---------------------------------------------------------------------------------------------
+class TestLogisticFixture:
+    maxit, tol = 9000, 1e-4
+
+    def test_xstar_is_the_fixed_point(self):
+        """x_star satisfies x = prox_{t g}(x - t * (1/N) sum grad f_i(x)) for the restated operators."""
+        p, g, L, x0, x_star = logistic()
+        grad = O.full_pass(p, x_star)
+        t = 0.1
+        assert np.abs(O.prox(g, x_star - t * grad, t) - x_star).max() < 1e-8
+
+    @pytest.mark.parametrize("sweeping", [1, 2, 3])
+    def test_nominal_finito(self, Stream, sweeping):                        # :55-59
+        p, g, L, x0, x_star = logistic()
+        x, it = RS.finito(p, g, x0, maxit=self.maxit, sweeping=sweeping, L=L, stream=Stream(0))
+        assert np.abs(x - x_star).max() < self.tol and it == self.maxit
+
+    @pytest.mark.parametrize("sweeping", [2, 3])
+    def test_lfinito(self, Stream, sweeping):                               # :62-68
+        p, g, L, x0, x_star = logistic()
+        x, _ = RS.finito(p, g, x0, maxit=self.maxit, sweeping=sweeping, lfinito=True, L=L, stream=Stream(0))
+        assert np.abs(x - x_star).max() < self.tol
+
+    @pytest.mark.parametrize("sweeping,batch", [(1, 2), (2, 2), (3, 3)])
+    def test_finito_minibatch(self, Stream, sweeping, batch):               # :71-81
+        p, g, L, x0, x_star = logistic()
+        x, _ = RS.finito(p, g, x0, maxit=self.maxit, sweeping=sweeping, batch=batch, L=L, stream=Stream(0))
+        assert np.abs(x - x_star).max() < self.tol
+
+    @pytest.mark.parametrize("sweeping,batch", [(2, 1), (2, 2), (3, 3)])
+    def test_lfinito_minibatch(self, Stream, sweeping, batch):              # :84-93
+        p, g, L, x0, x_star = logistic()
+        x, _ = RS.finito(p, g, x0, maxit=self.maxit, sweeping=sweeping, batch=batch, lfinito=True, L=L, stream=Stream(0))
+        assert np.abs(x - x_star).max() < self.tol
+
+    def test_scalar_gamma_and_L(self, Stream):                              # :96-108
+        p, g, L, x0, x_star = logistic()
+        x, _ = RS.finito(p, g, x0, maxit=self.maxit, gamma=p.N / L.max(), L=L, stream=Stream(0))
+        assert np.abs(x - x_star).max() < self.tol
+        x, _ = RS.finito(p, g, x0, maxit=self.maxit, L=float(L.max()), stream=Stream(0))
+        assert np.abs(x - x_star).max() < self.tol
+
+    def test_svrg_and_svrg_plus(self, Stream):                              # :125-137
+        p, g, L, x0, x_star = logistic()
+        gamma = 1 / (10 * L.max())
+        x, _ = RS.svrg(p, g, x0, maxit=self.maxit, gamma=gamma, stream=Stream(0))
+        assert np.linalg.norm(x - x_star) < self.tol
+        x, it = RS.svrg(p, g, x0, maxit=16, gamma=gamma, m=p.N, plus=True, stream=Stream(0))
+        assert np.linalg.norm(x - x_star) < self.tol and it == 16
+
+    def test_saga_converges_sag_does_not_reach_tol(self, Stream):           # :158-205 (lines without @test)
+        p, g, L, x0, x_star = logistic()
+        x, _ = RS.saga(p, g, x0, maxit=self.maxit, L=L, stream=Stream(0))
+        assert np.linalg.norm(x - x_star) < self.tol
+        x, _ = RS.saga(p, g, x0, maxit=self.maxit, L=L, sag=True, stream=Stream(0))
+        assert 1e-4 < np.linalg.norm(x - x_star) < 5e-2   # consistent with the reference not asserting it
+
+    @pytest.mark.parametrize("lf", [True, False])
+    def test_cyclic_iterator_equals_solver_exactly(self, Stream, lf):       # :111-122
+        p, g, L, x0, x_star = logistic()
+        x_f, n = RS.finito(p, g, x0, maxit=10, sweeping=2, lfinito=lf, L=L, stream=Stream(0))
+        cls = RS.LFinitoIterable if lf else RS.FinitoIterable
+        last = None
+        for k, st in zip(range(10), cls(p, g, x0, L, None, 2, 1, 0.999, Stream(0))):
+            last = st
+            assert RS.solution(st) is st.z
+        assert np.array_equal(RS.solution(last), x_f) and n == 10
+
+
+# ---- (2) test_lasso.jl ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T", [np.float32, np.float64])
+class TestLassoKnownAnswer:
+    maxit, tol = 1000, 1e-4
+
+    def test_generator_gives_the_minimiser(self, T):
+        p, g, L, x0, cost, f_star = lasso(np.float64)
+        A, b, _, lam, _, x_star, _ = P.lasso_known_answer()
+        grad = O.full_pass(p, x_star)   # (1/N) sum N a_i (a_i'x - b_i) = A'(Ax - b)
+        assert np.abs(O.prox(g, x_star - 0.05 * grad, 0.05) - x_star).max() < 1e-12
+        assert abs(cost(x_star) - f_star) < 1e-12
+
+    @pytest.mark.parametrize("sweeping", [1, 2, 3])
+    def test_finito(self, Stream, T, sweeping):                             # :70-75
+        p, g, L, x0, cost, f_star = lasso(T)
+        x, _ = RS.finito(p, g, x0, maxit=self.maxit, sweeping=sweeping, L=L, stream=Stream(0))
+        assert cost(x) - f_star < self.tol and x.dtype == T
+
+    @pytest.mark.parametrize("sweeping,batch,lf", [(2, 1, True), (3, 1, True), (1, 2, False), (2, 2, False), (3, 3, False),
+                                                    (2, 2, True), (3, 3, True)])
+    def test_finito_variants(self, Stream, T, sweeping, batch, lf):         # :78-125
+        p, g, L, x0, cost, f_star = lasso(T)
+        x, _ = RS.finito(p, g, x0, maxit=self.maxit, sweeping=sweeping, batch=batch, lfinito=lf, L=L, stream=Stream(0))
+        assert cost(x) - f_star < self.tol and x.dtype == T
+
+    def test_svrg(self, Stream, T):                                         # :164-176
+        p, g, L, x0, cost, f_star = lasso(T)
+        gamma = 1 / (7 * L.max())
+        x, _ = RS.svrg(p, g, x0, maxit=self.maxit, gamma=gamma, stream=Stream(0))
+        assert cost(x) - f_star < self.tol and x.dtype == T
+        x, _ = RS.svrg(p, g, x0, maxit=16, gamma=gamma, m=1, plus=True, stream=Stream(0))
+        assert cost(x) - f_star < self.tol and x.dtype == T
+
+    @pytest.mark.parametrize("sag", [False, True])
+    def test_saga_sag(self, Stream, T, sag):                                # :199-248
+        p, g, L, x0, cost, f_star = lasso(T)
+        x, _ = RS.saga(p, g, x0, maxit=10000 if sag else self.maxit, L=L, sag=sag, stream=Stream(0))
+        assert cost(x) - f_star < self.tol and x.dtype == T
+
+    def test_maxit_one_returns_the_init_state(self, Stream, T):             # :188-192, :224-228
+        p, g, L, x0, cost, f_star = lasso(T)
+        gamma = T(1 / (3 * L.max()))
+        x, n = RS.svrg(p, g, x0, maxit=1, gamma=gamma, stream=Stream(0))
+        assert np.array_equal(x, x0) and n == 1
+        x, n = RS.saga(p, g, x0, maxit=1, gamma=gamma, stream=Stream(0))
+        assert np.array_equal(x, O.prox(g, ((T(1) - gamma) * x0).astype(T), gamma)) and n == 1
+
+
+# ---- (4) invariants ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("loss", ["ls", "logistic"])
+def test_invariants(Stream, loss):
+    A, b, x0 = P.synthetic(loss, 40, 17, np.float64)
+    p = O.Problem(loss, A, b, 40.0 if loss == "ls" else 1.0)
+    g = O.Prox("l1", lam=0.01)
+    st = Stream(3)
+    av, z, zf, w = O.svrg_init(p, x0)
+    O.svrg_iterate(p, g, 0.01, st.rand_indices(40, 80), False, av, z, zf, w)
+    assert np.allclose(av, O.full_pass(p, zf), rtol=0, atol=1e-15)
+    table, av, z = O.saga_init(p, g, 0.01, x0)
+    O.saga_steps(p, g, 0.01, False, st.rand_indices(40, 300), table, av, z)
+    assert np.abs(av - table.mean(axis=0)).max() < 1e-13
+    gam = np.linspace(0.5, 2.0, 40)
+    table, av, z, hg = O.finito_init(p, g, gam, x0)
+    O.finito_steps(p, g, gam, hg, [st.sample_without_replacement(40, 5) for _ in range(30)], table, av, z)
+    assert np.abs(av - hg * (table / gam[:, None]).sum(axis=0)).max() < 1e-12
+
+
+def test_oracle_operators_against_closed_forms():
+    """O1-O4 formulas checked against numpy one-liners and finite differences."""
+    rng = np.random.default_rng(0)
+    a, x = rng.standard_normal(9), rng.standard_normal(9)
+    gy, f = O.gradient(O.LOSS_LS, a, 0.3, 2.5, x)
+    assert np.allclose(gy, 2.5 * (a @ x - 0.3) * a) and np.isclose(f, 1.25 * (a @ x - 0.3) ** 2)
+    for yv in (1.0, -1.0):
+        gy, f = O.gradient(O.LOSS_LOGISTIC, a, yv, 1.0, x)
+        assert np.allclose(gy, -yv * a / (1 + np.exp(yv * (a @ x)))) and np.isclose(f, np.log1p(np.exp(-yv * (a @ x))))
+        eps = 1e-6
+        fd = [(O.gradient(O.LOSS_LOGISTIC, a, yv, 1.0, x + eps * e)[1] - O.gradient(O.LOSS_LOGISTIC, a, yv, 1.0, x - eps * e)[1])
+              / (2 * eps) for e in np.eye(9)]
+        assert np.allclose(gy, fd, atol=1e-8)
+    v = np.array([-2.0, -0.5, 0.0, 0.4, 3.0])
+    assert np.array_equal(O.prox(O.Prox("l1", lam=2.0), v, 0.25), np.sign(v) * np.maximum(np.abs(v) - 0.5, 0))
+    assert np.array_equal(O.prox(O.Prox("zero"), v, 0.25), v)
+    assert np.array_equal(O.prox(O.Prox("box", lo=-1.0, hi=0.5), v, 9.0), np.clip(v, -1.0, 0.5))
+    lo, hi = np.full(5, -0.1), np.array([0.0, 0.1, 0.2, 0.3, 0.4])
+    assert np.array_equal(O.prox(O.Prox("box", lo=lo, hi=hi), v, 9.0), np.clip(v, lo, hi))
