@@ -1,0 +1,109 @@
+"""Secondary measurements reported under "extra" by `bench.py --extras` (and by tools/): the sequential chains
+(SURVEY.md section 8a rows S3, G3, F3 with r = 1) and the batch-parallel table kernels (G2, F2, F3).  These are reported
+honestly against the HBM bound although the chains are latency-bound by construction (one dependent step at a time).
+"""
+import time
+
+import numpy as np
+import torch
+
+
+def _problem(ctx, dev, N, d, tdt, logistic, seed=1):
+    from ciaoalgorithms_jl_amd import _lib as L
+    from ciaoalgorithms_jl_amd.device import PackedF
+    A = torch.empty((N, d), dtype=tdt, device=dev)
+    b = torch.empty((N,), dtype=tdt, device=dev)
+    ctx.synth_normal(A, 0, seed=seed, scale=1.0 / np.sqrt(d))
+    rng = np.random.default_rng(seed)
+    x_true = torch.from_numpy(rng.standard_normal(d) * (rng.random(d) < 0.05)).to(dev, tdt)
+    F = PackedF(L.LOSS_LOGISTIC if logistic else L.LOSS_LS, A, b, 1.0 if logistic else float(N))
+    ctx.synth_targets(F, x_true, noise=0.1, labels=logistic, seed=seed, b_out=b)
+    return F
+
+
+def _timed(ctx, fn, reps=1):
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def run(ctx, dev, quick=False):
+    from ciaoalgorithms_jl_amd import _lib as L
+    from ciaoalgorithms_jl_amd.device import ProxG
+    from ciaoalgorithms_jl_amd.sampling import IndexStream
+    out = {}
+    st = IndexStream(0)
+    scale = 4 if quick else 1
+
+    # ---- S3: SVRG inner cycle (sequential chain), Lasso N=1M d=1024 fp64 ------------------------------------------
+    N, d = 1_000_000 // scale, 1024
+    F = _problem(ctx, dev, N, d, torch.float64, False)
+    g = ProxG(L.PROX_L1, lam=1e-3)
+    gamma = 1.0 / (7 * 1.3 * N)
+    x0 = torch.zeros(d, dtype=torch.float64, device=dev)
+    av, z, zf, w = (torch.empty_like(x0) for _ in range(4))
+    ctx.svrg_init(F, x0, av, z, zf, w)
+    m = 200_000 // scale
+    idx = ctx._idx(st.rand_indices(N, m))
+    ctx.svrg_inner(F, g, gamma, idx[:1000], av, z, zf, w)   # warm
+    t = _timed(ctx, lambda: ctx.svrg_inner(F, g, gamma, idx, av, z, zf, w))
+    out["svrg_inner_f64_d1024"] = {"updates_per_s": m / t, "us_per_update": t / m * 1e6, "m": m, "N": N,
+                                   "alg_GBps": m * (d * 8 + 8) / t / 1e9, "kernel": ctx.last_kernel()}
+    # one full SVRG epoch with m = N (inner chain + tail + sweep)
+    if not quick:
+        idxN = ctx._idx(st.rand_indices(N, N))
+        t = _timed(ctx, lambda: ctx.svrg_iterate(F, g, gamma, idxN, False, av, z, zf, w))
+        out["svrg_epoch_m=N_f64_N1M_d1024"] = {"epochs_per_s": 1.0 / t, "seconds": t}
+    del F, idx
+    torch.cuda.empty_cache()
+
+    # ---- G2 / G3: SAGA init (table write sweep) and SAGA steps, l1-logistic d=1024 fp32 -----------------------------
+    N, d = 2_000_000 // scale, 1024
+    F = _problem(ctx, dev, N, d, torch.float32, True)
+    g = ProxG(L.PROX_L1, lam=1.0 / N)
+    gamma = 1.0 / (3 * 0.25 * 1.3)
+    x0 = torch.ones(d, dtype=torch.float32, device=dev)
+    table = torch.empty((N, d), dtype=torch.float32, device=dev)
+    av, z = torch.empty_like(x0), torch.empty_like(x0)
+    ctx.saga_init(F, g, gamma, x0, table, av, z)
+    ctx.timing_enable(True)
+    ctx.timing_read()
+    ctx.saga_init(F, g, gamma, x0, table, av, z)
+    ms, n = ctx.timing_read()
+    ctx.timing_enable(False)
+    out["saga_init_f32_d1024"] = {"kernel_ms": ms / max(n, 1), "alg_GBps": 2 * N * d * 4 / (ms / max(n, 1) * 1e-3) / 1e9,
+                                  "N": N, "kernel": ctx.last_kernel()}
+    k = 200_000 // scale
+    idx = ctx._idx(st.rand_indices(N, k))
+    ctx.saga_steps(F, g, gamma, False, idx[:1000], table, av, z)
+    t = _timed(ctx, lambda: ctx.saga_steps(F, g, gamma, False, idx, table, av, z))
+    out["saga_steps_f32_d1024"] = {"updates_per_s": k / t, "us_per_update": t / k * 1e6, "steps": k, "N": N,
+                                   "alg_GBps": k * (3 * d * 4 + 8) / t / 1e9, "kernel": ctx.last_kernel()}
+    del F, table, idx
+    torch.cuda.empty_cache()
+
+    # ---- F2 / F3: Finito init and batches, d=4096 fp32 ---------------------------------------------------------------------
+    N, d = 1_000_000 // scale, 4096
+    F = _problem(ctx, dev, N, d, torch.float32, False)
+    g = ProxG(L.PROX_L1, lam=1e-3)
+    gam = torch.full((N,), 0.999 * N / (1.3 * N), dtype=torch.float32, device=dev)
+    hg = ctx.hat_gamma(gam)
+    x0 = torch.zeros(d, dtype=torch.float32, device=dev)
+    table = torch.empty((N, d), dtype=torch.float32, device=dev)
+    av, z = torch.empty_like(x0), torch.empty_like(x0)
+    ctx.finito_init(F, g, gam, hg, x0, table, av, z)
+    for r in (1, 256, 4096, 65536 // scale):
+        nit = max(4, min(20000 // scale, (1 << 18) // r))
+        batches = [st.sample_without_replacement(N, r) for _ in range(nit)]
+        bptr = np.arange(nit + 1, dtype=np.int64) * r
+        bidx = ctx._idx(np.concatenate(batches))
+        ctx.finito_steps(F, g, gam, hg, bptr[:3], bidx[:2 * r], table, av, z)
+        t = _timed(ctx, lambda: ctx.finito_steps(F, g, gam, hg, bptr, bidx, table, av, z))
+        out[f"finito_batch_r{r}_f32_d4096"] = {"samples_per_s": nit * r / t, "iterations_per_s": nit / t,
+                                               "alg_GBps": nit * r * (3 * d * 4 + 16) / t / 1e9, "kernel": ctx.last_kernel()}
+    del F, table
+    torch.cuda.empty_cache()
+    return out

@@ -515,6 +515,8 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "chain_max_batch")) {
         CIAO_REQUIRE(value >= 0, "chain_max_batch must be >= 0");
         ctx->chain_max_batch = value;
+    } else if (!strcmp(key, "chain_no_dma")) {
+        ctx->chain_no_dma = value != 0;
     } else if (!strcmp(key, "force_generic")) {
         ctx->force_generic = value != 0;
     } else {

@@ -40,23 +40,78 @@ struct ChainArgs {
     int *errflag;          // device word set to 1 on an out-of-range index
 };
 
+template <typename T>
+struct VecOfC;
+template <>
+struct VecOfC<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct VecOfC<double> {
+    typedef double type __attribute__((ext_vector_type(2)));
+};
+
 constexpr int CHAIN_NT = 256;
 constexpr int CHAIN_NW = CHAIN_NT / WAVE;
+constexpr int CHAIN_CHUNK = 1024;   // steps whose indices / b_i / gamma_i are staged in LDS at a time
 
 template <int E>
 struct ChainDepth {
     static constexpr int value = E <= 4 ? 8 : (E <= 8 ? 4 : 2);
 };
 
-template <typename T, int E, int ALG>
+// Branch-free prox for one coordinate: soft threshold (gl = tau*lambda, 0 unless NormL1) then clamp (lo/hi = -/+inf
+// unless IndBox).  One straight-line form for Zero / NormL1 / IndBox keeps the dependent chain free of branches.
+template <typename T>
+__device__ __forceinline__ T prox_bf(T v, T gl, T lo, T hi)
+{
+    // soft threshold as v - clamp(v, -gl, gl): the same value as the reference's three-way form for every finite v
+    // (v > gl: v - gl; v < -gl: v + gl; else v - v = 0) in three instructions instead of compares + 64-bit selects
+    const T s = v - fmin2(fmax2(v, -gl), gl);
+    return fmin2(fmax2(s, lo), hi);
+}
+
+// LOSS is a template parameter here (CIAO_LOSS_LS also serves Zero(): lam = 0 and no data), FULL = every thread's E
+// elements are inside the vector (d == E*256): no per-element masks anywhere.
+template <typename T, int LOSS>
+__device__ __forceinline__ GradCoef<T> grad_coef_t(T dot, T bi, T lam)
+{
+    GradCoef<T> g;
+    if (LOSS == CIAO_LOSS_LOGISTIC) {
+        g.s1 = -bi / (T(1) + fexp(bi * dot));
+        g.s2 = T(1);
+    } else {
+        g.s1 = dot - bi;
+        g.s2 = lam;
+    }
+    return g;
+}
+
+// wave-uniform 64-bit value -> SGPR pair
+__device__ __forceinline__ int64_t uniform64(int64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <typename T, int E, int ALG, int LOSS, bool FULL>
 __global__ void __launch_bounds__(CHAIN_NT) chain_kernel(ChainArgs<T> a)
 {
     constexpr int DEPTH = ChainDepth<E>::value;
+    constexpr int CH = CHAIN_CHUNK;
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
     constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
     constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO);
+    static_assert(CH % DEPTH == 0, "ring slots must line up with chunk starts");
 
     __shared__ T red[2][CHAIN_NW][2];
+    // per-chunk staging of everything that is gathered by sample index: rows (with DEPTH entries of history in front
+    // and DEPTH entries of look-ahead behind), b_i, gamma_i and the table-row hazard flags
+    __shared__ int64_t s_row[CH + 2 * DEPTH];
+    __shared__ T s_b[CH];
+    __shared__ T s_g[PER_SAMPLE_GAM ? CH : 1];
+    __shared__ int s_stale[HAS_TABLE ? CH : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -64,168 +119,200 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_kernel(ChainArgs<T> a)
     const int64_t d = a.d;
 
     bool valid[E];
-    int64_t eidx[E];
+    int64_t eidx[E], ecl[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         eidx[j] = tid + (int64_t)j * CHAIN_NT;
-        valid[j] = eidx[j] < d;
+        valid[j] = FULL || eidx[j] < d;
+        ecl[j] = valid[j] ? eidx[j] : d - 1;   // clamped: loads stay unconditional and in bounds
     }
 
     // iterate state in registers:  p = the point the "moving" gradient is taken at (w for SVRG, z otherwise)
-    T av[E], p[E], zf[E], zs[E];
+    T av[E], p[E], zf[E], zs[E], plo[E], phi[E];
+    const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        av[j] = valid[j] ? a.av[eidx[j]] : T(0);
+        av[j] = valid[j] ? a.av[ecl[j]] : T(0);
         if (ALG == CA_SVRG) {
-            p[j] = valid[j] ? a.w[eidx[j]] : T(0);
-            zs[j] = valid[j] ? a.z[eidx[j]] : T(0);
+            p[j] = valid[j] ? a.w[ecl[j]] : T(0);
+            zs[j] = valid[j] ? a.z[ecl[j]] : T(0);
         } else {
-            p[j] = valid[j] ? a.z[eidx[j]] : T(0);
+            p[j] = valid[j] ? a.z[ecl[j]] : T(0);
             zs[j] = T(0);
         }
-        zf[j] = (TWO && valid[j]) ? a.zf[eidx[j]] : T(0);
+        zf[j] = (TWO && valid[j]) ? a.zf[ecl[j]] : T(0);
+        plo[j] = -INFINITY;
+        phi[j] = INFINITY;
+        if (a.g.kind == CIAO_PROX_BOX) {
+            plo[j] = a.g.lo_vec ? a.g.lo_vec[ecl[j]] : a.g.lo;
+            phi[j] = a.g.hi_vec ? a.g.hi_vec[ecl[j]] : a.g.hi;
+        }
     }
 
-    // prefetch rings (statically indexed through full unrolling)
+    // register prefetch rings (statically indexed through full unrolling)
     T ar[DEPTH][E], sr[DEPTH][E];
-    int64_t ring_row[DEPTH];
-    T ring_b[DEPTH], ring_g[DEPTH];
-    bool ring_stale[DEPTH];
-#pragma unroll
-    for (int u = 0; u < DEPTH; ++u) {
-        ring_row[u] = -1;
-        ring_b[u] = T(0);
-        ring_g[u] = T(1);
-        ring_stale[u] = false;
-    }
 
-    auto issue = [&](int u, int64_t step) {
-        if (step < a.nsteps) {
-            int64_t r = a.idx[step];
-            if ((uint64_t)r >= (uint64_t)a.N) {   // memory-safe: flag it, use row 0 (results are void once flagged)
-                if (tid == 0) *a.errflag = 1;
-                r = 0;
-            }
-            bool stale = false;
-            if (HAS_TABLE) {
+    // all loads of the ring refill are unconditional and straight-line, so that the compiler can retire them with
+    // counted s_waitcnt vmcnt(N) instead of draining the queue every step
+    auto refill = [&](int u, int64_t r) {
+        const T *ap = a.A + r * a.ld;   // never null here: Zero() terms alias a finite d-vector with ld = 0 (see launch)
 #pragma unroll
-                for (int u2 = 0; u2 < DEPTH; ++u2) stale |= (ring_row[u2] == r);
-            }
-            ring_row[u] = r;
-            ring_b[u] = a.b ? a.b[r] : T(0);
-            if (PER_SAMPLE_GAM) ring_g[u] = a.gam ? a.gam[r] : a.gam_uniform;
-            ring_stale[u] = stale;
-            const T *ap = a.A + r * a.ld;
+        for (int j = 0; j < E; ++j) ar[u][j] = ap[ecl[j]];
+        if (HAS_TABLE) {
+            const T *sp = a.table + r * d;
 #pragma unroll
-            for (int j = 0; j < E; ++j) ar[u][j] = (valid[j] && a.A) ? ap[eidx[j]] : T(0);
-            if (HAS_TABLE && !stale) {
-                const T *sp = a.table + r * d;
-#pragma unroll
-                for (int j = 0; j < E; ++j) sr[u][j] = valid[j] ? sp[eidx[j]] : T(0);
-            }
+            for (int j = 0; j < E; ++j) sr[u][j] = sp[ecl[j]];
         }
     };
 
-#pragma unroll
-    for (int u = 0; u < DEPTH; ++u) issue(u, u);
-
     int par = 0;
     int64_t inb = 0;   // position of the current sample inside its batch (FINITO / LFINITO)
-    for (int64_t base = 0; base < a.nsteps; base += DEPTH) {
-#pragma unroll
-        for (int u = 0; u < DEPTH; ++u) {
-            const int64_t step = base + u;
-            if (step >= a.nsteps) break;
-            const int64_t row = ring_row[u];
-            const T bi = ring_b[u];
+    for (int64_t base = 0; base < a.nsteps; base += CH) {
+        const int nch = (int)((a.nsteps - base) < CH ? (a.nsteps - base) : CH);
 
-            if (ALG == CA_LFINITO && inb == 0) {   // Finito_LFinito.jl:92  z = prox(av)
-#pragma unroll
-                for (int j = 0; j < E; ++j) p[j] = valid[j] ? prox_elem(a.g, av[j], a.hat_gamma, eidx[j]) : T(0);
+        // ---- stage this chunk's gathers in LDS --------------------------------------------------------------------------
+        __syncthreads();   // the previous chunk is fully consumed
+        int64_t hist = -1;
+        if (tid < DEPTH && base > 0) hist = s_row[CH + tid];   // last DEPTH rows of the previous (full) chunk
+        __syncthreads();
+        if (tid < DEPTH) s_row[tid] = hist;
+        for (int e = tid; e < nch + DEPTH; e += CHAIN_NT) {
+            int64_t st = base + e;
+            if (st > a.nsteps - 1) st = a.nsteps - 1;   // look-ahead past the end repeats the last row (harmless loads)
+            int64_t r = a.idx[st];
+            if ((uint64_t)r >= (uint64_t)a.N) {   // memory-safe: flag it, use row 0 (results are void once flagged)
+                *a.errflag = 1;
+                r = 0;
             }
-            if (HAS_TABLE && ring_stale[u]) {   // the row was rewritten after its prefetch slot was claimed
-                const T *sp = a.table + row * d;
-#pragma unroll
-                for (int j = 0; j < E; ++j) sr[u][j] = valid[j] ? sp[eidx[j]] : T(0);
+            s_row[DEPTH + e] = r;
+            if (e < nch) {
+                s_b[e] = a.b ? a.b[r] : T(0);
+                if (PER_SAMPLE_GAM) s_g[e] = a.gam ? a.gam[r] : a.gam_uniform;
             }
-
-            // block-wide dot products: a_i'p and (TWO) a_i'z_full
-            T d1 = T(0), d2 = T(0);
+        }
+        __syncthreads();
+        if (HAS_TABLE) {
+            for (int e = tid; e < nch; e += CHAIN_NT) {
+                const int64_t r = s_row[DEPTH + e];
+                bool st = false;
 #pragma unroll
-            for (int j = 0; j < E; ++j) {
-                d1 += ar[u][j] * p[j];
-                if (TWO) d2 += ar[u][j] * zf[j];
-            }
-            d1 = wave_allsum(d1);
-            if (TWO) d2 = wave_allsum(d2);
-            if (lane == 0) {
-                red[par][wib][0] = d1;
-                if (TWO) red[par][wib][1] = d2;
+                for (int k = 1; k <= DEPTH; ++k) st |= (s_row[DEPTH + e - k] == r);
+                s_stale[e] = st ? 1 : 0;
             }
             __syncthreads();
-            d1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
-            if (TWO) d2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
-            par ^= 1;
+        }
+        if (base == 0) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) refill(u, uniform64(s_row[DEPTH + u]));
+        }
 
-            const GradCoef<T> gp = grad_coef(a.loss, d1, bi, a.lam);
-            if (ALG == CA_SVRG) {                                            // SVRG_basic.jl:74-81
-                const GradCoef<T> gz = grad_coef(a.loss, d2, bi, a.lam);
+        // ---- the dependent chain ----------------------------------------------------------------------------------------
+        for (int s0 = 0; s0 < nch; s0 += DEPTH) {
 #pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    T t = gz.elem(ar[u][j]) - gp.elem(ar[u][j]);
-                    t -= av[j];
-                    t *= a.gamma;
-                    t += p[j];
-                    p[j] = valid[j] ? prox_elem(a.g, t, a.gamma, eidx[j]) : T(0);
-                    zs[j] += p[j];
+            for (int u = 0; u < DEPTH; ++u) {
+                const int s = s0 + u;
+                if (s >= nch) break;
+                const int64_t row = uniform64(s_row[DEPTH + s]);
+                const int64_t row_n = uniform64(s_row[DEPTH + s + DEPTH]);
+                const T bi = s_b[s];
+
+                if (ALG == CA_LFINITO && inb == 0) {   // Finito_LFinito.jl:92  z = prox(av)
+#pragma unroll
+                    for (int j = 0; j < E; ++j) p[j] = valid[j] ? prox_bf(av[j], a.hat_gamma * plam, plo[j], phi[j]) : T(0);
                 }
-            } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
-                T *sp = a.table + row * d;
+                if (HAS_TABLE && __builtin_amdgcn_readfirstlane(s_stale[s])) {
+                    // an intervening step rewrote this table row after it was prefetched: re-read it (the same thread
+                    // wrote these very elements, so program order makes the new values visible)
+                    const T *sp = a.table + row * d;
+#pragma unroll
+                    for (int j = 0; j < E; ++j) sr[u][j] = sp[ecl[j]];
+                }
+
+                // block-wide dot products: a_i'p and (TWO) a_i'z_full
+                T d1 = T(0), d2 = T(0);
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
-                    const T gn = gp.elem(ar[u][j]);
-                    const T del = (gn - sr[u][j]) * a.invN;
-                    T wv;
-                    if (a.sag) {
-                        av[j] += del;
-                        wv = p[j] - a.gamma * av[j];
-                    } else {
-                        wv = p[j] - a.gamma * (gn - sr[u][j] + av[j]);
-                        av[j] += del;
+                    const T aj = (FULL || valid[j]) ? ar[u][j] : T(0);
+                    d1 += aj * p[j];
+                    if (TWO) d2 += aj * zf[j];
+                }
+                d1 = wave_allsum(d1);
+                if (TWO) d2 = wave_allsum(d2);
+                if (lane == 0) {
+                    red[par][wib][0] = d1;
+                    if (TWO) red[par][wib][1] = d2;
+                }
+                __syncthreads();
+                d1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+                if (TWO) d2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+                par ^= 1;
+
+                const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
+                if (ALG == CA_SVRG) {                                            // SVRG_basic.jl:74-81
+                    const GradCoef<T> gz = grad_coef_t<T, LOSS>(d2, bi, a.lam);
+                    const T gl = a.gamma * plam;
+#pragma unroll
+                    for (int j = 0; j < E; ++j) {
+                        T t = gz.elem(ar[u][j]) - gp.elem(ar[u][j]);
+                        t -= av[j];
+                        t *= a.gamma;
+                        t += p[j];
+                        p[j] = valid[j] ? prox_bf(t, gl, plo[j], phi[j]) : T(0);
+                        zs[j] += p[j];
                     }
-                    p[j] = valid[j] ? prox_elem(a.g, wv, a.gamma, eidx[j]) : T(0);
-                    if (valid[j]) sp[eidx[j]] = gn;
-                }
-            } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
-                const T gi = ring_g[u];
-                const T cg = gi * a.invN;
-                const T rr = a.hat_gamma / gi;
-                T *sp = a.table + row * d;
+                } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
+                    T *sp = a.table + row * d;
+                    const T gl = a.gamma * plam;
 #pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    const T t = p[j] - cg * gp.elem(ar[u][j]);
-                    av[j] += (t - sr[u][j]) * rr;
-                    if (valid[j]) sp[eidx[j]] = t;
-                }
-                if (inb + 1 == a.batch || step + 1 == a.nsteps) {
+                    for (int j = 0; j < E; ++j) {
+                        const T gn = gp.elem(ar[u][j]);
+                        const T del = (gn - sr[u][j]) * a.invN;
+                        T wv;
+                        if (a.sag) {
+                            av[j] += del;
+                            wv = p[j] - a.gamma * av[j];
+                        } else {
+                            wv = p[j] - a.gamma * (gn - sr[u][j] + av[j]);
+                            av[j] += del;
+                        }
+                        p[j] = valid[j] ? prox_bf(wv, gl, plo[j], phi[j]) : T(0);
+                        if (FULL || valid[j]) sp[eidx[j]] = gn;
+                        if (!FULL && !valid[j]) av[j] = T(0);
+                    }
+                } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
+                    const T gi = s_g[s];
+                    const T cg = gi * a.invN;
+                    const T rr = a.hat_gamma / gi;
+                    T *sp = a.table + row * d;
 #pragma unroll
-                    for (int j = 0; j < E; ++j) p[j] = valid[j] ? prox_elem(a.g, av[j], a.hat_gamma, eidx[j]) : T(0);
-                }
-            } else {                                                         // Finito_LFinito.jl:93-98
-                const GradCoef<T> gzf = grad_coef(a.loss, d2, bi, a.lam);
-                const T gi = ring_g[u];
-                const T c = a.hat_gamma * a.invN;
-                const T rr = a.hat_gamma / gi;
+                    for (int j = 0; j < E; ++j) {
+                        const T t = p[j] - cg * gp.elem(ar[u][j]);
+                        av[j] += (t - sr[u][j]) * rr;
+                        if (FULL || valid[j]) sp[eidx[j]] = t;
+                        if (!FULL && !valid[j]) av[j] = T(0);
+                    }
+                    if (inb + 1 == a.batch || (base + s + 1) == a.nsteps) {
+                        const T gl = a.hat_gamma * plam;
 #pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    av[j] += c * gzf.elem(ar[u][j]);
-                    av[j] -= c * gp.elem(ar[u][j]);
-                    av[j] += rr * (p[j] - zf[j]);
+                        for (int j = 0; j < E; ++j) p[j] = valid[j] ? prox_bf(av[j], gl, plo[j], phi[j]) : T(0);
+                    }
+                } else {                                                         // Finito_LFinito.jl:93-98
+                    const GradCoef<T> gzf = grad_coef_t<T, LOSS>(d2, bi, a.lam);
+                    const T gi = s_g[s];
+                    const T c = a.hat_gamma * a.invN;
+                    const T rr = a.hat_gamma / gi;
+#pragma unroll
+                    for (int j = 0; j < E; ++j) {
+                        av[j] += c * gzf.elem(ar[u][j]);
+                        av[j] -= c * gp.elem(ar[u][j]);
+                        av[j] += rr * (p[j] - zf[j]);
+                        if (!FULL && !valid[j]) av[j] = T(0);
+                    }
                 }
-            }
 
-            if (++inb == a.batch) inb = 0;
-            issue(u, step + DEPTH);   // refill this slot (after this step's table store: program order)
+                if (++inb == a.batch) inb = 0;
+                refill(u, row_n);   // after this step's table store (program order); look-ahead entry always exists
+            }
         }
     }
 
@@ -240,6 +327,332 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_kernel(ChainArgs<T> a)
             a.av[eidx[j]] = av[j];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fast chain: LDS-DMA row ring.
+//
+// The register-ring kernel above leaves the waits to hipcc, which drains the whole vector-memory queue once per ring
+// revolution (its s_waitcnt bookkeeping is conservative across the loop back-edge).  Here the prefetched rows never
+// touch a register on their way in: every thread issues `global_load_lds_dwordx4` (16 B per lane, LDS destination =
+// wave base + lane*16) DEPTH steps ahead, and reads back ONLY the 16-byte chunks its own lanes loaded -- so the only
+// ordering needed is the issuing wave's own counted `s_waitcnt vmcnt(N)`, placed by hand (the compiler does not see
+// inline-asm memory operations, cdna_hip_programming.md section 5.7).  Counting, per step and per thread:
+//   J LDS-DMA loads of a_i, and for SAGA/Finito J LDS-DMA loads of the table row + J 16-byte table stores,
+// all unconditional and in program order; ops younger than the slot being consumed = (DEPTH-1) * that.  Anything the
+// compiler adds (the rare hazard re-read, chunk staging) only makes the hardware counter drain further: safe.
+//
+// Ownership: thread t owns the 16-byte chunks t + 256*j, j < J, of every d-vector (d*sizeof(T) == J*256*16).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// vmcnt(0) that hipcc's own wait bookkeeping also sees (simm16: vmcnt[3:0]=0, expcnt[6:4]=7, lgkmcnt[11:8]=15,
+// vmcnt[5:4] in bits 15:14 = 0).  Used where compiler-tracked loads must be retired BEFORE the hand-counted loop, so
+// that hipcc does not re-insert a draining wait for them inside it.
+__device__ __forceinline__ void drain_vmcnt_visible()
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+}
+
+template <int J>
+struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at ~0.25 us per step, within 64 KiB of LDS per ring
+    static constexpr int value = J <= 2 ? 4 : 2;
+};
+
+template <typename T, int J, int ALG, int LOSS>
+__global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
+{
+    using V = typename VecOfC<T>::type;
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int DEPTH = DmaDepth<J>::value;
+    constexpr int CH = CHAIN_CHUNK;
+    constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
+    constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
+    constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO);
+    constexpr int OPS_PER_STEP = HAS_TABLE ? 3 * J : J;
+    constexpr int WAIT_N = (DEPTH - 1) * OPS_PER_STEP;
+    constexpr int ROW_BYTES = J * CHAIN_NT * 16;
+    static_assert(CH % DEPTH == 0, "ring slots must line up with chunk starts");
+
+    // one dynamic LDS block, carved by hand (16-byte aligned pieces):
+    //   ringA[DEPTH][ROW_BYTES] | ringT[DEPTH][ROW_BYTES] (table algs) | s_row | s_b | s_g | s_stale | red
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned char *ringA = dsm;
+    unsigned char *ringT = ringA + DEPTH * ROW_BYTES;
+    unsigned char *cur = ringT + (HAS_TABLE ? DEPTH * ROW_BYTES : 0);
+    int64_t *s_row = reinterpret_cast<int64_t *>(cur);
+    cur += (CH + 2 * DEPTH) * sizeof(int64_t);
+    T *s_b = reinterpret_cast<T *>(cur);
+    cur += CH * sizeof(T);
+    T *s_g = reinterpret_cast<T *>(cur);
+    cur += (PER_SAMPLE_GAM ? CH : 0) * sizeof(T);
+    int *s_stale = reinterpret_cast<int *>(cur);
+    cur += (HAS_TABLE ? CH : 0) * sizeof(int);
+    cur += (16 - (reinterpret_cast<uintptr_t>(cur) & 15)) & 15;
+    T(*red)[CHAIN_NW][2] = reinterpret_cast<T(*)[CHAIN_NW][2]>(cur);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t d = a.d;
+    const uint32_t ringA_off = (uint32_t)(uintptr_t)ringA;   // LDS byte offsets (low 32 bits of the flat address)
+    const uint32_t ringT_off = (uint32_t)(uintptr_t)ringT;
+
+    // iterate state, in 16-byte chunks
+    V av[J], p[J], zf[J], zs[J], plo[J], phi[J];
+    const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int64_t c = tid + (int64_t)j * CHAIN_NT;
+        av[j] = reinterpret_cast<const V *>(a.av)[c];
+        if (ALG == CA_SVRG) {
+            p[j] = reinterpret_cast<const V *>(a.w)[c];
+            zs[j] = reinterpret_cast<const V *>(a.z)[c];
+        } else {
+            p[j] = reinterpret_cast<const V *>(a.z)[c];
+            zs[j] = V(T(0));
+        }
+        zf[j] = TWO ? reinterpret_cast<const V *>(a.zf)[c] : V(T(0));
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            plo[j][v] = -INFINITY;
+            phi[j][v] = INFINITY;
+            if (a.g.kind == CIAO_PROX_BOX) {
+                plo[j][v] = a.g.lo_vec ? a.g.lo_vec[c * VEC + v] : a.g.lo;
+                phi[j][v] = a.g.hi_vec ? a.g.hi_vec[c * VEC + v] : a.g.hi;
+            }
+        }
+    }
+
+    // issue the DMA of row r into ring slot u: J (+J) wave-instructions of 1 KiB each
+    auto refill = [&](int u, int64_t r) {
+        const unsigned char *ap = reinterpret_cast<const unsigned char *>(a.A + r * a.ld);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            glds16(ap + ((int64_t)j * CHAIN_NT + tid) * 16, ringA_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
+        if (HAS_TABLE) {
+            const unsigned char *sp = reinterpret_cast<const unsigned char *>(a.table + r * d);
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                glds16(sp + ((int64_t)j * CHAIN_NT + tid) * 16, ringT_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
+        }
+    };
+
+    int par = 0;
+    int64_t inb = 0;
+    for (int64_t base = 0; base < a.nsteps; base += CH) {
+        const int nch = (int)((a.nsteps - base) < CH ? (a.nsteps - base) : CH);
+
+        // ---- stage this chunk's gathers in LDS (ordinary loads: the compiler drains the queue here, once per chunk) ----
+        __syncthreads();
+        int64_t hist = -1;
+        if (tid < DEPTH && base > 0) hist = s_row[CH + tid];
+        __syncthreads();
+        if (tid < DEPTH) s_row[tid] = hist;
+        for (int e = tid; e < nch + DEPTH; e += CHAIN_NT) {
+            int64_t st = base + e;
+            if (st > a.nsteps - 1) st = a.nsteps - 1;
+            int64_t r = a.idx[st];
+            if ((uint64_t)r >= (uint64_t)a.N) {
+                *a.errflag = 1;
+                r = 0;
+            }
+            s_row[DEPTH + e] = r;
+            if (e < nch) {
+                s_b[e] = a.b ? a.b[r] : T(0);
+                if (PER_SAMPLE_GAM) s_g[e] = a.gam ? a.gam[r] : a.gam_uniform;
+            }
+        }
+        __syncthreads();
+        if (HAS_TABLE) {
+            for (int e = tid; e < nch; e += CHAIN_NT) {
+                const int64_t r = s_row[DEPTH + e];
+                bool st = false;
+#pragma unroll
+                for (int k = 1; k <= DEPTH; ++k) st |= (s_row[DEPTH + e - k] == r);
+                s_stale[e] = st ? 1 : 0;
+            }
+            __syncthreads();
+        }
+        if (base == 0) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) refill(u, uniform64(s_row[DEPTH + u]));
+        }
+        wait_vmcnt<0>();          // ring fully landed: the counted waits below assume the steady-state op sequence
+        drain_vmcnt_visible();    // ... and hipcc knows that the state / staging loads are retired too
+
+        // ---- the dependent chain ----------------------------------------------------------------------------------------
+        for (int s0 = 0; s0 < nch; s0 += DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                const int s = s0 + u;
+                if (s >= nch) break;
+                const int64_t row = uniform64(s_row[DEPTH + s]);
+                const int64_t row_n = uniform64(s_row[DEPTH + s + DEPTH]);
+                const T bi = s_b[s];
+
+                if (ALG == CA_LFINITO && inb == 0) {   // Finito_LFinito.jl:92  z = prox(av)
+                    const T gl = a.hat_gamma * plam;
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) p[j][v] = prox_bf(av[j][v], gl, plo[j][v], phi[j][v]);
+                }
+
+                wait_vmcnt<WAIT_N>();   // slot u's DMA (issued DEPTH steps ago) has landed in LDS
+                V ar[J], sr[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
+                    if (HAS_TABLE) sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
+                }
+                if (HAS_TABLE && __builtin_amdgcn_readfirstlane(s_stale[s])) {
+                    // an intervening step rewrote this table row after its DMA was issued: re-read it from memory (this
+                    // very thread stored these bytes, so program order makes them visible)
+                    const V *sp = reinterpret_cast<const V *>(a.table + row * d);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) sr[j] = sp[tid + j * CHAIN_NT];
+                }
+
+                T d1 = T(0), d2 = T(0);
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        d1 = fmad(ar[j][v], p[j][v], d1);
+                        if (TWO) d2 = fmad(ar[j][v], zf[j][v], d2);
+                    }
+                d1 = wave_allsum(d1);
+                if (TWO) d2 = wave_allsum(d2);
+                if (lane == 0) {
+                    red[par][wib][0] = d1;
+                    if (TWO) red[par][wib][1] = d2;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue
+                d1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+                if (TWO) d2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+                par ^= 1;
+
+                const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
+                if (ALG == CA_SVRG) {                                            // SVRG_basic.jl:74-81
+                    const GradCoef<T> gz = grad_coef_t<T, LOSS>(d2, bi, a.lam);
+                    const T gl = a.gamma * plam;
+                    const T dc = gz.coef() - gp.coef();   // temp = gamma*(a*(c_z - c_w) - av) + w, two FMAs per coordinate
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const T u2 = fmad(ar[j][v], dc, -av[j][v]);
+                            const T t = fmad(a.gamma, u2, p[j][v]);
+                            p[j][v] = prox_bf(t, gl, plo[j][v], phi[j][v]);
+                            zs[j][v] += p[j][v];
+                        }
+                } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
+                    V *sp = reinterpret_cast<V *>(a.table + row * d);
+                    const T gl = a.gamma * plam;
+                    const T cp = gp.coef();
+                    const T ngam = -a.gamma;
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        V gnv;
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const T gn = ar[j][v] * cp;
+                            const T del = gn - sr[j][v];
+                            T wv;
+                            if (a.sag) {
+                                av[j][v] = fmad(del, a.invN, av[j][v]);
+                                wv = fmad(ngam, av[j][v], p[j][v]);
+                            } else {
+                                wv = fmad(ngam, del + av[j][v], p[j][v]);
+                                av[j][v] = fmad(del, a.invN, av[j][v]);
+                            }
+                            p[j][v] = prox_bf(wv, gl, plo[j][v], phi[j][v]);
+                            gnv[v] = gn;
+                        }
+                        sp[tid + j * CHAIN_NT] = gnv;
+                    }
+                } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
+                    const T gi = s_g[s];
+                    const T ncc = -(gi * a.invN) * gp.coef();   // t = z - (gamma_i/N) * c * a
+                    const T rr = a.hat_gamma / gi;
+                    V *sp = reinterpret_cast<V *>(a.table + row * d);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        V tv;
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            tv[v] = fmad(ncc, ar[j][v], p[j][v]);
+                            av[j][v] = fmad(tv[v] - sr[j][v], rr, av[j][v]);
+                        }
+                        sp[tid + j * CHAIN_NT] = tv;
+                    }
+                    if (inb + 1 == a.batch || (base + s + 1) == a.nsteps) {
+                        const T gl = a.hat_gamma * plam;
+#pragma unroll
+                        for (int j = 0; j < J; ++j)
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) p[j][v] = prox_bf(av[j][v], gl, plo[j][v], phi[j][v]);
+                    }
+                } else {                                                         // Finito_LFinito.jl:93-98
+                    const GradCoef<T> gzf = grad_coef_t<T, LOSS>(d2, bi, a.lam);
+                    const T gi = s_g[s];
+                    const T dc = (a.hat_gamma * a.invN) * (gzf.coef() - gp.coef());
+                    const T rr = a.hat_gamma / gi;
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            av[j][v] = fmad(ar[j][v], dc, av[j][v]);
+                            av[j][v] = fmad(rr, p[j][v] - zf[j][v], av[j][v]);
+                        }
+                }
+
+                if (++inb == a.batch) inb = 0;
+                refill(u, row_n);   // after this step's table stores (program order); the look-ahead entry always exists
+            }
+        }
+    }
+    wait_vmcnt<0>();   // nothing may still be writing LDS when the workgroup retires
+
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int64_t c = tid + (int64_t)j * CHAIN_NT;
+        if (ALG == CA_SVRG) {
+            reinterpret_cast<V *>(a.w)[c] = p[j];
+            reinterpret_cast<V *>(a.z)[c] = zs[j];
+        } else {
+            reinterpret_cast<V *>(a.z)[c] = p[j];
+            reinterpret_cast<V *>(a.av)[c] = av[j];
+        }
+    }
+}
+
+template <typename T, int J, int ALG>
+constexpr size_t chain_dma_lds_bytes()
+{
+    constexpr int DEPTH = DmaDepth<J>::value;
+    constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
+    constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO);
+    return (size_t)DEPTH * J * CHAIN_NT * 16 * (HAS_TABLE ? 2 : 1) + (CHAIN_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
+           CHAIN_CHUNK * sizeof(T) * (PER_SAMPLE_GAM ? 2 : 1) + (HAS_TABLE ? CHAIN_CHUNK * sizeof(int) : 0) + 16 +
+           2 * CHAIN_NW * 2 * sizeof(T);
 }
 
 // single-sample gradient!(y, f_i, x) -- the L1 plugin call itself (one wave).

@@ -62,6 +62,12 @@ __device__ __forceinline__ T wave_allsum(T v)
 // ------------------------------------------------------------------------------------------------------------------
 // Operators (ProximalOperators.jl 0.14 formulas)
 // ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fmad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fmin2(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double fmin2(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float fmax2(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double fmax2(double a, double b) { return __builtin_fmax(a, b); }
 __device__ __forceinline__ float fexp(float x) { return expf(x); }
 __device__ __forceinline__ double fexp(double x) { return exp(x); }
 __device__ __forceinline__ float flog(float x) { return logf(x); }

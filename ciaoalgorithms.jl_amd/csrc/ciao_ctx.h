@@ -32,6 +32,8 @@ struct ciao_ctx {
     int64_t sweep_blocks_per_cu = 4;
     int64_t sweep_prefetch = 1;     // gradient sweeps: 1 = two-deep register pipeline, 0 = occupancy only
     int64_t chain_max_batch = 64;   // Finito/LFinito batches up to this size run as a sequential chain
+    int64_t chain_no_dma = 0;       // testing: route chains through the register-ring kernel instead of the LDS-DMA one
+    int chain_last_dma = 0;
     int64_t force_generic = 0;      // testing: route every rows launch through the generic kernel
 
     std::string last_kernel;

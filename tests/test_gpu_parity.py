@@ -231,13 +231,22 @@ def test_sweep_is_bitwise_reproducible(ctx):
 # ----------------------------------------------------------------------------------------------------------------------
 # SVRG
 # ----------------------------------------------------------------------------------------------------------------------
-CHAIN_SHAPES = [(6, 3), (8, 5), (50, 50), (40, 256), (30, 300), (64, 1024), (20, 1500), (10, 4096)]
+# d*sizeof(T) a multiple of 4096 B selects the LDS-DMA chain (f64: 512, 1024, 2048, 4096; f32: 1024, 2048, 4096);
+# everything else (and every shape again with chain_no_dma=1) runs the register-ring chain
+CHAIN_SHAPES = [(6, 3), (8, 5), (50, 50), (40, 256), (30, 300), (12, 512), (64, 1024), (20, 1500), (9, 2048), (10, 4096)]
+
+
+@pytest.fixture(params=[0, 1], ids=["dma", "regring"])
+def chain_variant(request, ctx):
+    ctx.set_option("chain_no_dma", request.param)
+    yield request.param
+    ctx.set_option("chain_no_dma", 0)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("loss", ["ls", "logistic"])
 @pytest.mark.parametrize("shape", CHAIN_SHAPES)
-def test_svrg_epochs(ctx, ciao, dtype, loss, shape):
+def test_svrg_epochs(ctx, ciao, chain_variant, dtype, loss, shape):
     """init + 3 x Base.iterate (inner cycle m = 2N, tail, full pass) vs the oracle, same index stream."""
     import torch
     from oracle import oracle as O
@@ -303,7 +312,7 @@ def test_svrg_plus_and_inner_only(ctx, ciao, dtype):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("sag", [False, True])
 @pytest.mark.parametrize("shape", CHAIN_SHAPES)
-def test_saga_steps(ctx, ciao, dtype, sag, shape):
+def test_saga_steps(ctx, ciao, chain_variant, dtype, sag, shape):
     """Table init + 4N steps.  Small N makes repeated indices inside the prefetch window the common case, which is
     exactly the read-after-write hazard of the table-row prefetch."""
     import torch
@@ -356,9 +365,9 @@ def _batches(stream, N, r, nit, mode):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape,r", [((6, 3), 1), ((8, 5), 2), ((8, 5), 3), ((50, 50), 7), ((40, 256), 1), ((64, 1024), 16),
-                                     ((300, 64), 100), ((20, 1500), 4), ((10, 4096), 3)])
+                                     ((300, 64), 100), ((20, 1500), 4), ((10, 4096), 3), ((33, 2048), 1)])
 @pytest.mark.parametrize("chain_max", [64, 0])
-def test_finito_steps(ctx, ciao, dtype, shape, r, chain_max):
+def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, chain_max):
     """chain_max=64: batches run in the sequential chain kernel; chain_max=0: every batch goes batch-parallel."""
     import torch
     from oracle import oracle as O
@@ -403,9 +412,9 @@ def test_finito_steps(ctx, ciao, dtype, shape, r, chain_max):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape,r", [((6, 3), 1), ((8, 5), 2), ((8, 5), 3), ((50, 50), 7), ((64, 1024), 16), ((300, 64), 100),
-                                     ((20, 1500), 1)])
+                                     ((20, 1500), 1), ((17, 2048), 2)])
 @pytest.mark.parametrize("chain_max", [64, 0])
-def test_lfinito_iterations(ctx, ciao, dtype, shape, r, chain_max):
+def test_lfinito_iterations(ctx, ciao, chain_variant, dtype, shape, r, chain_max):
     import torch
     from oracle import oracle as O
     N, d = shape
