@@ -60,7 +60,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        rank, world, local = init_process_group_from_env("nccl")
+        # RCCL ("nccl") is the product path; CIAO_BENCH_BACKEND=gloo exists only to rehearse several ranks on ONE GPU
+        rank, world, local = init_process_group_from_env(os.environ.get("CIAO_BENCH_BACKEND", "nccl"))
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:

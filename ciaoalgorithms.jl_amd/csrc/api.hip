@@ -285,7 +285,8 @@ static int32_t finito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_p
     int64_t t = 0;
     while (t < nit) {
         const int64_t r = bptr[t + 1] - bptr[t];
-        CIAO_REQUIRE(r >= 1, "Finito batch %lld is empty", (long long)t);
+        // on a row-sharded problem a batch may have no member on this rank: it still joins the all-reduce with a zero sum
+        CIAO_REQUIRE(r >= 1 || (ctx->hook && r == 0), "Finito batch %lld is empty", (long long)t);
         // a run of consecutive batches of the same size
         int64_t t1 = t + 1;
         while (t1 < nit && bptr[t1 + 1] - bptr[t1] == r) ++t1;
@@ -364,7 +365,7 @@ static int32_t lfinito_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const cia
     int64_t t = 0;
     while (t < nb) {
         const int64_t r = bptr[t + 1] - bptr[t];
-        CIAO_REQUIRE(r >= 1, "LFinito batch %lld is empty", (long long)t);
+        CIAO_REQUIRE(r >= 1 || (ctx->hook && r == 0), "LFinito batch %lld is empty", (long long)t);
         int64_t t1 = t + 1;
         while (t1 < nb && bptr[t1 + 1] - bptr[t1] == r) ++t1;
         if (!ctx->hook && r <= ctx->chain_max_batch) {
@@ -710,7 +711,7 @@ int32_t ciao_finito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
 {
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
-    CIAO_REQUIRE(nit >= 0 && (nit == 0 || (bptr_host && bidx)), "nit < 0 or NULL batch arrays");
+    CIAO_REQUIRE(nit >= 0 && (nit == 0 || (bptr_host && (bidx || bptr_host[nit] == bptr_host[0]))), "nit < 0 or NULL batch arrays");
     CIAO_REQUIRE(nit == 0 || p->N > 0, "cannot sample from an empty problem");
     CIAO_REQUIRE(table && av && z && gam, "NULL state vector / table / gam");
     CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
@@ -731,7 +732,7 @@ int32_t ciao_lfinito_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_pr
 {
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
-    CIAO_REQUIRE(nb >= 0 && (nb == 0 || (bptr_host && bidx)), "nb < 0 or NULL batch arrays");
+    CIAO_REQUIRE(nb >= 0 && (nb == 0 || (bptr_host && (bidx || bptr_host[nb] == bptr_host[0]))), "nb < 0 or NULL batch arrays");
     CIAO_REQUIRE(av && z && z_full && gam, "NULL state vector / gam");
     CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
     return DISPATCH(p->dtype, lfinito_iterate_t, ctx, p, g, gam, hat_gamma, nb, bptr_host, bidx, av, z, z_full);

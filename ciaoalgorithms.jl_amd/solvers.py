@@ -266,8 +266,6 @@ class FINITO_basic_iterable(_Iterable):
         batches = [_localise(self, self._next_batch(st)) for _ in range(n)]
         bptr = np.zeros(n + 1, np.int64)
         np.cumsum([len(b) for b in batches], out=bptr[1:])
-        if self.F.N != self.N and any(len(b) == 0 for b in batches):
-            raise ValueError("a Finito batch has no member on this rank: use batches that span all ranks")
         bidx = np.concatenate(batches) if batches else np.zeros(0, np.int64)
         self.ctx.finito_steps(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.s, st.av, st.z)
 
@@ -307,8 +305,6 @@ class FINITO_LFinito_iterable(_Iterable):
                 bidx = np.arange(N, dtype=np.int64)
             else:
                 batches = [_localise(self, _static_batch(N, r, int(j))) for j in st.inds]
-                if self.F.N != self.N and any(len(b) == 0 for b in batches):
-                    raise ValueError("an LFinito batch has no member on this rank: use batches that span all ranks")
                 bptr = np.zeros(len(batches) + 1, np.int64)
                 np.cumsum([len(b) for b in batches], out=bptr[1:])
                 bidx = np.concatenate(batches) if batches else np.zeros(0, np.int64)

@@ -1,0 +1,101 @@
+"""Row-sharded path on real hardware: two ranks share the one GPU of the test box (gloo rendezvous on 127.0.0.1; the
+all-reduce hook stages through host memory because RCCL refuses two ranks on one device).  Everything else -- the
+sharded rows kernels, the raw-sum hand-off to the hook, the epilogue after the reduce -- is the product path that the
+8-GPU run uses with backend "nccl".  Checked against the CPU oracle on the WHOLE problem."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    import ciao_loader
+    ciao_loader.load()
+    from ciaoalgorithms_jl_amd import _lib as L
+    from ciaoalgorithms_jl_amd.device import Context, PackedF, ProxG
+    from ciaoalgorithms_jl_amd.parallel import AllReduceHook, shard_rows
+    from ciaoalgorithms_jl_amd.solvers import Finito
+    from ciaoalgorithms_jl_amd.sampling import IndexStream
+    from oracle import oracle as O
+    from oracle import ref_solvers as RS
+    import problems as P
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = {}
+    try:
+        dev = torch.device("cuda", 0)
+        ctx = Context(0)
+        hook = AllReduceHook(dev)
+        ctx.set_allreduce(hook)
+        N, d = 403, 1024
+        A, b, x = P.synthetic("ls", N, d, np.float64, seed=12)
+        row0, n = shard_rows(N, rank, world)
+        F = PackedF(L.LOSS_LS, torch.from_numpy(A[row0:row0 + n]).to(dev), torch.from_numpy(b[row0:row0 + n]).to(dev), float(N),
+                    N_total=N, row0=row0)
+        g = ProxG(L.PROX_L1, lam=0.01)
+        og, op = O.Prox("l1", lam=0.01), O.Problem("ls", A, b, float(N))
+        xd = torch.from_numpy(x).to(dev)
+        av, y = torch.empty_like(xd), torch.empty_like(xd)
+        ctx.proxgrad_step(F, g, 0.05 / N, xd, av, y)
+        rav = O.full_pass(op, x)
+        ry = O.prox(og, x - (0.05 / N) * rav, 0.05 / N)
+        ok["av"] = bool(np.abs(av.cpu().numpy() - rav).max() <= 1e-10 * np.abs(rav).max())
+        ok["y"] = bool(np.abs(y.cpu().numpy() - ry).max() <= 1e-10 * max(np.abs(ry).max(), 1e-30) + 1e-14)
+        ok["hook_calls"] = hook.calls == 1
+        obj = ctx.objective(F, g, xd)
+        ok["objective"] = bool(abs(obj - O.objective(op, og, x)) <= 1e-9 * abs(obj))
+        # sharded Finito (batch-parallel: each rank updates the table rows it owns) and LFinito, through the solver API
+        Li = float(N) * np.sum(A * A, axis=1)
+        for lf in (False, True):
+            solver = Finito(np.float64, maxit=6, sweeping=2, minibatch=(True, 64), LFinito=lf)
+            xs, it = solver(np.zeros(d), F=F, g=g, L=Li, N=N, ctx=ctx, stream=IndexStream(0))
+            xr, _ = RS.finito(op, og, np.zeros(d), maxit=6, sweeping=2, batch=64, lfinito=lf, L=Li, stream=IndexStream(0))
+            ok[f"finito_lf{int(lf)}"] = bool(np.abs(xs - xr).max() <= 1e-9 * max(np.abs(xr).max(), 1e-30) + 1e-13)
+        # replicas stay bitwise identical across ranks
+        gathered = [torch.zeros(d, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, y.cpu())
+        ok["bitwise_replicas"] = all(torch.equal(gathered[0], t) for t in gathered)
+        # the sequential chains refuse a row-sharded problem (replicas only)
+        try:
+            ctx.svrg_inner(F, g, 0.1, np.zeros(3, np.int64), av, y, xd, torch.empty_like(xd))
+            ok["chain_refused"] = False
+        except L.CiaoError:
+            ok["chain_refused"] = True
+        ctx.synchronize()
+        ctx.close()
+        q.put((rank, ok))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, {"exception": repr(e)}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu():
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok in res:
+        assert all(v is True for v in ok.values()), f"rank {rank}: {ok}"
