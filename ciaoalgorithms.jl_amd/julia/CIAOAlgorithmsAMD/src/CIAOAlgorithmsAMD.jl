@@ -1,0 +1,312 @@
+# CIAOAlgorithmsAMD.jl -- Julia host side of the MI355X finite-sum path: the SVRG / SAGA / SAG / Finito constructors,
+# functors, `iterator` and `solution` of kul-optec/CIAOAlgorithms.jl, with the bodies of the hot loops replaced by
+# `ccall`s into libciao_hip.so (include/ciao_hip.h).  AMDGPU.jl is used ONLY for device/stream/buffer handles
+# (ROCArray, its pointer, the HIP stream); no KernelAbstractions, no CUDA.jl.
+#
+# STATUS: written against the C ABI and never executed -- the build image has no `julia` binary (DESIGN.md section 1).
+# The always-runnable twin of this file is ciaoalgorithms.jl_amd/solvers.py, which binds the same symbols with ctypes
+# and is what tests/ exercise.  Every `ccall` below has its ctypes counterpart in _lib.py (same order, same types).
+module CIAOAlgorithmsAMD
+
+using AMDGPU
+using LinearAlgebra
+using Printf
+using Random
+using ProximalOperators
+
+export solution
+
+const RealOrComplex{R} = Union{R,Complex{R}}      # CIAOAlgorithms.jl:3
+const Maybe{T} = Union{T,Nothing}                 # CIAOAlgorithms.jl:4
+
+const libciao = get(ENV, "CIAO_HIP_LIB", "libciao_hip.so")
+
+# ---- C structs (include/ciao_hip.h) ------------------------------------------------------------------------------------
+struct CiaoProblem
+    loss::Int32; dtype::Int32
+    N::Int64; d::Int64; ld::Int64; N_total::Int64
+    A::Ptr{Cvoid}; b::Ptr{Cvoid}
+    lam::Float64
+end
+struct CiaoProxDesc
+    kind::Int32; _pad::Int32
+    lam::Float64; lo::Float64; hi::Float64
+    lo_vec::Ptr{Cvoid}; hi_vec::Ptr{Cvoid}
+end
+const CIAO_F32, CIAO_F64 = Int32(0), Int32(1)
+const LOSS_LS, LOSS_LOGISTIC, LOSS_ZERO = Int32(0), Int32(1), Int32(2)
+const PROX_ZERO, PROX_L1, PROX_BOX = Int32(0), Int32(1), Int32(2)
+dtype_code(::Type{Float32}) = CIAO_F32
+dtype_code(::Type{Float64}) = CIAO_F64
+
+struct CiaoError <: Exception
+    status::Int32
+    msg::String
+end
+function check(status::Int32)
+    status == 0 && return nothing
+    throw(CiaoError(status, unsafe_string(ccall((:ciao_last_error, libciao), Cstring, ()))))
+end
+
+# ---- context: one device + the HIP stream AMDGPU.jl is using ----------------------------------------------------------
+mutable struct Context
+    h::Ptr{Cvoid}
+    function Context(device::Integer = AMDGPU.device_id(AMDGPU.device()) - 1)
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        stream = Base.unsafe_convert(Ptr{Cvoid}, AMDGPU.stream().stream)
+        check(ccall((:ciao_ctx_create, libciao), Int32, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, stream, out))
+        ctx = new(out[])
+        finalizer(c -> ccall((:ciao_ctx_destroy, libciao), Int32, (Ptr{Cvoid},), c.h), ctx)
+        return ctx
+    end
+end
+synchronize(ctx::Context) = check(ccall((:ciao_ctx_synchronize, libciao), Int32, (Ptr{Cvoid},), ctx.h))
+const default_ctx = Ref{Union{Nothing,Context}}(nothing)
+context() = (default_ctx[] === nothing && (default_ctx[] = Context()); default_ctx[])
+
+dptr(a::ROCArray) = Base.unsafe_convert(Ptr{Cvoid}, pointer(a))
+dptr(::Nothing) = C_NULL
+
+# ---- packing: recognise the operator families of the reference's tests (SURVEY.md section 8b) -------------------------
+# F::Vector of one-row LeastSquares / Precompose(LogisticLoss) / Zero  ->  (A as a d x N Julia matrix = row-major N x d)
+struct PackedF{R}
+    loss::Int32
+    A::Union{Nothing,ROCArray{R,2}}     # d x N column-major  ==  N x d row-major, ld = d
+    b::Union{Nothing,ROCArray{R,1}}
+    lam::Float64
+    N::Int
+    d::Int
+end
+function pack_F(::Type{R}, F, N::Int, d::Int) where {R}
+    F isa PackedF{R} && return F
+    if F === nothing || all(f -> f isa ProximalOperators.Zero, F)
+        return PackedF{R}(LOSS_ZERO, nothing, nothing, 0.0, N, d)
+    elseif all(f -> f isa ProximalOperators.LeastSquares, F)
+        lam = F[1].lambda
+        all(f -> f.lambda == lam && size(f.A) == (1, d), F) || throw(ArgumentError("unpackable LeastSquares terms"))
+        A = Matrix{R}(undef, d, N); b = Vector{R}(undef, N)
+        for i in 1:N
+            A[:, i] .= vec(F[i].A); b[i] = F[i].b[1]
+        end
+        return PackedF{R}(LOSS_LS, ROCArray(A), ROCArray(b), Float64(lam), N, d)
+    elseif all(f -> f isa ProximalOperators.Precompose && f.f isa ProximalOperators.LogisticLoss, F)
+        A = Matrix{R}(undef, d, N); y = Vector{R}(undef, N)
+        for i in 1:N
+            size(F[i].L) == (1, d) || throw(ArgumentError("unpackable Precompose term"))
+            A[:, i] .= vec(F[i].L); y[i] = F[i].f.y[1]
+        end
+        return PackedF{R}(LOSS_LOGISTIC, ROCArray(A), ROCArray(y), 1.0, N, d)
+    end
+    throw(ArgumentError("F is not a family the device path can pack (LeastSquares rows, Precompose(LogisticLoss) rows, Zero)"))
+end
+cproblem(p::PackedF{R}) where {R} =
+    CiaoProblem(p.loss, dtype_code(R), p.N, p.d, p.d, p.N, dptr(p.A), dptr(p.b), p.lam)
+
+function pack_g(::Type{R}, g, d::Int) where {R}
+    g isa ProximalOperators.Zero && return (CiaoProxDesc(PROX_ZERO, 0, 0.0, -Inf, Inf, C_NULL, C_NULL), nothing)
+    g isa ProximalOperators.NormL1 && g.lambda isa Real &&
+        return (CiaoProxDesc(PROX_L1, 0, Float64(g.lambda), -Inf, Inf, C_NULL, C_NULL), nothing)
+    if g isa ProximalOperators.IndBox
+        lo = g.lb isa Real ? nothing : ROCArray(R.(vec(g.lb)))
+        hi = g.ub isa Real ? nothing : ROCArray(R.(vec(g.ub)))
+        keep = (lo, hi)
+        return (CiaoProxDesc(PROX_BOX, 0, 0.0, g.lb isa Real ? Float64(g.lb) : -Inf, g.ub isa Real ? Float64(g.ub) : Inf,
+                             dptr(lo), dptr(hi)), keep)
+    end
+    throw(ArgumentError("g is not a family the device path supports (Zero, NormL1, IndBox)"))
+end
+
+# The reference draws from Julia's global RNG inside Base.iterate; here the draws are made on the host with the SAME
+# calls (so a Julia user keeps the reference's sample stream) and shipped as 0-based Int64 device arrays.
+to_dev_idx(idx::AbstractVector{<:Integer}) = ROCArray(Int64.(idx) .- 1)
+
+# ======================================================================================================================
+# SVRG  (src/algorithms/SVRG/SVRG.jl, SVRG_basic.jl)
+# ======================================================================================================================
+struct SVRG{R<:Real}
+    γ::Maybe{R}; maxit::Int; verbose::Bool; freq::Int; m::Maybe{Int}; plus::Bool
+    function SVRG{R}(; γ::Maybe{R} = nothing, maxit::Int = 10000, verbose::Bool = false, freq::Int = 1000,
+                     m::Maybe{Int} = nothing, plus::Bool = false) where {R}
+        @assert γ === nothing || γ > 0
+        @assert maxit > 0
+        @assert freq > 0
+        new(γ, maxit, verbose, freq, m, plus)
+    end
+end
+SVRG(::Type{R}; kwargs...) where {R} = SVRG{R}(; kwargs...)
+SVRG(; kwargs...) = SVRG(Float64; kwargs...)
+
+struct SVRG_basic_iterable{R<:Real,Tx}
+    F::PackedF{R}; g::CiaoProxDesc; gkeep::Any; x0::Tx; N::Int
+    L::Maybe{Union{Array{R},R}}; μ::Maybe{Union{Array{R},R}}; γ::Maybe{R}; m::Maybe{Int}; plus::Bool
+end
+mutable struct SVRG_basic_state{R<:Real}
+    γ::R; m::Int
+    av::ROCArray{R,1}; z::ROCArray{R,1}; z_full::ROCArray{R,1}; w::ROCArray{R,1}
+end
+
+function Base.iterate(iter::SVRG_basic_iterable{R}) where {R}          # SVRG_basic.jl:30-69
+    N = iter.N
+    m = iter.m === nothing ? N : iter.m
+    if iter.γ === nothing
+        if iter.plus
+            @warn "provide a stepsize γ"; return nothing
+        elseif iter.L === nothing || iter.μ === nothing
+            @warn "smoothness or convexity parameter absent"; return nothing
+        end
+        L_M, μ_M = maximum(iter.L), maximum(iter.μ)
+        γ = 1 / (10 * L_M)
+        rho = (1 + 4 * L_M * γ^2 * μ_M * (N + 1)) / (μ_M * γ * N * (1 - 4L_M * γ))
+        rho >= 1 && @warn "convergence condition violated...provide a stepsize!"
+    else
+        γ = iter.γ
+    end
+    x0d = ROCArray(R.(vec(iter.x0)))
+    av, z, z_full, w = (similar(x0d) for _ in 1:4)
+    p = Ref(cproblem(iter.F))
+    check(ccall((:ciao_svrg_init, libciao), Int32,
+                (Ptr{Cvoid}, Ref{CiaoProblem}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, p, dptr(x0d), dptr(av), dptr(z), dptr(z_full), dptr(w)))
+    state = SVRG_basic_state{R}(R(γ), m, av, z, z_full, w)
+    return state, state
+end
+
+function Base.iterate(iter::SVRG_basic_iterable{R}, state::SVRG_basic_state{R}) where {R}   # SVRG_basic.jl:71-96
+    idx = to_dev_idx(rand(1:iter.N, state.m))                                               # :73
+    p, g = Ref(cproblem(iter.F)), Ref(iter.g)
+    check(ccall((:ciao_svrg_iterate, libciao), Int32,
+                (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Int64, Ptr{Cvoid}, Int32,
+                 Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, p, g, Float64(state.γ), state.m, dptr(idx), Int32(iter.plus),
+                dptr(state.av), dptr(state.z), dptr(state.z_full), dptr(state.w)))
+    iter.plus && (state.m *= 2)                                                             # :93
+    return state, state
+end
+solution(state::SVRG_basic_state) = state.z_full                                            # SVRG_basic.jl:99
+
+function iterator(solver::SVRG{R}, x0::AbstractArray{C}; F = nothing, g = ProximalOperators.Zero(), L = nothing,
+                  μ = nothing, N) where {R,C<:RealOrComplex{R}}
+    C <: Complex && throw(ArgumentError("complex iterates are outside the device path"))
+    d = length(x0)
+    m = solver.m === nothing ? N : solver.m
+    gd, keep = pack_g(R, g, d)
+    return SVRG_basic_iterable{R,typeof(x0)}(pack_F(R, F, N, d), gd, keep, x0, N, L, μ, solver.γ, m, solver.plus)
+end
+
+function (solver::SVRG{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrComplex{R}}   # SVRG.jl:46-84
+    disp(it, state) = @printf "%5d | %.3e  \n" it state.γ
+    maxit = solver.maxit
+    if solver.plus && solver.maxit > 25
+        maxit = 25
+        @warn "exponential number of inner updates...reverted to 25 maximum iterations"
+    end
+    iter = iterator(solver, x0; kwargs...)
+    num_iters, state_final = nothing, nothing
+    for (it_, state_) in enumerate(Iterators.take(iter, maxit))
+        solver.verbose && mod(it_, solver.freq) == 0 && disp(it_, state_)
+        num_iters, state_final = it_, state_
+    end
+    solver.verbose && mod(num_iters, solver.freq) !== 0 && disp(num_iters, state_final)
+    synchronize(context())
+    return reshape(Array(solution(state_final)), size(x0)), num_iters
+end
+
+# ======================================================================================================================
+# SAGA / SAG  (src/algorithms/SAGA_SAG/SAGA.jl, SAGA_basic.jl)
+# ======================================================================================================================
+struct SAGA{R<:Real}
+    γ::Maybe{R}; maxit::Int; verbose::Bool; freq::Int; SAG_flag::Bool
+    function SAGA{R}(; γ::Maybe{R} = nothing, maxit::Int = 10000, verbose::Bool = false, freq::Int = 1000,
+                     SAG_flag::Bool = false) where {R}
+        @assert γ === nothing || γ > 0
+        @assert maxit > 0
+        @assert freq > 0
+        new(γ, maxit, verbose, freq, SAG_flag)
+    end
+end
+SAGA(::Type{R}; kwargs...) where {R} = SAGA{R}(; kwargs...)
+SAGA(; kwargs...) = SAGA(Float64; kwargs...)
+SAG(::Type{R}; kwargs...) where {R} = SAGA{R}(; kwargs..., SAG_flag = true)     # SAGA.jl:190-191
+SAG(; kwargs...) = SAG(Float64; kwargs...)
+
+struct SAGA_basic_iterable{R<:Real,Tx}
+    F::PackedF{R}; g::CiaoProxDesc; gkeep::Any; x0::Tx; N::Int
+    L::Maybe{Union{Array{R},R}}; γ::Maybe{R}; SAG::Bool
+end
+mutable struct SAGA_basic_state{R<:Real}
+    s::ROCArray{R,2}            # d x N  ==  row-major N x d table of last-seen gradients
+    γ::R
+    av::ROCArray{R,1}; z::ROCArray{R,1}
+    ind::Int
+end
+
+function Base.iterate(iter::SAGA_basic_iterable{R}) where {R}          # SAGA_basic.jl:26-51
+    if iter.γ === nothing
+        if iter.L === nothing
+            @warn "smoothness parameter absent"; return nothing
+        end
+        L_M = maximum(iter.L)
+        γ = iter.SAG ? 1 / (16 * L_M) : 1 / (3 * L_M)
+    else
+        γ = iter.γ
+    end
+    x0d = ROCArray(R.(vec(iter.x0)))
+    s = ROCArray{R}(undef, length(x0d), iter.N)
+    av, z = similar(x0d), similar(x0d)
+    p, g = Ref(cproblem(iter.F)), Ref(iter.g)
+    check(ccall((:ciao_saga_init, libciao), Int32,
+                (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, p, g, Float64(γ), dptr(x0d), dptr(s), dptr(av), dptr(z)))
+    state = SAGA_basic_state{R}(s, R(γ), av, z, 1)
+    return state, state
+end
+
+# `nsteps` consecutive reference iterations in one launch (the functor uses this; Base.iterate uses nsteps = 1)
+function saga_steps!(iter::SAGA_basic_iterable{R}, state::SAGA_basic_state{R}, draws::Vector{Int}) where {R}
+    idx = to_dev_idx(draws)
+    p, g = Ref(cproblem(iter.F)), Ref(iter.g)
+    check(ccall((:ciao_saga_steps, libciao), Int32,
+                (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, p, g, Float64(state.γ), Int32(iter.SAG), length(draws), dptr(idx),
+                dptr(state.s), dptr(state.av), dptr(state.z)))
+    state.ind = draws[end]
+    return state
+end
+function Base.iterate(iter::SAGA_basic_iterable{R}, state::SAGA_basic_state{R}) where {R}   # SAGA_basic.jl:53-68
+    saga_steps!(iter, state, [rand(1:iter.N)])                                              # :55
+    return state, state
+end
+solution(state::SAGA_basic_state) = state.z                                                 # SAGA_basic.jl:71
+
+function iterator(solver::SAGA{R}, x0::AbstractArray{C}; F = nothing, g = ProximalOperators.Zero(), L = nothing,
+                  N) where {R,C<:RealOrComplex{R}}
+    C <: Complex && throw(ArgumentError("complex iterates are outside the device path"))
+    d = length(x0)
+    gd, keep = pack_g(R, g, d)
+    return SAGA_basic_iterable{R,typeof(x0)}(pack_F(R, F, N, d), gd, keep, x0, N, L, solver.γ, solver.SAG_flag)
+end
+
+function (solver::SAGA{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrComplex{R}}   # SAGA.jl:44-73
+    disp(it, state) = @printf "%5d | %.3e  \n" it state.γ
+    iter = iterator(solver, x0; kwargs...)
+    next = iterate(iter)
+    next === nothing && return solution(nothing), nothing      # MethodError, as in the reference (SAGA.jl:72)
+    state, _ = next
+    num_iters = 1
+    # nothing observes intermediate states unless verbose: issue the remaining maxit-1 draws in large launches
+    while num_iters < solver.maxit
+        n = min(solver.maxit - num_iters, solver.verbose ? solver.freq - mod(num_iters, solver.freq) : 1 << 20)
+        saga_steps!(iter, state, rand(1:iter.N, n))
+        num_iters += n
+        solver.verbose && mod(num_iters, solver.freq) == 0 && disp(num_iters, state)
+    end
+    solver.verbose && mod(num_iters, solver.freq) !== 0 && disp(num_iters, state)
+    synchronize(context())
+    return reshape(Array(solution(state)), size(x0)), num_iters
+end
+
+# Finito / LFinito follow the same pattern over ciao_hat_gamma, ciao_finito_init, ciao_finito_steps,
+# ciao_lfinito_init and ciao_lfinito_iterate (batch construction Finito_basic.jl:49-59, :95-108 stays on the host
+# exactly as in solvers.py: FINITO_basic_iterable._next_batch); see INTEGRATION.md for their ccall signatures.
+
+end # module
