@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--extras", action="store_true", help="also time the sequential chains and the Finito batch (N=1)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary timings (sequential chains, table kernels; N=1 only)")
     return ap.parse_args()
 
 
@@ -58,7 +58,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = 0
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("CIAO_BENCH_FORCE_DIST") == "1"   # exercise the RCCL hook even with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         # RCCL ("nccl") is the product path; CIAO_BENCH_BACKEND=gloo exists only to rehearse several ranks on ONE GPU
         rank, world, local = init_process_group_from_env(os.environ.get("CIAO_BENCH_BACKEND", "nccl"))
@@ -95,7 +96,7 @@ def main():
     g = ProxG(L.PROX_L1, lam=lam_g)
     L_max = (lam_f if not logistic else 0.25) * 1.3                      # ||a_i||^2 <= ~1.3 for d = 1024
     gamma = 1.0 / (7.0 * L_max) if not logistic else 1.0 / (10.0 * L_max)   # test_lasso.jl:164 / test_logistic_l1.jl:126
-    if world > 1:
+    if world > 1 or force_dist:
         ctx.set_allreduce(AllReduceHook(dev))
     xa = torch.zeros(d, dtype=tdt, device=dev)                           # x0 = 0 (test_lasso.jl:60)
     xb = torch.empty_like(xa)
@@ -159,7 +160,7 @@ def main():
         "config": {"workload": f"{'l1_logistic' if logistic else 'lasso'}_svrg_fullgrad_prox_sweep",
                    "N_total": N_total, "rows_per_gpu": n_local, "d": d, "f": "LeastSquares(a_i,b_i,N)" if not logistic else "Precompose(LogisticLoss)",
                    "g": f"NormL1({lam_g:g})", "gamma": gamma, "parallelism": f"rows_sharded_x{world}",
-                   "collective": "rccl_allreduce(d+1)/step" if world > 1 else "none"},
+                   "collective": "rccl_allreduce(d+1)/step" if (world > 1 or force_dist) else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
                      "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_n, "algorithmic_bytes_per_launch": alg_bytes},
@@ -191,7 +192,7 @@ def main():
         except Exception as e:  # the baseline must never cost us the bench line
             out["cpu_baseline"] = {"value": None, "unit": "updates/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
 
-    if args.extras and world == 1 and rank == 0:
+    if not args.no_extras and world == 1 and rank == 0:
         try:
             import bench_extras
             del A, b, F

@@ -509,7 +509,7 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
 {
     CIAO_REQUIRE(ctx && key, "ctx or key is NULL");
     if (!strcmp(key, "sweep_blocks_per_cu")) {
-        CIAO_REQUIRE(value >= 1 && value <= 16, "sweep_blocks_per_cu must be in 1..16");
+        CIAO_REQUIRE(value >= 0 && value <= 16, "sweep_blocks_per_cu must be in 0..16 (0 = automatic)");
         ctx->sweep_blocks_per_cu = value;
     } else if (!strcmp(key, "sweep_prefetch")) {
         ctx->sweep_prefetch = value != 0;

@@ -51,6 +51,10 @@ struct VecOfC<double> {
     typedef double type __attribute__((ext_vector_type(2)));
 };
 
+#ifndef CIAO_CHAIN_DBG
+#define CIAO_CHAIN_DBG 0   // timing experiments only (tools/chain_probe.sh): 1 = no ring refill, 2 = no cross-wave exchange, 4 = no element-wise update
+#endif
+
 constexpr int CHAIN_NT = 256;
 constexpr int CHAIN_NW = CHAIN_NT / WAVE;
 constexpr int CHAIN_CHUNK = 1024;   // steps whose indices / b_i / gamma_i are staged in LDS at a time
@@ -67,8 +71,14 @@ __device__ __forceinline__ T prox_bf(T v, T gl, T lo, T hi)
 {
     // soft threshold as v - clamp(v, -gl, gl): the same value as the reference's three-way form for every finite v
     // (v > gl: v - gl; v < -gl: v + gl; else v - v = 0) in three instructions instead of compares + 64-bit selects
-    const T s = v - fmin2(fmax2(v, -gl), gl);
+    const T s = v - clamp_sym(v, gl);
     return fmin2(fmax2(s, lo), hi);
+}
+// the same without the box (g = Zero or NormL1: lo/hi are -/+inf and the clamp would be the identity)
+template <typename T>
+__device__ __forceinline__ T prox_l1(T v, T gl)
+{
+    return v - clamp_sym(v, gl);
 }
 
 // LOSS is a template parameter here (CIAO_LOSS_LS also serves Zero(): lam = 0 and no data), FULL = every thread's E
@@ -370,8 +380,8 @@ __device__ __forceinline__ void drain_vmcnt_visible()
 }
 
 template <int J>
-struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at ~0.25 us per step, within 64 KiB of LDS per ring
-    static constexpr int value = J <= 2 ? 4 : 2;
+struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at ~0.3 us per step, within 64 KiB of LDS per ring
+    static constexpr int value = J <= 2 ? 8 : (J <= 4 ? 4 : 2);   // 64 KiB of LDS per ring at most
 };
 
 template <typename T, int J, int ALG, int LOSS>
@@ -385,9 +395,13 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
     constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
     constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO);
     constexpr int OPS_PER_STEP = HAS_TABLE ? 3 * J : J;
-    constexpr int WAIT_N = (DEPTH - 1) * OPS_PER_STEP;
+    // PIPE: the LDS reads of step s+1 (its ring slot and its staged scalars) are issued at the top of step s and land
+    // while step s reduces its dot product, so only one LDS round trip (the 4-partial exchange) stays on the
+    // dependent path.  It costs one step of DMA lead, hence only with DEPTH >= 4.
+    constexpr bool PIPE = DEPTH >= 4;
+    constexpr int WAIT_N = (PIPE ? DEPTH - 2 : DEPTH - 1) * OPS_PER_STEP;
     constexpr int ROW_BYTES = J * CHAIN_NT * 16;
-    static_assert(CH % DEPTH == 0, "ring slots must line up with chunk starts");
+    static_assert(CH % DEPTH == 0 && DEPTH % 2 == 0, "ring slots must line up with chunk starts; ping-pong needs even DEPTH");
 
     // one dynamic LDS block, carved by hand (16-byte aligned pieces):
     //   ringA[DEPTH][ROW_BYTES] | ringT[DEPTH][ROW_BYTES] (table algs) | s_row | s_b | s_g | s_stale | red
@@ -416,6 +430,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
     // iterate state, in 16-byte chunks
     V av[J], p[J], zf[J], zs[J], plo[J], phi[J];
     const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
+    const bool hasbox = (a.g.kind == CIAO_PROX_BOX);   // wave-uniform: one branch per step selects the clamp-free prox
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int64_t c = tid + (int64_t)j * CHAIN_NT;
@@ -451,6 +466,27 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
             for (int j = 0; j < J; ++j)
                 glds16(sp + ((int64_t)j * CHAIN_NT + tid) * 16, ringT_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
         }
+    };
+
+    // everything step s needs from LDS: its ring slot and its staged scalars (two register sets, ping-pong by step parity)
+    struct StepIn {
+        V ar[J], sr[J];
+        int64_t row, row_n;
+        T bi, gi;
+        int stale;
+    };
+    StepIn in[2];
+    auto fetch = [&](StepIn &x, int u, int s) {   // plain LDS reads; the caller has retired slot u's DMA
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            x.ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
+            if (HAS_TABLE) x.sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
+        }
+        x.row = s_row[DEPTH + s];
+        x.row_n = s_row[DEPTH + s + DEPTH];
+        x.bi = s_b[s];
+        x.gi = PER_SAMPLE_GAM ? s_g[s] : T(1);
+        x.stale = HAS_TABLE ? s_stale[s] : 0;
     };
 
     int par = 0;
@@ -495,6 +531,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
         }
         wait_vmcnt<0>();          // ring fully landed: the counted waits below assume the steady-state op sequence
         drain_vmcnt_visible();    // ... and hipcc knows that the state / staging loads are retired too
+        if (PIPE) fetch(in[0], 0, 0);
 
         // ---- the dependent chain ----------------------------------------------------------------------------------------
         for (int s0 = 0; s0 < nch; s0 += DEPTH) {
@@ -502,31 +539,34 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
             for (int u = 0; u < DEPTH; ++u) {
                 const int s = s0 + u;
                 if (s >= nch) break;
-                const int64_t row = uniform64(s_row[DEPTH + s]);
-                const int64_t row_n = uniform64(s_row[DEPTH + s + DEPTH]);
-                const T bi = s_b[s];
+                StepIn &x = in[PIPE ? (u & 1) : 0];
+                if (PIPE) {
+                    if (s + 1 < nch) {   // next step's inputs: retire its DMA (one step less lead), read, do not wait
+                        wait_vmcnt<WAIT_N>();
+                        fetch(in[(u + 1) & 1], (u + 1) % DEPTH, s + 1);
+                    }
+                } else {
+                    wait_vmcnt<WAIT_N>();
+                    fetch(x, u, s);
+                }
+                const int64_t row = uniform64(x.row);
+                const int64_t row_n = uniform64(x.row_n);
+                const T bi = x.bi;
 
                 if (ALG == CA_LFINITO && inb == 0) {   // Finito_LFinito.jl:92  z = prox(av)
                     const T gl = a.hat_gamma * plam;
 #pragma unroll
                     for (int j = 0; j < J; ++j)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) p[j][v] = prox_bf(av[j][v], gl, plo[j][v], phi[j][v]);
+                        for (int v = 0; v < VEC; ++v) p[j][v] = hasbox ? prox_bf(av[j][v], gl, plo[j][v], phi[j][v]) : prox_l1(av[j][v], gl);
                 }
-
-                wait_vmcnt<WAIT_N>();   // slot u's DMA (issued DEPTH steps ago) has landed in LDS
-                V ar[J], sr[J];
-#pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
-                    if (HAS_TABLE) sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
-                }
-                if (HAS_TABLE && __builtin_amdgcn_readfirstlane(s_stale[s])) {
+                if (HAS_TABLE && __builtin_amdgcn_readfirstlane(x.stale)) {
                     // an intervening step rewrote this table row after its DMA was issued: re-read it from memory (this
                     // very thread stored these bytes, so program order makes them visible)
                     const V *sp = reinterpret_cast<const V *>(a.table + row * d);
 #pragma unroll
-                    for (int j = 0; j < J; ++j) sr[j] = sp[tid + j * CHAIN_NT];
+                    for (int j = 0; j < J; ++j) x.sr[j] = sp[tid + j * CHAIN_NT];
+                    drain_vmcnt_visible();   // retire it HERE, or hipcc puts a draining vmcnt(0) on the common path
                 }
 
                 T d1 = T(0), d2 = T(0);
@@ -534,8 +574,8 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                 for (int j = 0; j < J; ++j)
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
-                        d1 = fmad(ar[j][v], p[j][v], d1);
-                        if (TWO) d2 = fmad(ar[j][v], zf[j][v], d2);
+                        d1 = fmad(x.ar[j][v], p[j][v], d1);
+                        if (TWO) d2 = fmad(x.ar[j][v], zf[j][v], d2);
                     }
                 d1 = wave_allsum(d1);
                 if (TWO) d2 = wave_allsum(d2);
@@ -543,10 +583,12 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                     red[par][wib][0] = d1;
                     if (TWO) red[par][wib][1] = d2;
                 }
+                if (!(CIAO_CHAIN_DBG & 2)) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue
                 d1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
                 if (TWO) d2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+                }
                 par ^= 1;
 
                 const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
@@ -555,12 +597,12 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                     const T gl = a.gamma * plam;
                     const T dc = gz.coef() - gp.coef();   // temp = gamma*(a*(c_z - c_w) - av) + w, two FMAs per coordinate
 #pragma unroll
-                    for (int j = 0; j < J; ++j)
+                    for (int j = 0; j < ((CIAO_CHAIN_DBG & 4) ? 0 : J); ++j)
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
-                            const T u2 = fmad(ar[j][v], dc, -av[j][v]);
+                            const T u2 = fmad(x.ar[j][v], dc, -av[j][v]);
                             const T t = fmad(a.gamma, u2, p[j][v]);
-                            p[j][v] = prox_bf(t, gl, plo[j][v], phi[j][v]);
+                            p[j][v] = hasbox ? prox_bf(t, gl, plo[j][v], phi[j][v]) : prox_l1(t, gl);
                             zs[j][v] += p[j][v];
                         }
                 } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
@@ -573,23 +615,19 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                         V gnv;
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
-                            const T gn = ar[j][v] * cp;
-                            const T del = gn - sr[j][v];
-                            T wv;
-                            if (a.sag) {
-                                av[j][v] = fmad(del, a.invN, av[j][v]);
-                                wv = fmad(ngam, av[j][v], p[j][v]);
-                            } else {
-                                wv = fmad(ngam, del + av[j][v], p[j][v]);
-                                av[j][v] = fmad(del, a.invN, av[j][v]);
-                            }
-                            p[j][v] = prox_bf(wv, gl, plo[j][v], phi[j][v]);
+                            const T gn = x.ar[j][v] * cp;
+                            const T del = gn - x.sr[j][v];
+                            // SAGA steps with (g_new - s_i + av_old), SAG with av_new (SAGA_basic.jl:58-62)
+                            const T avn = fmad(del, a.invN, av[j][v]);
+                            const T wv = fmad(ngam, a.sag ? avn : del + av[j][v], p[j][v]);
+                            av[j][v] = avn;
+                            p[j][v] = hasbox ? prox_bf(wv, gl, plo[j][v], phi[j][v]) : prox_l1(wv, gl);
                             gnv[v] = gn;
                         }
                         sp[tid + j * CHAIN_NT] = gnv;
                     }
                 } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
-                    const T gi = s_g[s];
+                    const T gi = x.gi;
                     const T ncc = -(gi * a.invN) * gp.coef();   // t = z - (gamma_i/N) * c * a
                     const T rr = a.hat_gamma / gi;
                     V *sp = reinterpret_cast<V *>(a.table + row * d);
@@ -598,8 +636,8 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                         V tv;
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
-                            tv[v] = fmad(ncc, ar[j][v], p[j][v]);
-                            av[j][v] = fmad(tv[v] - sr[j][v], rr, av[j][v]);
+                            tv[v] = fmad(ncc, x.ar[j][v], p[j][v]);
+                            av[j][v] = fmad(tv[v] - x.sr[j][v], rr, av[j][v]);
                         }
                         sp[tid + j * CHAIN_NT] = tv;
                     }
@@ -608,24 +646,24 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
 #pragma unroll
                         for (int j = 0; j < J; ++j)
 #pragma unroll
-                            for (int v = 0; v < VEC; ++v) p[j][v] = prox_bf(av[j][v], gl, plo[j][v], phi[j][v]);
+                            for (int v = 0; v < VEC; ++v) p[j][v] = hasbox ? prox_bf(av[j][v], gl, plo[j][v], phi[j][v]) : prox_l1(av[j][v], gl);
                     }
                 } else {                                                         // Finito_LFinito.jl:93-98
                     const GradCoef<T> gzf = grad_coef_t<T, LOSS>(d2, bi, a.lam);
-                    const T gi = s_g[s];
+                    const T gi = x.gi;
                     const T dc = (a.hat_gamma * a.invN) * (gzf.coef() - gp.coef());
                     const T rr = a.hat_gamma / gi;
 #pragma unroll
                     for (int j = 0; j < J; ++j)
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
-                            av[j][v] = fmad(ar[j][v], dc, av[j][v]);
+                            av[j][v] = fmad(x.ar[j][v], dc, av[j][v]);
                             av[j][v] = fmad(rr, p[j][v] - zf[j][v], av[j][v]);
                         }
                 }
 
                 if (++inb == a.batch) inb = 0;
-                refill(u, row_n);   // after this step's table stores (program order); the look-ahead entry always exists
+                if (!(CIAO_CHAIN_DBG & 1)) refill(u, row_n);   // after this step's table stores (program order); the look-ahead entry always exists
             }
         }
     }

@@ -68,6 +68,9 @@ __device__ __forceinline__ float fmin2(float a, float b) { return __builtin_fmin
 __device__ __forceinline__ double fmin2(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ float fmax2(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ double fmax2(double a, double b) { return __builtin_fmax(a, b); }
+// clamp(v, -t, t) for t >= 0: one v_med3_f32 in single precision, max/min in double
+__device__ __forceinline__ float clamp_sym(float v, float t) { return __builtin_amdgcn_fmed3f(v, -t, t); }
+__device__ __forceinline__ double clamp_sym(double v, double t) { return __builtin_fmin(__builtin_fmax(v, -t), t); }
 __device__ __forceinline__ float fexp(float x) { return expf(x); }
 __device__ __forceinline__ double fexp(double x) { return exp(x); }
 __device__ __forceinline__ float flog(float x) { return logf(x); }

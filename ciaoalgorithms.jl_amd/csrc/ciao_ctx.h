@@ -29,7 +29,7 @@ struct ciao_ctx {
     int *errflag = nullptr;    // sticky device error word (out-of-range index)
 
     // tuning
-    int64_t sweep_blocks_per_cu = 4;
+    int64_t sweep_blocks_per_cu = 0;   // 0 = choose from the row size (rows_launch.inc)
     int64_t sweep_prefetch = 1;     // gradient sweeps: 1 = two-deep register pipeline, 0 = occupancy only
     int64_t chain_max_batch = 64;   // Finito/LFinito batches up to this size run as a sequential chain
     int64_t chain_no_dma = 0;       // testing: route chains through the register-ring kernel instead of the LDS-DMA one

@@ -368,34 +368,49 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
 // ------------------------------------------------------------------------------------------------------------------
 // finalize: sum the per-block partials in a fixed order and apply the epilogue.  Block = (64 columns) x (16 slices).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int FIN_SLICES = 16;
+// Block = COLS columns x SLICES slices of the partial rows (512 threads); COLS*sizeof(T) = 128 B, one L2 line per
+// partial row, so the d/COLS blocks spread the (grid x d) partial matrix over many CUs.
+constexpr int FIN_THREADS = 512;
 
 template <typename T>
-__global__ void __launch_bounds__(WAVE *FIN_SLICES)
+__global__ void __launch_bounds__(FIN_THREADS)
     finalize_kernel(const T *__restrict__ partial, int64_t pstride, int nparts, const T *__restrict__ pextra,
                     int64_t d, T *raw_out, Epilogue<T> ep)
 {
-    __shared__ T lds[FIN_SLICES][WAVE];
+    constexpr int COLS = 128 / sizeof(T);
+    constexpr int SLICES = FIN_THREADS / COLS;
+    __shared__ T lds[SLICES][COLS];
     __shared__ T lds_extra;
-    const int tx = threadIdx.x & (WAVE - 1);
-    const int ty = threadIdx.x >> 6;
-    const int64_t col = (int64_t)blockIdx.x * WAVE + tx;
+    const int tx = threadIdx.x % COLS;
+    const int ty = threadIdx.x / COLS;
+    const int64_t col = (int64_t)blockIdx.x * COLS + tx;
 
     T s = T(0);
-    if (col < d)
-        for (int p = ty; p < nparts; p += FIN_SLICES) s += partial[(int64_t)p * pstride + col];
+    if (col < d) {
+        // four independent chains keep several loads in flight; the association order is fixed
+        T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
+        int p = ty;
+        for (; p + 3 * SLICES < nparts; p += 4 * SLICES) {
+            s0 += partial[(int64_t)p * pstride + col];
+            s1 += partial[(int64_t)(p + SLICES) * pstride + col];
+            s2 += partial[(int64_t)(p + 2 * SLICES) * pstride + col];
+            s3 += partial[(int64_t)(p + 3 * SLICES) * pstride + col];
+        }
+        for (; p < nparts; p += SLICES) s0 += partial[(int64_t)p * pstride + col];
+        s = (s0 + s1) + (s2 + s3);
+    }
     lds[ty][tx] = s;
-    if (ty == 0) {
+    if (threadIdx.x < WAVE) {   // wave 0: the extra scalar (all 64 lanes active)
         T ex = T(0);
-        for (int p = tx; p < nparts; p += WAVE) ex += pextra[p];
+        for (int p = threadIdx.x; p < nparts; p += WAVE) ex += pextra[p];
         ex = wave_allsum(ex);
-        if (tx == 0) lds_extra = ex;
+        if (threadIdx.x == 0) lds_extra = ex;
     }
     __syncthreads();
     if (ty == 0 && col < d) {
         T tot = lds[0][tx];
 #pragma unroll
-        for (int y = 1; y < FIN_SLICES; ++y) tot += lds[y][tx];
+        for (int y = 1; y < SLICES; ++y) tot += lds[y][tx];
         const T extra = lds_extra;
         if (raw_out) {
             raw_out[col] = tot;
