@@ -95,9 +95,12 @@ __global__ void __launch_bounds__(256) synth_targets_kernel(const T *A, int64_t 
 }
 
 // ---- helpers ----------------------------------------------------------------------------------------------------------
-static int32_t check_problem(const ciao_ctx *ctx, const ciao_problem *p)
+static int32_t check_problem(ciao_ctx *ctx, const ciao_problem *p)
 {
     CIAO_REQUIRE(ctx, "ctx is NULL");
+    // Any entry point may overwrite the vector the cached a_i'z_full belong to; only ciao_svrg_iterate (which restores
+    // the key after this check) and ciao_svrg_inner (which never writes z_full) keep the cache alive.
+    ctx->rowdot_A = nullptr;
     CIAO_REQUIRE(p, "problem is NULL");
     CIAO_REQUIRE(p->dtype == CIAO_F32 || p->dtype == CIAO_F64, "problem.dtype must be CIAO_F32 or CIAO_F64 (got %d)", p->dtype);
     CIAO_REQUIRE(p->loss >= CIAO_LOSS_LS && p->loss <= CIAO_LOSS_ZERO, "unknown loss kind %d", p->loss);
@@ -176,10 +179,18 @@ static int32_t prox_launch(ciao_ctx *ctx, int64_t d, const ciao_prox_desc *g, co
 
 // ---- typed implementations -------------------------------------------------------------------------------------------
 template <typename T>
-static int32_t full_gradient_t(ciao_ctx *ctx, const ciao_problem *p, const void *x, void *av)
+static int32_t full_gradient_t(ciao_ctx *ctx, const ciao_problem *p, const void *x, void *av, bool keep_rowdots = false)
 {
     RowsArgs<T> a = rows_args<T>(p);
     a.x1 = (const T *)x;
+    ctx->rowdot_A = nullptr;   // whatever was cached belongs to an older pass
+    if (keep_rowdots && ctx->svrg_cache_rowdots && !ctx->hook && p->N > 0 && p->loss != CIAO_LOSS_ZERO) {
+        CIAO_TRY(ensure(ctx, &ctx->rowdot, &ctx->rowdot_bytes, (size_t)p->N * sizeof(T)));
+        a.rowdot_out = (T *)ctx->rowdot;
+        ctx->rowdot_A = p->A;
+        ctx->rowdot_x = x;
+        ctx->rowdot_N = p->N;
+    }
     Epilogue<T> e = epi_zero<T>();
     e.c_sum = a.invN;   // av = sum / N
     e.av_out = (T *)av;
@@ -206,7 +217,7 @@ static int32_t proxgrad_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
 
 template <typename T>
 static int32_t svrg_inner_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
-                            const int64_t *idx, const void *av, void *z, const void *z_full, void *w)
+                            const int64_t *idx, const void *av, void *z, const void *z_full, void *w, bool use_rowdots = false)
 {
     ChainArgs<T> a = chain_args<T>(p, g);
     a.nsteps = m;
@@ -216,6 +227,11 @@ static int32_t svrg_inner_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_pro
     a.z = (T *)z;
     a.zf = (T *)z_full;
     a.w = (T *)w;
+    // a_i'z_full for every row is already known if the last full pass on this ctx was the one at this z_full
+    if (use_rowdots && ctx->rowdot_A == p->A && ctx->rowdot_x == z_full && ctx->rowdot_N == p->N && ctx->rowdot_A) {
+        a.gam = (const T *)ctx->rowdot;
+        return launch_chain<T>(ctx, CA_SVRGC, a);
+    }
     return launch_chain<T>(ctx, CA_SVRG, a);
 }
 
@@ -223,11 +239,12 @@ template <typename T>
 static int32_t svrg_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
                               const int64_t *idx, int32_t plus, void *av, void *z, void *z_full, void *w)
 {
-    CIAO_TRY(svrg_inner_t<T>(ctx, p, g, gamma, m, idx, av, z, z_full, w));
+    CIAO_TRY(svrg_inner_t<T>(ctx, p, g, gamma, m, idx, av, z, z_full, w, true));
+    ctx->rowdot_A = nullptr;   // z_full is about to change
     hipLaunchKernelGGL((svrg_tail_kernel<T>), dim3((unsigned)((p->d + 255) / 256)), dim3(256), 0, ctx->stream, p->d, (T)m,
                        (int)plus, (T *)z, (T *)z_full, (T *)w);
     CIAO_HIP(hipGetLastError());
-    return full_gradient_t<T>(ctx, p, z_full, av);
+    return full_gradient_t<T>(ctx, p, z_full, av, true);
 }
 
 template <typename T>
@@ -469,6 +486,7 @@ int32_t ciao_ctx_destroy(ciao_ctx *ctx)
     if (ctx->partial) (void)hipFree(ctx->partial);
     if (ctx->pextra) (void)hipFree(ctx->pextra);
     if (ctx->sumbuf) (void)hipFree(ctx->sumbuf);
+    if (ctx->rowdot) (void)hipFree(ctx->rowdot);
     if (ctx->scal) (void)hipFree(ctx->scal);
     if (ctx->errflag) (void)hipFree(ctx->errflag);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -516,6 +534,9 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "chain_max_batch")) {
         CIAO_REQUIRE(value >= 0, "chain_max_batch must be >= 0");
         ctx->chain_max_batch = value;
+    } else if (!strcmp(key, "svrg_cache_rowdots")) {
+        ctx->svrg_cache_rowdots = value != 0;
+        ctx->rowdot_A = nullptr;
     } else if (!strcmp(key, "chain_no_dma")) {
         ctx->chain_no_dma = value != 0;
     } else if (!strcmp(key, "force_generic")) {
@@ -572,6 +593,7 @@ int32_t ciao_gradient(ciao_ctx *ctx, const ciao_problem *p, int64_t i, const voi
 int32_t ciao_prox(ciao_ctx *ctx, int32_t dtype, int64_t d, const ciao_prox_desc *g, const void *x, double gamma, void *y)
 {
     CIAO_REQUIRE(ctx, "ctx is NULL");
+    ctx->rowdot_A = nullptr;
     CIAO_REQUIRE(dtype == CIAO_F32 || dtype == CIAO_F64, "bad dtype %d", dtype);
     CIAO_REQUIRE(d >= 0 && (d == 0 || (x && y)), "bad d or NULL vector");
     CIAO_TRY(check_prox(g));
@@ -610,7 +632,8 @@ int32_t ciao_svrg_init(ciao_ctx *ctx, const ciao_problem *p, const void *x0, voi
     CIAO_TRY(check_problem(ctx, p));
     CIAO_REQUIRE(x0 && av && z && z_full && w, "NULL state vector");
     const size_t bytes = (size_t)p->d * (p->dtype == CIAO_F64 ? 8 : 4);
-    CIAO_TRY(DISPATCH(p->dtype, full_gradient_t, ctx, p, x0, av));
+    CIAO_TRY(p->dtype == CIAO_F64 ? full_gradient_t<double>(ctx, p, x0, av, true) : full_gradient_t<float>(ctx, p, x0, av, true));
+    if (ctx->rowdot_A) ctx->rowdot_x = z_full;   // z_full becomes a copy of x0: the cached a_i'x0 are a_i'z_full
     if (z_full != x0) CIAO_HIP(hipMemcpyAsync(z_full, x0, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     if (w != x0) CIAO_HIP(hipMemcpyAsync(w, x0, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     CIAO_HIP(hipMemsetAsync(z, 0, bytes, ctx->stream));
@@ -620,7 +643,9 @@ int32_t ciao_svrg_init(ciao_ctx *ctx, const ciao_problem *p, const void *x0, voi
 int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
                         const int64_t *idx, const void *av, void *z, const void *z_full, void *w)
 {
+    const void *keep = ctx ? ctx->rowdot_A : nullptr;
     CIAO_TRY(check_problem(ctx, p));
+    ctx->rowdot_A = keep;   // z_full is read-only here
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(m >= 0 && (m == 0 || idx), "m < 0 or idx is NULL");
     CIAO_REQUIRE(m == 0 || p->N > 0, "cannot sample from an empty problem");
@@ -633,7 +658,9 @@ int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_de
 int32_t ciao_svrg_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
                           const int64_t *idx, int32_t plus, void *av, void *z, void *z_full, void *w)
 {
+    const void *keep = ctx ? ctx->rowdot_A : nullptr;
     CIAO_TRY(check_problem(ctx, p));
+    ctx->rowdot_A = keep;   // valid iff the previous call on this ctx was svrg_init / svrg_iterate / svrg_inner
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(m >= 1 && idx, "m < 1 or idx is NULL");
     CIAO_REQUIRE(p->N > 0, "cannot sample from an empty problem");

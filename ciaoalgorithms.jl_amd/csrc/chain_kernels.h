@@ -16,7 +16,13 @@
 
 namespace ciao {
 
-enum ChainAlg { CA_SVRG = 0, CA_SAGA = 1, CA_FINITO = 2, CA_LFINITO = 3 };
+enum ChainAlg {
+    CA_SVRG = 0,
+    CA_SAGA = 1,
+    CA_FINITO = 2,
+    CA_LFINITO = 3,
+    CA_SVRGC = 4   // SVRG with a_i'z_full taken from the full pass that produced av (passed through `gam`): one dot per step
+};
 
 template <typename T>
 struct ChainArgs {
@@ -392,8 +398,9 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
     constexpr int DEPTH = DmaDepth<J>::value;
     constexpr int CH = CHAIN_CHUNK;
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
+    constexpr bool SVRG_ANY = (ALG == CA_SVRG || ALG == CA_SVRGC);
     constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
-    constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO);
+    constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO || ALG == CA_SVRGC);   // s_g staging
     constexpr int OPS_PER_STEP = HAS_TABLE ? 3 * J : J;
     // PIPE: the LDS reads of step s+1 (its ring slot and its staged scalars) are issued at the top of step s and land
     // while step s reduces its dot product, so only one LDS round trip (the 4-partial exchange) stays on the
@@ -435,7 +442,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
     for (int j = 0; j < J; ++j) {
         const int64_t c = tid + (int64_t)j * CHAIN_NT;
         av[j] = reinterpret_cast<const V *>(a.av)[c];
-        if (ALG == CA_SVRG) {
+        if (SVRG_ANY) {
             p[j] = reinterpret_cast<const V *>(a.w)[c];
             zs[j] = reinterpret_cast<const V *>(a.z)[c];
         } else {
@@ -453,6 +460,11 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
             }
         }
     }
+
+    // SVRG: av is constant over the inner cycle, so gamma*av is hoisted out of the chain
+    V gav[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) gav[j] = a.gamma * av[j];
 
     // issue the DMA of row r into ring slot u: J (+J) wave-instructions of 1 KiB each
     auto refill = [&](int u, int64_t r) {
@@ -583,6 +595,16 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                     red[par][wib][0] = d1;
                     if (TWO) red[par][wib][1] = d2;
                 }
+                // work that does not need the dot product goes between the LDS write and the barrier, where it overlaps the
+                // other waves' arrival:  temp = gamma*(a*dc - av) + w  =  (gamma*a)*dc + (w - gamma*av)
+                V q1[J], q2[J];
+                if (SVRG_ANY) {
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        q1[j] = a.gamma * x.ar[j];
+                        q2[j] = p[j] - gav[j];
+                    }
+                }
                 if (!(CIAO_CHAIN_DBG & 2)) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue
@@ -592,16 +614,16 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                 par ^= 1;
 
                 const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
-                if (ALG == CA_SVRG) {                                            // SVRG_basic.jl:74-81
-                    const GradCoef<T> gz = grad_coef_t<T, LOSS>(d2, bi, a.lam);
+                if (SVRG_ANY) {                                                  // SVRG_basic.jl:74-81
+                    // a_i'z_full: recomputed (CA_SVRG) or the value the last full pass stored for this row (CA_SVRGC)
+                    const GradCoef<T> gz = grad_coef_t<T, LOSS>(ALG == CA_SVRGC ? x.gi : d2, bi, a.lam);
                     const T gl = a.gamma * plam;
-                    const T dc = gz.coef() - gp.coef();   // temp = gamma*(a*(c_z - c_w) - av) + w, two FMAs per coordinate
+                    const T dc = gz.coef() - gp.coef();
 #pragma unroll
                     for (int j = 0; j < ((CIAO_CHAIN_DBG & 4) ? 0 : J); ++j)
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
-                            const T u2 = fmad(x.ar[j][v], dc, -av[j][v]);
-                            const T t = fmad(a.gamma, u2, p[j][v]);
+                            const T t = fmad(q1[j][v], dc, q2[j][v]);
                             p[j][v] = hasbox ? prox_bf(t, gl, plo[j][v], phi[j][v]) : prox_l1(t, gl);
                             zs[j][v] += p[j][v];
                         }
@@ -672,7 +694,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int64_t c = tid + (int64_t)j * CHAIN_NT;
-        if (ALG == CA_SVRG) {
+        if (SVRG_ANY) {
             reinterpret_cast<V *>(a.w)[c] = p[j];
             reinterpret_cast<V *>(a.z)[c] = zs[j];
         } else {
@@ -687,7 +709,7 @@ constexpr size_t chain_dma_lds_bytes()
 {
     constexpr int DEPTH = DmaDepth<J>::value;
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
-    constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO);
+    constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO || ALG == CA_SVRGC);
     return (size_t)DEPTH * J * CHAIN_NT * 16 * (HAS_TABLE ? 2 : 1) + (CHAIN_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
            CHAIN_CHUNK * sizeof(T) * (PER_SAMPLE_GAM ? 2 : 1) + (HAS_TABLE ? CHAIN_CHUNK * sizeof(int) : 0) + 16 +
            2 * CHAIN_NW * 2 * sizeof(T);

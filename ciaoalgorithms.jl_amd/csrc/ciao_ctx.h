@@ -25,6 +25,10 @@ struct ciao_ctx {
     size_t pextra_bytes = 0;
     void *sumbuf = nullptr;    // raw reduced sum (d + 1 elements) handed to the all-reduce hook
     size_t sumbuf_bytes = 0;
+    void *rowdot = nullptr;    // a_i'z_full per local row, written by the SVRG full pass, read by the SVRG chain
+    size_t rowdot_bytes = 0;
+    const void *rowdot_A = nullptr, *rowdot_x = nullptr;   // which (data matrix, z_full vector) the cache belongs to
+    int64_t rowdot_N = -1;
     double *scal = nullptr;    // small device scratch for scalar reductions (4096 doubles)
     int *errflag = nullptr;    // sticky device error word (out-of-range index)
 
@@ -32,6 +36,7 @@ struct ciao_ctx {
     int64_t sweep_blocks_per_cu = 0;   // 0 = choose from the row size (rows_launch.inc)
     int64_t sweep_prefetch = 1;     // gradient sweeps: 1 = two-deep register pipeline, 0 = occupancy only
     int64_t chain_max_batch = 64;   // Finito/LFinito batches up to this size run as a sequential chain
+    int64_t svrg_cache_rowdots = 1; // reuse a_i'z_full from the full pass inside the SVRG inner cycle (ciao_svrg_iterate)
     int64_t chain_no_dma = 0;       // testing: route chains through the register-ring kernel instead of the LDS-DMA one
     int chain_last_dma = 0;
     int64_t force_generic = 0;      // testing: route every rows launch through the generic kernel

@@ -39,6 +39,7 @@ struct RowsArgs {
     T invN;                // 1 / N_total
     T hat_gamma;
     int want_fval;
+    T *rowdot_out;         // GRAD only: if non-null, rowdot_out[row] = a_row'x1 (feeds the SVRG chain, chain_kernels.h CA_SVRGC)
     T *partial;            // [gridDim.x][pstride]
     int64_t pstride;
     T *pextra;             // [gridDim.x]
@@ -157,6 +158,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
 #pragma unroll
             for (int k = 0; k < K; ++k) acc[k] += c * cur[k];
             if (a.want_fval) extra += loss_value(a.loss, d1, bi, a.lam);
+            if (a.rowdot_out && lane == 0) a.rowdot_out[row] = d1;
         } else if (MODE == RM_GRAD2) {
             const GradCoef<T> g2 = grad_coef(a.loss, d2, bi, a.lam);
             const T c = g1.coef() - g2.coef();
@@ -322,6 +324,7 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
             const T c = g1.coef();
             for (int64_t e = lane; e < d; e += WAVE) acc[e] += c * (ap ? ap[e] : T(0));
             if (a.want_fval) extra += loss_value(a.loss, d1, bi, a.lam);
+            if (a.rowdot_out && lane == 0) a.rowdot_out[row] = d1;
         } else if (MODE == RM_GRAD2) {
             const GradCoef<T> g2 = grad_coef(a.loss, d2, bi, a.lam);
             const T c = g1.coef() - g2.coef();

@@ -38,8 +38,13 @@ class PackedF:
     """
 
     def __init__(self, loss: int, A: torch.Tensor | None, b: torch.Tensor | None, lam: float = 1.0, N_total: int | None = None,
-                 row0: int = 0, d: int | None = None, dtype: torch.dtype | None = None, N: int | None = None):
+                 row0: int = 0, d: int | None = None, dtype: torch.dtype | None = None, N: int | None = None,
+                 cyclic: tuple[int, int] | None = None):
         self.loss = int(loss)
+        # row ownership of a shard: contiguous block [row0, row0+N) (default), or cyclic=(rank, world): this rank owns the
+        # global rows i with i % world == rank, stored in order (local row = i // world).  Cyclic ownership spreads every
+        # static contiguous Finito batch (Finito_basic.jl:52-58) evenly over the ranks.
+        self.cyclic = cyclic
         if A is not None:
             assert A.is_cuda and A.dim() == 2 and A.stride(1) == 1, "A must be a row-major device matrix"
             assert A.dtype in _DT, f"unsupported dtype {A.dtype}"
@@ -65,6 +70,27 @@ class PackedF:
     @property
     def ref(self):
         return C.byref(self._c)
+
+    def localise(self, idx):
+        """Global sample indices -> the local row indices of the members this shard owns (order preserved)."""
+        import numpy as _np
+        idx = _np.asarray(idx, dtype=_np.int64)
+        if self.N == self.N_total and self.cyclic is None:
+            return idx
+        if self.cyclic is not None:
+            rank, world = self.cyclic
+            return idx[idx % world == rank] // world
+        sel = idx[(idx >= self.row0) & (idx < self.row0 + self.N)]
+        return sel - self.row0
+
+    def local_slice(self, vec):
+        """The entries of a global N_total-vector (L, gamma) that belong to this shard's rows."""
+        if self.N == self.N_total and self.cyclic is None:
+            return vec
+        if self.cyclic is not None:
+            rank, world = self.cyclic
+            return vec[rank::world]
+        return vec[self.row0:self.row0 + self.N]
 
     # reference-style constructors --------------------------------------------------------------------------------
     @staticmethod

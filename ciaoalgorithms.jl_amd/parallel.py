@@ -31,6 +31,13 @@ def shard_rows(N_total: int, rank: int, world: int) -> tuple[int, int]:
     return row0, n_local
 
 
+def shard_rows_cyclic(N_total: int, rank: int, world: int) -> int:
+    """Round-robin ownership (global row i belongs to rank i % world, local row i // world): number of local rows.
+    Use with PackedF(..., cyclic=(rank, world)) when static contiguous Finito batches should span every rank."""
+    assert 0 <= rank < world and N_total >= 0
+    return (N_total - rank + world - 1) // world
+
+
 class _DeviceBuffer:
     """Zero-copy view of library-owned device memory through the CUDA array interface (HIP pointers on ROCm)."""
 

@@ -195,12 +195,12 @@ def _finito_gammas(it):
             val = np_R(it.α) * np_R(N) / np_R(it.L)
             return torch.full((it.F.N,), float(val), dtype=R, device=dev)
         Lh = it.L.to(device=dev, dtype=R) if isinstance(it.L, torch.Tensor) else torch.from_numpy(np.asarray(it.L, dtype=np_R)).to(dev)
-        Lh = Lh[it.F.row0:it.F.row0 + it.F.N] if Lh.numel() == N and it.F.N != N else Lh
+        Lh = it.F.local_slice(Lh) if Lh.numel() == N and it.F.N != N else Lh
         return ((np_R(it.α) * np_R(N)) / Lh).contiguous()
     if np.ndim(it.γ) == 0 and not isinstance(it.γ, torch.Tensor):
         return torch.full((it.F.N,), float(np_R(it.γ)), dtype=R, device=dev)
     gh = it.γ.to(device=dev, dtype=R) if isinstance(it.γ, torch.Tensor) else torch.from_numpy(np.asarray(it.γ, dtype=np_R)).to(dev)
-    gh = gh[it.F.row0:it.F.row0 + it.F.N] if gh.numel() == N and it.F.N != N else gh
+    gh = it.F.local_slice(gh) if gh.numel() == N and it.F.N != N else gh
     return gh.contiguous()
 
 
@@ -212,11 +212,7 @@ def _static_batch(N, r, j):
 
 def _localise(it, batch):
     """Keep the members of a (global-index) batch that this rank owns, as local row indices (parallel.py)."""
-    if it.F.N == it.N:
-        return batch
-    lo, hi = it.F.row0, it.F.row0 + it.F.N
-    sel = batch[(batch >= lo) & (batch < hi)]
-    return sel - lo
+    return it.F.localise(batch)
 
 
 class FINITO_basic_state:

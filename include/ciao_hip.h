@@ -152,7 +152,12 @@ CIAO_API int32_t ciao_svrg_init(ciao_ctx *ctx, const ciao_problem *p, const void
 CIAO_API int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
                         const int64_t *idx, const void *av, void *z, const void *z_full, void *w);
 /* Base.iterate(iter, state), :71-96 = inner cycle + tail (z_full = z/m; basic: w = z_full; z = 0) + full pass.
- * (`state.m *= 2` of SVRG++ is host bookkeeping; pass the current m.) */
+ * (`state.m *= 2` of SVRG++ is host bookkeeping; pass the current m.)
+ * The full pass also stores a_i'z_full per row in the ctx workspace; when the NEXT call on this ctx is again
+ * ciao_svrg_iterate (or ciao_svrg_inner) with the same A and z_full pointers, the inner cycle reads those N scalars
+ * instead of recomputing the second dot product.  Between such calls the state vectors belong to
+ * the library: do not overwrite z_full from outside (any other ciao_* call drops the cache; option
+ * "svrg_cache_rowdots" = 0 disables it). */
 CIAO_API int32_t ciao_svrg_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
                           const int64_t *idx, int32_t plus, void *av, void *z, void *z_full, void *w);
 

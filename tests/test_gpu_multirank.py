@@ -67,6 +67,14 @@ def _worker(rank, world, port, q):
             xs, it = solver(np.zeros(d), F=F, g=g, L=Li, N=N, ctx=ctx, stream=IndexStream(0))
             xr, _ = RS.finito(op, og, np.zeros(d), maxit=6, sweeping=2, batch=64, lfinito=lf, L=Li, stream=IndexStream(0))
             ok[f"finito_lf{int(lf)}"] = bool(np.abs(xs - xr).max() <= 1e-9 * max(np.abs(xr).max(), 1e-30) + 1e-13)
+        # the same with round-robin row ownership: every contiguous batch of 64 now has members on both ranks
+        Fc = PackedF(L.LOSS_LS, torch.from_numpy(np.ascontiguousarray(A[rank::world])).to(dev),
+                     torch.from_numpy(np.ascontiguousarray(b[rank::world])).to(dev), float(N), N_total=N, cyclic=(rank, world))
+        for lf in (False, True):
+            solver = Finito(np.float64, maxit=6, sweeping=3, minibatch=(True, 64), LFinito=lf)
+            xs, it = solver(np.zeros(d), F=Fc, g=g, L=Li, N=N, ctx=ctx, stream=IndexStream(1))
+            xr, _ = RS.finito(op, og, np.zeros(d), maxit=6, sweeping=3, batch=64, lfinito=lf, L=Li, stream=IndexStream(1))
+            ok[f"finito_cyclic_lf{int(lf)}"] = bool(np.abs(xs - xr).max() <= 1e-9 * max(np.abs(xr).max(), 1e-30) + 1e-13)
         # replicas stay bitwise identical across ranks
         gathered = [torch.zeros(d, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(gathered, y.cpu())

