@@ -425,6 +425,59 @@ static int32_t lfinito_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const cia
 }
 
 template <typename T>
+static int32_t afinito_init_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha, const void *x0,
+                              void *table, void *meta, void *av, void *z, void *hat_gamma_dev)
+{
+    RowsArgs<T> a = rows_args<T>(p);
+    a.x1 = (const T *)x0;
+    a.table = (T *)table;
+    a.meta = (T *)meta;
+    a.alpha = (T)alpha;
+    Epilogue<T> e = epi_zero<T>();
+    e.c_sum = T(1);
+    e.inv_extra = 1;              // hat_gamma = 1 / sum_i 1/gamma_i ; av = hat_gamma * sum ; z = prox_{hat_gamma g}(av)
+    e.hg_out = (T *)hat_gamma_dev;
+    e.av_out = (T *)av;
+    e.z_out = (T *)z;
+    e.g = make_prox<T>(g);
+    return launch_rows<T>(ctx, RM_AFINITO_INIT, a, e);
+}
+
+template <typename T>
+static int32_t afinito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha, double tol_b,
+                               int64_t nsteps, const int64_t *idx, void *table, void *meta, void *av, void *z,
+                               void *hat_gamma_dev, int64_t *done_host, int64_t *trials_host)
+{
+    AFinitoArgs<T> a{};
+    a.A = (const T *)p->A;
+    a.b = (const T *)p->b;
+    a.ld = p->ld;
+    a.d = p->d;
+    a.N = p->N;
+    a.lam = (T)p->lam;
+    a.nsteps = nsteps;
+    a.idx = idx;
+    a.alpha = (T)alpha;
+    a.tol_b = (T)tol_b;
+    a.invN = T(1) / (T)p->N_total;
+    a.Nf = (T)p->N_total;
+    a.g = make_prox<T>(g);
+    a.table = (T *)table;
+    a.meta = (T *)meta;
+    a.av = (T *)av;
+    a.z = (T *)z;
+    a.hg = (T *)hat_gamma_dev;
+    a.counters = reinterpret_cast<long long *>(ctx->scal);
+    CIAO_TRY(launch_afinito<T>(ctx, p->loss, a));
+    long long c[2] = {0, 0};
+    CIAO_HIP(hipMemcpyAsync(c, ctx->scal, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    CIAO_HIP(hipStreamSynchronize(ctx->stream));
+    if (done_host) *done_host = c[0];
+    if (trials_host) *trials_host = c[1];
+    return CIAO_OK;
+}
+
+template <typename T>
 static int32_t objective_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *x, double *obj)
 {
     RowsArgs<T> a = rows_args<T>(p);
@@ -509,6 +562,11 @@ int32_t ciao_ctx_synchronize(ciao_ctx *ctx)
     CIAO_HIP(hipStreamSynchronize(ctx->stream));
     if (flag) {
         CIAO_HIP(hipMemsetAsync(ctx->errflag, 0, sizeof(int), ctx->stream));
+        if (flag == 2) {
+            set_error("adaptive Finito init: grad f_i(x0 .+ 1) == grad f_i(x0) for some i; the reference then probes random "
+                      "points (Finito_adaptive.jl:78-85), which this path does not do");
+            return CIAO_ERR_UNSUPPORTED;
+        }
         set_error("a sample index was outside [0, N): results since the last synchronize are invalid");
         return CIAO_ERR_ARG;
     }
@@ -763,6 +821,39 @@ int32_t ciao_lfinito_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_pr
     CIAO_REQUIRE(av && z && z_full && gam, "NULL state vector / gam");
     CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
     return DISPATCH(p->dtype, lfinito_iterate_t, ctx, p, g, gam, hat_gamma, nb, bptr_host, bidx, av, z, z_full);
+}
+
+int32_t ciao_afinito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha, const void *x0,
+                          void *table, void *meta, void *av, void *z, void *hat_gamma_dev)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(x0 && av && z && hat_gamma_dev && ((table && meta) || p->N == 0), "NULL state vector / table / meta");
+    CIAO_REQUIRE(alpha > 0 && alpha < 1, "alpha must be in (0, 1)");
+    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO, "adaptive Finito needs data terms (the Lipschitz probe of Zero() is degenerate)");
+    CIAO_REQUIRE(p->N >= 1, "adaptive Finito needs at least one term");
+    CIAO_REQUIRE(!ctx->hook, "adaptive Finito is a sequential chain: replicas only, not valid on a row-sharded problem");
+    return DISPATCH(p->dtype, afinito_init_t, ctx, p, g, alpha, x0, table, meta, av, z, hat_gamma_dev);
+}
+
+int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha, double tol_b,
+                           int64_t nsteps, const int64_t *idx, void *table, void *meta, void *av, void *z, void *hat_gamma_dev,
+                           int64_t *done_host, int64_t *trials_host)
+{
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(nsteps >= 0 && (nsteps == 0 || idx), "nsteps < 0 or idx is NULL");
+    CIAO_REQUIRE(table && meta && av && z && hat_gamma_dev, "NULL state vector / table / meta");
+    CIAO_REQUIRE(alpha > 0 && alpha < 1 && tol_b > 0, "need 0 < alpha < 1 and tol_b > 0");
+    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO && p->N >= 1, "adaptive Finito needs data terms");
+    CIAO_REQUIRE(!ctx->hook, "adaptive Finito is a sequential chain: replicas only, not valid on a row-sharded problem");
+    if (nsteps == 0) {
+        if (done_host) *done_host = 0;
+        if (trials_host) *trials_host = 0;
+        return CIAO_OK;
+    }
+    return DISPATCH(p->dtype, afinito_steps_t, ctx, p, g, alpha, tol_b, nsteps, idx, table, meta, av, z, hat_gamma_dev, done_host,
+                    trials_host);
 }
 
 int32_t ciao_synth_normal(ciao_ctx *ctx, int32_t dtype, void *out, int64_t nrows, int64_t d, int64_t ld, int64_t row0,

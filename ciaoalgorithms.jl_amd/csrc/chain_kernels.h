@@ -715,6 +715,214 @@ constexpr size_t chain_dma_lds_bytes()
            2 * CHAIN_NW * 2 * sizeof(T);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Adaptive Finito steps (Finito_adaptive.jl:118-150): one sample per iteration with a
+// data-dependent backtracking loop on that sample's stepsize.  Same one-workgroup, state-in-registers structure as the
+// chains above; the per-sample scalars live in `meta` (N x 4: c_i with grad f_i = c_i a_i, f_i(x_i), gamma_i, a_i'x_i),
+// so the reference's N x d gradient table collapses to N scalars for these row-structured f_i.  The next sample's
+// row, table row and scalars are loaded one step ahead (re-read when it is the sample being updated).  Every trial of
+// the backtracking needs a_i'z and ||z - x_i||^2: one 2-value exchange per trial.  All branches are workgroup-uniform
+// because every thread derives them from the same bitwise-identical reduced scalars.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct AFinitoArgs {
+    const T *A;
+    const T *b;
+    int64_t ld, d, N;
+    T lam;
+    int64_t nsteps;
+    const int64_t *idx;
+    T alpha, tol_b, invN, Nf;
+    ProxD<T> g;
+    T *table, *meta, *av, *z;
+    T *hg;                // device scalar: hat_gamma (in/out)
+    long long *counters;  // [0] steps completed, [1] backtracking trials (out)
+    int *errflag;
+};
+
+template <typename T, int E, int LOSS>
+__global__ void __launch_bounds__(CHAIN_NT) afinito_chain_kernel(AFinitoArgs<T> a)
+{
+    __shared__ T red[2][CHAIN_NW][2];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t d = a.d;
+
+    bool valid[E];
+    int64_t ecl[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int64_t e = tid + (int64_t)j * CHAIN_NT;
+        valid[j] = e < d;
+        ecl[j] = valid[j] ? e : d - 1;
+    }
+    T av[E], z[E], plo[E], phi[E];
+    const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        av[j] = valid[j] ? a.av[ecl[j]] : T(0);
+        z[j] = valid[j] ? a.z[ecl[j]] : T(0);
+        plo[j] = -INFINITY;
+        phi[j] = INFINITY;
+        if (a.g.kind == CIAO_PROX_BOX) {
+            plo[j] = a.g.lo_vec ? a.g.lo_vec[ecl[j]] : a.g.lo;
+            phi[j] = a.g.hi_vec ? a.g.hi_vec[ecl[j]] : a.g.hi;
+        }
+    }
+    T hg = *a.hg;
+    int par = 0;
+
+    auto row_of = [&](int64_t s) -> int64_t {
+        int64_t r = a.idx[s];
+        if ((uint64_t)r >= (uint64_t)a.N) {
+            if (tid == 0) *a.errflag = 1;
+            r = 0;
+        }
+        return r;
+    };
+    auto load = [&](int64_t r, T(&ar)[E], T(&sr)[E], T(&m)[4], T &bi) {
+        const T *ap = a.A + r * a.ld;
+        const T *sp = a.table + r * d;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            ar[j] = ap[ecl[j]];
+            sr[j] = sp[ecl[j]];
+        }
+        // the per-sample scalars are written by thread 0 and read by every thread: agent-scope loads go to L2 (no stale
+        // L1 line); ordering comes from the vmcnt(0) + barrier of the __syncthreads() between the store and this load
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = __hip_atomic_load(a.meta + r * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bi = a.b ? a.b[r] : T(0);
+    };
+
+    T ar[E], sr[E], m[4], bi = T(0);
+    T arn[E], srn[E], mn[4], bin = T(0);
+    int64_t row = 0, rown = 0;
+    if (a.nsteps > 0) {
+        row = row_of(0);
+        load(row, ar, sr, m, bi);
+    }
+    int64_t done = 0, trials = 0;
+    for (int64_t s = 0; s < a.nsteps; ++s) {
+        const bool more = s + 1 < a.nsteps;
+        bool same = false;
+        if (more) {
+            rown = row_of(s + 1);
+            same = (rown == row);
+            if (!same) load(rown, arn, srn, mn, bin);   // in flight while this step computes
+        }
+        const T c_old = m[0], fi_x = m[1], as_i = m[3];
+        T gi = m[2];
+        T res[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) res[j] = valid[j] ? z[j] - sr[j] : T(0);
+        T dz = T(0), fi_z = T(0);
+        bool stop = false;
+        while (true) {
+            if (gi < a.tol_b * a.invN) {          // Finito_adaptive.jl:121-124: the stepsize collapsed
+                stop = true;
+                break;
+            }
+            ++trials;
+            T p1 = T(0), p2 = T(0);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                p1 = fmad(valid[j] ? ar[j] : T(0), z[j], p1);
+                p2 = fmad(res[j], res[j], p2);
+            }
+            p1 = wave_allsum(p1);
+            p2 = wave_allsum(p2);
+            if (lane == 0) {
+                red[par][wib][0] = p1;
+                red[par][wib][1] = p2;
+            }
+            __syncthreads();
+            dz = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+            const T n2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+            par ^= 1;
+            fi_z = loss_value(LOSS, dz, bi, a.lam);                                     // :125
+            const T fi_model = fi_x + c_old * (dz - as_i) + (T(0.5) * a.Nf * a.alpha / gi) * n2;   // :126-129
+            const T tol = T(10) * Eps<T>::value * (T(1) + fabs2(fi_z));                 // :130
+            if (fi_z <= fi_model + tol) break;                                          // :131
+            const T gb = gi;                                                            // :133
+            gi *= T(0.8);                                                               // :134
+            const T hg_old = hg;
+            hg = T(1) / (T(1) / hg_old + T(1) / gi - T(1) / gb);                        // :139
+            const T gl = hg * plam;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                T t = av[j] / hg_old;                                                   // :136
+                t += sr[j] / gi;                                                        // :137
+                t -= sr[j] / gb;                                                        // :138
+                t *= hg;                                                                // :140
+                av[j] = valid[j] ? t : T(0);
+                z[j] = valid[j] ? prox_bf(av[j], gl, plo[j], phi[j]) : T(0);            // :141
+                res[j] = valid[j] ? z[j] - sr[j] : T(0);                                // :142
+            }
+        }
+        if (stop) break;
+        // the main step, :145-150
+        const GradCoef<T> gn = grad_coef_t<T, LOSS>(dz, bi, a.lam);
+        const T c_new = gn.coef();
+        const T r1 = hg / gi;
+        const T r2 = (hg * a.invN) * (c_old - c_new);   // + (hg/N) grad_old - (hg/N) grad_new, both multiples of a_i
+        const T gl = hg * plam;
+        T *sp = a.table + row * d;
+        T znew[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            znew[j] = z[j];
+            if (valid[j]) sp[ecl[j]] = z[j];                                             // :146  s_i = z
+            T t = fmad(r1, res[j], av[j]);                                               // :145
+            t = fmad(r2, ar[j], t);                                                      // :147, :149
+            av[j] = valid[j] ? t : T(0);
+            z[j] = valid[j] ? prox_bf(av[j], gl, plo[j], phi[j]) : T(0);                // :150
+        }
+        if (tid == 0) {
+            T *mp = a.meta + row * 4;
+            mp[0] = c_new;
+            mp[1] = fi_z;                                                                // :148 fi_x[i] = f_i(z)
+            mp[2] = gi;
+            mp[3] = dz;
+        }
+        ++done;
+        if (more) {
+            if (same) {
+                // the next step works on the sample just updated: its row stays, its table row is the z stored above and
+                // its scalars are the ones just computed (no memory round trip, and no cross-thread visibility question)
+#pragma unroll
+                for (int j = 0; j < E; ++j) sr[j] = znew[j];
+                m[0] = c_new;
+                m[1] = fi_z;
+                m[2] = gi;
+                m[3] = dz;
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    ar[j] = arn[j];
+                    sr[j] = srn[j];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) m[q] = mn[q];
+                bi = bin;
+                row = rown;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        if (!valid[j]) continue;
+        a.av[ecl[j]] = av[j];
+        a.z[ecl[j]] = z[j];
+    }
+    if (tid == 0) {
+        *a.hg = hg;
+        a.counters[0] = done;
+        a.counters[1] = trials;
+    }
+}
+
 // single-sample gradient!(y, f_i, x) -- the L1 plugin call itself (one wave).
 template <typename T>
 __global__ void __launch_bounds__(WAVE)

@@ -71,6 +71,20 @@ __device__ __forceinline__ double fmax2(double a, double b) { return __builtin_f
 // clamp(v, -t, t) for t >= 0: one v_med3_f32 in single precision, max/min in double
 __device__ __forceinline__ float clamp_sym(float v, float t) { return __builtin_amdgcn_fmed3f(v, -t, t); }
 __device__ __forceinline__ double clamp_sym(double v, double t) { return __builtin_fmin(__builtin_fmax(v, -t), t); }
+__device__ __forceinline__ float fsqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double fsqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float fabs2(float x) { return fabsf(x); }
+__device__ __forceinline__ double fabs2(double x) { return fabs(x); }
+template <typename T>
+struct Eps;
+template <>
+struct Eps<float> {
+    static constexpr float value = 1.1920928955078125e-07f;
+};
+template <>
+struct Eps<double> {
+    static constexpr double value = 2.220446049250313e-16;
+};
 __device__ __forceinline__ float fexp(float x) { return expf(x); }
 __device__ __forceinline__ double fexp(double x) { return exp(x); }
 __device__ __forceinline__ float flog(float x) { return logf(x); }
@@ -185,12 +199,16 @@ struct Epilogue {
     T tau, p0, p1;
     const T *pw;
     ProxD<T> g;
+    int inv_extra;   // adaptive Finito init: hat_gamma = 1/extra; c_sum and tau are multiplied by it; *hg_out = hat_gamma
+    T *hg_out;
 };
 
 template <typename T>
 __device__ __forceinline__ void epilogue_apply(const Epilogue<T> &e, int64_t k, T sum, T extra)
 {
-    T a = e.c_sum * sum;
+    const T hgx = e.inv_extra ? T(1) / extra : T(1);
+    if (e.inv_extra && e.hg_out && k == 0) *e.hg_out = hgx;
+    T a = (e.c_sum * hgx) * sum;
     if (e.acc_in) a += e.c_acc * e.acc_in[k];
     T cu = e.uv_extra ? e.c_u * extra : e.c_u;
     T cv = e.uv_extra ? e.c_v * extra : e.c_v;
@@ -200,7 +218,7 @@ __device__ __forceinline__ void epilogue_apply(const Epilogue<T> &e, int64_t k, 
     if (e.z_out) {
         T t = e.p0 * a;
         if (e.pw) t += e.p1 * e.pw[k];
-        e.z_out[k] = prox_elem(e.g, t, e.tau, k);
+        e.z_out[k] = prox_elem(e.g, t, e.inv_extra ? hgx : e.tau, k);
     }
 }
 

@@ -17,4 +17,8 @@ int32_t launch_rows_raw(ciao_ctx *ctx, int mode, RowsArgs<T> &a);
 template <typename T>
 int32_t launch_chain(ciao_ctx *ctx, int alg, ChainArgs<T> &a);
 
+// adaptive Finito chain (one sample per step, backtracking).  Specialised in chain_f32.hip / chain_f64.hip.
+template <typename T>
+int32_t launch_afinito(ciao_ctx *ctx, int loss, AFinitoArgs<T> &a);
+
 }  // namespace ciao

@@ -20,7 +20,9 @@ enum RowMode {
     RM_GRAD2 = 1,        // acc += (coef(a'x1) - coef(a'x2)) * a ; extra += hg/gam_i  (LFinito batch, Finito_LFinito.jl:93-98)
     RM_SAGA_INIT = 2,    // table_i = grad f_i(x1) ; acc += table_i                   (SAGA_basic.jl:42-47)
     RM_FINITO_INIT = 3,  // table_i = x1 - (gam_i/N) grad f_i(x1) ; acc += table_i/gam_i   (Finito_basic.jl:77-83)
-    RM_FINITO_BATCH = 4  // t = x1 - (gam_i/N) grad f_i(x1) ; acc += (t - table_i)*(hg/gam_i) ; table_i = t  (:110-117)
+    RM_FINITO_BATCH = 4, // t = x1 - (gam_i/N) grad f_i(x1) ; acc += (t - table_i)*(hg/gam_i) ; table_i = t  (:110-117)
+    RM_AFINITO_INIT = 5  // adaptive Finito init (Finito_adaptive.jl:65-93): table_i = x1; Lipschitz probe at x1 .+ 1 ->
+                         // gam_i; meta_i = {c_i, f_i(x1), gam_i, a_i'x1}; acc += x1/gam_i - (c_i/N) a_i; extra += 1/gam_i
 };
 
 template <typename T>
@@ -39,6 +41,8 @@ struct RowsArgs {
     T invN;                // 1 / N_total
     T hat_gamma;
     int want_fval;
+    T *meta;               // AFINITO_INIT: N x 4 per-sample scalars {c_i, f_i, gam_i, a_i's_i}
+    T alpha;               // AFINITO_INIT: the solver's α
     T *rowdot_out;         // GRAD only: if non-null, rowdot_out[row] = a_row'x1 (feeds the SVRG chain, chain_kernels.h CA_SVRGC)
     T *partial;            // [gridDim.x][pstride]
     int64_t pstride;
@@ -72,7 +76,7 @@ constexpr int ROWS_WAVES = ROWS_BLOCK / WAVE;
 // +1 for the Finito table row) and ~44 (f32) / ~76 (f64) registers of addressing / dot-product temporaries.
 template <int ES, int K, int MODE, int PF>
 struct RowsWaves {
-    static constexpr int budget = 4 * K * (2 + PF) + (MODE == RM_FINITO_BATCH ? 2 * K + 16 : 0) + (ES == 8 ? 76 : 44);
+    static constexpr int budget = 4 * K * (2 + PF) + ((MODE == RM_FINITO_BATCH || MODE == RM_AFINITO_INIT) ? 2 * K + 16 : 0) + (ES == 8 ? 76 : 44);
     static constexpr int raw = 512 / ((budget + 7) / 8 * 8);
     static constexpr int value = raw < 1 ? 1 : (raw > 8 ? 8 : raw);
 };
@@ -84,7 +88,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
     constexpr int VEC = VecOf<T>::N;
     constexpr int D = K * WAVE * VEC;
     constexpr bool TWO = (MODE == RM_GRAD2);
-    constexpr bool TABLE = (MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH);
+    constexpr bool TABLE = (MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH || MODE == RM_AFINITO_INIT);
 
     // LDS: the iterate(s) during the sweep, then the cross-wave reduction buffer.
     __shared__ __attribute__((aligned(16))) T lds[(TWO ? 2 : 1) * D];
@@ -175,6 +179,44 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
                 for (int v = 0; v < VEC; ++v) gv[v] = g1.elem(cur[k][v]);
                 sp[k * WAVE + lane] = gv;
                 acc[k] += gv;
+            }
+        } else if (MODE == RM_AFINITO_INIT) {
+            // both probe gradients are multiples of a_i:  ||grad f_i(x1 .+ 1) - grad f_i(x1)|| = |c(d1 + sum a) - c(d1)| ||a||
+            T sa = T(0), n2 = T(0);
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    sa += cur[k][v];
+                    n2 += cur[k][v] * cur[k][v];
+                }
+            sa = wave_allsum(sa);
+            n2 = wave_allsum(n2);
+            const T c0 = g1.coef();
+            const T c1 = grad_coef(a.loss, d1 + sa, bi, a.lam).coef();
+            T nmg = fabs2(c1 - c0) * fsqrt(n2);
+            if (nmg < Eps<T>::value) {   // the reference retries at random probe points here (:78-85): not on this path
+                if (lane == 0) *a.errflag = 2;
+                nmg = Eps<T>::value;
+            }
+            const T gi = a.alpha / ((nmg / fsqrt((T)a.d)) * a.invN);
+            const T rinv = T(1) / gi;
+            const T cn = c0 * a.invN;
+            V *sp = reinterpret_cast<V *>(tp);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const V xv = x1v[k * WAVE];
+                sp[k * WAVE + lane] = xv;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[k][v] += xv[v] * rinv - cn * cur[k][v];
+            }
+            extra += rinv;
+            if (lane == 0) {
+                T *mp = a.meta + row * 4;
+                mp[0] = c0;
+                mp[1] = loss_value(a.loss, d1, bi, a.lam);
+                mp[2] = gi;
+                mp[3] = d1;
             }
         } else {  // FINITO_INIT / FINITO_BATCH
             const T gi = a.gam ? a.gam[row] : a.gam_uniform;
@@ -336,6 +378,38 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
                 const T gv = g1.elem(ap ? ap[e] : T(0));
                 tp[e] = gv;
                 acc[e] += gv;
+            }
+        } else if (MODE == RM_AFINITO_INIT) {
+            T sa = T(0), n2 = T(0);
+            for (int64_t e = lane; e < d; e += WAVE) {
+                const T av = ap ? ap[e] : T(0);
+                sa += av;
+                n2 += av * av;
+            }
+            sa = wave_allsum(sa);
+            n2 = wave_allsum(n2);
+            const T c0 = g1.coef();
+            const T c1 = grad_coef(a.loss, d1 + sa, bi, a.lam).coef();
+            T nmg = fabs2(c1 - c0) * fsqrt(n2);
+            if (nmg < Eps<T>::value) {
+                if (lane == 0) *a.errflag = 2;
+                nmg = Eps<T>::value;
+            }
+            const T gi = a.alpha / ((nmg / fsqrt((T)d)) * a.invN);
+            const T rinv = T(1) / gi;
+            const T cn = c0 * a.invN;
+            for (int64_t e = lane; e < d; e += WAVE) {
+                const T xv = x1s[e];
+                tp[e] = xv;
+                acc[e] += xv * rinv - cn * (ap ? ap[e] : T(0));
+            }
+            extra += rinv;
+            if (lane == 0) {
+                T *mp = a.meta + row * 4;
+                mp[0] = c0;
+                mp[1] = loss_value(a.loss, d1, bi, a.lam);
+                mp[2] = gi;
+                mp[3] = d1;
             }
         } else {
             const T gi = a.gam ? a.gam[row] : a.gam_uniform;

@@ -13,7 +13,8 @@ Differences forced by the device boundary (documented in DESIGN.md):
   * F must be one of the packable families (operators.py), or an already packed `PackedF` living on the device;
   * state vectors are torch device tensors; `solution(state)` returns the state's own tensor (identity, as in
     test/test_lasso.jl:185), and the solver returns it as a numpy array when x0 was a numpy array;
-  * the adaptive Finito variant (Finito_adaptive.jl) is out of scope for this path.
+  * adaptive Finito (Finito_adaptive.jl) keeps its per-sample scalars in an N x 4 device
+    array instead of an N x d gradient table (grad f_i = c_i a_i for the packable families).
 """
 from __future__ import annotations
 
@@ -93,7 +94,10 @@ class _Iterable:
             return self._state
         if self._state is None:
             raise StopIteration
-        self._step(self._state, 1)
+        done = self._step(self._state, 1)   # None = all done; adaptive Finito may end early (`return nothing`)
+        if done is not None and done < 1:
+            self._state = None
+            raise StopIteration
         return self._state
 
 
@@ -307,6 +311,65 @@ class FINITO_LFinito_iterable(_Iterable):
             self.ctx.lfinito_iterate(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.av, st.z, st.z_full)
 
 
+class FINITO_adaptive_state:
+    """Finito_adaptive.jl:13-29.  For the row-structured f_i of this path grad f_i = c_i a_i, so the reference's N x d
+    gradient table `∇f` is the first column of `meta` (N x 4: c_i, f_i(x_i), γ_i, a_i'x_i); γ and fi_x are views of it."""
+
+    def __init__(self, s, meta, hat_γ_dev, av, z, N):
+        self.s, self.meta, self.hat_γ_dev, self.av, self.z = s, meta, hat_γ_dev, av, z
+        self.ind = np.arange(N, dtype=np.int64)
+        self.idx, self.idxr = 0, 0
+        self.trials = 0
+
+    γ = property(lambda self: self.meta[:, 2])
+    fi_x = property(lambda self: self.meta[:, 1])
+    hat_γ = property(lambda self: float(self.hat_γ_dev.item()))
+    hat_gamma = hat_γ
+
+
+class FINITO_adaptive_iterable(_Iterable):
+    """FINITO_adaptive_iterable (Finito_adaptive.jl): per-sample backtracking on γ_i; no minibatch (:162)."""
+
+    def __init__(self, R, F, g, x0, N, L, tol, tol_b, sweeping, α, ctx=None, stream=None):
+        super().__init__(R, F, g, x0, N, ctx, stream)
+        self.L, self.tol, self.tol_b, self.sweeping, self.α = L, tol, tol_b, int(sweeping), α
+        if self.F.row0 != 0 or self.F.N != self.N:
+            raise ValueError("adaptive Finito is a sequential chain: it needs the whole problem on one device")
+
+    def _init(self):                                                       # Finito_adaptive.jl:59-98
+        dev = self._x0_dev.device
+        s = torch.empty((self.N, self.d), dtype=self.R, device=dev)
+        meta = torch.empty((self.N, 4), dtype=self.R, device=dev)
+        hg = torch.empty(1, dtype=self.R, device=dev)
+        av, z = self._new(), self._new()
+        self.ctx.afinito_init(self.F, self.g, self.α, self._x0_dev, s, meta, av, z, hg)
+        self.ctx.synchronize()   # surfaces the degenerate-probe case (reference :78-85) as an error
+        return FINITO_adaptive_state(s, meta, hg, av, z, self.N)
+
+    def _next_index(self, st):                                             # :104-116 (1-based idxr like the reference)
+        N = self.N
+        if self.sweeping == 1:
+            st.idxr = int(self.stream.rand_indices(N, 1)[0]) + 1
+        elif self.sweeping == 2:
+            st.idxr = st.idxr % N + 1
+        elif self.sweeping == 3:
+            if st.idx == N:
+                st.ind = self.stream.randperm(N)
+                st.idx = 1
+            else:
+                st.idx += 1
+            st.idxr = int(st.ind[st.idx - 1]) + 1
+        return st.idxr - 1
+
+    def _step(self, st, n):                                                # :118-150, n iterations in one launch
+        idx = np.fromiter((self._next_index(st) for _ in range(n)), dtype=np.int64, count=n)
+        done, trials = self.ctx.afinito_steps(self.F, self.g, self.α, self.tol_b, idx, st.s, st.meta, st.av, st.z, st.hat_γ_dev)
+        st.trials += trials
+        if done < n:                                                       # :121-124  @warn + return nothing
+            warnings.warn("parameter `γ` became too small")
+        return done
+
+
 # ======================================================================================================================
 # solution(state)   -- SVRG_basic.jl:99, SAGA_basic.jl:71, Finito_basic.jl:123, Finito_LFinito.jl:105
 # ======================================================================================================================
@@ -344,10 +407,13 @@ class _Solver:
                 if self.verbose:
                     n = min(n, self.freq - num_iters % self.freq)
                 n = min(n, self._chunk if it._chunkable else 1)
-                it._step(state, n)
-                num_iters += n
+                done = it._step(state, n)
+                done = n if done is None else done
+                num_iters += done
                 if self.verbose and num_iters % self.freq == 0:
                     disp(num_iters, state)
+                if done < n:   # the iterable ended early (adaptive Finito: stepsize collapsed, Finito_adaptive.jl:121-124)
+                    break
             if self.verbose and num_iters % self.freq != 0:
                 disp(num_iters, state)
         sol = solution(state)
@@ -359,6 +425,7 @@ SVRG_basic_iterable._chunkable = False
 SAGA_basic_iterable._chunkable = True
 FINITO_basic_iterable._chunkable = True
 FINITO_LFinito_iterable._chunkable = False
+FINITO_adaptive_iterable._chunkable = True
 
 
 class SVRG(_Solver):
@@ -429,8 +496,8 @@ class Finito(_Solver):
             return FINITO_LFinito_iterable(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α,
                                            ctx=ctx, stream=stream)
         if self.adaptive:
-            raise NotImplementedError("adaptive Finito (Finito_adaptive.jl) is outside the device hot path "
-                                      "(data-dependent per-sample backtracking; SURVEY.md section 8f)")
+            return FINITO_adaptive_iterable(self.R, F, g, x0, N, L, self.tol, self.tol_b, self.sweeping, self.α,
+                                            ctx=ctx, stream=stream)
         return FINITO_basic_iterable(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α,
                                      ctx=ctx, stream=stream)
 

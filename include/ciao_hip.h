@@ -194,6 +194,23 @@ CIAO_API int32_t ciao_lfinito_iterate(ciao_ctx *ctx, const ciao_problem *p, cons
                              double hat_gamma, int64_t nb, const int64_t *bptr_host, const int64_t *bidx,
                              void *av, void *z, void *z_full);
 
+/* ---- adaptive Finito  (Finito/Finito_adaptive.jl) -------------------------------- */
+/* For the row-structured f_i here grad f_i = c_i a_i, so the reference's N x d gradient table is N scalars: `meta` is a
+ * device N x 4 array of R holding {c_i, f_i(x_i), gamma_i, a_i'x_i} per sample; `table` is the N x d table of points
+ * x_i; `hat_gamma_dev` is a DEVICE scalar of R (it changes during backtracking).
+ * Base.iterate(iter), :59-98: x_i = x0; gamma_i = alpha / L_i with L_i = ||grad f_i(x0 .+ 1) - grad f_i(x0)|| / (sqrt(d) N);
+ * hat_gamma = 1/sum 1/gamma_i; av = hat_gamma (sum x_i/gamma_i - sum grad f_i / N); z = prox_{hat_gamma g}(av).
+ * (The reference's random re-probe when the two gradients coincide, :78-85, is reported as CIAO_ERR_UNSUPPORTED by the
+ * next ciao_ctx_synchronize.) */
+CIAO_API int32_t ciao_afinito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha,
+                                   const void *x0, void *table, void *meta, void *av, void *z, void *hat_gamma_dev);
+/* nsteps consecutive Base.iterate(iter,state), :118-150, for the samples idx[0..nsteps) (the selection :104-116 is host
+ * logic).  Synchronises; *done_host = steps completed (< nsteps iff a stepsize fell below tol_b/N: the reference then
+ * warns and ends the iteration, :121-124), *trials_host = backtracking trials taken. */
+CIAO_API int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha,
+                                    double tol_b, int64_t nsteps, const int64_t *idx, void *table, void *meta, void *av,
+                                    void *z, void *hat_gamma_dev, int64_t *done_host, int64_t *trials_host);
+
 /* ---- synthetic data (bench / tests): counter-based generator, reproducible per (seed, row, col) ------------- */
 /* out[i*ld + k] = scale * N(0,1) for rows row0 .. row0+nrows, keyed by the GLOBAL (row, col). */
 CIAO_API int32_t ciao_synth_normal(ciao_ctx *ctx, int32_t dtype, void *out, int64_t nrows, int64_t d, int64_t ld,

@@ -6,6 +6,7 @@
  */
 #include "ciao_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -20,22 +21,34 @@
 #define SFX(n) n##_f64
 #define R_EXP exp
 #define R_LOG log
+#define R_SQRT sqrt
+#define R_FABS fabs
+#define R_EPS DBL_EPSILON
 #include "ciao_oracle_impl.inc"
 #undef R
 #undef SFX
 #undef R_EXP
 #undef R_LOG
+#undef R_SQRT
+#undef R_FABS
+#undef R_EPS
 
 /* ---- fp32 instance (the reference keeps Float32 problems in Float32: test_lasso.jl:74) ---- */
 #define R float
 #define SFX(n) n##_f32
 #define R_EXP expf
 #define R_LOG logf
+#define R_SQRT sqrtf
+#define R_FABS fabsf
+#define R_EPS FLT_EPSILON
 #include "ciao_oracle_impl.inc"
 #undef R
 #undef SFX
 #undef R_EXP
 #undef R_LOG
+#undef R_SQRT
+#undef R_FABS
+#undef R_EPS
 
 /*
  * Best-case CPU full-gradient sweep on all host cores -- NOT a restatement of the reference (which is

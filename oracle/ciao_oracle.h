@@ -66,6 +66,12 @@ typedef struct {
     void orc_lfinito_iterate_##S(const orc_problem *p, const orc_prox_desc *g, const R *gam, R hat_gamma,      \
                                  int64_t nb, const int64_t *bptr, const int64_t *bidx, R *av, R *z,            \
                                  R *z_full);                                                                   \
+    int orc_afinito_init_##S(const orc_problem *p, const orc_prox_desc *g, R alpha, const R *x0, R *table,      \
+                             R *gtable, R *gam, R *fi_x, R *av, R *z, R *hat_gamma, const R *retry_signs,     \
+                             int64_t *nretry);                                                                 \
+    int64_t orc_afinito_steps_##S(const orc_problem *p, const orc_prox_desc *g, R alpha, R tol_b,              \
+                                  int64_t nsteps, const int64_t *idx, R *table, R *gtable, R *gam, R *fi_x,   \
+                                  R *hat_gamma, R *av, R *z, int64_t *ntrials);                                \
     double orc_objective_##S(const orc_problem *p, const orc_prox_desc *g, const R *x);
 
 ORC_DECL(double, f64)

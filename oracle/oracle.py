@@ -234,5 +234,33 @@ def lfinito_iterate(p: Problem, g: Prox, gam, hat_gamma, batches, av, z, z_full)
                                                          C.c_int64(len(batches)), _p(bptr), _p(bidx), _p(av), _p(z), _p(z_full))
 
 
+def afinito_init(p: Problem, g: Prox, alpha, x0, retry_signs=None):
+    """Finito_adaptive.jl:59-98 -> (table, gtable, gam, fi_x, av, z, hat_gamma)."""
+    table, gtable = np.empty((p.N, p.d), p.dtype), np.empty((p.N, p.d), p.dtype)
+    gam, fi_x = np.empty(p.N, p.dtype), np.empty(p.N, p.dtype)
+    av, z = np.empty(p.d, p.dtype), np.empty(p.d, p.dtype)
+    hg = _ct(p.dtype)(0)
+    nretry = C.c_int64(0 if retry_signs is None else len(retry_signs))
+    rs = None if retry_signs is None else np.ascontiguousarray(retry_signs, dtype=p.dtype)
+    rc = getattr(lib(), f"orc_afinito_init_{_sfx(p.dtype)}")(p.ref, g.ref, _ct(p.dtype)(alpha), _p(_chk(x0, p.dtype, (p.d,))),
+                                                             _p(table), _p(gtable), _p(gam), _p(fi_x), _p(av), _p(z), C.byref(hg),
+                                                             _p(rs), C.byref(nretry))
+    if rc != 0:
+        raise RuntimeError("adaptive Finito init: the Lipschitz probe needs random retries that were not supplied")
+    return table, gtable, gam, fi_x, av, z, p.dtype.type(hg.value)
+
+
+def afinito_steps(p: Problem, g: Prox, alpha, tol_b, idx, table, gtable, gam, fi_x, hat_gamma, av, z):
+    """Finito_adaptive.jl:118-155 for the samples idx -> (steps completed, new hat_gamma, backtracking trials)."""
+    idx = _idx(idx)
+    hg = _ct(p.dtype)(hat_gamma)
+    ntr = C.c_int64(0)
+    fn = getattr(lib(), f"orc_afinito_steps_{_sfx(p.dtype)}")
+    fn.restype = C.c_int64
+    done = fn(p.ref, g.ref, _ct(p.dtype)(alpha), _ct(p.dtype)(tol_b), C.c_int64(len(idx)), _p(idx), _p(table), _p(gtable),
+              _p(gam), _p(fi_x), C.byref(hg), _p(av), _p(z), C.byref(ntr))
+    return int(done), p.dtype.type(hg.value), int(ntr.value)
+
+
 def objective(p: Problem, g: Prox, x):
     return getattr(lib(), f"orc_objective_{_sfx(p.dtype)}")(p.ref, g.ref, _p(_chk(x, p.dtype, (p.d,))))

@@ -195,6 +195,49 @@ class LFinitoIterable:
             yield st
 
 
+class AdaptiveFinitoState:
+    def __init__(self, s, gf, gam, hat_gamma, fi_x, av, z, N):
+        self.s, self.grad_f, self.gamma, self.hat_gamma, self.fi_x, self.av, self.z = s, gf, gam, hat_gamma, fi_x, av, z
+        self.ind = np.arange(N, dtype=np.int64)   # Finito_adaptive.jl:52 (copy(indr)): identity order at first
+        self.idx, self.idxr = 0, 0                # :53-54 (idxr is 1-based in the reference; 0 = "none yet")
+        self.trials = 0
+
+
+class AdaptiveFinitoIterable:
+    """FINITO_adaptive_iterable (Finito_adaptive.jl).  minibatch is not supported by the reference (:162)."""
+
+    def __init__(self, problem, g, x0, L=None, tol=1e-8, tol_b=1e-9, sweeping=1, alpha=0.999, stream=None):
+        self.p, self.g, self.x0, self.L = problem, g, x0, L
+        self.tol, self.tol_b, self.sweeping, self.alpha, self.stream = tol, tol_b, sweeping, alpha, stream
+
+    def __iter__(self):
+        p = self.p
+        N = p.N
+        R = p.dtype.type
+        s, gf, gam, fi_x, av, z, hg = O.afinito_init(p, self.g, R(self.alpha), self.x0)     # :59-98
+        st = AdaptiveFinitoState(s, gf, gam, hg, fi_x, av, z, N)
+        yield st
+        while True:
+            if self.sweeping == 1:                                        # :105-106
+                st.idxr = int(self.stream.rand_indices(N, 1)[0]) + 1
+            elif self.sweeping == 2:                                      # :107-108
+                st.idxr = st.idxr % N + 1
+            elif self.sweeping == 3:                                      # :109-116
+                if st.idx == N:
+                    st.ind = self.stream.randperm(N)
+                    st.idx = 1
+                else:
+                    st.idx += 1
+                st.idxr = int(st.ind[st.idx - 1]) + 1
+            done, st.hat_gamma, tr = O.afinito_steps(p, self.g, R(self.alpha), R(self.tol_b), [st.idxr - 1], st.s, st.grad_f,
+                                                     st.gamma, st.fi_x, st.hat_gamma, st.av, st.z)
+            st.trials += tr
+            if done < 1:
+                warnings.warn("parameter `γ` became too small")          # :122-123: return nothing
+                return
+            yield st
+
+
 def solution(state):
     """SVRG_basic.jl:99, SAGA_basic.jl:71, Finito_basic.jl:123, Finito_LFinito.jl:105."""
     return state.z_full if isinstance(state, SVRGState) else state.z
@@ -224,6 +267,11 @@ def saga(problem, g, x0, maxit=10000, gamma=None, sag=False, L=None, stream=None
 
 
 def finito(problem, g, x0, maxit=10000, gamma=None, sweeping=1, lfinito=False, batch=1, alpha=0.999, L=None,
-           stream=None):
-    cls = LFinitoIterable if lfinito else FinitoIterable                  # Finito.jl:80-116
-    return run(cls(problem, g, x0, L, gamma, sweeping, batch, alpha, stream), maxit)
+           stream=None, adaptive=False, tol=1e-8, tol_b=1e-9):
+    if lfinito:                                                           # Finito.jl:80-116 (LFinito wins over adaptive)
+        it = LFinitoIterable(problem, g, x0, L, gamma, sweeping, batch, alpha, stream)
+    elif adaptive:
+        it = AdaptiveFinitoIterable(problem, g, x0, L, tol, tol_b, sweeping, alpha, stream)
+    else:
+        it = FinitoIterable(problem, g, x0, L, gamma, sweeping, batch, alpha, stream)
+    return run(it, maxit)

@@ -500,6 +500,75 @@ def test_lfinito_iterations(ctx, ciao, chain_variant, dtype, shape, r, chain_max
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# adaptive Finito
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(6, 3), (8, 5), (50, 50), (40, 256), (30, 300), (24, 1024), (10, 4096)])
+def test_adaptive_finito_steps(ctx, ciao, dtype, shape):
+    """Init (Lipschitz probe, hat_gamma, av, z) and 3N backtracking steps against the oracle, same sample sequence --
+    including immediate repeats of a sample (the register hand-over path) and repeats two steps apart."""
+    import torch
+    from oracle import oracle as O
+    N, d = shape
+    A, b, x0 = P.synthetic("ls", N, d, dtype, seed=21)
+    lam_f = float(N)
+    op, dp = make("ls", A, b, lam_f, dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.02)
+    alpha, tol_b = 0.999, 1e-9
+    tdt = dev(x0).dtype
+    table = torch.empty((N, d), dtype=tdt, device="cuda")
+    meta = torch.empty((N, 4), dtype=tdt, device="cuda")
+    hg = torch.empty(1, dtype=tdt, device="cuda")
+    av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+    ctx.afinito_init(dp, dg, alpha, dev(x0), table, meta, av, z, hg)
+    ctx.synchronize()
+    rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(alpha), x0)
+    S = 50 if dtype == np.float64 else 10
+    close(meta[:, 2], rgam, dtype, scale=S, what="adaptive init gamma_i")
+    close(meta[:, 1], rfi, dtype, scale=S, what="adaptive init f_i(x0)")
+    close(hg, [rhg], dtype, scale=S, what="adaptive init hat_gamma")
+    close(av, rav, dtype, scale=S, what="adaptive init av")
+    close(z, rz, dtype, scale=S, what="adaptive init z")
+    assert torch.equal(table, dev(x0).expand(N, d))
+    st = ciao.IndexStream(4)
+    idx = st.rand_indices(N, 3 * N)
+    idx[5:8] = idx[5]          # the same sample three times in a row
+    idx[10] = idx[8]           # ... and again two steps later
+    done, trials = ctx.afinito_steps(dp, dg, alpha, tol_b, idx, table, meta, av, z, hg)
+    rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(alpha), dtype(tol_b), idx, rt, rg, rgam, rfi, rhg, rav, rz)
+    assert done == rdone == len(idx)
+    if dtype == np.float64:
+        assert trials == rtrials, "same backtracking decisions in fp64"
+    S = 2000 if dtype == np.float64 else 200
+    close(z, rz, dtype, scale=S, what=f"adaptive z ({ctx.last_kernel()})")
+    close(av, rav, dtype, scale=S, what="adaptive av")
+    close(hg, [rhg], dtype, scale=S, what="adaptive hat_gamma")
+    close(meta[:, 2], rgam, dtype, scale=S, what="adaptive gamma_i")
+    close(table, rt, dtype, scale=S, what="adaptive table")
+    # grad f_i = c_i a_i: the oracle's full gradient table against the device's N scalars
+    gdev = meta[:, 0:1].double().cpu().numpy() * A.astype(np.float64)
+    close(gdev, rg, dtype, scale=S, what="adaptive gradient table (c_i a_i)")
+    ctx.synchronize()
+
+
+def test_adaptive_finito_stops_when_the_stepsize_collapses(ctx, ciao):
+    """tol_b so large that the very first step finds gamma_i < tol_b/N: the chain ends (reference :121-124)."""
+    import torch
+    N, d = 12, 64
+    A, b, x0 = P.synthetic("ls", N, d, np.float64, seed=2)
+    _, dp = make("ls", A, b, float(N), np.float64)
+    _, dg = make_g("l1", np.float64, d)
+    table = torch.empty((N, d), dtype=torch.float64, device="cuda")
+    meta = torch.empty((N, 4), dtype=torch.float64, device="cuda")
+    hg = torch.empty(1, dtype=torch.float64, device="cuda")
+    av, z = torch.empty(d, dtype=torch.float64, device="cuda"), torch.empty(d, dtype=torch.float64, device="cuda")
+    ctx.afinito_init(dp, dg, 0.999, dev(x0), table, meta, av, z, hg)
+    done, trials = ctx.afinito_steps(dp, dg, 0.999, 1e12, np.arange(5, dtype=np.int64), table, meta, av, z, hg)
+    assert done == 0 and trials == 0
+    ctx.synchronize()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # error behaviour at the boundary
 # ----------------------------------------------------------------------------------------------------------------------
 def test_out_of_range_index_is_reported_not_faulted(ctx, ciao):

@@ -171,6 +171,16 @@ class TestLasso:
         x, it = S.Finito(T, maxit=self.maxit, sweeping=sweeping, LFinito=True)(x0, F=F, g=g, L=L, N=N)
         assert cost(x) - f_star < self.tol and x.dtype == T
 
+    @pytest.mark.parametrize("sweeping", [1, 2, 3])
+    def test_adaptive_finito(self, api, T, sweeping):                       # :88-98
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        solver = S.Finito(T, maxit=self.maxit, tol=T(1e-5), sweeping=sweeping, adaptive=True)
+        x, it = solver(x0, F=F, g=g, L=L, N=N)
+        assert cost(x) - f_star < self.tol and x.dtype == T and it == self.maxit
+        state = next(iter(S.iterator(S.Finito(T, sweeping=sweeping, adaptive=True), x0, F=F, g=g, L=L, N=N)))   # :143-157
+        assert S.solution(state) is state.z and state.γ.shape == (N,)
+
     @pytest.mark.parametrize("sweeping,batch", [(1, 2), (2, 2), (3, 3)])
     def test_finito_minibatch(self, api, T, sweeping, batch):               # :101-111
         S, ops = api

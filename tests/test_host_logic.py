@@ -91,8 +91,6 @@ def test_solver_constructors_validate_like_the_reference():
         S.Finito(tol=0.0)
     with pytest.raises(TypeError):
         S.SVRG(γ=0.1, gamma=0.1)
-    with pytest.raises(NotImplementedError):
-        S.Finito(adaptive=True)._iterable(np.zeros(3), N=2)
 
 
 def test_operator_descriptions_validate():

@@ -124,6 +124,12 @@ class TestLassoKnownAnswer:
         x, _ = RS.finito(p, g, x0, maxit=self.maxit, sweeping=sweeping, batch=batch, lfinito=lf, L=L, stream=Stream(0))
         assert cost(x) - f_star < self.tol and x.dtype == T
 
+    @pytest.mark.parametrize("sweeping", [1, 2, 3])
+    def test_adaptive_finito(self, Stream, T, sweeping):                    # :88-98
+        p, g, L, x0, cost, f_star = lasso(T)
+        x, it = RS.finito(p, g, x0, maxit=self.maxit, sweeping=sweeping, adaptive=True, tol=T(1e-5), stream=Stream(0))
+        assert cost(x) - f_star < self.tol and x.dtype == T and it == self.maxit
+
     def test_svrg(self, Stream, T):                                         # :164-176
         p, g, L, x0, cost, f_star = lasso(T)
         gamma = 1 / (7 * L.max())
