@@ -36,10 +36,17 @@ class ProxDesc(C.Structure):
                 ("lo_vec", C.c_void_p), ("hi_vec", C.c_void_p)]
 
 
+class SepQuad(C.Structure):
+    """ciao_sepquad"""
+    _fields_ = [("dtype", C.c_int32), ("_pad", C.c_int32), ("N", C.c_int64), ("d", C.c_int64), ("ld", C.c_int64),
+                ("N_total", C.c_int64), ("Q", C.c_void_p), ("q", C.c_void_p), ("eta", C.c_double), ("lo", C.c_double),
+                ("hi", C.c_double)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
-_PP, _GP = C.POINTER(Problem), C.POINTER(ProxDesc)
+_PP, _GP, _SP = C.POINTER(Problem), C.POINTER(ProxDesc), C.POINTER(SepQuad)
 
 # name -> (restype, argtypes): one row per declaration in include/ciao_hip.h
 SIGNATURES = {
@@ -71,6 +78,9 @@ SIGNATURES = {
     "ciao_lfinito_iterate": (_i32, [_vp, _PP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ciao_afinito_init": (_i32, [_vp, _PP, _GP, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ciao_afinito_steps": (_i32, [_vp, _PP, _GP, _f64, _f64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "ciao_proshi_init": (_i32, [_vp, _SP, _GP, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ciao_proshi_steps": (_i32, [_vp, _SP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ciao_proshi_solution": (_i32, [_vp, _SP, _vp, _vp, _vp]),
     "ciao_synth_normal": (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _i64, C.c_uint64, _f64]),
     "ciao_synth_targets": (_i32, [_vp, _PP, _vp, _f64, _i32, _i64, C.c_uint64, _vp]),
 }

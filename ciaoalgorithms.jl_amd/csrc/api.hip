@@ -478,6 +478,79 @@ static int32_t afinito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_
 }
 
 template <typename T>
+static ProshiArgs<T> proshi_args(const ciao_sepquad *f, const void *gam, void *table)
+{
+    ProshiArgs<T> a{};
+    a.Q = (const T *)f->Q;
+    a.q = (const T *)f->q;
+    a.ld = f->ld;
+    a.d = f->d;
+    a.N = f->N;
+    a.eta = (T)f->eta;
+    a.lo = (T)f->lo;
+    a.hi = (T)f->hi;
+    a.gam = (const T *)gam;
+    a.invN = T(1) / (T)f->N_total;
+    a.table = (T *)table;
+    return a;
+}
+
+template <typename T>
+static int32_t proshi_init_t(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_desc *g, const void *gam, const void *x0,
+                             void *table, void *av, void *z, void *hat_gamma_dev)
+{
+    ProshiArgs<T> a = proshi_args<T>(f, gam, table);
+    a.x = (const T *)x0;
+    a.nrows = f->N;
+    a.idx = nullptr;
+    Epilogue<T> e = epi_zero<T>();
+    e.c_sum = T(1);            // av = sum_i s_i
+    e.inv_extra = 2;           // hat_gamma = sum_i gam_i
+    e.hg_out = (T *)hat_gamma_dev;
+    e.av_out = (T *)av;
+    e.z_out = (T *)z;          // z = (prox_{hat_gamma g}(av) - av) / hat_gamma
+    e.zmode = 1;
+    e.g = make_prox<T>(g);
+    return launch_proshi<T>(ctx, true, a, e);
+}
+
+template <typename T>
+static int32_t proshi_steps_t(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_desc *g, const void *gam, double hat_gamma,
+                              int64_t nit, const int64_t *bptr, const int64_t *bidx, void *table, void *av, void *z)
+{
+    for (int64_t t = 0; t < nit; ++t) {
+        const int64_t r = bptr[t + 1] - bptr[t];
+        CIAO_REQUIRE(r >= 1 || (ctx->hook && r == 0), "ProShI batch %lld is empty", (long long)t);
+        ProshiArgs<T> a = proshi_args<T>(f, gam, table);
+        a.x = (const T *)z;
+        a.nrows = r;
+        a.idx = bidx + bptr[t];
+        Epilogue<T> e = epi_zero<T>();
+        e.c_acc = T(1);        // av += sum_{i in batch} (s_i_new - s_i_old)
+        e.acc_in = (const T *)av;
+        e.c_sum = T(1);
+        e.av_out = (T *)av;
+        e.z_out = (T *)z;
+        e.zmode = 1;
+        e.tau = (T)hat_gamma;
+        e.g = make_prox<T>(g);
+        CIAO_TRY(launch_proshi<T>(ctx, false, a, e));
+    }
+    return CIAO_OK;
+}
+
+static int32_t check_sepquad(ciao_ctx *ctx, const ciao_sepquad *f)
+{
+    CIAO_REQUIRE(ctx && f, "ctx or problem is NULL");
+    ctx->rowdot_A = nullptr;
+    CIAO_REQUIRE(f->dtype == CIAO_F32 || f->dtype == CIAO_F64, "bad dtype %d", f->dtype);
+    CIAO_REQUIRE(f->N >= 0 && f->d >= 1 && f->ld >= f->d && f->N_total >= f->N && f->N_total >= 1, "bad shape");
+    CIAO_REQUIRE(f->N == 0 || (f->Q && f->q), "Q or q is NULL");
+    CIAO_REQUIRE(f->eta >= 0 && f->lo <= f->hi, "need eta >= 0 and lo <= hi");
+    return CIAO_OK;
+}
+
+template <typename T>
 static int32_t objective_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *x, double *obj)
 {
     RowsArgs<T> a = rows_args<T>(p);
@@ -854,6 +927,43 @@ int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox
     }
     return DISPATCH(p->dtype, afinito_steps_t, ctx, p, g, alpha, tol_b, nsteps, idx, table, meta, av, z, hat_gamma_dev, done_host,
                     trials_host);
+}
+
+int32_t ciao_proshi_init(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_desc *g, const void *gam, const void *x0,
+                         void *table, void *av, void *z, void *hat_gamma_dev)
+{
+    CIAO_TRY(check_sepquad(ctx, f));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(x0 && av && z && hat_gamma_dev && ((table && gam) || f->N == 0), "NULL state vector / table / gam");
+    return DISPATCH(f->dtype, proshi_init_t, ctx, f, g, gam, x0, table, av, z, hat_gamma_dev);
+}
+
+int32_t ciao_proshi_steps(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_desc *g, const void *gam, double hat_gamma,
+                          int64_t nit, const int64_t *bptr_host, const int64_t *bidx, void *table, void *av, void *z)
+{
+    CIAO_TRY(check_sepquad(ctx, f));
+    CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(nit >= 0 && (nit == 0 || (bptr_host && (bidx || bptr_host[nit] == bptr_host[0]))), "nit < 0 or NULL batch arrays");
+    CIAO_REQUIRE(table && gam && av && z, "NULL state vector / table / gam");
+    CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
+    return DISPATCH(f->dtype, proshi_steps_t, ctx, f, g, gam, hat_gamma, nit, bptr_host, bidx, table, av, z);
+}
+
+int32_t ciao_proshi_solution(ciao_ctx *ctx, const ciao_sepquad *f, const void *gam, const void *z, void *table)
+{
+    CIAO_TRY(check_sepquad(ctx, f));
+    CIAO_REQUIRE((table && gam && z) || f->N == 0, "NULL argument");
+    if (f->N == 0) return CIAO_OK;
+    int64_t grid = (f->N * f->d + 255) / 256;
+    if (grid > (int64_t)ctx->num_cu * 16) grid = (int64_t)ctx->num_cu * 16;
+    if (f->dtype == CIAO_F64)
+        hipLaunchKernelGGL((proshi_solution_kernel<double>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, f->N, f->d,
+                           (const double *)gam, (const double *)z, (double *)table);
+    else
+        hipLaunchKernelGGL((proshi_solution_kernel<float>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, f->N, f->d,
+                           (const float *)gam, (const float *)z, (float *)table);
+    CIAO_HIP(hipGetLastError());
+    return CIAO_OK;
 }
 
 int32_t ciao_synth_normal(ciao_ctx *ctx, int32_t dtype, void *out, int64_t nrows, int64_t d, int64_t ld, int64_t row0,

@@ -199,16 +199,18 @@ struct Epilogue {
     T tau, p0, p1;
     const T *pw;
     ProxD<T> g;
-    int inv_extra;   // adaptive Finito init: hat_gamma = 1/extra; c_sum and tau are multiplied by it; *hg_out = hat_gamma
+    int inv_extra;   // 1 (adaptive Finito init): hat_gamma = 1/extra scales c_sum and is the prox parameter;
+                     // 2 (ProShI init): hat_gamma = extra is the prox parameter;  both: *hg_out = hat_gamma
     T *hg_out;
+    int zmode;       // 0: z = prox(..) ; 1 (ProShI, ProShI_basic.jl:84-86, :119-121): z = (prox_{tau g}(a) - a) / tau
 };
 
 template <typename T>
 __device__ __forceinline__ void epilogue_apply(const Epilogue<T> &e, int64_t k, T sum, T extra)
 {
-    const T hgx = e.inv_extra ? T(1) / extra : T(1);
+    const T hgx = e.inv_extra == 1 ? T(1) / extra : (e.inv_extra == 2 ? extra : T(1));
     if (e.inv_extra && e.hg_out && k == 0) *e.hg_out = hgx;
-    T a = (e.c_sum * hgx) * sum;
+    T a = (e.inv_extra == 1 ? e.c_sum * hgx : e.c_sum) * sum;
     if (e.acc_in) a += e.c_acc * e.acc_in[k];
     T cu = e.uv_extra ? e.c_u * extra : e.c_u;
     T cv = e.uv_extra ? e.c_v * extra : e.c_v;
@@ -218,7 +220,9 @@ __device__ __forceinline__ void epilogue_apply(const Epilogue<T> &e, int64_t k, 
     if (e.z_out) {
         T t = e.p0 * a;
         if (e.pw) t += e.p1 * e.pw[k];
-        e.z_out[k] = prox_elem(e.g, t, e.inv_extra ? hgx : e.tau, k);
+        const T tau = e.inv_extra ? hgx : e.tau;
+        const T pz = prox_elem(e.g, t, tau, k);
+        e.z_out[k] = e.zmode == 1 ? (pz - t) / tau : pz;
     }
 }
 

@@ -3,6 +3,7 @@
 
 #include "chain_kernels.h"
 #include "ciao_ctx.h"
+#include "proshi_kernels.h"
 #include "rows_kernels.h"
 
 namespace ciao {
@@ -17,6 +18,9 @@ int32_t launch_rows_raw(ciao_ctx *ctx, int mode, RowsArgs<T> &a);
 template <typename T>
 int32_t launch_chain(ciao_ctx *ctx, int alg, ChainArgs<T> &a);
 
+// ProShI agent rows (init or one batch) + finalize + epilogue.  Specialised in rows_f32.hip / rows_f64.hip.
+template <typename T>
+int32_t launch_proshi(ciao_ctx *ctx, bool init, ProshiArgs<T> &a, const Epilogue<T> &ep);
 // adaptive Finito chain (one sample per step, backtracking).  Specialised in chain_f32.hip / chain_f64.hip.
 template <typename T>
 int32_t launch_afinito(ciao_ctx *ctx, int loss, AFinitoArgs<T> &a);

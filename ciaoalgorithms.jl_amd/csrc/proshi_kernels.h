@@ -1,0 +1,106 @@
+// proshi_kernels.h -- ProShI (src/algorithms/ProShI/ProShI_basic.jl) for the operator
+// family of the reference's own test:  f_i = Sum(Quadratic(diagm(Q_i), q_i), SqrDistL2(IndBox(lo, hi), eta)).
+// Every agent's update is element-wise in its own row (no dot product), agents of a batch are independent given z, and
+// the only coupling is av = sum_i s_i: one wave per agent row, the same per-wave LDS accumulators, per-block partials and
+// fixed-order finalize as the rows kernels.  HBM-bound: 3 rows read (Q_i, q_i, s_i) + 1 written per agent = 4*d*s bytes.
+#pragma once
+
+#include "ciao_common.h"
+
+namespace ciao {
+
+template <typename T>
+struct ProshiArgs {
+    const T *Q, *q;        // N x ld each
+    int64_t ld, d, N;
+    T eta, lo, hi;
+    const T *gam;          // per-agent stepsizes
+    T invN;
+    const T *x;            // INIT: x0 ; STEP: z
+    T *table;              // N x d
+    int64_t nrows;
+    const int64_t *idx;    // STEP: batch members; INIT: nullptr (all rows)
+    T *partial;
+    int64_t pstride;
+    T *pextra;
+    int *errflag;
+};
+
+// grad f_i(x)_k = Q_k x_k + q_k + eta (x_k - clamp(x_k, lo, hi))
+template <typename T>
+__device__ __forceinline__ T sq_grad(T Qk, T qk, T eta, T lo, T hi, T x)
+{
+    const T pr = x < lo ? lo : (x > hi ? hi : x);
+    return (Qk * x + qk) + eta * (x - pr);
+}
+
+template <typename T, bool INIT, int PROSHI_NW>
+__global__ void __launch_bounds__(PROSHI_NW *WAVE) proshi_rows_kernel(ProshiArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *xs = reinterpret_cast<T *>(smem_raw);          // x0 or z
+    T *accs = xs + a.d;                               // [PROSHI_NW][d]
+    __shared__ T red_extra[PROSHI_NW];
+    const int64_t d = a.d;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t nwaves = (int64_t)gridDim.x * PROSHI_NW;
+    T *acc = accs + (int64_t)wib * d;
+    for (int64_t e = threadIdx.x; e < d; e += PROSHI_NW * WAVE) xs[e] = a.x[e];
+    for (int64_t e = threadIdx.x; e < (int64_t)PROSHI_NW * d; e += PROSHI_NW * WAVE) accs[e] = T(0);
+    __syncthreads();
+
+    T extra = T(0);
+    for (int64_t u = (int64_t)blockIdx.x * PROSHI_NW + wib; u < a.nrows; u += nwaves) {
+        int64_t row = a.idx ? a.idx[u] : u;
+        if ((uint64_t)row >= (uint64_t)a.N) {
+            if (lane == 0) *a.errflag = 1;
+            row = 0;
+        }
+        const T *Qp = a.Q + row * a.ld, *qp = a.q + row * a.ld;
+        T *sp = a.table + row * d;
+        const T gi = a.gam[row];
+        const T c = gi * a.invN;
+        for (int64_t e = lane; e < d; e += WAVE) {
+            if (INIT) {                                                     // ProShI_basic.jl:77-79
+                const T x0 = xs[e];
+                const T t = x0 - c * sq_grad(Qp[e], qp[e], a.eta, a.lo, a.hi, x0);
+                sp[e] = t;
+                acc[e] += t;
+            } else {                                                        // :111-117
+                const T s = sp[e];
+                const T s2 = s + gi * xs[e];
+                const T t = s2 - c * sq_grad(Qp[e], qp[e], a.eta, a.lo, a.hi, s2);
+                sp[e] = t;
+                acc[e] += t - s;
+            }
+        }
+        if (INIT) extra += gi;                                              // :82  hat_γ = sum(γ)
+    }
+    if (lane == 0) red_extra[wib] = extra;
+    __syncthreads();
+    T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
+    for (int64_t e = threadIdx.x; e < d; e += PROSHI_NW * WAVE) {
+        T s = accs[e];
+        for (int w = 1; w < PROSHI_NW; ++w) s += accs[(int64_t)w * d + e];
+        pout[e] = s;
+    }
+    if (threadIdx.x == 0) {
+        T ex = T(0);
+        for (int w = 0; w < PROSHI_NW; ++w) ex += red_extra[w];
+        a.pextra[blockIdx.x] = ex;
+    }
+}
+
+// solution(state): s_i += γ_i z for every agent, in place (ProShI_basic.jl:127-132)
+template <typename T>
+__global__ void __launch_bounds__(256) proshi_solution_kernel(int64_t N, int64_t d, const T *gam, const T *z, T *table)
+{
+    const int64_t total = N * d;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = t / d, k = t - i * d;
+        table[t] += gam[i] * z[k];
+    }
+}
+
+}  // namespace ciao

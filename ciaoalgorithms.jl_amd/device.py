@@ -108,6 +108,30 @@ class PackedF:
         return PackedF(L.LOSS_ZERO, None, None, 0.0, d=d, dtype=dtype, N=N)
 
 
+class PackedSepQuad:
+    """F = [f_1..f_N] with f_i = Sum(Quadratic(diagm(Q_i), q_i), SqrDistL2(IndBox(lo, hi), eta)) packed for the device
+    (the operator family of test/test_sharing.jl:16-25): Q, q row-major N x d device matrices."""
+
+    def __init__(self, Q: torch.Tensor, q: torch.Tensor, eta: float = 0.0, lo: float = 0.0, hi: float = 0.0,
+                 N_total: int | None = None, row0: int = 0):
+        assert Q.is_cuda and q.is_cuda and Q.shape == q.shape and Q.dim() == 2 and Q.dtype == q.dtype and Q.dtype in _DT
+        assert Q.is_contiguous() and q.is_contiguous()
+        self.Q, self.q, self.eta, self.lo, self.hi = Q, q, float(eta), float(lo), float(hi)
+        self.N, self.d = int(Q.shape[0]), int(Q.shape[1])
+        self.dtype, self.device = Q.dtype, Q.device
+        self.N_total = int(N_total) if N_total is not None else self.N
+        self.row0, self.cyclic = int(row0), None
+        self._c = L.SepQuad(_DT[self.dtype], 0, self.N, self.d, self.d, self.N_total, Q.data_ptr() if self.N else None,
+                            q.data_ptr() if self.N else None, self.eta, self.lo, self.hi)
+
+    @property
+    def ref(self):
+        return C.byref(self._c)
+
+    localise = PackedF.localise
+    local_slice = PackedF.local_slice
+
+
 class ProxG:
     """g packed for the device: Zero / NormL1(λ) / IndBox(lo, hi)."""
 
@@ -302,6 +326,24 @@ class Context:
                                             self._vec(av, p, "av"), self._vec(z, p, "z"), self._vec(hat_gamma_dev, p, "hat_gamma", 1),
                                             C.byref(done), C.byref(trials)))
         return done.value, trials.value
+
+    # -- ProShI ------------------------------------------------------------------------------------------------------------
+    def proshi_init(self, f, g, gam, x0, table, av, z, hat_gamma_dev):
+        L.check(self.lib.ciao_proshi_init(self._h, f.ref, g.ref, self._vec(gam, f, "gam", f.N), self._vec(x0, f, "x0"),
+                                          self._vec(table, f, "table", f.N * f.d), self._vec(av, f, "av"), self._vec(z, f, "z"),
+                                          self._vec(hat_gamma_dev, f, "hat_gamma", 1)))
+
+    def proshi_steps(self, f, g, gam, hat_gamma, bptr: np.ndarray, bidx, table, av, z):
+        bptr = np.ascontiguousarray(bptr, dtype=np.int64)
+        bidx = self._idx(bidx)
+        assert bptr[0] == 0 and bptr[-1] == bidx.numel()
+        L.check(self.lib.ciao_proshi_steps(self._h, f.ref, g.ref, self._vec(gam, f, "gam", f.N), float(hat_gamma), len(bptr) - 1,
+                                           C.c_void_p(bptr.ctypes.data), _ptr(bidx), self._vec(table, f, "table", f.N * f.d),
+                                           self._vec(av, f, "av"), self._vec(z, f, "z")))
+
+    def proshi_solution(self, f, gam, z, table):
+        L.check(self.lib.ciao_proshi_solution(self._h, f.ref, self._vec(gam, f, "gam", f.N), self._vec(z, f, "z"),
+                                              self._vec(table, f, "table", f.N * f.d)))
 
     # -- synthetic data -------------------------------------------------------------------------------------------------
     def synth_normal(self, out: torch.Tensor, row0: int, seed: int, scale: float):

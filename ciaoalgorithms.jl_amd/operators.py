@@ -82,6 +82,32 @@ class Precompose:
         self.f, self.L, self.mu, self.b = f, np.atleast_2d(np.asarray(Lmat)), float(mu), b
 
 
+class Quadratic:
+    """ProximalOperators.Quadratic(Q, q): f(x) = 1/2 <x, Q x> + <q, x>.  Only diagonal Q is packable (test_sharing.jl:21-22
+    builds Q = diagm(d_i))."""
+
+    def __init__(self, Q, q):
+        self.Q, self.q = np.atleast_2d(np.asarray(Q)), np.atleast_1d(np.asarray(q))
+        if self.Q.shape != (self.q.shape[0], self.q.shape[0]):
+            raise ValueError("Quadratic: Q must be n x n and q of length n")
+
+
+class SqrDistL2:
+    """ProximalOperators.SqrDistL2(ind, λ): f(x) = λ/2 dist²(x, set of `ind`); here `ind` must be an IndBox with scalar bounds."""
+
+    def __init__(self, ind, lam=1.0):
+        if float(lam) < 0:
+            raise ValueError("SqrDistL2: λ must be nonnegative")
+        self.ind, self.lam = ind, float(lam)
+
+
+class Sum:
+    """ProximalOperators.Sum(f1, f2, ...): x ↦ Σ f_k(x)."""
+
+    def __init__(self, *fs):
+        self.fs = fs
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # packing
 # ------------------------------------------------------------------------------------------------------------------------
@@ -154,3 +180,41 @@ def pack_g(g, d: int, R, device=None) -> ProxG:
             hi = float(g.hi)
         return ProxG(L.PROX_BOX, lo=lo, hi=hi, lo_vec=lo_vec, hi_vec=hi_vec)
     raise TypeError(f"g of type {type(g).__name__} is not a family the device path supports (Zero, NormL1, IndBox)")
+
+
+def pack_sharing_F(F, N: int, d: int, R, device=None):
+    """Recognise F::Vector of Sum(Quadratic(diagonal Q, q), SqrDistL2(IndBox(lo, hi), η)) (test/test_sharing.jl:16-25), or a
+    lone Quadratic, and pack it as a PackedSepQuad.  Anything else raises TypeError."""
+    from .device import PackedSepQuad
+    dtype = torch_dtype(R)
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if isinstance(F, PackedSepQuad):
+        if F.dtype != dtype or F.d != d:
+            raise TypeError("packed F does not match the solver's real type / x0")
+        return F
+    F = list(F)
+    if len(F) != N:
+        raise ValueError(f"F has {len(F)} terms but N={N}")
+    Qs, qs, eta, lo, hi = [], [], None, None, None
+    for f in F:
+        parts = list(f.fs) if isinstance(f, Sum) else [f]
+        quad = [t for t in parts if isinstance(t, Quadratic)]
+        dist = [t for t in parts if isinstance(t, SqrDistL2)]
+        if len(quad) != 1 or len(dist) > 1 or len(quad) + len(dist) != len(parts):
+            raise TypeError("ProShI device path: each f_i must be Quadratic or Sum(Quadratic, SqrDistL2(IndBox, η))")
+        Q = quad[0].Q
+        if Q.shape != (d, d) or np.any(Q - np.diag(np.diag(Q)) != 0):
+            raise TypeError("ProShI device path: only diagonal Quadratic terms of size d x d are packable")
+        Qs.append(np.diag(Q))
+        qs.append(quad[0].q)
+        e, l, h = (0.0, 0.0, 0.0)
+        if dist:
+            box = dist[0].ind
+            if not isinstance(box, IndBox) or np.ndim(box.lo) or np.ndim(box.hi):
+                raise TypeError("ProShI device path: SqrDistL2 must wrap an IndBox with scalar bounds")
+            e, l, h = dist[0].lam, float(box.lo), float(box.hi)
+        if eta is None:
+            eta, lo, hi = e, l, h
+        elif (eta, lo, hi) != (e, l, h):
+            raise TypeError("ProShI device path: all agents must share the same soft box (η, lo, hi)")
+    return PackedSepQuad(_dev(np.stack(Qs), dtype, device), _dev(np.stack(qs), dtype, device), eta, lo, hi)

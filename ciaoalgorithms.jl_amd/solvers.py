@@ -24,10 +24,10 @@ import numpy as np
 import torch
 
 from .device import Context, PackedF, default_context, torch_dtype
-from .operators import pack_F, pack_g
+from .operators import pack_F, pack_g, pack_sharing_F
 from .sampling import IndexStream
 
-__all__ = ["SVRG", "SAGA", "SAG", "Finito", "iterator", "solution"]
+__all__ = ["SVRG", "SAGA", "SAG", "Finito", "Proshi", "iterator", "solution"]
 
 
 def _pick(greek, ascii_, name):
@@ -371,12 +371,63 @@ class FINITO_adaptive_iterable(_Iterable):
 
 
 # ======================================================================================================================
+# ProShI  (src/algorithms/ProShI/ProShI_basic.jl) -- sharing problems: the solution is the whole N x d table
+# ======================================================================================================================
+class Proshi_basic_state:
+    def __init__(self, it, s, γ, hat_γ, av, z, d):
+        self._it, self.s, self.γ, self.hat_γ, self.av, self.z, self.d = it, s, γ, hat_γ, av, z, d
+        self.idxr, self.idx, self.inds = 1, 0, np.arange(d, dtype=np.int64)   # ProShI_basic.jl:37-39
+
+    hat_gamma = property(lambda self: self.hat_γ)
+
+
+class Proshi_basic_iterable(_Iterable):
+    def __init__(self, R, F, g, x0, N, L, γ, sweeping, batch, α, ctx=None, stream=None):
+        if N is None:
+            raise TypeError("N (number of agents) is required")
+        self.R = torch_dtype(R)
+        self.x0, self.N = x0, int(N)
+        self._x0_dev, self._numpy = _x0_to_device(x0, self.R)
+        self.d = self._x0_dev.numel()
+        self.ctx = ctx if ctx is not None else default_context()
+        self.F = pack_sharing_F(F, self.N, self.d, self.R, self._x0_dev.device)
+        self.g = pack_g(g, self.d, self.R, self._x0_dev.device)
+        self.stream = stream if stream is not None else IndexStream(0)
+        self._state, self._started = None, False
+        self.L, self.γ, self.sweeping, self.batch, self.α = L, γ, int(sweeping), int(batch), α
+
+    def _init(self):                                                       # ProShI_basic.jl:44-89
+        N, r = self.N, self.batch
+        gam = _finito_gammas(self)                                         # :61-74 (the same rule as Finito)
+        if gam is None:
+            return None
+        dev = self._x0_dev.device
+        s = torch.empty((self.F.N, self.d), dtype=self.R, device=dev)
+        av, z = self._new(), self._new()
+        hg = torch.empty(1, dtype=self.R, device=dev)
+        self.ctx.proshi_init(self.F, self.g, gam, self._x0_dev, s, av, z, hg)   # :76-87
+        return Proshi_basic_state(self, s, gam, float(hg.item()), av, z, -(-N // r) if N > 0 else 0)
+
+    _next_batch = FINITO_basic_iterable._next_batch                        # :95-107 is Finito's batch logic verbatim
+
+    def _step(self, st, n):                                                # :109-121
+        batches = [self.F.localise(self._next_batch(st)) for _ in range(n)]
+        bptr = np.zeros(n + 1, np.int64)
+        np.cumsum([len(b) for b in batches], out=bptr[1:])
+        bidx = np.concatenate(batches) if batches else np.zeros(0, np.int64)
+        self.ctx.proshi_steps(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.s, st.av, st.z)
+
+
+# ======================================================================================================================
 # solution(state)   -- SVRG_basic.jl:99, SAGA_basic.jl:71, Finito_basic.jl:123, Finito_LFinito.jl:105
 # ======================================================================================================================
 def solution(state):
     if state is None:
         raise TypeError("solution(nothing): no method matching solution(::Nothing) -- the iterable ended before yielding "
                         "a state (invalid configuration, see the warning above)")
+    if isinstance(state, Proshi_basic_state):                              # ProShI_basic.jl:127-132: shifts s IN PLACE
+        state._it.ctx.proshi_solution(state._it.F, state.γ, state.z, state.s)
+        return state.s
     return state.z_full if isinstance(state, SVRG_basic_state) else state.z
 
 
@@ -418,6 +469,8 @@ class _Solver:
                 disp(num_iters, state)
         sol = solution(state)
         it.ctx.synchronize()
+        if isinstance(state, Proshi_basic_state):   # Array{Array{R,1}}: one x_i per agent (test_sharing.jl:45)
+            return ([row for row in sol.cpu().numpy()] if it._numpy else sol), num_iters
         return (sol.cpu().numpy().reshape(np.shape(it.x0)) if it._numpy else sol), num_iters
 
 
@@ -503,6 +556,31 @@ class Finito(_Solver):
 
     def __call__(self, x0, **kw):                                          # Finito.jl:66-133
         return self._drive(self._iterable(x0, **kw), self.maxit, lambda it, st: print("%5d | %.3e  " % (it, st.hat_γ)))
+
+
+class Proshi(_Solver):
+    """Proshi{R}(; γ, sweeping=1, minibatch=(false,1), maxit=10000, verbose=false, freq=10000, α=0.999)   (ProShI.jl:18-40)"""
+
+    def __init__(self, R=np.float64, *, γ=None, gamma=None, sweeping=1, minibatch=(False, 1), maxit=10000, verbose=False,
+                 freq=10000, α=None, alpha=None):
+        γ = _pick(γ, gamma, "γ")
+        α = _pick(α, alpha, "α")
+        α = 0.999 if α is None else α
+        assert γ is None or np.min(np.asarray(γ.cpu() if isinstance(γ, torch.Tensor) else γ)) > 0
+        assert maxit > 0
+        assert freq > 0
+        self.R, self.γ, self.sweeping, self.minibatch = R, γ, sweeping, tuple(minibatch)
+        self.maxit, self.verbose, self.freq, self.α = int(maxit), verbose, int(freq), α
+
+    def _iterable(self, x0, F=None, g=None, L=None, N=None, ctx=None, stream=None):
+        return Proshi_basic_iterable(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α, ctx=ctx,
+                                     stream=stream)
+
+    def __call__(self, x0, **kw):                                          # ProShI.jl:42-83
+        return self._drive(self._iterable(x0, **kw), self.maxit, lambda it, st: print("%5d | %.3e  " % (it, st.hat_γ)))
+
+
+Proshi_basic_iterable._chunkable = True
 
 
 def iterator(solver, x0, **kw):

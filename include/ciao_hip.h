@@ -211,6 +211,33 @@ CIAO_API int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const 
                                     double tol_b, int64_t nsteps, const int64_t *idx, void *table, void *meta, void *av,
                                     void *z, void *hat_gamma_dev, int64_t *done_host, int64_t *trials_host);
 
+/* ---- ProShI  (ProShI/ProShI_basic.jl) ------------------------------------------------ */
+/* minimize (1/N) sum_i f_i(x_i) + g(sum_i x_i): the solution is the whole N x d table.  Operator family of the reference's
+ * own test (test/test_sharing.jl:16-25): f_i = Sum(Quadratic(diagm(Q_i), q_i), SqrDistL2(IndBox(lo, hi), eta)), i.e.
+ * grad f_i(x)_k = Q_ik x_k + q_ik + eta (x_k - clamp(x_k, lo, hi)) -- element-wise in each agent's own row. */
+typedef struct {
+    int32_t dtype;     /* CIAO_F32 / CIAO_F64                                  */
+    int32_t _pad;
+    int64_t N;         /* local agents (rows)                                  */
+    int64_t d;
+    int64_t ld;        /* row stride of Q and q in elements (>= d)             */
+    int64_t N_total;   /* global number of agents (the 1/N factor)             */
+    const void *Q;     /* device N x ld: the diagonals of the Quadratic terms  */
+    const void *q;     /* device N x ld: their linear terms                    */
+    double eta, lo, hi; /* SqrDistL2(IndBox(lo, hi), eta); eta = 0 drops it    */
+} ciao_sepquad;
+/* Base.iterate(iter), :76-87: table_i = x0 - (gam_i/N) grad f_i(x0); hat_gamma = sum gam_i (written to the device scalar
+ * hat_gamma_dev); av = sum_i table_i; z = (prox_{hat_gamma g}(av) - av) / hat_gamma. */
+CIAO_API int32_t ciao_proshi_init(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_desc *g, const void *gam,
+                                  const void *x0, void *table, void *av, void *z, void *hat_gamma_dev);
+/* nit consecutive Base.iterate(iter,state), :109-121; iteration t updates the agents bidx[bptr_host[t]..bptr_host[t+1])
+ * (device int64, LOCAL rows): av -= s_i; s_i += gam_i z; s_i -= (gam_i/N) grad f_i(s_i); av += s_i; then the z update. */
+CIAO_API int32_t ciao_proshi_steps(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_desc *g, const void *gam,
+                                   double hat_gamma, int64_t nit, const int64_t *bptr_host, const int64_t *bidx,
+                                   void *table, void *av, void *z);
+/* solution(state), :127-132: table_i += gam_i z for every agent, IN PLACE (as the reference does). */
+CIAO_API int32_t ciao_proshi_solution(ciao_ctx *ctx, const ciao_sepquad *f, const void *gam, const void *z, void *table);
+
 /* ---- synthetic data (bench / tests): counter-based generator, reproducible per (seed, row, col) ------------- */
 /* out[i*ld + k] = scale * N(0,1) for rows row0 .. row0+nrows, keyed by the GLOBAL (row, col). */
 CIAO_API int32_t ciao_synth_normal(ciao_ctx *ctx, int32_t dtype, void *out, int64_t nrows, int64_t d, int64_t ld,

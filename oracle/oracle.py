@@ -262,5 +262,42 @@ def afinito_steps(p: Problem, g: Prox, alpha, tol_b, idx, table, gtable, gam, fi
     return int(done), p.dtype.type(hg.value), int(ntr.value)
 
 
+class SepQuad:
+    """F = [f_1..f_N], f_i = Sum(Quadratic(diagm(Q_i), q_i), SqrDistL2(IndBox(lo, hi), eta))  (test/test_sharing.jl:16-25)."""
+
+    def __init__(self, Q, q, eta, lo, hi):
+        self.Q = np.ascontiguousarray(Q)
+        self.dtype = self.Q.dtype
+        self.q = np.ascontiguousarray(q, dtype=self.dtype)
+        assert self.Q.shape == self.q.shape and self.Q.ndim == 2
+        self.N, self.d = self.Q.shape
+        self.eta, self.lo, self.hi = float(eta), float(lo), float(hi)
+
+    def args(self):
+        ct = _ct(self.dtype)
+        return (C.c_int64(self.N), C.c_int64(self.d), _p(self.Q), _p(self.q), ct(self.eta), ct(self.lo), ct(self.hi))
+
+
+def proshi_init(f: SepQuad, g: Prox, gam, x0):
+    gam = _chk(gam, f.dtype, (f.N,))
+    table = np.empty((f.N, f.d), f.dtype)
+    av, z = np.empty(f.d, f.dtype), np.empty(f.d, f.dtype)
+    hg = _ct(f.dtype)(0)
+    getattr(lib(), f"orc_proshi_init_{_sfx(f.dtype)}")(*f.args(), g.ref, _p(gam), _p(_chk(x0, f.dtype, (f.d,))), _p(table), _p(av),
+                                                     _p(z), C.byref(hg))
+    return table, av, z, f.dtype.type(hg.value)
+
+
+def proshi_steps(f: SepQuad, g: Prox, gam, hat_gamma, batches, table, av, z):
+    bptr, bidx = _csr(batches)
+    getattr(lib(), f"orc_proshi_steps_{_sfx(f.dtype)}")(*f.args(), g.ref, _p(gam), _ct(f.dtype)(hat_gamma), C.c_int64(len(batches)),
+                                                      _p(bptr), _p(bidx), _p(table), _p(av), _p(z))
+
+
+def proshi_solution(f: SepQuad, gam, z, table):
+    getattr(lib(), f"orc_proshi_solution_{_sfx(f.dtype)}")(C.c_int64(f.N), C.c_int64(f.d), _p(gam), _p(z), _p(table))
+    return table
+
+
 def objective(p: Problem, g: Prox, x):
     return getattr(lib(), f"orc_objective_{_sfx(p.dtype)}")(p.ref, g.ref, _p(_chk(x, p.dtype, (p.d,))))

@@ -238,6 +238,64 @@ class AdaptiveFinitoIterable:
             yield st
 
 
+class ProshiState:
+    def __init__(self, s, gam, hat_gamma, av, z, ind, d):
+        self.s, self.gamma, self.hat_gamma, self.av, self.z, self.ind, self.d = s, gam, hat_gamma, av, z, ind, d
+        self.idxr, self.idx, self.inds = 0, 0, np.arange(d, dtype=np.int64)   # ProShI_basic.jl:37-39 (0-based idxr)
+
+
+class ProshiIterable:
+    """Proshi_basic_iterable (src/algorithms/ProShI/ProShI_basic.jl); batch logic identical to Finito's (:47-59, :95-107)."""
+
+    def __init__(self, f, g, x0, L=None, gamma=None, sweeping=1, batch=1, alpha=0.999, stream=None):
+        self.f, self.g, self.x0, self.L, self.gamma = f, g, x0, L, gamma
+        self.sweeping, self.batch, self.alpha, self.stream = sweeping, batch, alpha, stream
+
+    def __iter__(self):
+        f = self.f
+        N, r = f.N, self.batch
+        ind = [np.arange(r, dtype=np.int64)] if self.sweeping == 1 else _static_batches(N, r)
+        d = -(-N // r)
+        gam = _finito_gammas(f.dtype, N, self.L, self.gamma, self.alpha)      # :61-74 (same rule as Finito)
+        if gam is None:
+            return
+        s, av, z, hg = O.proshi_init(f, self.g, gam, self.x0)                 # :76-87
+        st = ProshiState(s, gam, hg, av, z, ind, d)
+        yield st
+        while True:
+            if self.sweeping == 1:
+                st.ind = [self.stream.sample_without_replacement(N, r)]
+            elif self.sweeping == 2:
+                st.idxr = (st.idxr + 1) % st.d
+            elif self.sweeping == 3:
+                if st.idx == st.d:
+                    st.inds = self.stream.randperm(st.d)
+                    st.idx = 1
+                else:
+                    st.idx += 1
+                st.idxr = int(st.inds[st.idx - 1])
+            O.proshi_steps(f, self.g, st.gamma, st.hat_gamma, [st.ind[st.idxr]], st.s, st.av, st.z)   # :109-121
+            yield st
+
+
+def proshi_solution(iterable, state):
+    """solution(state::Proshi_basic_state), ProShI_basic.jl:127-132: shifts the table IN PLACE and returns it."""
+    return O.proshi_solution(iterable.f, state.gamma, state.z, state.s)
+
+
+def proshi(f, g, x0, maxit=10000, gamma=None, sweeping=1, batch=1, alpha=0.999, L=None, stream=None):
+    """Proshi functor (ProShI.jl:42-83): returns (solution(state_final), num_iters)."""
+    itb = ProshiIterable(f, g, x0, L, gamma, sweeping, batch, alpha, stream)
+    it, last = 0, None
+    for st in itb:
+        it, last = it + 1, st
+        if it >= maxit:
+            break
+    if last is None:
+        raise TypeError("solution(nothing)")
+    return proshi_solution(itb, last), it
+
+
 def solution(state):
     """SVRG_basic.jl:99, SAGA_basic.jl:71, Finito_basic.jl:123, Finito_LFinito.jl:105."""
     return state.z_full if isinstance(state, SVRGState) else state.z

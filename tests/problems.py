@@ -69,3 +69,16 @@ def synthetic(loss, N, d, dtype=np.float64, seed=1):
         b = np.where(t >= 0, 1.0, -1.0).astype(dtype)
     x = (0.3 * rng.standard_normal(d)).astype(dtype)
     return A, b, x
+
+
+# ---- test/test_sharing.jl:11-31 (literal) -------------------------------------------------------------------------------
+def sharing_fixture(dtype=np.float64):
+    """(Q, q, eta, lo, hi, L, g_hi, x0, sum_star): N = 3 agents, n = 2;  f_i = Sum(Quadratic(diagm(d_i), ones), SqrDistL2(IndBox(-2,2), eta)),
+    eta = N*10, g = IndBox(-Inf, ones): sum_i x_i <= 1.  L_i = opnorm(Q[i]) + eta where Q[i] is the i-th ENTRY (linear index)
+    of the 2 x 2 matrix diagm(d_i) -- a quirk of the reference test (:23): entries 1, 0, 0  ->  L = [31, 30, 30]."""
+    dd = np.array([[1.0, 2.0], [-1.0, 3.0], [0.0, 10.0]])
+    N, n = dd.shape
+    eta = N * 10.0
+    L = np.array([abs(dd[0, 0]) + eta, 0.0 + eta, 0.0 + eta])
+    return (dd.astype(dtype), np.ones((N, n), dtype), eta, -2.0, 2.0, L.astype(dtype), np.ones(n, dtype), np.zeros(n, dtype),
+            np.array([-5.136781609195401, -0.9333333333333327]))

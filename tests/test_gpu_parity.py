@@ -569,6 +569,53 @@ def test_adaptive_finito_stops_when_the_stepsize_collapses(ctx, ciao):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# ProShI
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape,r", [((3, 2), 1), ((3, 2), 2), ((40, 7), 5), ((64, 256), 8), ((30, 1000), 30), ((9, 4096), 4)])
+def test_proshi_steps(ctx, ciao, dtype, shape, r):
+    import torch
+    from oracle import oracle as O
+    from ciaoalgorithms_jl_amd.device import PackedSepQuad
+    N, d = shape
+    rng = np.random.default_rng(N + d)
+    Q = rng.uniform(-1.0, 3.0, (N, d)).astype(dtype)
+    q = rng.standard_normal((N, d)).astype(dtype)
+    eta, lo, hi = 3.0 * N, -2.0, 2.0
+    x0 = (0.5 * rng.standard_normal(d)).astype(dtype)
+    gam = (0.999 * N / (np.abs(Q).max(axis=1) + eta)).astype(dtype)
+    g_hi = np.linspace(0.5, 1.5, d).astype(dtype)
+    of, og = O.SepQuad(Q, q, eta, lo, hi), O.Prox("box", lo=-np.inf, hi=g_hi, dtype=dtype)
+    from ciaoalgorithms_jl_amd.device import ProxG
+    import ciaoalgorithms_jl_amd._lib as L
+    df = PackedSepQuad(dev(Q), dev(q), eta, lo, hi)
+    dg = ProxG(L.PROX_BOX, lo=-float("inf"), hi_vec=dev(g_hi))
+    tdt = dev(x0).dtype
+    table = torch.empty((N, d), dtype=tdt, device="cuda")
+    av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+    hg = torch.empty(1, dtype=tdt, device="cuda")
+    ctx.proshi_init(df, dg, dev(gam), dev(x0), table, av, z, hg)
+    rt, rav, rz, rhg = O.proshi_init(of, og, gam, x0)
+    close(table, rt, dtype, scale=4, what="proshi init table")
+    close(hg, [rhg], dtype, scale=4, what="proshi hat_gamma")
+    close(av, rav, dtype, scale=20, what="proshi init av")
+    close(z, rz, dtype, scale=200, what="proshi init z")
+    st = ciao.IndexStream(2)
+    batches = [st.sample_without_replacement(N, r) for _ in range(12)]
+    bptr = np.arange(len(batches) + 1, dtype=np.int64) * r
+    ctx.proshi_steps(df, dg, dev(gam), float(hg.item()), bptr, np.concatenate(batches), table, av, z)
+    O.proshi_steps(of, og, gam, rhg, batches, rt, rav, rz)
+    S = 500 if dtype == np.float64 else 100
+    close(table, rt, dtype, scale=S, what=f"proshi table ({ctx.last_kernel()})")
+    close(av, rav, dtype, scale=S, what="proshi av")
+    close(z, rz, dtype, scale=10 * S, what="proshi z")
+    close(av, table.double().sum(dim=0).cpu().numpy(), dtype, scale=S, what="invariant av == sum_i s_i")
+    ctx.proshi_solution(df, dev(gam), z, table)
+    close(table, O.proshi_solution(of, gam, rz, rt), dtype, scale=10 * S, what="proshi solution")
+    ctx.synchronize()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # error behaviour at the boundary
 # ----------------------------------------------------------------------------------------------------------------------
 def test_out_of_range_index_is_reported_not_faulted(ctx, ciao):

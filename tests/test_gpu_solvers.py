@@ -301,3 +301,56 @@ def test_default_g_and_default_F(api):
     assert np.allclose(x, x0, rtol=1e-15, atol=0) and it == 4
     x, it = S.SAGA(np.float64, γ=0.5, maxit=4)(x0, N=5)
     assert np.allclose(x, 0.5 * x0)   # z0 = prox((1-γ) x0) = 0.5 x0, then z <- z - γ*0
+
+
+# ======================================================================================================================
+# test/test_sharing.jl  (ProShI) -- literal fixture, hard-coded sum_star
+# ======================================================================================================================
+class TestSharing:
+    T = np.float64
+    maxit, tol = 1000, 1e-4
+
+    def _problem(self, ops):
+        Q, q, eta, lo, hi, L, g_hi, x0, sum_star = P.sharing_fixture(self.T)
+        N = Q.shape[0]
+        box = ops.IndBox(lo, hi)
+        F = [ops.Sum(ops.Quadratic(np.diag(Q[i]), q[i]), ops.SqrDistL2(box, eta)) for i in range(N)]   # test_sharing.jl:18-24
+        return F, ops.IndBox(-np.inf, g_hi), L, x0, sum_star, N
+
+    @pytest.mark.parametrize("sweeping", [1, 2, 3])
+    def test_basic_proshi(self, api, sweeping):                             # :41-46
+        S, ops = api
+        F, g, L, x0, sum_star, N = self._problem(ops)
+        x, it = S.Proshi(self.T, maxit=self.maxit, sweeping=sweeping)(x0, F=F, g=g, L=L, N=N)
+        assert np.abs(np.sum(x, axis=0) - sum_star).max() < self.tol and it == self.maxit
+        assert len(x) == N and all(xi.dtype == self.T and xi.shape == (2,) for xi in x)      # eltype == Array{T,1}
+
+    @pytest.mark.parametrize("sweeping,batch", [(1, 2), (2, 2), (3, 3)])
+    def test_proshi_minibatch(self, api, sweeping, batch):                  # :49-59
+        S, ops = api
+        F, g, L, x0, sum_star, N = self._problem(ops)
+        x, it = S.Proshi(self.T, maxit=self.maxit, sweeping=sweeping, minibatch=(True, batch))(x0, F=F, g=g, L=L, N=N)
+        assert np.abs(np.sum(x, axis=0) - sum_star).max() < self.tol
+
+    def test_gamma_and_L_as_scalars(self, api):                             # :62-74
+        S, ops = api
+        F, g, L, x0, sum_star, N = self._problem(ops)
+        x, _ = S.Proshi(self.T, maxit=self.maxit, γ=N / np.max(L))(x0, F=F, g=g, L=L, N=N)
+        assert np.abs(np.sum(x, axis=0) - sum_star).max() < self.tol
+        x, _ = S.Proshi(self.T, maxit=self.maxit)(x0, F=F, g=g, L=float(np.max(L)), N=N)
+        assert np.abs(np.sum(x, axis=0) - sum_star).max() < self.tol
+
+    @pytest.mark.parametrize("sweeping", [1, 2, 3])
+    def test_iterator(self, api, sweeping):                                 # :77-85
+        S, ops = api
+        F, g, L, x0, sum_star, N = self._problem(ops)
+        it = S.iterator(S.Proshi(self.T, sweeping=sweeping), x0, F=F, g=g, L=L, N=N)
+        assert it.x0 is x0
+        for k, state in zip(range(2), it):
+            assert S.solution(state) is state.s
+
+    def test_unpackable_family_is_refused(self, api):
+        S, ops = api
+        F, g, L, x0, sum_star, N = self._problem(ops)
+        with pytest.raises(TypeError):
+            S.Proshi(self.T, maxit=3)(x0, F=[ops.Quadratic(np.ones((2, 2)), np.ones(2))] * N, g=g, L=L, N=N)   # dense Q

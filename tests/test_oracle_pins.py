@@ -191,3 +191,31 @@ def test_oracle_operators_against_closed_forms():
     assert np.array_equal(O.prox(O.Prox("box", lo=-1.0, hi=0.5), v, 9.0), np.clip(v, -1.0, 0.5))
     lo, hi = np.full(5, -0.1), np.array([0.0, 0.1, 0.2, 0.3, 0.4])
     assert np.array_equal(O.prox(O.Prox("box", lo=lo, hi=hi), v, 9.0), np.clip(v, lo, hi))
+
+
+# ---- test_sharing.jl (ProShI) -------------------------------------------------------------------
+class TestSharingFixture:
+    maxit, tol = 1000, 1e-4
+
+    def _setup(self):
+        Q, q, eta, lo, hi, L, g_hi, x0, sum_star = P.sharing_fixture()
+        return O.SepQuad(Q, q, eta, lo, hi), O.Prox("box", lo=-np.inf, hi=g_hi), L, x0, sum_star
+
+    @pytest.mark.parametrize("sweeping", [1, 2, 3])
+    def test_basic_proshi(self, Stream, sweeping):                          # test_sharing.jl:41-46
+        f, g, L, x0, sum_star = self._setup()
+        x, it = RS.proshi(f, g, x0, maxit=self.maxit, sweeping=sweeping, L=L, stream=Stream(0))
+        assert np.abs(x.sum(axis=0) - sum_star).max() < self.tol and x.shape == (3, 2) and x.dtype == np.float64
+
+    @pytest.mark.parametrize("sweeping,batch", [(1, 2), (2, 2), (3, 3)])
+    def test_proshi_minibatch(self, Stream, sweeping, batch):               # :49-59
+        f, g, L, x0, sum_star = self._setup()
+        x, it = RS.proshi(f, g, x0, maxit=self.maxit, sweeping=sweeping, batch=batch, L=L, stream=Stream(0))
+        assert np.abs(x.sum(axis=0) - sum_star).max() < self.tol
+
+    def test_scalar_gamma_and_L(self, Stream):                              # :62-74
+        f, g, L, x0, sum_star = self._setup()
+        x, _ = RS.proshi(f, g, x0, maxit=self.maxit, gamma=f.N / L.max(), L=L, stream=Stream(0))
+        assert np.abs(x.sum(axis=0) - sum_star).max() < self.tol
+        x, _ = RS.proshi(f, g, x0, maxit=self.maxit, L=float(L.max()), stream=Stream(0))
+        assert np.abs(x.sum(axis=0) - sum_star).max() < self.tol
