@@ -127,4 +127,34 @@ def run(ctx, dev, quick=False):
                                               "trials_per_step": trials / max(done, 1), "kernel": ctx.last_kernel()}
     del F, table
     torch.cuda.empty_cache()
+
+    # ---- ProShI agent batches: separable quadratic + soft box, d=1024 fp64 -----------------------------
+    from ciaoalgorithms_jl_amd.device import PackedSepQuad
+    N, d = 1_000_000 // scale, 1024
+    Q = torch.empty((N, d), dtype=torch.float64, device=dev)
+    q = torch.empty((N, d), dtype=torch.float64, device=dev)
+    ctx.synth_normal(Q, 0, seed=7, scale=1.0)
+    ctx.synth_normal(q, 0, seed=8, scale=1.0)
+    Q.abs_()
+    f = PackedSepQuad(Q, q, eta=30.0, lo=-2.0, hi=2.0)
+    gbox = ProxG(L.PROX_BOX, lo=-float("inf"), hi=1.0)
+    gam = torch.full((N,), 0.999 * N / 40.0, dtype=torch.float64, device=dev)
+    x0 = torch.zeros(d, dtype=torch.float64, device=dev)
+    table = torch.empty((N, d), dtype=torch.float64, device=dev)
+    av, z = torch.empty_like(x0), torch.empty_like(x0)
+    hgd = torch.empty(1, dtype=torch.float64, device=dev)
+    t = _timed(ctx, lambda: ctx.proshi_init(f, gbox, gam, x0, table, av, z, hgd))
+    out["proshi_init_f64_d1024"] = {"seconds": t, "alg_GBps": N * 3 * d * 8 / t / 1e9, "N": N, "kernel": ctx.last_kernel()}
+    hg = float(hgd.item())
+    for r in (4096, 65536 // scale):
+        nit = 16
+        batches = [st.sample_without_replacement(N, r) for _ in range(nit)]
+        bptr = np.arange(nit + 1, dtype=np.int64) * r
+        bidx = ctx._idx(np.concatenate(batches))
+        ctx.proshi_steps(f, gbox, gam, hg, bptr[:2], bidx[:r], table, av, z)
+        t = _timed(ctx, lambda: ctx.proshi_steps(f, gbox, gam, hg, bptr, bidx, table, av, z))
+        out[f"proshi_batch_r{r}_f64_d1024"] = {"agents_per_s": nit * r / t, "alg_GBps": nit * r * 4 * d * 8 / t / 1e9,
+                                               "kernel": ctx.last_kernel()}
+    del Q, q, table, f
+    torch.cuda.empty_cache()
     return out
