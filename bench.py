@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--loss", choices=["ls", "logistic"], default="ls")
     ap.add_argument("--prefetch", type=int, default=None, help="sweep_prefetch option (tuning)")
     ap.add_argument("--blocks-per-cu", type=int, default=None, help="sweep_blocks_per_cu option (tuning)")
+    ap.add_argument("--grid", type=int, default=None, help="sweep_grid option (tuning)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -76,6 +77,8 @@ def main():
         ctx.set_option("sweep_prefetch", args.prefetch)
     if args.blocks_per_cu is not None:
         ctx.set_option("sweep_blocks_per_cu", args.blocks_per_cu)
+    if args.grid is not None:
+        ctx.set_option("sweep_grid", args.grid)
 
     # ---- synthetic problem, generated on the device, keyed by the GLOBAL (row, col): SURVEY.md section 8d ------------
     n_local, d = args.rows_per_gpu, args.d

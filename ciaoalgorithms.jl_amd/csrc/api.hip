@@ -660,8 +660,11 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
     if (!strcmp(key, "sweep_blocks_per_cu")) {
         CIAO_REQUIRE(value >= 0 && value <= 16, "sweep_blocks_per_cu must be in 0..16 (0 = automatic)");
         ctx->sweep_blocks_per_cu = value;
+    } else if (!strcmp(key, "sweep_grid")) {
+        CIAO_REQUIRE(value >= 0 && value <= 65535, "sweep_grid must be in 0..65535");
+        ctx->sweep_grid = value;
     } else if (!strcmp(key, "sweep_prefetch")) {
-        ctx->sweep_prefetch = value != 0;
+        ctx->sweep_prefetch = value < 0 ? -1 : (value != 0);
     } else if (!strcmp(key, "chain_max_batch")) {
         CIAO_REQUIRE(value >= 0, "chain_max_batch must be >= 0");
         ctx->chain_max_batch = value;

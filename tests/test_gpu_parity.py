@@ -161,7 +161,7 @@ def test_full_gradient_padded_rows_and_prefetch_variants(ctx, dtype):
         assert "rows_fast_kernel" in ctx.last_kernel()
         close(av, ref, dtype, scale=4, what=f"padded rows prefetch={pf}")
         outs.append(av.cpu().numpy())
-    ctx.set_option("sweep_prefetch", 1)
+    ctx.set_option("sweep_prefetch", -1)
     # the two pipelining flavours assign the same rows to the same waves: identical summation order
     assert np.array_equal(outs[0], outs[1])
     op2, dp2 = make("logistic", A, b, 1.0, dtype, pad=3)    # ld = 259: unaligned rows -> generic path

@@ -21,8 +21,9 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = Context(0)
     rows = []
-    for dt, d, N in ((torch.float64, 1024, 2_000_000), (torch.float32, 1024, 4_000_000), (torch.float32, 4096, 1_000_000),
-                     (torch.float64, 2048, 1_000_000), (torch.float32, 256, 8_000_000)):
+    for dt, d, N in ((torch.float64, 1024, 4_000_000), (torch.float32, 1024, 8_000_000), (torch.float32, 4096, 2_000_000),
+                     (torch.float64, 2048, 2_000_000), (torch.float32, 512, 16_000_000), (torch.float32, 256, 16_000_000),
+                     (torch.float64, 128, 16_000_000)):
         es = 8 if dt == torch.float64 else 4
         A = torch.empty((N, d), dtype=dt, device=dev)
         b = torch.empty((N,), dtype=dt, device=dev)
@@ -31,10 +32,12 @@ def main():
         ctx.synth_targets(F, torch.ones(d, dtype=dt, device=dev), 0.01, False, 0, b)
         g = ProxG(L.PROX_L1, lam=1e-3)
         x, av, y = (torch.zeros(d, dtype=dt, device=dev) for _ in range(3))
-        for pf in (1, 0):
-            for bpc in (1, 2, 3, 4, 6, 8):
+        for pf in (0, 1):
+            for grid in (128, 192, 256, 384, 512, 768, 1024, 2048):
+                bpc = grid
                 ctx.set_option("sweep_prefetch", pf)
-                ctx.set_option("sweep_blocks_per_cu", bpc)
+                ctx.set_option("sweep_blocks_per_cu", 16)
+                ctx.set_option("sweep_grid", grid)
                 for _ in range(2):
                     ctx.proxgrad_step(F, g, 1e-9, x, av, y)
                 ctx.timing_enable(True)
