@@ -799,6 +799,10 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_chain_kernel(AFinitoArgs<T> 
     T ar[E], sr[E], m[4], bi = T(0);
     T arn[E], srn[E], mn[4], bin = T(0);
     int64_t row = 0, rown = 0;
+    // the sample updated by the step that has just finished, and the scalars it stored: a prefetch issued right after
+    // that store (no barrier in between) must not read them back from memory -- other waves may run ahead of thread 0
+    int64_t row_prev = -1;
+    T m_prev[4] = {T(0), T(0), T(0), T(0)};
     if (a.nsteps > 0) {
         row = row_of(0);
         load(row, ar, sr, m, bi);
@@ -810,7 +814,13 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_chain_kernel(AFinitoArgs<T> 
         if (more) {
             rown = row_of(s + 1);
             same = (rown == row);
-            if (!same) load(rown, arn, srn, mn, bin);   // in flight while this step computes
+            if (!same) {
+                load(rown, arn, srn, mn, bin);   // in flight while this step computes
+                if (rown == row_prev) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mn[q] = m_prev[q];
+                }
+            }
         }
         const T c_old = m[0], fi_x = m[1], as_i = m[3];
         T gi = m[2];
@@ -887,6 +897,11 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_chain_kernel(AFinitoArgs<T> 
             mp[3] = dz;
         }
         ++done;
+        row_prev = row;
+        m_prev[0] = c_new;
+        m_prev[1] = fi_z;
+        m_prev[2] = gi;
+        m_prev[3] = dz;
         if (more) {
             if (same) {
                 // the next step works on the sample just updated: its row stays, its table row is the z stored above and

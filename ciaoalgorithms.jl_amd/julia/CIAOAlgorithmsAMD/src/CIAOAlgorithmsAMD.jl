@@ -305,8 +305,151 @@ function (solver::SAGA{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrCo
     return reshape(Array(solution(state)), size(x0)), num_iters
 end
 
-# Finito / LFinito follow the same pattern over ciao_hat_gamma, ciao_finito_init, ciao_finito_steps,
-# ciao_lfinito_init and ciao_lfinito_iterate (batch construction Finito_basic.jl:49-59, :95-108 stays on the host
-# exactly as in solvers.py: FINITO_basic_iterable._next_batch); see INTEGRATION.md for their ccall signatures.
+# ======================================================================================================================
+# Finito / LFinito  (src/algorithms/Finito/Finito.jl, Finito_basic.jl, Finito_LFinito.jl)
+# ======================================================================================================================
+struct Finito{R<:Real}
+    γ::Maybe{Union{Array{R},R}}; sweeping::Int8; LFinito::Bool; adaptive::Bool; minibatch::Tuple{Bool,Int}
+    maxit::Int; verbose::Bool; freq::Int; α::R; tol::R; tol_b::R
+    function Finito{R}(; γ::Maybe{Union{Array{R},R}} = nothing, sweeping = 1, LFinito::Bool = false, adaptive::Bool = false,
+                       minibatch::Tuple{Bool,Int} = (false, 1), maxit::Int = 10000, verbose::Bool = false,
+                       freq::Int = 10000, α::R = R(0.999), tol::R = R(1e-8), tol_b::R = R(1e-9)) where {R}
+        @assert γ === nothing || minimum(γ) > 0
+        @assert maxit > 0
+        @assert tol > 0
+        @assert tol_b > 0
+        @assert freq > 0
+        new(γ, sweeping, LFinito, adaptive, minibatch, maxit, verbose, freq, α, tol, tol_b)
+    end
+end
+Finito(::Type{R}; kwargs...) where {R} = Finito{R}(; kwargs...)
+Finito(; kwargs...) = Finito(Float64; kwargs...)
+
+struct FINITO_iterable{R<:Real,Tx}          # basic and LFinito share the fields (Finito_basic.jl:1-11, Finito_LFinito.jl:1-11)
+    F::PackedF{R}; g::CiaoProxDesc; gkeep::Any; x0::Tx; N::Int
+    L::Maybe{Union{Array{R},R}}; γ::Maybe{Union{Array{R},R}}; sweeping::Int8; batch::Int; α::R; lfinito::Bool
+end
+mutable struct FINITO_state{R<:Real}
+    s::Union{Nothing,ROCArray{R,2}}         # basic only: d x N table of x_i - (γ_i/N) ∇f_i(x_i)
+    γ::ROCArray{R,1}; hat_γ::R
+    av::ROCArray{R,1}; z::ROCArray{R,1}; z_full::Union{Nothing,ROCArray{R,1}}
+    ind::Vector{Vector{Int}}; d::Int; idxr::Int; idx::Int; inds::Vector{Int}
+end
+
+function static_batches(N::Int, r::Int)      # Finito_basic.jl:52-58
+    ind = Vector{Vector{Int}}(undef, 0)
+    d = Int(floor(N / r))
+    for i in 1:d
+        push!(ind, collect(r*(i-1)+1:i*r))
+    end
+    r * d < N && push!(ind, collect(r*d+1:N))
+    return ind
+end
+
+function finito_gammas(iter::FINITO_iterable{R}) where {R}   # Finito_basic.jl:61-74
+    N = iter.N
+    if iter.γ === nothing
+        if iter.L === nothing
+            @warn "--> smoothness parameter absent"; return nothing
+        end
+        return isa(iter.L, R) ? fill(iter.α * R(N) / iter.L, (N,)) : R[iter.α * R(N) / iter.L[i] for i in 1:N]
+    end
+    return isa(iter.γ, R) ? fill(iter.γ, (N,)) : iter.γ
+end
+
+function Base.iterate(iter::FINITO_iterable{R}) where {R}    # Finito_basic.jl:44-89 / Finito_LFinito.jl:40-76
+    N, r = iter.N, iter.batch
+    ind = (iter.sweeping == 1 && !iter.lfinito) ? [collect(1:r)] : static_batches(N, r)
+    γh = finito_gammas(iter)
+    γh === nothing && return nothing
+    γ = ROCArray(γh)
+    hg = Ref{Float64}(0.0)
+    check(ccall((:ciao_hat_gamma, libciao), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ref{Float64}),
+                context().h, dtype_code(R), N, dptr(γ), hg))
+    x0d = ROCArray(R.(vec(iter.x0)))
+    av, z = similar(x0d), similar(x0d)
+    p, g = Ref(cproblem(iter.F)), Ref(iter.g)
+    if iter.lfinito
+        z_full = similar(x0d)
+        check(ccall((:ciao_lfinito_init, libciao), Int32,
+                    (Ptr{Cvoid}, Ref{CiaoProblem}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    context().h, p, hg[], dptr(x0d), dptr(av), dptr(z), dptr(z_full)))
+        state = FINITO_state{R}(nothing, γ, R(hg[]), av, z, z_full, ind, cld(N, r), 1, 0, collect(1:cld(N, r)))
+    else
+        s = ROCArray{R}(undef, length(x0d), N)
+        check(ccall((:ciao_finito_init, libciao), Int32,
+                    (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    context().h, p, g, dptr(γ), hg[], dptr(x0d), dptr(s), dptr(av), dptr(z)))
+        state = FINITO_state{R}(s, γ, R(hg[]), av, z, nothing, ind, cld(N, r), 1, 0, collect(1:cld(N, r)))
+    end
+    return state, state
+end
+
+function next_batch!(iter::FINITO_iterable, state::FINITO_state)   # Finito_basic.jl:95-108
+    if iter.sweeping == 1
+        state.ind = [randperm(iter.N)[1:iter.batch]]               # sample(1:N, batch, replace=false)
+    elseif iter.sweeping == 2
+        state.idxr = mod(state.idxr, state.d) + 1
+    elseif iter.sweeping == 3
+        if state.idx == state.d
+            state.inds = randperm(state.d); state.idx = 1
+        else
+            state.idx += 1
+        end
+        state.idxr = state.inds[state.idx]
+    end
+    return state.ind[state.idxr]
+end
+
+function Base.iterate(iter::FINITO_iterable{R}, state::FINITO_state{R}) where {R}
+    p, g = Ref(cproblem(iter.F)), Ref(iter.g)
+    if iter.lfinito                                                # Finito_LFinito.jl:78-103
+        iter.sweeping == 3 && (state.inds = randperm(state.d))
+        batches = [state.ind[j] for j in state.inds]
+        bptr = Int64[0; cumsum(length.(batches))]
+        bidx = to_dev_idx(vcat(batches...))
+        check(ccall((:ciao_lfinito_iterate, libciao), Int32,
+                    (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    context().h, p, g, dptr(state.γ), Float64(state.hat_γ), length(batches), bptr, dptr(bidx),
+                    dptr(state.av), dptr(state.z), dptr(state.z_full)))
+    else                                                           # Finito_basic.jl:91-121
+        batch = next_batch!(iter, state)
+        bptr = Int64[0, length(batch)]
+        bidx = to_dev_idx(batch)
+        check(ccall((:ciao_finito_steps, libciao), Int32,
+                    (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    context().h, p, g, dptr(state.γ), Float64(state.hat_γ), 1, bptr, dptr(bidx),
+                    dptr(state.s), dptr(state.av), dptr(state.z)))
+    end
+    return state, state
+end
+solution(state::FINITO_state) = state.z                            # Finito_basic.jl:123, Finito_LFinito.jl:105
+
+function iterator(solver::Finito{R}, x0::AbstractArray{C}; F = nothing, g = ProximalOperators.Zero(), L = nothing,
+                  N) where {R,C<:RealOrComplex{R}}
+    C <: Complex && throw(ArgumentError("complex iterates are outside the device path"))
+    solver.adaptive && !solver.LFinito &&
+        throw(ArgumentError("adaptive Finito: bind ciao_afinito_init / ciao_afinito_steps as in solvers.py (FINITO_adaptive_iterable)"))
+    d = length(x0)
+    gd, keep = pack_g(R, g, d)
+    return FINITO_iterable{R,typeof(x0)}(pack_F(R, F, N, d), gd, keep, x0, N, L, solver.γ, solver.sweeping,
+                                         solver.minibatch[2], solver.α, solver.LFinito)
+end
+
+function (solver::Finito{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrComplex{R}}   # Finito.jl:66-133
+    disp(it, state) = @printf "%5d | %.3e  \n" it state.hat_γ
+    iter = iterator(solver, x0; kwargs...)
+    num_iters, state_final = nothing, nothing
+    for (it_, state_) in enumerate(Iterators.take(iter, solver.maxit))
+        solver.verbose && mod(it_, solver.freq) == 0 && disp(it_, state_)
+        num_iters, state_final = it_, state_
+    end
+    solver.verbose && mod(num_iters, solver.freq) !== 0 && disp(num_iters, state_final)
+    synchronize(context())
+    return reshape(Array(solution(state_final)), size(x0)), num_iters
+end
+
+# Proshi binds ciao_proshi_init / ciao_proshi_steps / ciao_proshi_solution the same way (solvers.py: Proshi_basic_iterable);
+# INTEGRATION.md lists their ccall signatures.
 
 end # module

@@ -534,6 +534,8 @@ def test_adaptive_finito_steps(ctx, ciao, dtype, shape):
     idx = st.rand_indices(N, 3 * N)
     idx[5:8] = idx[5]          # the same sample three times in a row
     idx[10] = idx[8]           # ... and again two steps later
+    idx[20:40:2] = idx[20]     # a long run of "every other step" repeats (the previous-step hand-over)
+    idx[21:41:2] = idx[21]
     done, trials = ctx.afinito_steps(dp, dg, alpha, tol_b, idx, table, meta, av, z, hg)
     rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(alpha), dtype(tol_b), idx, rt, rg, rgam, rfi, rhg, rav, rz)
     assert done == rdone == len(idx)
