@@ -534,22 +534,38 @@ def test_adaptive_finito_steps(ctx, ciao, dtype, shape):
     idx = st.rand_indices(N, 3 * N)
     idx[5:8] = idx[5]          # the same sample three times in a row
     idx[10] = idx[8]           # ... and again two steps later
-    idx[20:40:2] = idx[20]     # a long run of "every other step" repeats (the previous-step hand-over)
-    idx[21:41:2] = idx[21]
+    if len(idx) > 41:
+        idx[20:40:2] = idx[20]     # a long run of "every other step" repeats (the previous-step hand-over)
+        idx[21:41:2] = idx[21]
     done, trials = ctx.afinito_steps(dp, dg, alpha, tol_b, idx, table, meta, av, z, hg)
     rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(alpha), dtype(tol_b), idx, rt, rg, rgam, rfi, rhg, rav, rz)
     assert done == rdone == len(idx)
     if dtype == np.float64:
         assert trials == rtrials, "same backtracking decisions in fp64"
     S = 2000 if dtype == np.float64 else 200
-    close(z, rz, dtype, scale=S, what=f"adaptive z ({ctx.last_kernel()})")
-    close(av, rav, dtype, scale=S, what="adaptive av")
-    close(hg, [rhg], dtype, scale=S, what="adaptive hat_gamma")
-    close(meta[:, 2], rgam, dtype, scale=S, what="adaptive gamma_i")
-    close(table, rt, dtype, scale=S, what="adaptive table")
-    # grad f_i = c_i a_i: the oracle's full gradient table against the device's N scalars
-    gdev = meta[:, 0:1].double().cpu().numpy() * A.astype(np.float64)
-    close(gdev, rg, dtype, scale=S, what="adaptive gradient table (c_i a_i)")
+    # In fp32 a backtracking test  f_i(z) <= model + tol  that sits on the boundary can legitimately flip between two
+    # correct implementations (a stepsize then differs by the factor 0.8), so the iterate comparison is only meaningful
+    # when both took the same decisions; the state invariant below is checked unconditionally.
+    if trials == rtrials:
+        close(z, rz, dtype, scale=S, what=f"adaptive z ({ctx.last_kernel()})")
+        close(av, rav, dtype, scale=S, what="adaptive av")
+        close(hg, [rhg], dtype, scale=S, what="adaptive hat_gamma")
+        close(meta[:, 2], rgam, dtype, scale=S, what="adaptive gamma_i")
+        close(table, rt, dtype, scale=S, what="adaptive table")
+        # grad f_i = c_i a_i: the oracle's full gradient table against the device's N scalars
+        gdev = meta[:, 0:1].double().cpu().numpy() * A.astype(np.float64)
+        close(gdev, rg, dtype, scale=S, what="adaptive gradient table (c_i a_i)")
+    # invariant of the algorithm (Finito_adaptive.jl:93 and every update after it):
+    #   av == hat_gamma * (sum_i x_i/gamma_i - (1/N) sum_i grad f_i),   hat_gamma == 1 / sum_i 1/gamma_i
+    md = meta.double()
+    hgd = float(hg.item())
+    assert abs(hgd - 1.0 / float((1.0 / md[:, 2]).sum())) <= (1e-10 if dtype == np.float64 else 2e-4) * hgd
+    inv = hgd * ((table.double() / md[:, 2:3]).sum(dim=0) - (md[:, 0:1] * dev(A).double()).sum(dim=0) / N)
+    close(av, inv.cpu().numpy(), dtype, scale=S, what="adaptive invariant av")
+    # the stored scalars are consistent with the stored points: a_i'x_i, c_i = coef(a_i'x_i), f_i(x_i)
+    dots = (dev(A).double() * table.double()).sum(dim=1)
+    close(md[:, 3], dots.cpu().numpy(), dtype, scale=S, what="adaptive a_i'x_i")
+    close(md[:, 0], (lam_f * (dots - dev(b).double())).cpu().numpy(), dtype, scale=S, what="adaptive c_i")
     ctx.synchronize()
 
 
