@@ -81,6 +81,14 @@ struct RowsWaves {
     static constexpr int value = raw < 1 ? 1 : (raw > 8 ? 8 : raw);
 };
 
+// table rows are written once per visit and not re-read by this kernel: non-temporal stores (CIAO_PLAIN_STORES: timing
+// experiment with default-policy stores)
+#ifdef CIAO_PLAIN_STORES
+#define TSTORE(val, ptr) (*(ptr) = (val))
+#else
+#define TSTORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
+#endif
+
 template <typename T, int K, int MODE, int PF>
 __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>::value)) rows_fast_kernel(RowsArgs<T> a)
 {
@@ -185,7 +193,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
                 V gv;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) gv[v] = g1.elem(cur[k][v]);
-                sp[k * WAVE + lane] = gv;
+                TSTORE(gv, &sp[k * WAVE + lane]);
                 acc[k] += gv;
             }
         } else if (MODE == RM_AFINITO_INIT) {
@@ -214,7 +222,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const V xv = x1v[k * WAVE];
-                sp[k * WAVE + lane] = xv;
+                TSTORE(xv, &sp[k * WAVE + lane]);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc[k][v] += xv[v] * rinv - cn * cur[k][v];
             }
@@ -245,7 +253,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) acc[k][v] += (tv[v] - sv[v]) * rr;
                 }
-                sp[k * WAVE + lane] = tv;
+                TSTORE(tv, &sp[k * WAVE + lane]);
                 // keep the scheduler from hoisting every x / table fragment read to the top (register pressure)
                 if (K >= 8 && (k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
@@ -321,6 +329,8 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
         a.pextra[blockIdx.x] = ex;
     }
 }
+
+#undef TSTORE
 
 // ------------------------------------------------------------------------------------------------------------------
 // Generic path: any d, any alignment.  Lane l owns elements l, l+64, ...; the per-wave accumulator lives in LDS

@@ -359,6 +359,21 @@ class Context:
 _default_ctx: dict[int, Context] = {}
 
 
+def _close_default_contexts():
+    # destroy the library workspaces while the HIP runtime is still alive (not from __del__ during interpreter teardown)
+    for c in list(_default_ctx.values()):
+        try:
+            c.close()
+        except Exception:
+            pass
+    _default_ctx.clear()
+
+
+import atexit  # noqa: E402
+
+atexit.register(_close_default_contexts)
+
+
 def default_context() -> Context:
     """A per-device Context bound to torch's current stream at first use."""
     dev = torch.cuda.current_device()
