@@ -12,6 +12,8 @@
 // comparing indices at prefetch time and re-read at use time (same thread wrote it: program order).
 #pragma once
 
+#include <type_traits>
+
 #include "ciao_common.h"
 
 namespace ciao {
@@ -613,76 +615,85 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                 }
                 par ^= 1;
 
-                const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
-                if (SVRG_ANY) {                                                  // SVRG_basic.jl:74-81
-                    // a_i'z_full: recomputed (CA_SVRG) or the value the last full pass stored for this row (CA_SVRGC)
-                    const GradCoef<T> gz = grad_coef_t<T, LOSS>(ALG == CA_SVRGC ? x.gi : d2, bi, a.lam);
-                    const T gl = a.gamma * plam;
-                    const T dc = gz.coef() - gp.coef();
-#pragma unroll
-                    for (int j = 0; j < ((CIAO_CHAIN_DBG & 4) ? 0 : J); ++j)
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            const T t = fmad(q1[j][v], dc, q2[j][v]);
-                            p[j][v] = hasbox ? prox_bf(t, gl, plo[j][v], phi[j][v]) : prox_l1(t, gl);
-                            zs[j][v] += p[j][v];
+                // everything after the exchange, instantiated twice: with the IndBox clamp and without it (g = Zero / NormL1),
+                // selected by ONE workgroup-uniform branch per step instead of a select per coordinate
+                auto update = [&](auto hb_tag) {
+                    constexpr bool HB = decltype(hb_tag)::value;
+                    const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
+                    if (SVRG_ANY) {                                                  // SVRG_basic.jl:74-81
+                        // a_i'z_full: recomputed (CA_SVRG) or the value the last full pass stored for this row (CA_SVRGC)
+                        const GradCoef<T> gz = grad_coef_t<T, LOSS>(ALG == CA_SVRGC ? x.gi : d2, bi, a.lam);
+                        const T gl = a.gamma * plam;
+                        const T dc = gz.coef() - gp.coef();
+    #pragma unroll
+                        for (int j = 0; j < ((CIAO_CHAIN_DBG & 4) ? 0 : J); ++j)
+    #pragma unroll
+                            for (int v = 0; v < VEC; ++v) {
+                                const T t = fmad(q1[j][v], dc, q2[j][v]);
+                                p[j][v] = HB ? prox_bf(t, gl, plo[j][v], phi[j][v]) : prox_l1(t, gl);
+                                zs[j][v] += p[j][v];
+                            }
+                    } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
+                        V *sp = reinterpret_cast<V *>(a.table + row * d);
+                        const T gl = a.gamma * plam;
+                        const T cp = gp.coef();
+                        const T ngam = -a.gamma;
+    #pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            V gnv;
+    #pragma unroll
+                            for (int v = 0; v < VEC; ++v) {
+                                const T gn = x.ar[j][v] * cp;
+                                const T del = gn - x.sr[j][v];
+                                // SAGA steps with (g_new - s_i + av_old), SAG with av_new (SAGA_basic.jl:58-62)
+                                const T avn = fmad(del, a.invN, av[j][v]);
+                                const T wv = fmad(ngam, a.sag ? avn : del + av[j][v], p[j][v]);
+                                av[j][v] = avn;
+                                p[j][v] = HB ? prox_bf(wv, gl, plo[j][v], phi[j][v]) : prox_l1(wv, gl);
+                                gnv[v] = gn;
+                            }
+                            sp[tid + j * CHAIN_NT] = gnv;
                         }
-                } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
-                    V *sp = reinterpret_cast<V *>(a.table + row * d);
-                    const T gl = a.gamma * plam;
-                    const T cp = gp.coef();
-                    const T ngam = -a.gamma;
-#pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        V gnv;
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            const T gn = x.ar[j][v] * cp;
-                            const T del = gn - x.sr[j][v];
-                            // SAGA steps with (g_new - s_i + av_old), SAG with av_new (SAGA_basic.jl:58-62)
-                            const T avn = fmad(del, a.invN, av[j][v]);
-                            const T wv = fmad(ngam, a.sag ? avn : del + av[j][v], p[j][v]);
-                            av[j][v] = avn;
-                            p[j][v] = hasbox ? prox_bf(wv, gl, plo[j][v], phi[j][v]) : prox_l1(wv, gl);
-                            gnv[v] = gn;
+                    } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
+                        const T gi = x.gi;
+                        const T ncc = -(gi * a.invN) * gp.coef();   // t = z - (gamma_i/N) * c * a
+                        const T rr = a.hat_gamma / gi;
+                        V *sp = reinterpret_cast<V *>(a.table + row * d);
+    #pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            V tv;
+    #pragma unroll
+                            for (int v = 0; v < VEC; ++v) {
+                                tv[v] = fmad(ncc, x.ar[j][v], p[j][v]);
+                                av[j][v] = fmad(tv[v] - x.sr[j][v], rr, av[j][v]);
+                            }
+                            sp[tid + j * CHAIN_NT] = tv;
                         }
-                        sp[tid + j * CHAIN_NT] = gnv;
-                    }
-                } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
-                    const T gi = x.gi;
-                    const T ncc = -(gi * a.invN) * gp.coef();   // t = z - (gamma_i/N) * c * a
-                    const T rr = a.hat_gamma / gi;
-                    V *sp = reinterpret_cast<V *>(a.table + row * d);
-#pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        V tv;
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            tv[v] = fmad(ncc, x.ar[j][v], p[j][v]);
-                            av[j][v] = fmad(tv[v] - x.sr[j][v], rr, av[j][v]);
+                        if (inb + 1 == a.batch || (base + s + 1) == a.nsteps) {
+                            const T gl = a.hat_gamma * plam;
+    #pragma unroll
+                            for (int j = 0; j < J; ++j)
+    #pragma unroll
+                                for (int v = 0; v < VEC; ++v) p[j][v] = HB ? prox_bf(av[j][v], gl, plo[j][v], phi[j][v]) : prox_l1(av[j][v], gl);
                         }
-                        sp[tid + j * CHAIN_NT] = tv;
-                    }
-                    if (inb + 1 == a.batch || (base + s + 1) == a.nsteps) {
-                        const T gl = a.hat_gamma * plam;
-#pragma unroll
+                    } else {                                                         // Finito_LFinito.jl:93-98
+                        const GradCoef<T> gzf = grad_coef_t<T, LOSS>(d2, bi, a.lam);
+                        const T gi = x.gi;
+                        const T dc = (a.hat_gamma * a.invN) * (gzf.coef() - gp.coef());
+                        const T rr = a.hat_gamma / gi;
+    #pragma unroll
                         for (int j = 0; j < J; ++j)
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v) p[j][v] = hasbox ? prox_bf(av[j][v], gl, plo[j][v], phi[j][v]) : prox_l1(av[j][v], gl);
+    #pragma unroll
+                            for (int v = 0; v < VEC; ++v) {
+                                av[j][v] = fmad(x.ar[j][v], dc, av[j][v]);
+                                av[j][v] = fmad(rr, p[j][v] - zf[j][v], av[j][v]);
+                            }
                     }
-                } else {                                                         // Finito_LFinito.jl:93-98
-                    const GradCoef<T> gzf = grad_coef_t<T, LOSS>(d2, bi, a.lam);
-                    const T gi = x.gi;
-                    const T dc = (a.hat_gamma * a.invN) * (gzf.coef() - gp.coef());
-                    const T rr = a.hat_gamma / gi;
-#pragma unroll
-                    for (int j = 0; j < J; ++j)
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) {
-                            av[j][v] = fmad(x.ar[j][v], dc, av[j][v]);
-                            av[j][v] = fmad(rr, p[j][v] - zf[j][v], av[j][v]);
-                        }
-                }
+                };
+                if (hasbox)
+                    update(std::true_type{});
+                else
+                    update(std::false_type{});
 
                 if (++inb == a.batch) inb = 0;
                 if (!(CIAO_CHAIN_DBG & 1)) refill(u, row_n);   // after this step's table stores (program order); the look-ahead entry always exists
