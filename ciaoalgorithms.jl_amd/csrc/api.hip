@@ -660,6 +660,8 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
     if (!strcmp(key, "sweep_blocks_per_cu")) {
         CIAO_REQUIRE(value >= 0 && value <= 16, "sweep_blocks_per_cu must be in 0..16 (0 = automatic)");
         ctx->sweep_blocks_per_cu = value;
+    } else if (!strcmp(key, "sweep_multi")) {
+        ctx->sweep_multi = value != 0;
     } else if (!strcmp(key, "sweep_grid")) {
         CIAO_REQUIRE(value >= 0 && value <= 65535, "sweep_grid must be in 0..65535");
         ctx->sweep_grid = value;

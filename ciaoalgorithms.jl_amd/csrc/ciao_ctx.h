@@ -34,6 +34,7 @@ struct ciao_ctx {
 
     // tuning
     int64_t sweep_blocks_per_cu = 0;   // 0 = choose from the row size (rows_launch.inc)
+    int64_t sweep_multi = 1;           // short rows (<= 4 KiB): several rows per wave per iteration (rows_multi_kernel)
     int64_t sweep_grid = 0;            // testing: absolute grid override for the rows kernels (0 = automatic)
     int64_t sweep_prefetch = -1;    // gradient sweeps: 1 = two-deep register pipeline, 0 = occupancy only, -1 = by row size
     int64_t chain_max_batch = 64;   // Finito/LFinito batches up to this size run as a sequential chain

@@ -333,6 +333,137 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
 #undef TSTORE
 
 // ------------------------------------------------------------------------------------------------------------------
+// Short-row variant of the gradient sweeps (GRAD / GRAD2): R rows per wave per iteration.
+// The chip streams fastest with about 8 KiB of loads in flight per wave at one block per CU (tools/tune_sweep.py); a
+// 4 KiB (d=1024 fp32) or shorter row leaves a wave with too little in flight and too much per-row latency (dot ->
+// DPP chain -> link function) exposed.  Here a wave fetches R rows at once (R*K 16-byte loads per lane in flight) and
+// runs their R reductions interleaved, so R*rowbytes = 8 KiB whatever the row size.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int K, int R, int MODE>
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_multi_kernel(RowsArgs<T> a)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int VEC = VecOf<T>::N;
+    constexpr int D = K * WAVE * VEC;
+    constexpr bool TWO = (MODE == RM_GRAD2);
+    static_assert(MODE == RM_GRAD || MODE == RM_GRAD2, "gradient sweeps only");
+
+    __shared__ __attribute__((aligned(16))) T lds[(TWO ? 2 : 1) * D];
+    __shared__ T red_extra[ROWS_WAVES];
+
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t nwaves = (int64_t)gridDim.x * ROWS_WAVES;
+    const int64_t wave = (int64_t)blockIdx.x * ROWS_WAVES + wib;
+
+    for (int e = threadIdx.x; e < D; e += ROWS_BLOCK) {
+        lds[e] = a.x1[e];
+        if (TWO) lds[D + e] = a.x2[e];
+    }
+    __syncthreads();
+
+    V acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = V(T(0));
+    T extra = T(0);
+
+    // group g of this wave = rows q0 + r, r < R, with q0 = (g*nwaves + wave)*R : R consecutive rows (one 8 KiB stretch)
+    for (int64_t q0 = wave * R; q0 < a.nrows; q0 += nwaves * R) {
+        V cur[R][K];
+        int64_t row[R];
+        T bi[R];
+        bool live[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t q = q0 + r;
+            live[r] = q < a.nrows;
+            int64_t rr = live[r] ? (a.idx ? a.idx[q] : a.row0 + q) : 0;
+            if (a.idx && live[r] && (uint64_t)rr >= (uint64_t)a.N) {
+                if (lane == 0) *a.errflag = 1;
+                rr = 0;
+            }
+            row[r] = rr;
+            if (a.A) {
+                const V *ap = reinterpret_cast<const V *>(a.A + rr * a.ld);
+#pragma unroll
+                for (int k = 0; k < K; ++k) cur[r][k] = __builtin_nontemporal_load(&ap[k * WAVE + lane]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k) cur[r][k] = V(T(0));
+            }
+            bi[r] = (a.b && live[r]) ? a.b[rr] : T(0);
+        }
+        int xl = lane;
+        asm volatile("" : "+v"(xl));
+        const V *x1v = reinterpret_cast<const V *>(lds) + xl;
+        const V *x2v = reinterpret_cast<const V *>(lds + D) + xl;
+        T d1[R], d2[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) d1[r] = d2[r] = T(0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const V xv = x1v[k * WAVE];
+            V yv;
+            if (TWO) yv = x2v[k * WAVE];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    d1[r] += cur[r][k][v] * xv[v];
+                    if (TWO) d2[r] += cur[r][k][v] * yv[v];
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            d1[r] = wave_allsum(d1[r]);
+            if (TWO) d2[r] = wave_allsum(d2[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const GradCoef<T> g1 = grad_coef(a.loss, d1[r], bi[r], a.lam);
+            T c = g1.coef();
+            if (TWO) c -= grad_coef(a.loss, d2[r], bi[r], a.lam).coef();
+            if (!live[r]) c = T(0);
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += c * cur[r][k];
+            if (live[r]) {
+                if (MODE == RM_GRAD) {
+                    if (a.want_fval) extra += loss_value(a.loss, d1[r], bi[r], a.lam);
+                    if (a.rowdot_out && lane == 0) a.rowdot_out[row[r]] = d1[r];
+                } else {
+                    const T gi = a.gam ? a.gam[row[r]] : a.gam_uniform;
+                    extra += a.hat_gamma / gi;
+                }
+            }
+        }
+    }
+
+    __syncthreads();
+    V *red = reinterpret_cast<V *>(lds);
+    for (int w = 0; w < ROWS_WAVES; ++w) {
+        if (wib == w) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (w == 0)
+                    red[k * WAVE + lane] = acc[k];
+                else
+                    red[k * WAVE + lane] += acc[k];
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0) red_extra[wib] = extra;
+    __syncthreads();
+    T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
+    for (int e = threadIdx.x; e < D; e += ROWS_BLOCK) pout[e] = lds[e];
+    if (threadIdx.x == 0) {
+        T ex = T(0);
+        for (int w = 0; w < ROWS_WAVES; ++w) ex += red_extra[w];
+        a.pextra[blockIdx.x] = ex;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Generic path: any d, any alignment.  Lane l owns elements l, l+64, ...; the per-wave accumulator lives in LDS
 // (wave-private region, so no atomics and no barriers in the loop); the row is read twice (second read is an L1/L2
 // hit).  Correctness path for small / odd shapes (e.g. the reference's own N=6,d=3 and N=8,d=5 tests).

@@ -135,7 +135,7 @@ def test_full_gradient_generic_equals_fast(ctx, dtype):
     av1 = torch.empty(512, dtype=dev(x).dtype, device="cuda")
     av2 = torch.empty_like(av1)
     ctx.full_gradient(dp, dev(x), av1)
-    assert "rows_fast_kernel" in ctx.last_kernel()
+    assert "rows_fast_kernel" in ctx.last_kernel() or "rows_multi_kernel" in ctx.last_kernel()
     ctx.set_option("force_generic", 1)
     try:
         ctx.full_gradient(dp, dev(x), av2)
@@ -158,7 +158,7 @@ def test_full_gradient_padded_rows_and_prefetch_variants(ctx, dtype):
         ctx.set_option("sweep_prefetch", pf)
         av = torch.empty(256, dtype=dev(x).dtype, device="cuda")
         ctx.full_gradient(dp, dev(x), av)
-        assert "rows_fast_kernel" in ctx.last_kernel()
+        assert "rows_fast_kernel" in ctx.last_kernel() or "rows_multi_kernel" in ctx.last_kernel()
         close(av, ref, dtype, scale=4, what=f"padded rows prefetch={pf}")
         outs.append(av.cpu().numpy())
     ctx.set_option("sweep_prefetch", -1)
@@ -169,6 +169,30 @@ def test_full_gradient_padded_rows_and_prefetch_variants(ctx, dtype):
     ctx.full_gradient(dp2, dev(x), av)
     assert "rows_generic_kernel" in ctx.last_kernel()
     close(av, ref, dtype, scale=4, what="unaligned rows")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d", [256, 512, 1024])
+def test_multi_row_sweep_matches_single_row_sweep(ctx, dtype, d):
+    """Short rows go through rows_multi_kernel (R rows per wave per iteration); same result as one row per wave, also
+    when the row count is not a multiple of R and with an index list (LFinito-style two-point batch)."""
+    import torch
+    from oracle import oracle as O
+    N = 1003
+    A, b, x = P.synthetic("logistic", N, d, dtype, seed=d)
+    op, dp = make("logistic", A, b, 1.0, dtype)
+    outs = {}
+    for multi in (1, 0):
+        ctx.set_option("sweep_multi", multi)
+        av = torch.empty(d, dtype=dev(x).dtype, device="cuda")
+        ctx.full_gradient(dp, dev(x), av)
+        outs[multi] = (av.cpu().numpy(), ctx.last_kernel())
+    ctx.set_option("sweep_multi", 1)
+    if d * np.dtype(dtype).itemsize in (2048, 4096):
+        assert "rows_multi_kernel" in outs[1][1] and "rows_fast_kernel" in outs[0][1]
+    ref = O.full_pass(op, x)
+    close(outs[1][0], ref, dtype, scale=4, what="multi-row sweep")
+    close(outs[0][0], ref, dtype, scale=4, what="single-row sweep")
 
 
 def test_full_gradient_empty_problem(ctx):

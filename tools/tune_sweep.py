@@ -32,10 +32,13 @@ def main():
         ctx.synth_targets(F, torch.ones(d, dtype=dt, device=dev), 0.01, False, 0, b)
         g = ProxG(L.PROX_L1, lam=1e-3)
         x, av, y = (torch.zeros(d, dtype=dt, device=dev) for _ in range(3))
-        for pf in (0, 1):
+        for pf in (0, 2):   # 2 = multi-row kernel (short rows only)
+            if pf == 2 and d * es > 4096:
+                continue
+            ctx.set_option("sweep_multi", 1 if pf == 2 else 0)
             for grid in (128, 192, 256, 384, 512, 768, 1024, 2048):
                 bpc = grid
-                ctx.set_option("sweep_prefetch", pf)
+                ctx.set_option("sweep_prefetch", 0 if pf == 2 else pf)
                 ctx.set_option("sweep_blocks_per_cu", 16)
                 ctx.set_option("sweep_grid", grid)
                 for _ in range(2):
