@@ -14,7 +14,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libciao_oracle.so")
+# CIAO_ORACLE_LIB selects another build of the same sources (the AddressSanitizer/UBSan one from `make -C oracle asan`)
+_LIB_PATH = os.environ.get("CIAO_ORACLE_LIB") or os.path.join(_HERE, "libciao_oracle.so")
 
 LOSS_LS, LOSS_LOGISTIC, LOSS_ZERO = 0, 1, 2
 PROX_ZERO, PROX_L1, PROX_BOX = 0, 1, 2
@@ -34,6 +35,8 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
     srcs = [os.path.join(_HERE, f) for f in ("ciao_oracle.c", "ciao_oracle_impl.inc", "ciao_oracle.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if os.environ.get("CIAO_ORACLE_LIB"):
+        return _LIB_PATH
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
     return _LIB_PATH

@@ -84,6 +84,15 @@ def test_context_creation_fails_loudly_without_a_gpu(ciao):
         Context(0)
 
 
+def test_missing_extension_fails_loudly(ciao, monkeypatch):
+    """No libciao_hip.so -> ImportError with build instructions; never a silent CPU path."""
+    L = ciao._lib
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", os.path.join(ROOT, "ciaoalgorithms.jl_amd", "no_such_libciao_hip.so"))
+    with pytest.raises(ImportError, match="HIP extension is not built"):
+        L.load()
+
+
 def test_null_arguments_are_rejected_before_any_launch(ciao):
     lib = ciao._lib.load()
     assert lib.ciao_ctx_create(0, None, None) == ciao._lib.ERR_ARG
