@@ -113,15 +113,15 @@ def run(ctx, dev, quick=False):
     g = ProxG(L.PROX_L1, lam=1e-3)
     x0 = torch.zeros(d, dtype=torch.float64, device=dev)
     table = torch.empty((N, d), dtype=torch.float64, device=dev)
-    meta = torch.empty((N, 4), dtype=torch.float64, device=dev)
+    meta4 = torch.empty((N, 4, 4), dtype=torch.float64, device=dev)
     hgd = torch.empty(1, dtype=torch.float64, device=dev)
     av, z = torch.empty_like(x0), torch.empty_like(x0)
-    ctx.afinito_init(F, g, 0.999, x0, table, meta, av, z, hgd)
+    ctx.afinito_init(F, g, 0.999, x0, table, meta4, av, z, hgd)
     k = 100_000 // scale
     idx = ctx._idx(st.rand_indices(N, k))
-    ctx.afinito_steps(F, g, 0.999, 1e-9, idx[:1000], table, meta, av, z, hgd)
+    ctx.afinito_steps(F, g, 0.999, 1e-9, idx[:1000], table, meta4, av, z, hgd)
     t0 = time.perf_counter()
-    done, trials = ctx.afinito_steps(F, g, 0.999, 1e-9, idx, table, meta, av, z, hgd)
+    done, trials = ctx.afinito_steps(F, g, 0.999, 1e-9, idx, table, meta4, av, z, hgd)
     t = time.perf_counter() - t0
     out["adaptive_finito_steps_f64_d1024"] = {"updates_per_s": done / t, "us_per_update": t / max(done, 1) * 1e6, "steps": done,
                                               "trials_per_step": trials / max(done, 1), "kernel": ctx.last_kernel()}

@@ -729,7 +729,9 @@ constexpr size_t chain_dma_lds_bytes()
 // ------------------------------------------------------------------------------------------------------------------
 // Adaptive Finito steps (Finito_adaptive.jl:118-150): one sample per iteration with a
 // data-dependent backtracking loop on that sample's stepsize.  Same one-workgroup, state-in-registers structure as the
-// chains above; the per-sample scalars live in `meta` (N x 4: c_i with grad f_i = c_i a_i, f_i(x_i), gamma_i, a_i'x_i),
+// chains above; the per-sample scalars live in `meta` ({c_i with grad f_i = c_i a_i, f_i(x_i), gamma_i, a_i'x_i}, kept in
+// FOUR identical copies per sample, N x 4 x 4: wave w of the workgroup writes and reads only copy w, so every read of a
+// scalar follows its last write in the SAME wave's program order and needs neither a barrier nor a drained memory queue),
 // so the reference's N x d gradient table collapses to N scalars for these row-structured f_i.  The next sample's
 // row, table row and scalars are loaded one step ahead (re-read when it is the sample being updated).  Every trial of
 // the backtracking needs a_i'z and ||z - x_i||^2: one 2-value exchange per trial.  All branches are workgroup-uniform
@@ -800,10 +802,9 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_chain_kernel(AFinitoArgs<T> 
             ar[j] = ap[ecl[j]];
             sr[j] = sp[ecl[j]];
         }
-        // the per-sample scalars are written by thread 0 and read by every thread: agent-scope loads go to L2 (no stale
-        // L1 line); ordering comes from the vmcnt(0) + barrier of the __syncthreads() between the store and this load
+        // this wave's own copy of the per-sample scalars (written by this wave's lane 0)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) m[q] = __hip_atomic_load(a.meta + r * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 4; ++q) m[q] = a.meta[(r * CHAIN_NW + wib) * 4 + q];
         bi = a.b ? a.b[r] : T(0);
     };
 
@@ -858,7 +859,8 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_chain_kernel(AFinitoArgs<T> 
                 red[par][wib][0] = p1;
                 red[par][wib][1] = p2;
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // raw barrier: the next sample's loads stay in flight across it
             dz = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
             const T n2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
             par ^= 1;
@@ -900,8 +902,8 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_chain_kernel(AFinitoArgs<T> 
             av[j] = valid[j] ? t : T(0);
             z[j] = valid[j] ? prox_bf(av[j], gl, plo[j], phi[j]) : T(0);                // :150
         }
-        if (tid == 0) {
-            T *mp = a.meta + row * 4;
+        if (lane == 0) {
+            T *mp = a.meta + (row * CHAIN_NW + wib) * 4;
             mp[0] = c_new;
             mp[1] = fi_z;                                                                // :148 fi_x[i] = f_i(z)
             mp[2] = gi;
@@ -941,6 +943,313 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_chain_kernel(AFinitoArgs<T> 
         if (!valid[j]) continue;
         a.av[ecl[j]] = av[j];
         a.z[ecl[j]] = z[j];
+    }
+    if (tid == 0) {
+        *a.hg = hg;
+        a.counters[0] = done;
+        a.counters[1] = trials;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Adaptive Finito, fast path: the same step as afinito_chain_kernel with the inputs of step s (row a_i, table row s_i,
+// this wave's copy of the sample's scalars) brought in by LDS-DMA DEPTH steps ahead and retired with hand-counted waits,
+// exactly as chain_dma_kernel does (the compiler-scheduled version above drains the whole memory queue twice per step:
+// once behind the index load, once behind the prefetch it has just issued).  Ops per step and thread that are certain to
+// be issued, in program order: J stores of the table row, then 2J + 1 LDS-DMA loads; the scalar stores of lane 0 are
+// left out of the count, which only makes the waits stricter.  A sample that recurs within the look-ahead window has
+// its table row / scalars re-read from memory at use (the same thread / the same wave wrote them: program order).
+// Needs d*sizeof(T) == J*4096 and 16-byte aligned rows, table, scalars and vectors; otherwise the kernel above runs.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+constexpr int AF_CHUNK = 512;
+
+template <typename T, int J>
+constexpr size_t afinito_dma_lds_bytes()
+{
+    constexpr int DEPTH = DmaDepth<J>::value;
+    return (size_t)2 * DEPTH * J * CHAIN_NT * 16 + (size_t)DEPTH * CHAIN_NW * 256 + (AF_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
+           AF_CHUNK * sizeof(T) + AF_CHUNK * sizeof(int) + 16 + 2 * CHAIN_NW * 2 * sizeof(T);
+}
+
+template <typename T, int J, int LOSS>
+__global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
+{
+    using V = typename VecOfC<T>::type;
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int DEPTH = DmaDepth<J>::value;
+    constexpr int CH = AF_CHUNK;
+    constexpr int OPS_PER_STEP = 3 * J + 1;
+    constexpr bool PIPE = DEPTH >= 4;
+    constexpr int WAIT_N = (PIPE ? DEPTH - 2 : DEPTH - 1) * OPS_PER_STEP;
+    constexpr int ROW_BYTES = J * CHAIN_NT * 16;
+    constexpr int MDW = 4 * sizeof(T) / 4;   // dwords in one copy of a sample's scalars
+    static_assert(CH % DEPTH == 0 && DEPTH % 2 == 0, "ring slots must line up with chunk starts; ping-pong needs even DEPTH");
+    static_assert(WAIT_N <= 63, "vmcnt is a 6-bit counter");
+
+    // ringA[DEPTH][ROW_BYTES] | ringT[DEPTH][ROW_BYTES] | ringM[DEPTH][NW][256 B] | s_row | s_b | s_stale | red
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned char *ringA = dsm;
+    unsigned char *ringT = ringA + DEPTH * ROW_BYTES;
+    unsigned char *ringM = ringT + DEPTH * ROW_BYTES;
+    unsigned char *cur = ringM + DEPTH * CHAIN_NW * 256;
+    int64_t *s_row = reinterpret_cast<int64_t *>(cur);
+    cur += (CH + 2 * DEPTH) * sizeof(int64_t);
+    T *s_b = reinterpret_cast<T *>(cur);
+    cur += CH * sizeof(T);
+    int *s_stale = reinterpret_cast<int *>(cur);
+    cur += CH * sizeof(int);
+    cur += (16 - (reinterpret_cast<uintptr_t>(cur) & 15)) & 15;
+    T(*red)[CHAIN_NW][2] = reinterpret_cast<T(*)[CHAIN_NW][2]>(cur);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t d = a.d;
+    const uint32_t ringA_off = (uint32_t)(uintptr_t)ringA;
+    const uint32_t ringT_off = (uint32_t)(uintptr_t)ringT;
+    const uint32_t ringM_off = (uint32_t)(uintptr_t)ringM;
+
+    V av[J], p[J], plo[J], phi[J];
+    const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
+    const bool hasbox = (a.g.kind == CIAO_PROX_BOX);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int64_t c = tid + (int64_t)j * CHAIN_NT;
+        av[j] = reinterpret_cast<const V *>(a.av)[c];
+        p[j] = reinterpret_cast<const V *>(a.z)[c];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            plo[j][v] = -INFINITY;
+            phi[j][v] = INFINITY;
+            if (hasbox) {
+                plo[j][v] = a.g.lo_vec ? a.g.lo_vec[c * VEC + v] : a.g.lo;
+                phi[j][v] = a.g.hi_vec ? a.g.hi_vec[c * VEC + v] : a.g.hi;
+            }
+        }
+    }
+    T hg = *a.hg;
+
+    auto prox_all = [&](T gl) {   // p = prox_{hg g}(av): one workgroup-uniform branch instead of a clamp per coordinate
+        if (hasbox) {
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) p[j][v] = prox_bf(av[j][v], gl, plo[j][v], phi[j][v]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) p[j][v] = prox_l1(av[j][v], gl);
+        }
+    };
+
+    auto refill = [&](int u, int64_t r) {
+        const unsigned char *ap = reinterpret_cast<const unsigned char *>(a.A + r * a.ld);
+        const unsigned char *sp = reinterpret_cast<const unsigned char *>(a.table + r * d);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            glds16(ap + ((int64_t)j * CHAIN_NT + tid) * 16, ringA_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            glds16(sp + ((int64_t)j * CHAIN_NT + tid) * 16, ringT_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
+        // this wave's copy of the scalars: lanes l and l + MDW fetch the same dword, only the first MDW LDS dwords are read back
+        const unsigned char *mp = reinterpret_cast<const unsigned char *>(a.meta + (r * CHAIN_NW + wib) * 4);
+        glds4(mp + (lane & (MDW - 1)) * 4, ringM_off + (uint32_t)((u * CHAIN_NW + wib) * 256));
+    };
+
+    struct StepIn {
+        V ar[J], sr[J];
+        T m[4];
+        int64_t row, row_n;
+        T bi;
+        int stale;
+    };
+    StepIn in[2];
+    auto fetch = [&](StepIn &x, int u, int s) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            x.ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
+            x.sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
+        }
+        const T *mp = reinterpret_cast<const T *>(ringM + (u * CHAIN_NW + wib) * 256);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x.m[q] = mp[q];
+        x.row = s_row[DEPTH + s];
+        x.row_n = s_row[DEPTH + s + DEPTH];
+        x.bi = s_b[s];
+        x.stale = s_stale[s];
+    };
+
+    int par = 0;
+    long long done = 0, trials = 0;
+    bool stop = false;
+    for (int64_t base = 0; base < a.nsteps && !stop; base += CH) {
+        const int nch = (int)((a.nsteps - base) < CH ? (a.nsteps - base) : CH);
+
+        __syncthreads();
+        int64_t hist = -1;
+        if (tid < DEPTH && base > 0) hist = s_row[CH + tid];
+        __syncthreads();
+        if (tid < DEPTH) s_row[tid] = hist;
+        for (int e = tid; e < nch + DEPTH; e += CHAIN_NT) {
+            int64_t st = base + e;
+            if (st > a.nsteps - 1) st = a.nsteps - 1;
+            int64_t r = a.idx[st];
+            if ((uint64_t)r >= (uint64_t)a.N) {
+                *a.errflag = 1;
+                r = 0;
+            }
+            s_row[DEPTH + e] = r;
+            if (e < nch) s_b[e] = a.b ? a.b[r] : T(0);
+        }
+        __syncthreads();
+        for (int e = tid; e < nch; e += CHAIN_NT) {
+            const int64_t r = s_row[DEPTH + e];
+            bool st = false;
+#pragma unroll
+            for (int k = 1; k <= DEPTH; ++k) st |= (s_row[DEPTH + e - k] == r);
+            s_stale[e] = st ? 1 : 0;
+        }
+        __syncthreads();
+        if (base == 0) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) refill(u, uniform64(s_row[DEPTH + u]));
+        }
+        wait_vmcnt<0>();
+        drain_vmcnt_visible();
+        if (PIPE) fetch(in[0], 0, 0);
+
+        for (int s0 = 0; s0 < nch && !stop; s0 += DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                const int s = s0 + u;
+                if (s >= nch || stop) break;
+                StepIn &x = in[PIPE ? (u & 1) : 0];
+                if (PIPE) {
+                    if (s + 1 < nch) {
+                        wait_vmcnt<WAIT_N>();
+                        fetch(in[(u + 1) & 1], (u + 1) % DEPTH, s + 1);
+                    }
+                } else {
+                    wait_vmcnt<WAIT_N>();
+                    fetch(x, u, s);
+                }
+                const int64_t row = uniform64(x.row);
+                const int64_t row_n = uniform64(x.row_n);
+                const T bi = x.bi;
+                if (__builtin_amdgcn_readfirstlane(x.stale)) {
+                    const V *sp = reinterpret_cast<const V *>(a.table + row * d);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) x.sr[j] = sp[tid + j * CHAIN_NT];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x.m[q] = a.meta[(row * CHAIN_NW + wib) * 4 + q];
+                    drain_vmcnt_visible();
+                }
+                const T c_old = x.m[0], fi_x = x.m[1], as_i = x.m[3];
+                T gi = x.m[2];
+                V res[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) res[j] = p[j] - x.sr[j];
+                T dz = T(0), fi_z = T(0), r1_acc = T(0);
+                while (true) {
+                    if (gi < a.tol_b * a.invN) {          // Finito_adaptive.jl:121-124: the stepsize collapsed
+                        stop = true;
+                        break;
+                    }
+                    ++trials;
+                    T p1 = T(0), p2 = T(0);
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            p1 = fmad(x.ar[j][v], p[j][v], p1);
+                            p2 = fmad(res[j][v], res[j][v], p2);
+                        }
+                    p1 = wave_allsum(p1);
+                    p2 = wave_allsum(p2);
+                    if (lane == 0) {
+                        red[par][wib][0] = p1;
+                        red[par][wib][1] = p2;
+                    }
+                    // the two divisions of the step depend only on gamma_i and hat_gamma: issued here, they run in the shadow of
+                    // the exchange instead of behind it
+                    const T qc = T(0.5) * a.Nf * a.alpha / gi;                                  // :128
+                    const T r1 = hg / gi;                                                       // :145
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue
+                    dz = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+                    const T n2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+                    par ^= 1;
+                    fi_z = loss_value(LOSS, dz, bi, a.lam);                                     // :125
+                    const T fi_model = fi_x + c_old * (dz - as_i) + qc * n2;                    // :126-129
+                    const T tol = T(10) * Eps<T>::value * (T(1) + fabs2(fi_z));                 // :130
+                    if (fi_z <= fi_model + tol) {                                               // :131
+                        r1_acc = r1;
+                        break;
+                    }
+                    const T gb = gi;                                                            // :133
+                    gi *= T(0.8);                                                               // :134
+                    const T hg_old = hg;
+                    hg = T(1) / (T(1) / hg_old + T(1) / gi - T(1) / gb);                        // :139
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            T t = av[j][v] / hg_old;                                            // :136
+                            t += x.sr[j][v] / gi;                                               // :137
+                            t -= x.sr[j][v] / gb;                                               // :138
+                            t *= hg;                                                            // :140
+                            av[j][v] = t;
+                        }
+                    prox_all(hg * plam);                                                        // :141
+#pragma unroll
+                    for (int j = 0; j < J; ++j) res[j] = p[j] - x.sr[j];                        // :142
+                }
+                if (stop) break;
+                // the main step, :145-150
+                const GradCoef<T> gn = grad_coef_t<T, LOSS>(dz, bi, a.lam);
+                const T c_new = gn.coef();
+                const T r1 = r1_acc;
+                const T r2 = (hg * a.invN) * (c_old - c_new);   // + (hg/N) grad_old - (hg/N) grad_new, both multiples of a_i
+                V *sp = reinterpret_cast<V *>(a.table + row * d);
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    sp[tid + j * CHAIN_NT] = p[j];                                              // :146  s_i = z
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const T t = fmad(r1, res[j][v], av[j][v]);                              // :145
+                        av[j][v] = fmad(r2, x.ar[j][v], t);                                     // :147, :149
+                    }
+                }
+                prox_all(hg * plam);                                                            // :150
+                if (lane == 0) {
+                    T *mp = a.meta + (row * CHAIN_NW + wib) * 4;
+                    mp[0] = c_new;
+                    mp[1] = fi_z;                                                               // :148 fi_x[i] = f_i(z)
+                    mp[2] = gi;
+                    mp[3] = dz;
+                }
+                ++done;
+                refill(u, row_n);   // after this step's stores (program order); the look-ahead entry always exists
+            }
+        }
+    }
+    wait_vmcnt<0>();   // nothing may still be writing LDS when the workgroup retires
+
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int64_t c = tid + (int64_t)j * CHAIN_NT;
+        reinterpret_cast<V *>(a.av)[c] = av[j];
+        reinterpret_cast<V *>(a.z)[c] = p[j];
     }
     if (tid == 0) {
         *a.hg = hg;

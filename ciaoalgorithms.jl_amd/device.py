@@ -314,7 +314,7 @@ class Context:
     # -- adaptive Finito -------------------------------------------------------------------------------------------------
     def afinito_init(self, p, g, alpha, x0, table, meta, av, z, hat_gamma_dev):
         L.check(self.lib.ciao_afinito_init(self._h, p.ref, g.ref, float(alpha), self._vec(x0, p, "x0"),
-                                           self._vec(table, p, "table", p.N * p.d), self._vec(meta, p, "meta", p.N * 4),
+                                           self._vec(table, p, "table", p.N * p.d), self._vec(meta, p, "meta", p.N * 16),
                                            self._vec(av, p, "av"), self._vec(z, p, "z"), self._vec(hat_gamma_dev, p, "hat_gamma", 1)))
 
     def afinito_steps(self, p, g, alpha, tol_b, idx, table, meta, av, z, hat_gamma_dev) -> tuple[int, int]:
@@ -322,7 +322,7 @@ class Context:
         idx = self._idx(idx)
         done, trials = C.c_int64(0), C.c_int64(0)
         L.check(self.lib.ciao_afinito_steps(self._h, p.ref, g.ref, float(alpha), float(tol_b), idx.numel(), _ptr(idx),
-                                            self._vec(table, p, "table", p.N * p.d), self._vec(meta, p, "meta", p.N * 4),
+                                            self._vec(table, p, "table", p.N * p.d), self._vec(meta, p, "meta", p.N * 16),
                                             self._vec(av, p, "av"), self._vec(z, p, "z"), self._vec(hat_gamma_dev, p, "hat_gamma", 1),
                                             C.byref(done), C.byref(trials)))
         return done.value, trials.value

@@ -313,7 +313,7 @@ class FINITO_LFinito_iterable(_Iterable):
 
 class FINITO_adaptive_state:
     """Finito_adaptive.jl:13-29.  For the row-structured f_i of this path grad f_i = c_i a_i, so the reference's N x d
-    gradient table `∇f` is the first column of `meta` (N x 4: c_i, f_i(x_i), γ_i, a_i'x_i); γ and fi_x are views of it."""
+    gradient table `∇f` is the column c_i of `meta` (N x 4 copies x 4: c_i, f_i(x_i), γ_i, a_i'x_i); γ and fi_x are views."""
 
     def __init__(self, s, meta, hat_γ_dev, av, z, N):
         self.s, self.meta, self.hat_γ_dev, self.av, self.z = s, meta, hat_γ_dev, av, z
@@ -321,8 +321,8 @@ class FINITO_adaptive_state:
         self.idx, self.idxr = 0, 0
         self.trials = 0
 
-    γ = property(lambda self: self.meta[:, 2])
-    fi_x = property(lambda self: self.meta[:, 1])
+    γ = property(lambda self: self.meta[:, 0, 2])
+    fi_x = property(lambda self: self.meta[:, 0, 1])
     hat_γ = property(lambda self: float(self.hat_γ_dev.item()))
     hat_gamma = hat_γ
 
@@ -339,7 +339,7 @@ class FINITO_adaptive_iterable(_Iterable):
     def _init(self):                                                       # Finito_adaptive.jl:59-98
         dev = self._x0_dev.device
         s = torch.empty((self.N, self.d), dtype=self.R, device=dev)
-        meta = torch.empty((self.N, 4), dtype=self.R, device=dev)
+        meta = torch.empty((self.N, 4, 4), dtype=self.R, device=dev)
         hg = torch.empty(1, dtype=self.R, device=dev)
         av, z = self._new(), self._new()
         self.ctx.afinito_init(self.F, self.g, self.α, self._x0_dev, s, meta, av, z, hg)

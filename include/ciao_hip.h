@@ -196,7 +196,8 @@ CIAO_API int32_t ciao_lfinito_iterate(ciao_ctx *ctx, const ciao_problem *p, cons
 
 /* ---- adaptive Finito  (Finito/Finito_adaptive.jl) -------------------------------- */
 /* For the row-structured f_i here grad f_i = c_i a_i, so the reference's N x d gradient table is N scalars: `meta` is a
- * device N x 4 array of R holding {c_i, f_i(x_i), gamma_i, a_i'x_i} per sample; `table` is the N x d table of points
+ * device N x 4 x 4 array of R: per sample FOUR identical copies of {c_i, f_i(x_i), gamma_i, a_i'x_i} (one per wave of
+ * the step kernel, which makes every read follow its write in one wave's program order); `table` is the N x d table of points
  * x_i; `hat_gamma_dev` is a DEVICE scalar of R (it changes during backtracking).
  * Base.iterate(iter), :59-98: x_i = x0; gamma_i = alpha / L_i with L_i = ||grad f_i(x0 .+ 1) - grad f_i(x0)|| / (sqrt(d) N);
  * hat_gamma = 1/sum 1/gamma_i; av = hat_gamma (sum x_i/gamma_i - sum grad f_i / N); z = prox_{hat_gamma g}(av).

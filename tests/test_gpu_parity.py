@@ -527,7 +527,7 @@ def test_lfinito_iterations(ctx, ciao, chain_variant, dtype, shape, r, chain_max
 # adaptive Finito
 # ----------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("shape", [(6, 3), (8, 5), (50, 50), (40, 256), (30, 300), (24, 1024), (10, 4096)])
+@pytest.mark.parametrize("shape", [(6, 3), (8, 5), (50, 50), (40, 256), (30, 300), (24, 1024), (10, 4096), (700, 512), (200, 2048)])
 def test_adaptive_finito_steps(ctx, ciao, dtype, shape):
     """Init (Lipschitz probe, hat_gamma, av, z) and 3N backtracking steps against the oracle, same sample sequence --
     including immediate repeats of a sample (the register hand-over path) and repeats two steps apart."""
@@ -541,10 +541,11 @@ def test_adaptive_finito_steps(ctx, ciao, dtype, shape):
     alpha, tol_b = 0.999, 1e-9
     tdt = dev(x0).dtype
     table = torch.empty((N, d), dtype=tdt, device="cuda")
-    meta = torch.empty((N, 4), dtype=tdt, device="cuda")
+    meta4 = torch.empty((N, 4, 4), dtype=tdt, device="cuda")
+    meta = meta4[:, 0, :]
     hg = torch.empty(1, dtype=tdt, device="cuda")
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
-    ctx.afinito_init(dp, dg, alpha, dev(x0), table, meta, av, z, hg)
+    ctx.afinito_init(dp, dg, alpha, dev(x0), table, meta4, av, z, hg)
     ctx.synchronize()
     rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(alpha), x0)
     S = 50 if dtype == np.float64 else 10
@@ -559,11 +560,16 @@ def test_adaptive_finito_steps(ctx, ciao, dtype, shape):
     idx[5:8] = idx[5]          # the same sample three times in a row
     idx[10] = idx[8]           # ... and again two steps later
     if len(idx) > 41:
-        idx[20:40:2] = idx[20]     # a long run of "every other step" repeats (the previous-step hand-over)
-        idx[21:41:2] = idx[21]
-    done, trials = ctx.afinito_steps(dp, dg, alpha, tol_b, idx, table, meta, av, z, hg)
+        # a run of "every other step" repeats (the previous-step hand-over).  Kept short: hammering two samples drives
+        # z towards their common fixed point, where the backtracking test f_i(z) <= model + tol degenerates into an
+        # equality up to rounding and two correct implementations may legitimately decide differently even in fp64
+        idx[20:30:2] = idx[20]
+        idx[21:31:2] = idx[21]
+    done, trials = ctx.afinito_steps(dp, dg, alpha, tol_b, idx, table, meta4, av, z, hg)
     rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(alpha), dtype(tol_b), idx, rt, rg, rgam, rfi, rhg, rav, rz)
     assert done == rdone == len(idx)
+    if (d * np.dtype(dtype).itemsize) % 4096 == 0 and d * np.dtype(dtype).itemsize <= 32768:
+        assert "afinito_dma_kernel" in ctx.last_kernel(), "whole-4-KiB rows take the LDS-DMA path"
     if dtype == np.float64:
         assert trials == rtrials, "same backtracking decisions in fp64"
     S = 2000 if dtype == np.float64 else 200
@@ -593,19 +599,58 @@ def test_adaptive_finito_steps(ctx, ciao, dtype, shape):
     ctx.synchronize()
 
 
-def test_adaptive_finito_stops_when_the_stepsize_collapses(ctx, ciao):
+@pytest.mark.parametrize("kind,gkind", [("logistic", "l1"), ("ls", "box"), ("logistic", "zero")])
+@pytest.mark.parametrize("no_dma", [0, 1])
+def test_adaptive_finito_variants(ctx, ciao, kind, gkind, no_dma):
+    """The other loss / g combinations on a shape that takes the LDS-DMA path (d = 1024 fp64: J = 2), with samples that
+    recur inside the look-ahead window (N = 5 < ring depth: nearly every row is re-read at use), and the same through the
+    compiler-scheduled fallback kernel."""
+    import torch
+    from oracle import oracle as O
+    N, d, dtype = 5, 1024, np.float64
+    A, b, x0 = P.synthetic(kind, N, d, dtype, seed=33)
+    lam_f = 1.0 if kind == "logistic" else float(N)
+    op, dp = make(kind, A, b, lam_f, dtype)
+    og, dg = make_g(gkind, dtype, d, lam=0.01)
+    alpha, tol_b = 0.999, 1e-9
+    table = torch.empty((N, d), dtype=torch.float64, device="cuda")
+    meta4 = torch.empty((N, 4, 4), dtype=torch.float64, device="cuda")
+    hg = torch.empty(1, dtype=torch.float64, device="cuda")
+    av, z = torch.empty(d, dtype=torch.float64, device="cuda"), torch.empty(d, dtype=torch.float64, device="cuda")
+    ctx.set_option("chain_no_dma", no_dma)
+    try:
+        ctx.afinito_init(dp, dg, alpha, dev(x0), table, meta4, av, z, hg)
+        rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(alpha), x0)
+        idx = ciao.IndexStream(9).rand_indices(N, 1300)   # three chunks of the staged index stream
+        done, trials = ctx.afinito_steps(dp, dg, alpha, tol_b, idx, table, meta4, av, z, hg)
+        assert ("afinito_dma_kernel" in ctx.last_kernel()) == (no_dma == 0)
+    finally:
+        ctx.set_option("chain_no_dma", 0)
+    rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(alpha), dtype(tol_b), idx, rt, rg, rgam, rfi, rhg, rav, rz)
+    assert done == rdone == len(idx) and trials == rtrials
+    close(z, rz, dtype, scale=5000, what=f"adaptive z ({ctx.last_kernel()})")
+    close(av, rav, dtype, scale=5000, what="adaptive av")
+    close(hg, [rhg], dtype, scale=5000, what="adaptive hat_gamma")
+    close(table, rt, dtype, scale=5000, what="adaptive table")
+    assert torch.equal(meta4[:, 0], meta4[:, 1]) and torch.equal(meta4[:, 0], meta4[:, 2]) and torch.equal(meta4[:, 0], meta4[:, 3])
+    ctx.synchronize()
+
+
+@pytest.mark.parametrize("d", [64, 1024])
+def test_adaptive_finito_stops_when_the_stepsize_collapses(ctx, ciao, d):
     """tol_b so large that the very first step finds gamma_i < tol_b/N: the chain ends (reference :121-124)."""
     import torch
-    N, d = 12, 64
+    N = 12
     A, b, x0 = P.synthetic("ls", N, d, np.float64, seed=2)
     _, dp = make("ls", A, b, float(N), np.float64)
     _, dg = make_g("l1", np.float64, d)
     table = torch.empty((N, d), dtype=torch.float64, device="cuda")
-    meta = torch.empty((N, 4), dtype=torch.float64, device="cuda")
+    meta4 = torch.empty((N, 4, 4), dtype=torch.float64, device="cuda")
+    meta = meta4[:, 0, :]
     hg = torch.empty(1, dtype=torch.float64, device="cuda")
     av, z = torch.empty(d, dtype=torch.float64, device="cuda"), torch.empty(d, dtype=torch.float64, device="cuda")
-    ctx.afinito_init(dp, dg, 0.999, dev(x0), table, meta, av, z, hg)
-    done, trials = ctx.afinito_steps(dp, dg, 0.999, 1e12, np.arange(5, dtype=np.int64), table, meta, av, z, hg)
+    ctx.afinito_init(dp, dg, 0.999, dev(x0), table, meta4, av, z, hg)
+    done, trials = ctx.afinito_steps(dp, dg, 0.999, 1e12, np.arange(5, dtype=np.int64), table, meta4, av, z, hg)
     assert done == 0 and trials == 0
     ctx.synchronize()
 
