@@ -295,6 +295,27 @@ static int32_t finito_init_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_pr
     return launch_rows<T>(ctx, RM_FINITO_INIT, a, e);
 }
 
+// Batches of r samples: r dependent chain steps in one persistent workgroup, or one batch-parallel rows launch?
+// "chain_max_batch" >= 0 fixes the crossover; -1 (default) derives it from measurements on MI355X: a batch-parallel step
+// costs ~10 us of launches + latency whatever r (tools/finito_batch_time.py), a chain step 0.45-1.5 us growing with the row.
+template <typename T>
+static bool batch_as_chain(const ciao_ctx *ctx, const ciao_problem *p, int64_t r)
+{
+    if (ctx->hook) return false;                       // sharded batches need the all-reduce between kernels
+    if (p->d > 16 * CHAIN_NT) return false;            // the chain keeps d/256 elements per thread in registers
+    int64_t lim = ctx->chain_max_batch;
+    if (lim < 0) {
+        // whole-4-KiB rows: rows_split_kernel batches cost ~6.5 us up to r = 64, LDS-DMA chain steps 0.47 / 0.55 / 0.8 / 1.5 us at
+        // 4 / 8 / 16 / 32 KiB rows; other shapes: ~14 us per wave-per-row batch against ~1 us per register-chain step
+        const int64_t rowb = p->d * (int64_t)sizeof(T);
+        if (rowb % 4096 == 0 && rowb <= 32768 && rowb != 12288 && rowb != 20480 && rowb != 24576 && rowb != 28672)
+            lim = rowb == 4096 ? 14 : (rowb == 8192 ? 12 : (rowb == 16384 ? 8 : 4));
+        else
+            lim = 14;
+    }
+    return r <= lim;
+}
+
 template <typename T>
 static int32_t finito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
                               int64_t nit, const int64_t *bptr, const int64_t *bidx, void *table, void *av, void *z)
@@ -307,7 +328,7 @@ static int32_t finito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_p
         // a run of consecutive batches of the same size
         int64_t t1 = t + 1;
         while (t1 < nit && bptr[t1 + 1] - bptr[t1] == r) ++t1;
-        if (!ctx->hook && r <= ctx->chain_max_batch) {
+        if (batch_as_chain<T>(ctx, p, r)) {
             ChainArgs<T> a = chain_args<T>(p, g);
             a.nsteps = (t1 - t) * r;
             a.idx = bidx + bptr[t];
@@ -385,7 +406,7 @@ static int32_t lfinito_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const cia
         CIAO_REQUIRE(r >= 1 || (ctx->hook && r == 0), "LFinito batch %lld is empty", (long long)t);
         int64_t t1 = t + 1;
         while (t1 < nb && bptr[t1 + 1] - bptr[t1] == r) ++t1;
-        if (!ctx->hook && r <= ctx->chain_max_batch) {
+        if (batch_as_chain<T>(ctx, p, r)) {
             ChainArgs<T> a = chain_args<T>(p, g);
             a.nsteps = (t1 - t) * r;
             a.idx = bidx + bptr[t];
@@ -662,13 +683,19 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
         ctx->sweep_blocks_per_cu = value;
     } else if (!strcmp(key, "sweep_multi")) {
         ctx->sweep_multi = value != 0;
+    } else if (!strcmp(key, "split_max_rows")) {
+        CIAO_REQUIRE(value >= -1, "split_max_rows must be >= -1");
+        ctx->split_max_rows = value;
+    } else if (!strcmp(key, "split_blocks_per_cu")) {
+        CIAO_REQUIRE(value >= 0 && value <= 16, "split_blocks_per_cu must be in 0..16");
+        ctx->split_blocks_per_cu = value;
     } else if (!strcmp(key, "sweep_grid")) {
         CIAO_REQUIRE(value >= 0 && value <= 65535, "sweep_grid must be in 0..65535");
         ctx->sweep_grid = value;
     } else if (!strcmp(key, "sweep_prefetch")) {
         ctx->sweep_prefetch = value < 0 ? -1 : (value != 0);
     } else if (!strcmp(key, "chain_max_batch")) {
-        CIAO_REQUIRE(value >= 0, "chain_max_batch must be >= 0");
+        CIAO_REQUIRE(value >= -1, "chain_max_batch must be >= -1 (-1 = automatic)");
         ctx->chain_max_batch = value;
     } else if (!strcmp(key, "svrg_cache_rowdots")) {
         ctx->svrg_cache_rowdots = value != 0;

@@ -35,9 +35,11 @@ struct ciao_ctx {
     // tuning
     int64_t sweep_blocks_per_cu = 0;   // 0 = choose from the row size (rows_launch.inc)
     int64_t sweep_multi = 1;           // short rows (<= 4 KiB): several rows per wave per iteration (rows_multi_kernel)
+    int64_t split_max_rows = -1;       // batches up to this many rows run one workgroup per row (rows_split_kernel); -1 = automatic
+    int64_t split_blocks_per_cu = 0;   // its grid cap in blocks per CU (0 = automatic)
     int64_t sweep_grid = 0;            // testing: absolute grid override for the rows kernels (0 = automatic)
     int64_t sweep_prefetch = -1;    // gradient sweeps: 1 = two-deep register pipeline, 0 = occupancy only, -1 = by row size
-    int64_t chain_max_batch = 64;   // Finito/LFinito batches up to this size run as a sequential chain
+    int64_t chain_max_batch = -1;   // Finito/LFinito batches up to this size run as a sequential chain (-1 = automatic)
     int64_t svrg_cache_rowdots = 1; // reuse a_i'z_full from the full pass inside the SVRG inner cycle (ciao_svrg_iterate)
     int64_t chain_no_dma = 0;       // testing: route chains through the register-ring kernel instead of the LDS-DMA one
     int chain_last_dma = 0;

@@ -333,6 +333,127 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
 #undef TSTORE
 
 // ------------------------------------------------------------------------------------------------------------------
+// Small-batch variant of the batch steps (FINITO_BATCH, and GRAD2 = the LFinito batch): ONE WORKGROUP per row.
+// A batch of a few hundred rows gives the wave-per-row kernel above one row per wave and nothing to hide its serial
+// latencies behind (row -> dot -> table row -> store: two dependent HBM round trips on 16 loads per lane).  Here the four
+// waves of a workgroup share a row -- thread t owns the 16-byte chunks t + 256*j, j < J, as in the chain kernels -- so
+// the row and its table row are requested together in J loads per lane, the dot product costs one 4-partial LDS
+// exchange, and the per-thread accumulators need no cross-wave combine: a block's partial is stored straight from
+// registers.  Needs d*sizeof(T) == J*4096 with J in {1,2,4,8} and 16-byte aligned rows.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int J, int MODE>
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
+{
+    using V = typename VecOf<T>::type;
+    constexpr int VEC = VecOf<T>::N;
+    constexpr bool TWO = (MODE == RM_GRAD2);
+    constexpr bool TABLE = (MODE == RM_FINITO_BATCH);
+    static_assert(MODE == RM_GRAD2 || MODE == RM_FINITO_BATCH, "batch steps only");
+
+    __shared__ T red[2][ROWS_WAVES][2];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    V x1[J], x2[J], acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        x1[j] = reinterpret_cast<const V *>(a.x1)[tid + j * ROWS_BLOCK];
+        x2[j] = TWO ? reinterpret_cast<const V *>(a.x2)[tid + j * ROWS_BLOCK] : V(T(0));
+        acc[j] = V(T(0));
+    }
+    T extra = T(0);
+    int par = 0;
+
+    struct RowIn {
+        V ar[J], sr[J];
+        V *sp;
+        T bi, gi;
+    };
+    // request everything row q needs at once: the row, its table row and its scalars
+    auto issue = [&](RowIn &x, int64_t q) {
+        int64_t row = a.idx ? a.idx[q] : a.row0 + q;
+        if (a.idx && (uint64_t)row >= (uint64_t)a.N) {
+            if (tid == 0) *a.errflag = 1;
+            row = 0;
+        }
+        x.sp = TABLE ? reinterpret_cast<V *>(a.table + row * a.d) : nullptr;
+        if (a.A) {
+            const V *ap = reinterpret_cast<const V *>(a.A + row * a.ld);
+#pragma unroll
+            for (int j = 0; j < J; ++j) x.ar[j] = __builtin_nontemporal_load(&ap[tid + j * ROWS_BLOCK]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < J; ++j) x.ar[j] = V(T(0));
+        }
+        if (TABLE) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) x.sr[j] = __builtin_nontemporal_load(&x.sp[tid + j * ROWS_BLOCK]);
+        }
+        x.bi = a.b ? a.b[row] : T(0);
+        x.gi = a.gam ? a.gam[row] : a.gam_uniform;
+    };
+    auto process = [&](RowIn &x) {
+        T d1 = T(0), d2 = T(0);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                d1 += x.ar[j][v] * x1[j][v];
+                if (TWO) d2 += x.ar[j][v] * x2[j][v];
+            }
+        d1 = wave_allsum(d1);
+        if (TWO) d2 = wave_allsum(d2);
+        if (lane == 0) {
+            red[par][wib][0] = d1;
+            if (TWO) red[par][wib][1] = d2;
+        }
+        // one raw barrier per row (LDS traffic only, no memory fence needed); the slots alternate, so a wave that is one
+        // row ahead writes the other pair
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        d1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+        if (TWO) d2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+        par ^= 1;
+
+        const GradCoef<T> g1 = grad_coef(a.loss, d1, x.bi, a.lam);
+        if (MODE == RM_GRAD2) {                       // Finito_LFinito.jl:93-98
+            const T c = g1.coef() - grad_coef(a.loss, d2, x.bi, a.lam).coef();
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc[j] += c * x.ar[j];
+            extra += a.hat_gamma / x.gi;
+        } else {                                      // Finito_basic.jl:110-117
+            const T cg = x.gi * a.invN;
+            const T rr = a.hat_gamma / x.gi;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                V tv;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    tv[v] = x1[j][v] - cg * g1.elem(x.ar[j][v]);
+                    acc[j][v] += (tv[v] - x.sr[j][v]) * rr;
+                }
+                __builtin_nontemporal_store(tv, &x.sp[tid + j * ROWS_BLOCK]);
+            }
+        }
+    };
+
+    // One row at a time per workgroup.  (A two-deep register pipeline -- next row in flight while this one is reduced --
+    // was measured and bought nothing: 29.1 vs 28.5 us at r = 2048, 5.1 vs 5.5 TB/s at r = 65536; with one workgroup per
+    // CU the chip already has 256 rows in flight, and the per-batch cost is launch + finalize, not row latency.)
+    RowIn cur;
+    for (int64_t q = blockIdx.x; q < a.nrows; q += gridDim.x) {
+        issue(cur, q);
+        process(cur);
+    }
+
+    V *pout = reinterpret_cast<V *>(a.partial + (int64_t)blockIdx.x * a.pstride);
+#pragma unroll
+    for (int j = 0; j < J; ++j) pout[tid + j * ROWS_BLOCK] = acc[j];
+    if (tid == 0) a.pextra[blockIdx.x] = extra;   // extra is workgroup-uniform
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Short-row variant of the gradient sweeps (GRAD / GRAD2): R rows per wave per iteration.
 // The chip streams fastest with about 8 KiB of loads in flight per wave at one block per CU (tools/tune_sweep.py); a
 // 4 KiB (d=1024 fp32) or shorter row leaves a wave with too little in flight and too much per-row latency (dot ->

@@ -108,8 +108,12 @@ CIAO_API int32_t ciao_ctx_destroy(ciao_ctx *ctx);
 CIAO_API int32_t ciao_ctx_set_stream(ciao_ctx *ctx, void *stream);
 CIAO_API int32_t ciao_ctx_synchronize(ciao_ctx *ctx);
 CIAO_API int32_t ciao_ctx_set_allreduce(ciao_ctx *ctx, ciao_allreduce_fn fn, void *user); /* fn = NULL: single GPU */
-/* Tuning knobs (performance only, never results-changing beyond summation order): key "sweep_blocks_per_cu",
- * "chain_prefetch" ... ; returns CIAO_ERR_ARG for unknown keys. */
+/* Tuning knobs (performance only, never results-changing beyond summation order); returns CIAO_ERR_ARG for unknown keys:
+ *   "sweep_blocks_per_cu", "sweep_grid", "sweep_prefetch", "sweep_multi", "force_generic"   grid / variant of the rows kernels
+ *   "chain_max_batch"      Finito / LFinito batches up to this size run as one sequential chain (-1 = measured crossover)
+ *   "split_max_rows"       batches up to this size run one workgroup per row instead of one wave per row (-1 = 16384)
+ *   "split_blocks_per_cu"  grid cap of that kernel (0 = one block per CU)
+ *   "chain_no_dma", "svrg_cache_rowdots"                                                    chain kernel variants */
 CIAO_API int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value);
 /* Kernel timing for bench.py's roofline line: when enabled, every launch of the dominant streaming kernel of an entry
  * point (rows_fast_kernel / rows_generic_kernel) is bracketed by HIP events on the ctx's stream.  _read synchronises,
@@ -178,7 +182,9 @@ CIAO_API int32_t ciao_finito_init(ciao_ctx *ctx, const ciao_problem *p, const ci
                          double hat_gamma, const void *x0, void *table, void *av, void *z);
 /* nit consecutive Base.iterate(iter,state), :109-118.  Iteration t uses the samples
  * bidx[bptr_host[t] .. bptr_host[t+1]) (bidx: device int64, LOCAL rows; bptr_host: HOST int64[nit+1]); the batch
- * choice (:95-108) is host logic.  Small batches run as one persistent chain; large ones batch-parallel. */
+ * choice (:95-108) is host logic.  Small batches run as one persistent chain; large ones batch-parallel.
+ * The samples of one batch must be distinct, as every batch the reference can build is (sample(1:N, r, replace=false),
+ * :97, or a static block, :49-59): the members of a batch are updated concurrently. */
 CIAO_API int32_t ciao_finito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam,
                           double hat_gamma, int64_t nit, const int64_t *bptr_host, const int64_t *bidx,
                           void *table, void *av, void *z);

@@ -435,10 +435,11 @@ def _batches(stream, N, r, nit, mode):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape,r", [((6, 3), 1), ((8, 5), 2), ((8, 5), 3), ((50, 50), 7), ((40, 256), 1), ((64, 1024), 16),
-                                     ((300, 64), 100), ((20, 1500), 4), ((10, 4096), 3), ((33, 2048), 1)])
-@pytest.mark.parametrize("chain_max", [64, 0])
-def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, chain_max):
-    """chain_max=64: batches run in the sequential chain kernel; chain_max=0: every batch goes batch-parallel."""
+                                     ((300, 64), 100), ((20, 1500), 4), ((10, 4096), 3), ((33, 2048), 1), ((1500, 1024), 700)])
+@pytest.mark.parametrize("path", ["chain", "block_per_row", "wave_per_row"])
+def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, path):
+    """The three routes of a batch: the sequential chain kernel; batch-parallel with one workgroup per row (whole-4-KiB rows
+    only, otherwise it falls through to the next); batch-parallel with one wave per row."""
     import torch
     from oracle import oracle as O
     N, d = shape
@@ -460,7 +461,8 @@ def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, chain_max):
     close(table, rt, dtype, scale=4, what="finito_init table")
     close(av, rav, dtype, scale=20, what="finito_init av")
     close(z, rz, dtype, scale=20, what="finito_init z")
-    ctx.set_option("chain_max_batch", chain_max)
+    ctx.set_option("chain_max_batch", 64 if path == "chain" else 0)
+    ctx.set_option("split_max_rows", 0 if path == "wave_per_row" else -1)
     try:
         st = ciao.IndexStream(33)
         for mode, nit in (("random", 5), ("cyclic", 2 * (-(-N // r)) + 1)):
@@ -473,7 +475,8 @@ def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, chain_max):
             close(av, rav, dtype, scale=200, what=f"finito av {mode}")
             close(table, rt, dtype, scale=200, what=f"finito table {mode}")
     finally:
-        ctx.set_option("chain_max_batch", 64)
+        ctx.set_option("chain_max_batch", -1)
+        ctx.set_option("split_max_rows", -1)
     # invariant av == hat_gamma * sum_i s_i / gamma_i   (row F3)
     inv = (table.double() / dgam.double()[:, None]).sum(dim=0).cpu().numpy() * hg
     close(av, inv, dtype, scale=200, what="finito av invariant")
@@ -482,9 +485,9 @@ def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, chain_max):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape,r", [((6, 3), 1), ((8, 5), 2), ((8, 5), 3), ((50, 50), 7), ((64, 1024), 16), ((300, 64), 100),
-                                     ((20, 1500), 1), ((17, 2048), 2)])
-@pytest.mark.parametrize("chain_max", [64, 0])
-def test_lfinito_iterations(ctx, ciao, chain_variant, dtype, shape, r, chain_max):
+                                     ((20, 1500), 1), ((17, 2048), 2), ((1300, 1024), 600)])
+@pytest.mark.parametrize("path", ["chain", "block_per_row", "wave_per_row"])
+def test_lfinito_iterations(ctx, ciao, chain_variant, dtype, shape, r, path):
     import torch
     from oracle import oracle as O
     N, d = shape
@@ -505,7 +508,8 @@ def test_lfinito_iterations(ctx, ciao, chain_variant, dtype, shape, r, chain_max
     assert torch.equal(z, av) and torch.equal(zf, av)
     nb = -(-N // r)
     static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in range(nb)]
-    ctx.set_option("chain_max_batch", chain_max)
+    ctx.set_option("chain_max_batch", 64 if path == "chain" else 0)
+    ctx.set_option("split_max_rows", 0 if path == "wave_per_row" else -1)
     try:
         st = ciao.IndexStream(8)
         for it in range(3):
@@ -519,7 +523,8 @@ def test_lfinito_iterations(ctx, ciao, chain_variant, dtype, shape, r, chain_max
             close(z, rz, dtype, scale=200, what=f"lfinito z it {it} ({ctx.last_kernel()})")
             close(av, rav, dtype, scale=200, what=f"lfinito av it {it}")
     finally:
-        ctx.set_option("chain_max_batch", 64)
+        ctx.set_option("chain_max_batch", -1)
+        ctx.set_option("split_max_rows", -1)
     ctx.synchronize()
 
 

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Times Finito batch steps (d = 4096 f32, N = 250k) for the batch sizes given on the command line; prints us per batch."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ciao_loader
+ciao_loader.load()
+from ciaoalgorithms_jl_amd import _lib as L
+from ciaoalgorithms_jl_amd.device import Context, PackedF, ProxG
+from ciaoalgorithms_jl_amd.sampling import IndexStream
+torch.cuda.set_device(0)
+ctx = Context(0)
+for kv in os.environ.get("CIAO_OPTS", "").split(","):
+    if "=" in kv:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+rs = [int(a) for a in sys.argv[1:]] or [64, 256, 1024, 4096]
+N, d, dt = 250_000, 4096, torch.float32
+A = torch.empty((N, d), dtype=dt, device="cuda"); b = torch.empty((N,), dtype=dt, device="cuda")
+ctx.synth_normal(A, 0, 1, 1 / np.sqrt(d))
+F = PackedF(L.LOSS_LS, A, b, float(N))
+ctx.synth_targets(F, torch.ones(d, dtype=dt, device="cuda"), 0.1, False, 1, b)
+g = ProxG(L.PROX_L1, lam=1e-3)
+gam = torch.full((N,), 0.999 * N / (1.3 * N), dtype=dt, device="cuda")
+hg = ctx.hat_gamma(gam)
+x0 = torch.zeros(d, dtype=dt, device="cuda")
+table = torch.empty((N, d), dtype=dt, device="cuda")
+av, z = torch.empty_like(x0), torch.empty_like(x0)
+ctx.finito_init(F, g, gam, hg, x0, table, av, z)
+st = IndexStream(0)
+out = []
+for r in rs:
+    nit = max(8, min(2000, (1 << 20) // r))
+    bidx = ctx._idx(np.concatenate([st.sample_without_replacement(N, r) for _ in range(nit)]))
+    bptr = np.arange(nit + 1, dtype=np.int64) * r
+    ctx.finito_steps(F, g, gam, hg, bptr[:3], bidx[:2 * r], table, av, z); ctx.synchronize()
+    t0 = time.perf_counter(); ctx.finito_steps(F, g, gam, hg, bptr, bidx, table, av, z); ctx.synchronize()
+    t = time.perf_counter() - t0
+    out.append(f"r={r}: {t / nit * 1e6:.2f} us/batch, {nit * r * (3 * d * 4 + 16) / t / 1e9:.0f} GB/s [{ctx.last_kernel()}]")
+print("\n".join(out))
