@@ -92,6 +92,86 @@ __global__ void __launch_bounds__(PROSHI_NW *WAVE) proshi_rows_kernel(ProshiArgs
     }
 }
 
+// Vectorised variant: one workgroup per agent row, thread t owns the 16-byte chunks t + 256*j (j < J) of every d-vector,
+// accumulators in registers, non-temporal 16-byte loads / stores (every byte is touched once per visit), no LDS and no
+// barrier at all -- the update is element-wise.  Needs 16-byte aligned rows and d*sizeof(T) <= J*4096, J in {1,2,4,8};
+// the tail of the last chunk group is masked.
+template <typename T>
+struct PVec;
+template <>
+struct PVec<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+    static constexpr int N = 4;
+};
+template <>
+struct PVec<double> {
+    typedef double type __attribute__((ext_vector_type(2)));
+    static constexpr int N = 2;
+};
+
+template <typename T, bool INIT, int J>
+__global__ void __launch_bounds__(256) proshi_vec_kernel(ProshiArgs<T> a)
+{
+    using V = typename PVec<T>::type;
+    constexpr int VEC = PVec<T>::N;
+    const int tid = threadIdx.x;
+    const int64_t nchunks = a.d / VEC;
+    bool ok[J];
+    V xs[J], acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        ok[j] = tid + j * 256 < nchunks;
+        xs[j] = ok[j] ? reinterpret_cast<const V *>(a.x)[tid + j * 256] : V(T(0));
+        acc[j] = V(T(0));
+    }
+    T extra = T(0);
+    for (int64_t u = blockIdx.x; u < a.nrows; u += gridDim.x) {
+        int64_t row = a.idx ? a.idx[u] : u;
+        if ((uint64_t)row >= (uint64_t)a.N) {
+            if (tid == 0) *a.errflag = 1;
+            row = 0;
+        }
+        const V *Qp = reinterpret_cast<const V *>(a.Q + row * a.ld);
+        const V *qp = reinterpret_cast<const V *>(a.q + row * a.ld);
+        V *sp = reinterpret_cast<V *>(a.table + row * a.d);
+        const T gi = a.gam[row];
+        const T c = gi * a.invN;
+        V Qv[J], qv[J], sv[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (!ok[j]) continue;
+            Qv[j] = __builtin_nontemporal_load(&Qp[tid + j * 256]);
+            qv[j] = __builtin_nontemporal_load(&qp[tid + j * 256]);
+            if (!INIT) sv[j] = __builtin_nontemporal_load(&sp[tid + j * 256]);
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (!ok[j]) continue;
+            V tv;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                if (INIT) {                                                 // ProShI_basic.jl:77-79
+                    const T x0 = xs[j][v];
+                    tv[v] = x0 - c * sq_grad(Qv[j][v], qv[j][v], a.eta, a.lo, a.hi, x0);
+                    acc[j][v] += tv[v];
+                } else {                                                    // :111-117
+                    const T s = sv[j][v];
+                    const T s2 = s + gi * xs[j][v];
+                    tv[v] = s2 - c * sq_grad(Qv[j][v], qv[j][v], a.eta, a.lo, a.hi, s2);
+                    acc[j][v] += tv[v] - s;
+                }
+            }
+            __builtin_nontemporal_store(tv, &sp[tid + j * 256]);
+        }
+        if (INIT) extra += gi;                                              // :82  hat_γ = sum(γ)
+    }
+    V *pout = reinterpret_cast<V *>(a.partial + (int64_t)blockIdx.x * a.pstride);
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+        if (ok[j]) pout[tid + j * 256] = acc[j];
+    if (tid == 0) a.pextra[blockIdx.x] = extra;
+}
+
 // solution(state): s_i += γ_i z for every agent, in place (ProShI_basic.jl:127-132)
 template <typename T>
 __global__ void __launch_bounds__(256) proshi_solution_kernel(int64_t N, int64_t d, const T *gam, const T *z, T *table)

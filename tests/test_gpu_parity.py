@@ -664,9 +664,15 @@ def test_adaptive_finito_stops_when_the_stepsize_collapses(ctx, ciao, d):
 # ProShI
 # ----------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("shape,r", [((3, 2), 1), ((3, 2), 2), ((40, 7), 5), ((64, 256), 8), ((30, 1000), 30), ((9, 4096), 4)])
-def test_proshi_steps(ctx, ciao, dtype, shape, r):
+@pytest.mark.parametrize("shape,r", [((3, 2), 1), ((3, 2), 2), ((40, 7), 5), ((64, 256), 8), ((30, 1000), 30), ((9, 4096), 4),
+                                     ((700, 1100), 600), ((12, 8192), 5)])
+@pytest.mark.parametrize("generic", [0, 1])
+def test_proshi_steps(ctx, ciao, dtype, shape, r, generic):
+    """generic=0: proshi_vec_kernel wherever rows are whole 16-byte chunks (masked tail at d = 1000, 1100; several rows per
+    workgroup at N = 700); generic=1: the scalar kernel for every shape."""
     import torch
+    if generic and shape[1] * np.dtype(dtype).itemsize * 2 > 144 * 1024:
+        pytest.skip("beyond the generic kernel's LDS budget")
     from oracle import oracle as O
     from ciaoalgorithms_jl_amd.device import PackedSepQuad
     N, d = shape
@@ -686,7 +692,14 @@ def test_proshi_steps(ctx, ciao, dtype, shape, r):
     table = torch.empty((N, d), dtype=tdt, device="cuda")
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
     hg = torch.empty(1, dtype=tdt, device="cuda")
-    ctx.proshi_init(df, dg, dev(gam), dev(x0), table, av, z, hg)
+    ctx.set_option("force_generic", generic)
+    try:
+        ctx.proshi_init(df, dg, dev(gam), dev(x0), table, av, z, hg)
+        rowb = d * np.dtype(dtype).itemsize
+        vec_ok = rowb % 16 == 0 and rowb <= 32768 and not generic
+        assert ("proshi_vec_kernel" in ctx.last_kernel()) == vec_ok, ctx.last_kernel()
+    finally:
+        ctx.set_option("force_generic", 0)
     rt, rav, rz, rhg = O.proshi_init(of, og, gam, x0)
     close(table, rt, dtype, scale=4, what="proshi init table")
     close(hg, [rhg], dtype, scale=4, what="proshi hat_gamma")
@@ -695,7 +708,11 @@ def test_proshi_steps(ctx, ciao, dtype, shape, r):
     st = ciao.IndexStream(2)
     batches = [st.sample_without_replacement(N, r) for _ in range(12)]
     bptr = np.arange(len(batches) + 1, dtype=np.int64) * r
-    ctx.proshi_steps(df, dg, dev(gam), float(hg.item()), bptr, np.concatenate(batches), table, av, z)
+    ctx.set_option("force_generic", generic)
+    try:
+        ctx.proshi_steps(df, dg, dev(gam), float(hg.item()), bptr, np.concatenate(batches), table, av, z)
+    finally:
+        ctx.set_option("force_generic", 0)
     O.proshi_steps(of, og, gam, rhg, batches, rt, rav, rz)
     S = 500 if dtype == np.float64 else 100
     close(table, rt, dtype, scale=S, what=f"proshi table ({ctx.last_kernel()})")
