@@ -401,6 +401,7 @@ static int32_t lfinito_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const cia
         CIAO_TRY(launch_rows<T>(ctx, RM_GRAD, a, e));
     }
     int64_t t = 0;
+    bool z_ready = false;
     while (t < nb) {
         const int64_t r = bptr[t + 1] - bptr[t];
         CIAO_REQUIRE(r >= 1 || (ctx->hook && r == 0), "LFinito batch %lld is empty", (long long)t);
@@ -417,9 +418,11 @@ static int32_t lfinito_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const cia
             a.z = (T *)z;
             a.zf = (T *)z_full;
             CIAO_TRY(launch_chain<T>(ctx, CA_LFINITO, a));
+            z_ready = false;
         } else {
             for (int64_t tt = t; tt < t1; ++tt) {
-                CIAO_TRY(prox_launch<T>(ctx, p->d, g, (const T *)av, hg, T(1), (T *)z));   // :92
+                // z = prox_{hg g}(av), :92 -- already written by the previous batch's epilogue when there was one
+                if (!z_ready) CIAO_TRY(prox_launch<T>(ctx, p->d, g, (const T *)av, hg, T(1), (T *)z));
                 RowsArgs<T> a = rows_args<T>(p);
                 a.nrows = r;
                 a.idx = bidx + bptr[tt];
@@ -437,6 +440,15 @@ static int32_t lfinito_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const cia
                 e.c_v = T(-1);
                 e.v = (const T *)z_full;
                 e.av_out = (T *)av;
+                // every batch but the last also leaves the NEXT batch's z = prox_{hg g}(av) (one launch less per batch;
+                // each thread reads its own z[k] above before it overwrites it).  After the last batch z stays the z that
+                // batch worked with: that is the reference's `solution` (Finito_LFinito.jl:105).
+                z_ready = (tt + 1 < nb);
+                if (z_ready) {
+                    e.z_out = (T *)z;
+                    e.tau = hg;
+                    e.g = make_prox<T>(g);
+                }
                 CIAO_TRY(launch_rows<T>(ctx, RM_GRAD2, a, e));
             }
         }

@@ -734,16 +734,35 @@ __global__ void __launch_bounds__(FIN_THREADS)
 
     T s = T(0);
     if (col < d) {
-        // four independent chains keep several loads in flight; the association order is fixed
+        // eight loads in flight per thread (the partials sit in L2 / Infinity Cache: the cost is round trips, not bytes);
+        // the association order is fixed: four chains, combined pairwise
         T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
         int p = ty;
-        for (; p + 3 * SLICES < nparts; p += 4 * SLICES) {
-            s0 += partial[(int64_t)p * pstride + col];
-            s1 += partial[(int64_t)(p + SLICES) * pstride + col];
-            s2 += partial[(int64_t)(p + 2 * SLICES) * pstride + col];
-            s3 += partial[(int64_t)(p + 3 * SLICES) * pstride + col];
+        for (; p + 7 * SLICES < nparts; p += 8 * SLICES) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(p + u * SLICES) * pstride + col];
+            s0 += v[0];
+            s1 += v[1];
+            s2 += v[2];
+            s3 += v[3];
+            s0 += v[4];
+            s1 += v[5];
+            s2 += v[6];
+            s3 += v[7];
         }
-        for (; p < nparts; p += SLICES) s0 += partial[(int64_t)p * pstride + col];
+        {   // up to seven left: issue them together as well
+            T v[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) v[u] = (p + u * SLICES < nparts) ? partial[(int64_t)(p + u * SLICES) * pstride + col] : T(0);
+            s0 += v[0];
+            s1 += v[1];
+            s2 += v[2];
+            s3 += v[3];
+            s0 += v[4];
+            s1 += v[5];
+            s2 += v[6];
+        }
         s = (s0 + s1) + (s2 + s3);
     }
     lds[ty][tx] = s;

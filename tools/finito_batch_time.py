@@ -38,4 +38,15 @@ for r in rs:
     t0 = time.perf_counter(); ctx.finito_steps(F, g, gam, hg, bptr, bidx, table, av, z); ctx.synchronize()
     t = time.perf_counter() - t0
     out.append(f"r={r}: {t / nit * 1e6:.2f} us/batch, {nit * r * (3 * d * 4 + 16) / t / 1e9:.0f} GB/s [{ctx.last_kernel()}]")
+if os.environ.get("CIAO_LFINITO"):
+    zf = torch.empty_like(x0)
+    ctx.lfinito_init(F, hg, x0, av, z, zf)
+    for r in rs:
+        nb = N // r
+        bidx = ctx._idx(np.arange(nb * r, dtype=np.int64))
+        bptr = np.arange(nb + 1, dtype=np.int64) * r
+        ctx.lfinito_iterate(F, g, gam, hg, bptr[:3], bidx[:2 * r], av, z, zf); ctx.synchronize()
+        t0 = time.perf_counter(); ctx.lfinito_iterate(F, g, gam, hg, bptr, bidx, av, z, zf); ctx.synchronize()
+        t = time.perf_counter() - t0
+        out.append(f"LFinito r={r}: {t * 1e3:.2f} ms per iteration ({nb} batches + full sweep), {2 * N * d * 4 / t / 1e9:.0f} GB/s [{ctx.last_kernel()}]")
 print("\n".join(out))
