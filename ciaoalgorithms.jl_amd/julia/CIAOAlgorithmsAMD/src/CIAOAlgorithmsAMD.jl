@@ -3,6 +3,8 @@
 # `ccall`s into libciao_hip.so (include/ciao_hip.h).  AMDGPU.jl is used ONLY for device/stream/buffer handles
 # (ROCArray, its pointer, the HIP stream); no KernelAbstractions, no CUDA.jl.
 #
+# Covers every constructor of the reference: SVRG, SAGA, SAG, Finito (basic, LFinito, adaptive) and Proshi.
+#
 # STATUS: written against the C ABI and never executed -- the build image has no `julia` binary (DESIGN.md section 1).
 # The always-runnable twin of this file is ciaoalgorithms.jl_amd/solvers.py, which binds the same symbols with ctypes
 # and is what tests/ exercise.  Every `ccall` below has its ctypes counterpart in _lib.py (same order, same types).
@@ -346,7 +348,7 @@ function static_batches(N::Int, r::Int)      # Finito_basic.jl:52-58
     return ind
 end
 
-function finito_gammas(iter::FINITO_iterable{R}) where {R}   # Finito_basic.jl:61-74
+function finito_gammas(iter, ::Type{R}) where {R}   # Finito_basic.jl:61-74 (ProShI_basic.jl:61-74 is the same rule)
     N = iter.N
     if iter.γ === nothing
         if iter.L === nothing
@@ -360,7 +362,7 @@ end
 function Base.iterate(iter::FINITO_iterable{R}) where {R}    # Finito_basic.jl:44-89 / Finito_LFinito.jl:40-76
     N, r = iter.N, iter.batch
     ind = (iter.sweeping == 1 && !iter.lfinito) ? [collect(1:r)] : static_batches(N, r)
-    γh = finito_gammas(iter)
+    γh = finito_gammas(iter, R)
     γh === nothing && return nothing
     γ = ROCArray(γh)
     hg = Ref{Float64}(0.0)
@@ -385,7 +387,7 @@ function Base.iterate(iter::FINITO_iterable{R}) where {R}    # Finito_basic.jl:4
     return state, state
 end
 
-function next_batch!(iter::FINITO_iterable, state::FINITO_state)   # Finito_basic.jl:95-108
+function next_batch!(iter, state)   # Finito_basic.jl:95-108 (and ProShI_basic.jl:95-107)
     if iter.sweeping == 1
         state.ind = [randperm(iter.N)[1:iter.batch]]               # sample(1:N, batch, replace=false)
     elseif iter.sweeping == 2
@@ -428,10 +430,12 @@ solution(state::FINITO_state) = state.z                            # Finito_basi
 function iterator(solver::Finito{R}, x0::AbstractArray{C}; F = nothing, g = ProximalOperators.Zero(), L = nothing,
                   N) where {R,C<:RealOrComplex{R}}
     C <: Complex && throw(ArgumentError("complex iterates are outside the device path"))
-    solver.adaptive && !solver.LFinito &&
-        throw(ArgumentError("adaptive Finito: bind ciao_afinito_init / ciao_afinito_steps as in solvers.py (FINITO_adaptive_iterable)"))
     d = length(x0)
     gd, keep = pack_g(R, g, d)
+    if solver.adaptive && !solver.LFinito                          # Finito.jl:95-108: no minibatch in the adaptive mode
+        solver.minibatch[1] && @warn "minibatch is not supported for adaptive Finito"
+        return FINITO_adaptive_iterable{R,typeof(x0)}(pack_F(R, F, N, d), gd, keep, x0, N, solver.tol_b, solver.sweeping, solver.α)
+    end
     return FINITO_iterable{R,typeof(x0)}(pack_F(R, F, N, d), gd, keep, x0, N, L, solver.γ, solver.sweeping,
                                          solver.minibatch[2], solver.α, solver.LFinito)
 end
@@ -449,7 +453,182 @@ function (solver::Finito{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOr
     return reshape(Array(solution(state_final)), size(x0)), num_iters
 end
 
-# Proshi binds ciao_proshi_init / ciao_proshi_steps / ciao_proshi_solution the same way (solvers.py: Proshi_basic_iterable);
-# INTEGRATION.md lists their ccall signatures.
+# ======================================================================================================================
+# adaptive Finito  (src/algorithms/Finito/Finito_adaptive.jl)
+# ======================================================================================================================
+struct FINITO_adaptive_iterable{R<:Real,Tx}
+    F::PackedF{R}; g::CiaoProxDesc; gkeep::Any; x0::Tx; N::Int; tol_b::R; sweeping::Int8; α::R
+end
+mutable struct FINITO_adaptive_state{R<:Real}
+    s::ROCArray{R,2}                 # d x N table of points x_i
+    meta::ROCArray{R,3}              # 4 x 4 x N: per sample four copies of {c_i, f_i(x_i), γ_i, a_i'x_i} (grad f_i = c_i a_i)
+    hat_γ::ROCArray{R,1}             # device scalar, updated by the backtracking
+    av::ROCArray{R,1}; z::ROCArray{R,1}
+    ind::Vector{Int}; idxr::Int; idx::Int
+end
+
+function Base.iterate(iter::FINITO_adaptive_iterable{R}) where {R}      # Finito_adaptive.jl:59-98
+    N = iter.N
+    x0d = ROCArray(R.(vec(iter.x0)))
+    s = ROCArray{R}(undef, length(x0d), N)
+    meta = ROCArray{R}(undef, 4, 4, N)
+    hg = ROCArray{R}(undef, 1)
+    av, z = similar(x0d), similar(x0d)
+    check(ccall((:ciao_afinito_init, libciao), Int32,
+                (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, Ref(cproblem(iter.F)), Ref(iter.g), Float64(iter.α), dptr(x0d), dptr(s), dptr(meta), dptr(av), dptr(z), dptr(hg)))
+    synchronize(context())           # a degenerate Lipschitz probe (reference :78-85 re-draws) surfaces here as an error
+    state = FINITO_adaptive_state{R}(s, meta, hg, av, z, collect(1:N), 0, 0)
+    return state, state
+end
+
+function Base.iterate(iter::FINITO_adaptive_iterable{R}, state::FINITO_adaptive_state{R}) where {R}
+    N = iter.N
+    if iter.sweeping == 1                                               # :104-116
+        state.idxr = rand(1:N)
+    elseif iter.sweeping == 2
+        state.idxr = mod(state.idxr, N) + 1
+    elseif iter.sweeping == 3
+        if state.idx == N
+            state.ind = randperm(N); state.idx = 1
+        else
+            state.idx += 1
+        end
+        state.idxr = state.ind[state.idx]
+    end
+    done, trials = Ref{Int64}(0), Ref{Int64}(0)
+    idx = to_dev_idx([state.idxr])
+    check(ccall((:ciao_afinito_steps, libciao), Int32,
+                (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Float64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int64}, Ref{Int64}),
+                context().h, Ref(cproblem(iter.F)), Ref(iter.g), Float64(iter.α), Float64(iter.tol_b), 1, dptr(idx),
+                dptr(state.s), dptr(state.meta), dptr(state.av), dptr(state.z), dptr(state.hat_γ), done, trials))
+    if done[] < 1                                                       # :121-124
+        @warn "parameter `γ` became too small"
+        return nothing
+    end
+    return state, state
+end
+solution(state::FINITO_adaptive_state) = state.z                        # Finito_adaptive.jl:155
+
+# ======================================================================================================================
+# ProShI  (src/algorithms/ProShI/ProShI.jl, ProShI_basic.jl) -- sharing problems; the solution is the whole table
+# ======================================================================================================================
+struct CiaoSepQuad
+    dtype::Int32; _pad::Int32
+    N::Int64; d::Int64; ld::Int64; N_total::Int64
+    Q::Ptr{Cvoid}; q::Ptr{Cvoid}
+    eta::Float64; lo::Float64; hi::Float64
+end
+struct PackedSepQuad{R}
+    Q::ROCArray{R,2}; q::ROCArray{R,2}          # d x N column-major == N x d row-major
+    eta::Float64; lo::Float64; hi::Float64; N::Int; d::Int
+end
+csepquad(f::PackedSepQuad{R}) where {R} =
+    CiaoSepQuad(dtype_code(R), 0, f.N, f.d, f.d, f.N, dptr(f.Q), dptr(f.q), f.eta, f.lo, f.hi)
+
+# F::Vector of Sum(Quadratic(diagonal Q, q), SqrDistL2(IndBox(lo, hi), η)) (test/test_sharing.jl:16-25) or lone Quadratic
+function pack_sharing_F(::Type{R}, F, N::Int, d::Int) where {R}
+    F isa PackedSepQuad{R} && return F
+    Q = Matrix{R}(undef, d, N); q = Matrix{R}(undef, d, N)
+    eta, lo, hi = nothing, 0.0, 0.0
+    for i in 1:N
+        parts = F[i] isa ProximalOperators.Sum ? collect(F[i].fs) : [F[i]]
+        quad = filter(t -> t isa ProximalOperators.Quadratic, parts)
+        dist = filter(t -> t isa ProximalOperators.SqrDistL2, parts)
+        (length(quad) == 1 && length(dist) <= 1 && length(quad) + length(dist) == length(parts)) ||
+            throw(ArgumentError("ProShI device path: each f_i must be Quadratic or Sum(Quadratic, SqrDistL2(IndBox, η))"))
+        Qi = Matrix(quad[1].Q)
+        (size(Qi) == (d, d) && isdiag(Qi)) || throw(ArgumentError("ProShI device path: only diagonal Quadratic terms are packable"))
+        Q[:, i] .= diag(Qi); q[:, i] .= quad[1].q
+        e, l, h = 0.0, 0.0, 0.0
+        if !isempty(dist)
+            box = dist[1].ind
+            (box isa ProximalOperators.IndBox && box.lb isa Real && box.ub isa Real) ||
+                throw(ArgumentError("ProShI device path: SqrDistL2 must wrap an IndBox with scalar bounds"))
+            e, l, h = Float64(dist[1].lambda), Float64(box.lb), Float64(box.ub)
+        end
+        eta === nothing && ((eta, lo, hi) = (e, l, h))
+        (eta, lo, hi) == (e, l, h) || throw(ArgumentError("ProShI device path: all agents must share the same soft box"))
+    end
+    return PackedSepQuad{R}(ROCArray(Q), ROCArray(q), eta === nothing ? 0.0 : eta, lo, hi, N, d)
+end
+
+struct Proshi{R<:Real}
+    γ::Maybe{Union{Array{R},R}}; sweeping::Int8; minibatch::Tuple{Bool,Int}; maxit::Int; verbose::Bool; freq::Int; α::R
+    function Proshi{R}(; γ::Maybe{Union{Array{R},R}} = nothing, sweeping = 1, minibatch::Tuple{Bool,Int} = (false, 1),
+                       maxit::Int = 10000, verbose::Bool = false, freq::Int = 10000, α::R = R(0.999)) where {R}
+        @assert γ === nothing || minimum(γ) > 0
+        @assert maxit > 0
+        @assert freq > 0
+        new(γ, sweeping, minibatch, maxit, verbose, freq, α)
+    end
+end
+Proshi(::Type{R}; kwargs...) where {R} = Proshi{R}(; kwargs...)
+Proshi(; kwargs...) = Proshi(Float64; kwargs...)
+
+struct Proshi_basic_iterable{R<:Real,Tx}
+    F::PackedSepQuad{R}; g::CiaoProxDesc; gkeep::Any; x0::Tx; N::Int
+    L::Maybe{Union{Array{R},R}}; γ::Maybe{Union{Array{R},R}}; sweeping::Int8; batch::Int; α::R
+end
+mutable struct Proshi_basic_state{R<:Real}
+    s::ROCArray{R,2}; γ::ROCArray{R,1}; hat_γ::R; av::ROCArray{R,1}; z::ROCArray{R,1}
+    ind::Vector{Vector{Int}}; d::Int; idxr::Int; idx::Int; inds::Vector{Int}
+    F::PackedSepQuad{R}
+end
+
+function Base.iterate(iter::Proshi_basic_iterable{R}) where {R}          # ProShI_basic.jl:44-89
+    N, r = iter.N, iter.batch
+    ind = iter.sweeping == 1 ? [collect(1:r)] : static_batches(N, r)
+    γh = finito_gammas(iter, R)                                          # :61-74, the same rule as Finito
+    γh === nothing && return nothing
+    γ = ROCArray(γh)
+    x0d = ROCArray(R.(vec(iter.x0)))
+    s = ROCArray{R}(undef, length(x0d), N)
+    av, z, hg = similar(x0d), similar(x0d), ROCArray{R}(undef, 1)
+    check(ccall((:ciao_proshi_init, libciao), Int32,
+                (Ptr{Cvoid}, Ref{CiaoSepQuad}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, Ref(csepquad(iter.F)), Ref(iter.g), dptr(γ), dptr(x0d), dptr(s), dptr(av), dptr(z), dptr(hg)))
+    state = Proshi_basic_state{R}(s, γ, Array(hg)[1], av, z, ind, cld(N, r), 1, 0, collect(1:cld(N, r)), iter.F)
+    return state, state
+end
+
+function Base.iterate(iter::Proshi_basic_iterable{R}, state::Proshi_basic_state{R}) where {R}   # :91-124
+    batch = next_batch!(iter, state)                                     # :95-107 is Finito's batch logic verbatim
+    bptr = Int64[0, length(batch)]
+    bidx = to_dev_idx(batch)
+    check(ccall((:ciao_proshi_steps, libciao), Int32,
+                (Ptr{Cvoid}, Ref{CiaoSepQuad}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, Ref(csepquad(iter.F)), Ref(iter.g), dptr(state.γ), Float64(state.hat_γ), 1, bptr, dptr(bidx),
+                dptr(state.s), dptr(state.av), dptr(state.z)))
+    return state, state
+end
+
+function solution(state::Proshi_basic_state)                             # :127-132: s_i += γ_i z IN PLACE, returns the table
+    check(ccall((:ciao_proshi_solution, libciao), Int32, (Ptr{Cvoid}, Ref{CiaoSepQuad}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, Ref(csepquad(state.F)), dptr(state.γ), dptr(state.z), dptr(state.s)))
+    return state.s
+end
+
+function iterator(solver::Proshi{R}, x0::AbstractArray{C}; F, g = ProximalOperators.Zero(), L = nothing, N) where {R,C<:RealOrComplex{R}}
+    C <: Complex && throw(ArgumentError("complex iterates are outside the device path"))
+    d = length(x0)
+    gd, keep = pack_g(R, g, d)
+    return Proshi_basic_iterable{R,typeof(x0)}(pack_sharing_F(R, F, N, d), gd, keep, x0, N, L, solver.γ, solver.sweeping,
+                                               solver.minibatch[2], solver.α)
+end
+
+function (solver::Proshi{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrComplex{R}}   # ProShI.jl:42-83
+    disp(it, state) = @printf "%5d | %.3e  \n" it state.hat_γ
+    iter = iterator(solver, x0; kwargs...)
+    num_iters, state_final = nothing, nothing
+    for (it_, state_) in enumerate(Iterators.take(iter, solver.maxit))
+        solver.verbose && mod(it_, solver.freq) == 0 && disp(it_, state_)
+        num_iters, state_final = it_, state_
+    end
+    solver.verbose && mod(num_iters, solver.freq) !== 0 && disp(num_iters, state_final)
+    sol = Array(solution(state_final))                                    # d x N (column i = agent i), as the reference's vector of x_i
+    synchronize(context())
+    return [sol[:, i] for i in 1:size(sol, 2)], num_iters
+end
 
 end # module
