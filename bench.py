@@ -77,6 +77,7 @@ def main():
         ctx.set_option("sweep_prefetch", args.prefetch)
     if args.blocks_per_cu is not None:
         ctx.set_option("sweep_blocks_per_cu", args.blocks_per_cu)
+        ctx.set_option("split_blocks_per_cu", min(args.blocks_per_cu, 16))
     if args.grid is not None:
         ctx.set_option("sweep_grid", args.grid)
 

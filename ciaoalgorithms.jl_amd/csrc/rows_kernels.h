@@ -333,33 +333,42 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
 #undef TSTORE
 
 // ------------------------------------------------------------------------------------------------------------------
-// Small-batch variant of the batch steps (FINITO_BATCH, and GRAD2 = the LFinito batch): ONE WORKGROUP per row.
-// A batch of a few hundred rows gives the wave-per-row kernel above one row per wave and nothing to hide its serial
-// latencies behind (row -> dot -> table row -> store: two dependent HBM round trips on 16 loads per lane).  Here the four
-// waves of a workgroup share a row -- thread t owns the 16-byte chunks t + 256*j, j < J, as in the chain kernels -- so
-// the row and its table row are requested together in J loads per lane, the dot product costs one 4-partial LDS
-// exchange, and the per-thread accumulators need no cross-wave combine: a block's partial is stored straight from
-// registers.  Needs d*sizeof(T) == J*4096 with J in {1,2,4,8} and 16-byte aligned rows.
+// ONE WORKGROUP per row (rows_split_kernel).  Two jobs:
+//
+// (1) Small and medium batches of the batch steps (FINITO_BATCH, and GRAD2 = the LFinito batch).  A batch of a few
+//     hundred rows gives the wave-per-row kernel above one row per wave and nothing to hide its serial latencies behind
+//     (row -> dot -> table row -> store: two dependent HBM round trips on 16 loads per lane).  Here the four waves of a
+//     workgroup share a row -- thread t owns the 16-byte chunks t + 256*j, j < J, as in the chain kernels -- so the row
+//     and its table row are requested together in J loads per lane, the dot product costs one 4-partial LDS exchange,
+//     and the per-thread accumulators need no cross-wave combine: a block's partial is stored straight from registers.
+//
+// (2) Every row length the wave-per-row fast path does not cover (it needs d = 64*VEC*{1,2,4,8,16} exactly): with
+//     MASKED the last chunk group is predicated, so any 16-byte aligned row of up to J*4096 bytes, J <= 16, runs here
+//     (d = 1000, 1536, 3000 ...; also d = 4096 fp64) instead of on the scalar generic kernel.
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int J, int MODE>
+template <typename T, int J, int MODE, bool MASKED>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
 {
     using V = typename VecOf<T>::type;
     constexpr int VEC = VecOf<T>::N;
     constexpr bool TWO = (MODE == RM_GRAD2);
-    constexpr bool TABLE = (MODE == RM_FINITO_BATCH);
-    static_assert(MODE == RM_GRAD2 || MODE == RM_FINITO_BATCH, "batch steps only");
+    constexpr bool TABLE = (MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH);
+    constexpr bool TREAD = (MODE == RM_FINITO_BATCH);
+    static_assert(MODE != RM_AFINITO_INIT, "the adaptive init keeps to the wave-per-row kernels");
 
     __shared__ T red[2][ROWS_WAVES][2];
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t nchunks = a.d / VEC;
 
+    bool ok[J];
     V x1[J], x2[J], acc[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        x1[j] = reinterpret_cast<const V *>(a.x1)[tid + j * ROWS_BLOCK];
-        x2[j] = TWO ? reinterpret_cast<const V *>(a.x2)[tid + j * ROWS_BLOCK] : V(T(0));
+        ok[j] = !MASKED || (tid + j * ROWS_BLOCK < nchunks);
+        x1[j] = ok[j] ? reinterpret_cast<const V *>(a.x1)[tid + j * ROWS_BLOCK] : V(T(0));
+        x2[j] = (TWO && ok[j]) ? reinterpret_cast<const V *>(a.x2)[tid + j * ROWS_BLOCK] : V(T(0));
         acc[j] = V(T(0));
     }
     T extra = T(0);
@@ -369,6 +378,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
         V ar[J], sr[J];
         V *sp;
         T bi, gi;
+        int64_t row;
     };
     // request everything row q needs at once: the row, its table row and its scalars
     auto issue = [&](RowIn &x, int64_t q) {
@@ -377,21 +387,22 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
             if (tid == 0) *a.errflag = 1;
             row = 0;
         }
+        x.row = row;
         x.sp = TABLE ? reinterpret_cast<V *>(a.table + row * a.d) : nullptr;
         if (a.A) {
             const V *ap = reinterpret_cast<const V *>(a.A + row * a.ld);
 #pragma unroll
-            for (int j = 0; j < J; ++j) x.ar[j] = __builtin_nontemporal_load(&ap[tid + j * ROWS_BLOCK]);
+            for (int j = 0; j < J; ++j) x.ar[j] = ok[j] ? __builtin_nontemporal_load(&ap[tid + j * ROWS_BLOCK]) : V(T(0));
         } else {
 #pragma unroll
             for (int j = 0; j < J; ++j) x.ar[j] = V(T(0));
         }
-        if (TABLE) {
+        if (TREAD) {
 #pragma unroll
-            for (int j = 0; j < J; ++j) x.sr[j] = __builtin_nontemporal_load(&x.sp[tid + j * ROWS_BLOCK]);
+            for (int j = 0; j < J; ++j) x.sr[j] = ok[j] ? __builtin_nontemporal_load(&x.sp[tid + j * ROWS_BLOCK]) : V(T(0));
         }
         x.bi = a.b ? a.b[row] : T(0);
-        x.gi = a.gam ? a.gam[row] : a.gam_uniform;
+        x.gi = (MODE == RM_GRAD || MODE == RM_SAGA_INIT) ? T(1) : (a.gam ? a.gam[row] : a.gam_uniform);
     };
     auto process = [&](RowIn &x) {
         T d1 = T(0), d2 = T(0);
@@ -417,23 +428,41 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
         par ^= 1;
 
         const GradCoef<T> g1 = grad_coef(a.loss, d1, x.bi, a.lam);
-        if (MODE == RM_GRAD2) {                       // Finito_LFinito.jl:93-98
+        if (MODE == RM_GRAD) {                        // SVRG_basic.jl:58-63, :87-92
+            const T c = g1.coef();
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc[j] += c * x.ar[j];
+            if (a.want_fval) extra += loss_value(a.loss, d1, x.bi, a.lam);
+            if (a.rowdot_out && tid == 0) a.rowdot_out[x.row] = d1;
+        } else if (MODE == RM_GRAD2) {                // Finito_LFinito.jl:93-98
             const T c = g1.coef() - grad_coef(a.loss, d2, x.bi, a.lam).coef();
 #pragma unroll
             for (int j = 0; j < J; ++j) acc[j] += c * x.ar[j];
             extra += a.hat_gamma / x.gi;
-        } else {                                      // Finito_basic.jl:110-117
+        } else if (MODE == RM_SAGA_INIT) {            // SAGA_basic.jl:42-47
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                V gv;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) gv[v] = g1.elem(x.ar[j][v]);
+                acc[j] += gv;
+                if (ok[j]) __builtin_nontemporal_store(gv, &x.sp[tid + j * ROWS_BLOCK]);
+            }
+        } else {                                      // Finito_basic.jl:77-83 (init) / :110-117 (batch)
             const T cg = x.gi * a.invN;
-            const T rr = a.hat_gamma / x.gi;
+            const T rr = (MODE == RM_FINITO_INIT) ? T(1) / x.gi : a.hat_gamma / x.gi;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 V tv;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     tv[v] = x1[j][v] - cg * g1.elem(x.ar[j][v]);
-                    acc[j][v] += (tv[v] - x.sr[j][v]) * rr;
+                    if (MODE == RM_FINITO_INIT)
+                        acc[j][v] += tv[v] * rr;
+                    else
+                        acc[j][v] += (tv[v] - x.sr[j][v]) * rr;
                 }
-                __builtin_nontemporal_store(tv, &x.sp[tid + j * ROWS_BLOCK]);
+                if (ok[j]) __builtin_nontemporal_store(tv, &x.sp[tid + j * ROWS_BLOCK]);
             }
         }
     };
@@ -449,7 +478,8 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
 
     V *pout = reinterpret_cast<V *>(a.partial + (int64_t)blockIdx.x * a.pstride);
 #pragma unroll
-    for (int j = 0; j < J; ++j) pout[tid + j * ROWS_BLOCK] = acc[j];
+    for (int j = 0; j < J; ++j)
+        if (ok[j]) pout[tid + j * ROWS_BLOCK] = acc[j];
     if (tid == 0) a.pextra[blockIdx.x] = extra;   // extra is workgroup-uniform
 }
 

@@ -66,7 +66,8 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-SHAPES = [(1, 1), (6, 3), (8, 5), (37, 50), (200, 64), (129, 128), (300, 256), (64, 1024), (33, 1000), (16, 2048), (5, 4096)]
+SHAPES = [(1, 1), (6, 3), (8, 5), (37, 50), (200, 64), (129, 128), (300, 256), (64, 1024), (33, 1000), (16, 2048), (5, 4096),
+          (40, 1536), (12, 3000), (9, 8192), (700, 1100)]
 
 
 # ----------------------------------------------------------------------------------------------------------------------
