@@ -392,7 +392,7 @@ struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at ~0.3 us p
     static constexpr int value = J <= 2 ? 8 : (J <= 4 ? 4 : 2);   // 64 KiB of LDS per ring at most
 };
 
-template <typename T, int J, int ALG, int LOSS>
+template <typename T, int J, int ALG, int LOSS, bool MASKED>
 __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
 {
     using V = typename VecOfC<T>::type;
@@ -403,7 +403,9 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
     constexpr bool SVRG_ANY = (ALG == CA_SVRG || ALG == CA_SVRGC);
     constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
     constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO || ALG == CA_SVRGC);   // s_g staging
-    constexpr int OPS_PER_STEP = HAS_TABLE ? 3 * J : J;
+    // MASKED (rows shorter than J*4096 bytes): the table stores of chunk groups beyond the row are predicated off and may
+    // not issue at all, so only the (always issued, address-clamped) LDS-DMA loads are counted -- stricter waits, still safe
+    constexpr int OPS_PER_STEP = HAS_TABLE ? (MASKED ? 2 * J : 3 * J) : J;
     // PIPE: the LDS reads of step s+1 (its ring slot and its staged scalars) are issued at the top of step s and land
     // while step s reduces its dot product, so only one LDS round trip (the 4-partial exchange) stays on the
     // dependent path.  It costs one step of DMA lead, hence only with DEPTH >= 4.
@@ -436,13 +438,24 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
     const uint32_t ringA_off = (uint32_t)(uintptr_t)ringA;   // LDS byte offsets (low 32 bits of the flat address)
     const uint32_t ringT_off = (uint32_t)(uintptr_t)ringT;
 
+    // chunk ownership: thread t owns 16-byte chunks t + 256*j; with MASKED those at or beyond the row's end are dead (their
+    // state stays zero, their loads are redirected to chunk 0 and discarded, their stores are predicated off)
+    const int64_t nchunks = d / VEC;
+    bool ok[J];
+    int64_t cl[J];   // chunk to address: own chunk, or 0 when dead
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int64_t c = tid + (int64_t)j * CHAIN_NT;
+        ok[j] = !MASKED || c < nchunks;
+        cl[j] = ok[j] ? c : 0;
+    }
     // iterate state, in 16-byte chunks
     V av[J], p[J], zf[J], zs[J], plo[J], phi[J];
     const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
     const bool hasbox = (a.g.kind == CIAO_PROX_BOX);   // wave-uniform: one branch per step selects the clamp-free prox
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const int64_t c = tid + (int64_t)j * CHAIN_NT;
+        const int64_t c = cl[j];
         av[j] = reinterpret_cast<const V *>(a.av)[c];
         if (SVRG_ANY) {
             p[j] = reinterpret_cast<const V *>(a.w)[c];
@@ -452,11 +465,12 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
             zs[j] = V(T(0));
         }
         zf[j] = TWO ? reinterpret_cast<const V *>(a.zf)[c] : V(T(0));
+        if (!ok[j]) av[j] = p[j] = zs[j] = zf[j] = V(T(0));
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             plo[j][v] = -INFINITY;
             phi[j][v] = INFINITY;
-            if (a.g.kind == CIAO_PROX_BOX) {
+            if (a.g.kind == CIAO_PROX_BOX && ok[j]) {   // dead chunks keep -inf/+inf: their zeros stay zeros
                 plo[j][v] = a.g.lo_vec ? a.g.lo_vec[c * VEC + v] : a.g.lo;
                 phi[j][v] = a.g.hi_vec ? a.g.hi_vec[c * VEC + v] : a.g.hi;
             }
@@ -473,12 +487,12 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
         const unsigned char *ap = reinterpret_cast<const unsigned char *>(a.A + r * a.ld);
 #pragma unroll
         for (int j = 0; j < J; ++j)
-            glds16(ap + ((int64_t)j * CHAIN_NT + tid) * 16, ringA_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
+            glds16(ap + cl[j] * 16, ringA_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
         if (HAS_TABLE) {
             const unsigned char *sp = reinterpret_cast<const unsigned char *>(a.table + r * d);
 #pragma unroll
             for (int j = 0; j < J; ++j)
-                glds16(sp + ((int64_t)j * CHAIN_NT + tid) * 16, ringT_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
+                glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
         }
     };
 
@@ -495,6 +509,10 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
         for (int j = 0; j < J; ++j) {
             x.ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
             if (HAS_TABLE) x.sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
+            if (MASKED && !ok[j]) {
+                x.ar[j] = V(T(0));
+                if (HAS_TABLE) x.sr[j] = V(T(0));
+            }
         }
         x.row = s_row[DEPTH + s];
         x.row_n = s_row[DEPTH + s + DEPTH];
@@ -579,7 +597,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                     // very thread stored these bytes, so program order makes them visible)
                     const V *sp = reinterpret_cast<const V *>(a.table + row * d);
 #pragma unroll
-                    for (int j = 0; j < J; ++j) x.sr[j] = sp[tid + j * CHAIN_NT];
+                    for (int j = 0; j < J; ++j) x.sr[j] = ok[j] ? sp[cl[j]] : V(T(0));
                     drain_vmcnt_visible();   // retire it HERE, or hipcc puts a draining vmcnt(0) on the common path
                 }
 
@@ -652,7 +670,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                                 p[j][v] = HB ? prox_bf(wv, gl, plo[j][v], phi[j][v]) : prox_l1(wv, gl);
                                 gnv[v] = gn;
                             }
-                            sp[tid + j * CHAIN_NT] = gnv;
+                            if (ok[j]) sp[cl[j]] = gnv;
                         }
                     } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
                         const T gi = x.gi;
@@ -667,7 +685,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                                 tv[v] = fmad(ncc, x.ar[j][v], p[j][v]);
                                 av[j][v] = fmad(tv[v] - x.sr[j][v], rr, av[j][v]);
                             }
-                            sp[tid + j * CHAIN_NT] = tv;
+                            if (ok[j]) sp[cl[j]] = tv;
                         }
                         if (inb + 1 == a.batch || (base + s + 1) == a.nsteps) {
                             const T gl = a.hat_gamma * plam;
@@ -704,7 +722,8 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
 
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const int64_t c = tid + (int64_t)j * CHAIN_NT;
+        if (!ok[j]) continue;
+        const int64_t c = cl[j];
         if (SVRG_ANY) {
             reinterpret_cast<V *>(a.w)[c] = p[j];
             reinterpret_cast<V *>(a.z)[c] = zs[j];

@@ -43,6 +43,7 @@ struct ciao_ctx {
     int64_t svrg_cache_rowdots = 1; // reuse a_i'z_full from the full pass inside the SVRG inner cycle (ciao_svrg_iterate)
     int64_t chain_no_dma = 0;       // testing: route chains through the register-ring kernel instead of the LDS-DMA one
     int chain_last_dma = 0;
+    bool chain_last_masked = false;
     int64_t force_generic = 0;      // testing: route every rows launch through the generic kernel
 
     std::string last_kernel;

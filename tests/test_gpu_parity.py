@@ -302,6 +302,38 @@ def test_svrg_epochs(ctx, ciao, chain_variant, dtype, loss, shape):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d,expect", [(1024, "chain_dma_kernel<{t},J{j},alg0>"), (1000, "chain_dma_kernel<{t},J{j},alg0,masked>"),
+                                      (1500, "chain_dma_kernel<{t},J{jj},alg0,masked>"), (7, "chain_kernel<")])
+def test_chain_path_selection(ctx, ciao, dtype, d, expect):
+    """Which kernel runs the SVRG inner cycle: the LDS-DMA ring for every row of whole 16-byte chunks up to 32 KiB (dead
+    chunks masked when the row is not J*4096 bytes), the register ring otherwise -- and each against the oracle with
+    per-coordinate box bounds, which the dead chunks must not read."""
+    import torch
+    from oracle import oracle as O
+    N = 40
+    A, b, x0 = P.synthetic("ls", N, d, dtype, seed=d)
+    op, dp = make("ls", A, b, float(N), dtype)
+    og, dg = make_g("boxvec", dtype, d)
+    tdt = dev(x0).dtype
+    av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+    ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+    rav, rz, rzf, rw = O.svrg_init(op, x0)
+    idx = ciao.IndexStream(3).rand_indices(N, 3000)   # three chunks of the staged index stream
+    gamma = 0.02
+    ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
+    es = np.dtype(dtype).itemsize
+    j = 1
+    while j * 4096 < d * es:
+        j *= 2
+    name = expect.format(t="f64" if es == 8 else "f32", j=j, jj=j)
+    assert name in ctx.last_kernel(), ctx.last_kernel()
+    O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
+    close(w, rw, dtype, scale=500, what=f"svrg_inner w ({ctx.last_kernel()})")
+    close(z, rz, dtype, scale=500 * 30, what="svrg_inner z (sum of 3000 iterates)")
+    ctx.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_svrg_plus_and_inner_only(ctx, ciao, dtype):
     import torch
     from oracle import oracle as O

@@ -13,7 +13,7 @@ torch.cuda.set_device(0)
 ctx = Context(0)
 out = []
 for dt in (torch.float64, torch.float32):
-    N, d, m = 200_000, 1024, 100_000
+    N, d, m = 200_000, int(os.environ.get("CIAO_D", "1024")), 100_000
     A = torch.empty((N, d), dtype=dt, device="cuda"); b = torch.empty((N,), dtype=dt, device="cuda")
     ctx.synth_normal(A, 0, 1, 1 / np.sqrt(d))
     F = PackedF(L.LOSS_LS, A, b, float(N))
