@@ -112,7 +112,8 @@ CIAO_API int32_t ciao_ctx_set_allreduce(ciao_ctx *ctx, ciao_allreduce_fn fn, voi
  *   "sweep_blocks_per_cu", "sweep_grid", "sweep_prefetch", "sweep_multi", "force_generic"   grid / variant of the rows kernels
  *   "chain_max_batch"      Finito / LFinito batches up to this size run as one sequential chain (-1 = measured crossover)
  *   "split_max_rows"       batches up to this size run one workgroup per row instead of one wave per row (-1 = 16384)
- *   "split_blocks_per_cu"  grid cap of that kernel (0 = one block per CU)
+ *   "split_blocks_per_cu"  grid cap of that kernel (0 = automatic)
+ *   "split_all"            experiment: that kernel for every mode and size (tools/tune_split.py)
  *   "chain_no_dma", "svrg_cache_rowdots"                                                    chain kernel variants */
 CIAO_API int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value);
 /* Kernel timing for bench.py's roofline line: when enabled, every launch of the dominant streaming kernel of an entry
