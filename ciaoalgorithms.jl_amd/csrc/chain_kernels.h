@@ -999,14 +999,14 @@ constexpr size_t afinito_dma_lds_bytes()
            AF_CHUNK * sizeof(T) + AF_CHUNK * sizeof(int) + 16 + 2 * CHAIN_NW * 2 * sizeof(T);
 }
 
-template <typename T, int J, int LOSS>
+template <typename T, int J, int LOSS, bool MASKED>
 __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
 {
     using V = typename VecOfC<T>::type;
     constexpr int VEC = 16 / sizeof(T);
     constexpr int DEPTH = DmaDepth<J>::value;
     constexpr int CH = AF_CHUNK;
-    constexpr int OPS_PER_STEP = 3 * J + 1;
+    constexpr int OPS_PER_STEP = (MASKED ? 2 * J : 3 * J) + 1;   // MASKED: predicated table stores are not counted (chain_dma_kernel)
     constexpr bool PIPE = DEPTH >= 4;
     constexpr int WAIT_N = (PIPE ? DEPTH - 2 : DEPTH - 1) * OPS_PER_STEP;
     constexpr int ROW_BYTES = J * CHAIN_NT * 16;
@@ -1037,19 +1037,29 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
     const uint32_t ringT_off = (uint32_t)(uintptr_t)ringT;
     const uint32_t ringM_off = (uint32_t)(uintptr_t)ringM;
 
+    // chunk ownership and dead chunks exactly as in chain_dma_kernel
+    const int64_t nchunks = d / VEC;
+    bool ok[J];
+    int64_t cl[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int64_t c = tid + (int64_t)j * CHAIN_NT;
+        ok[j] = !MASKED || c < nchunks;
+        cl[j] = ok[j] ? c : 0;
+    }
     V av[J], p[J], plo[J], phi[J];
     const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
     const bool hasbox = (a.g.kind == CIAO_PROX_BOX);
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const int64_t c = tid + (int64_t)j * CHAIN_NT;
-        av[j] = reinterpret_cast<const V *>(a.av)[c];
-        p[j] = reinterpret_cast<const V *>(a.z)[c];
+        const int64_t c = cl[j];
+        av[j] = ok[j] ? reinterpret_cast<const V *>(a.av)[c] : V(T(0));
+        p[j] = ok[j] ? reinterpret_cast<const V *>(a.z)[c] : V(T(0));
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             plo[j][v] = -INFINITY;
             phi[j][v] = INFINITY;
-            if (hasbox) {
+            if (hasbox && ok[j]) {
                 plo[j][v] = a.g.lo_vec ? a.g.lo_vec[c * VEC + v] : a.g.lo;
                 phi[j][v] = a.g.hi_vec ? a.g.hi_vec[c * VEC + v] : a.g.hi;
             }
@@ -1076,10 +1086,10 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
         const unsigned char *sp = reinterpret_cast<const unsigned char *>(a.table + r * d);
 #pragma unroll
         for (int j = 0; j < J; ++j)
-            glds16(ap + ((int64_t)j * CHAIN_NT + tid) * 16, ringA_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
+            glds16(ap + cl[j] * 16, ringA_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
 #pragma unroll
         for (int j = 0; j < J; ++j)
-            glds16(sp + ((int64_t)j * CHAIN_NT + tid) * 16, ringT_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
+            glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
         // this wave's copy of the scalars: lanes l and l + MDW fetch the same dword, only the first MDW LDS dwords are read back
         const unsigned char *mp = reinterpret_cast<const unsigned char *>(a.meta + (r * CHAIN_NW + wib) * 4);
         glds4(mp + (lane & (MDW - 1)) * 4, ringM_off + (uint32_t)((u * CHAIN_NW + wib) * 256));
@@ -1098,6 +1108,7 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
         for (int j = 0; j < J; ++j) {
             x.ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
             x.sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
+            if (MASKED && !ok[j]) x.ar[j] = x.sr[j] = V(T(0));
         }
         const T *mp = reinterpret_cast<const T *>(ringM + (u * CHAIN_NW + wib) * 256);
 #pragma unroll
@@ -1168,7 +1179,7 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
                 if (__builtin_amdgcn_readfirstlane(x.stale)) {
                     const V *sp = reinterpret_cast<const V *>(a.table + row * d);
 #pragma unroll
-                    for (int j = 0; j < J; ++j) x.sr[j] = sp[tid + j * CHAIN_NT];
+                    for (int j = 0; j < J; ++j) x.sr[j] = ok[j] ? sp[cl[j]] : V(T(0));
 #pragma unroll
                     for (int q = 0; q < 4; ++q) x.m[q] = a.meta[(row * CHAIN_NW + wib) * 4 + q];
                     drain_vmcnt_visible();
@@ -1242,7 +1253,7 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
                 V *sp = reinterpret_cast<V *>(a.table + row * d);
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
-                    sp[tid + j * CHAIN_NT] = p[j];                                              // :146  s_i = z
+                    if (ok[j]) sp[cl[j]] = p[j];                                                // :146  s_i = z
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         const T t = fmad(r1, res[j][v], av[j][v]);                              // :145
@@ -1266,9 +1277,9 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
 
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const int64_t c = tid + (int64_t)j * CHAIN_NT;
-        reinterpret_cast<V *>(a.av)[c] = av[j];
-        reinterpret_cast<V *>(a.z)[c] = p[j];
+        if (!ok[j]) continue;
+        reinterpret_cast<V *>(a.av)[cl[j]] = av[j];
+        reinterpret_cast<V *>(a.z)[cl[j]] = p[j];
     }
     if (tid == 0) {
         *a.hg = hg;

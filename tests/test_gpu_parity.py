@@ -606,8 +606,9 @@ def test_adaptive_finito_steps(ctx, ciao, dtype, shape):
     done, trials = ctx.afinito_steps(dp, dg, alpha, tol_b, idx, table, meta4, av, z, hg)
     rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(alpha), dtype(tol_b), idx, rt, rg, rgam, rfi, rhg, rav, rz)
     assert done == rdone == len(idx)
-    if (d * np.dtype(dtype).itemsize) % 4096 == 0 and d * np.dtype(dtype).itemsize <= 32768:
-        assert "afinito_dma_kernel" in ctx.last_kernel(), "whole-4-KiB rows take the LDS-DMA path"
+    if (d * np.dtype(dtype).itemsize) % 16 == 0 and d * np.dtype(dtype).itemsize <= 32768:
+        assert "afinito_dma_kernel" in ctx.last_kernel(), "rows of whole 16-byte chunks take the LDS-DMA path"
+        assert ("masked" in ctx.last_kernel()) == ((d * np.dtype(dtype).itemsize) % 4096 != 0)
     if dtype == np.float64:
         assert trials == rtrials, "same backtracking decisions in fp64"
     S = 2000 if dtype == np.float64 else 200
