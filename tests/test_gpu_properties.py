@@ -170,3 +170,57 @@ def test_finito_invariant_after_batches(ctx, ciao):
     ctx.synchronize()
     inv = hg * (table / gam[:, None]).sum(dim=0)
     assert float(torch.max(torch.abs(av - inv))) <= 1e-9 * float(torch.max(torch.abs(inv)))
+
+
+@pytest.mark.parametrize("tdt,d", [("float64", 1000), ("float64", 3000), ("float32", 1500), ("float64", 4096)])
+def test_odd_row_lengths_at_scale(ctx, ciao, tdt, d):
+    """Rows that are not 64*VEC*{1,2,4,8,16} elements run the masked workgroup-per-row kernel and the masked LDS-DMA chain:
+    the sweep against a dense fp64 matrix product, then the SAGA and Finito aggregate invariants after chains and batches."""
+    import torch
+    import ciaoalgorithms_jl_amd._lib as L
+    from ciaoalgorithms_jl_amd.device import PackedF, ProxG
+    dt = getattr(torch, tdt)
+    n = 200_000
+    dev = torch.device("cuda", 0)
+    A = torch.empty((n, d), dtype=dt, device=dev)
+    b = torch.empty((n,), dtype=dt, device=dev)
+    ctx.synth_normal(A, 0, seed=9, scale=1.0 / np.sqrt(d))
+    F = PackedF(L.LOSS_LS, A, b, float(n))
+    xt = torch.from_numpy(np.random.default_rng(9).standard_normal(d) * 0.1).to(dev, dt)
+    ctx.synth_targets(F, xt, 0.01, False, 9, b)
+    x = torch.from_numpy(np.random.default_rng(10).standard_normal(d) * 0.05).to(dev, dt)
+    av = torch.empty(d, dtype=dt, device=dev)
+    ctx.full_gradient(F, x, av)
+    assert "rows_split_kernel" in ctx.last_kernel() and "masked" in ctx.last_kernel(), ctx.last_kernel()
+    ref = torch.zeros(d, dtype=torch.float64, device=dev)
+    for lo in range(0, n, 50_000):   # dense reference in fp64, in slabs
+        Ad = A[lo:lo + 50_000].double()
+        ref += Ad.T @ (Ad @ x.double() - b[lo:lo + 50_000].double())
+    tol = 1e-11 if dt == torch.float64 else 2e-4
+    assert float(torch.max(torch.abs(av.double() - ref))) <= tol * float(torch.max(torch.abs(ref)))
+
+    g = ProxG(L.PROX_L1, lam=1e-3)
+    table = torch.empty((n, d), dtype=dt, device=dev)
+    z = torch.empty(d, dtype=dt, device=dev)
+    st = ciao.IndexStream(12)
+    # SAGA: av == mean of the table after 20 000 dependent steps
+    gamma = 1.0 / (3.0 * 1.5 * n)
+    ctx.saga_init(F, g, gamma, x, table, av, z)
+    ctx.saga_steps(F, g, gamma, False, st.rand_indices(n, 20_000), table, av, z)
+    assert "chain_dma_kernel" in ctx.last_kernel() and ("masked" in ctx.last_kernel()) == ((d * A.element_size()) % 4096 != 0)
+    mean = table.double().mean(dim=0)
+    rtol = 1e-9 if dt == torch.float64 else 5e-3
+    assert float(torch.max(torch.abs(av.double() - mean))) <= rtol * float(torch.max(torch.abs(mean)))
+    # Finito: av == hat_gamma * sum_i s_i / gamma_i after chains and batch-parallel steps
+    gam = (0.999 * n / (float(n) * (A.double() ** 2).sum(1))).to(dt).contiguous()
+    hg = ctx.hat_gamma(gam)
+    ctx.finito_init(F, g, gam, hg, x, table, av, z)
+    for r, nit in ((1, 3000), (300, 20), (5000, 4)):
+        batches = [st.sample_without_replacement(n, r) for _ in range(nit)]
+        ctx.finito_steps(F, g, gam, hg, np.arange(nit + 1, dtype=np.int64) * r, np.concatenate(batches), table, av, z)
+    ctx.synchronize()
+    inv = hg * (table.double() / gam.double()[:, None]).sum(dim=0)
+    assert float(torch.max(torch.abs(av.double() - inv))) <= rtol * float(torch.max(torch.abs(inv)))
+    assert bool(torch.isfinite(z).all())
+    del A, table
+    torch.cuda.empty_cache()
