@@ -83,6 +83,7 @@ SIGNATURES = {
     "ciao_proshi_solution": (_i32, [_vp, _SP, _vp, _vp, _vp]),
     "ciao_synth_normal": (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _i64, C.c_uint64, _f64]),
     "ciao_synth_targets": (_i32, [_vp, _PP, _vp, _f64, _i32, _i64, C.c_uint64, _vp]),
+    "ciao_sample_batches": (_i32, [C.c_uint64, C.c_uint64, _i64, _i64, _i64, _vp, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "ciao_ctx.h"
@@ -1048,6 +1049,61 @@ int32_t ciao_synth_targets(ciao_ctx *ctx, const ciao_problem *p, const void *x_t
         hipLaunchKernelGGL((synth_targets_kernel<float>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const float *)p->A,
                            p->N, p->d, p->ld, (const float *)x_true, (float)noise, (int)labels, row0, seed, (float *)b_out);
     CIAO_HIP(hipGetLastError());
+    return CIAO_OK;
+}
+
+// ---- host helper: n x sample(1:N, r, replace=false) from the splitmix64 index stream (sampling.py is its reference) ----
+namespace {
+inline uint64_t splitmix_at(uint64_t seed, uint64_t k)   // output number k (0-based) of the stream: counter-based
+{
+    uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+}  // namespace
+
+int32_t ciao_sample_batches(uint64_t seed, uint64_t pos, int64_t N, int64_t r, int64_t n, int64_t *out_host,
+                            uint64_t *pos_out_host)
+{
+    CIAO_REQUIRE(N > 0 && N < (1ll << 32) && r >= 1 && 2 * r <= N && n >= 0, "need 0 < N < 2^32, r >= 1, 2r <= N, n >= 0");
+    CIAO_REQUIRE((out_host || n == 0) && pos_out_host, "NULL output");
+    // open-addressing set of the indices held by the current batch: one 8-byte word per slot = (batch tag << 32) | index, so
+    // a probe touches one cache line and nothing is cleared between batches (a stale tag reads as an empty slot)
+    uint64_t cap = 16;
+    while (cap < (uint64_t)(2 * r)) cap <<= 1;
+    std::vector<uint64_t> slots(cap, 0);
+    uint32_t tag = 0;
+    for (int64_t t = 0; t < n; ++t) {
+        if (++tag == 0) {   // 2^32 batches later the tags would repeat: start over with clean slots
+            std::fill(slots.begin(), slots.end(), 0);
+            tag = 1;
+        }
+        int64_t *out = out_host + t * r;
+        int64_t have = 0;
+        while (have < r) {
+            const int64_t need = r - have;   // one round: as many candidates as are still missing (>= 1)
+            for (int64_t c = 0; c < need; ++c) {
+                const uint64_t u = splitmix_at(seed, pos++) >> 32;
+                const uint64_t v = (u * (uint64_t)N) >> 32;   // uniform in 0..N-1, the rule of IndexStream.rand_indices
+                const uint64_t word = ((uint64_t)tag << 32) | v;
+                uint64_t h = ((v * 0x9E3779B97F4A7C15ull) >> 24) & (cap - 1);
+                bool seen = false;
+                while ((slots[h] >> 32) == tag) {
+                    if (slots[h] == word) {
+                        seen = true;
+                        break;
+                    }
+                    h = (h + 1) & (cap - 1);
+                }
+                if (!seen) {
+                    slots[h] = word;
+                    out[have++] = (int64_t)v;
+                }
+            }
+        }
+    }
+    *pos_out_host = pos;
     return CIAO_OK;
 }
 

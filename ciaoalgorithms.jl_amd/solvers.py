@@ -219,6 +219,62 @@ def _localise(it, batch):
     return it.F.localise(batch)
 
 
+def _pack_batches(batches):
+    bptr = np.zeros(len(batches) + 1, np.int64)
+    np.cumsum([len(b) for b in batches], out=bptr[1:])
+    bidx = np.concatenate(batches) if batches else np.zeros(0, np.int64)
+    return bptr, bidx
+
+
+def _static_batches_packed(N, r, js):
+    """(bptr, bidx) of the static batches number js[0], js[1], ... (Finito_basic.jl:52-58), without a Python loop."""
+    js = np.asarray(js, dtype=np.int64)
+    starts = r * js
+    lens = np.minimum(r, N - starts)
+    bptr = np.zeros(js.size + 1, np.int64)
+    np.cumsum(lens, out=bptr[1:])
+    bidx = np.arange(bptr[-1], dtype=np.int64) + np.repeat(starts - bptr[:-1], lens)
+    return bptr, bidx
+
+
+def _next_static_numbers(it, st, n):
+    """The 0-based static batch numbers of the next n iterations for sweeping 2 (cyclic, Finito_basic.jl:99: the first
+    step uses batch 2) and 3 (a fresh randperm(d) whenever a pass is complete, :100-108; the first pass is the identity
+    order); advances st.idxr / st.idx / st.inds exactly as n single steps would."""
+    d = st.d
+    if it.sweeping == 2:
+        js = (st.idxr + np.arange(n, dtype=np.int64)) % d              # idxr is 1-based: next 0-based number = idxr % d
+        st.idxr = int(js[-1]) + 1
+        return js
+    out, left = [], n
+    while left > 0:
+        if st.idx == d:
+            st.inds = it.stream.randperm(d)
+            st.idx = 0
+        take = min(left, d - st.idx)
+        out.append(np.asarray(st.inds[st.idx:st.idx + take], dtype=np.int64))
+        st.idx += take
+        left -= take
+    js = np.concatenate(out)
+    st.idxr = int(js[-1]) + 1
+    return js
+
+
+def _next_batches_packed(it, st, n):
+    """(bptr, bidx) of the next n iterations' batches (Finito_basic.jl:95-108 / ProShI_basic.jl:95-107 applied n times).
+    On one device nothing here loops in Python per iteration: a device batch takes 0.5-50 us."""
+    N, r = it.N, it.batch
+    whole = it.F.N == it.F.N_total and getattr(it.F, "cyclic", None) is None
+    if it.sweeping == 1:
+        if whole and hasattr(it.stream, "sample_batches"):
+            return np.arange(n + 1, dtype=np.int64) * r, it.stream.sample_batches(N, r, n).reshape(-1)   # :97
+        return _pack_batches([_localise(it, it.stream.sample_without_replacement(N, r)) for _ in range(n)])
+    js = _next_static_numbers(it, st, n)
+    if whole:
+        return _static_batches_packed(N, r, js)
+    return _pack_batches([_localise(it, _static_batch(N, r, int(j))) for j in js])
+
+
 class FINITO_basic_state:
     def __init__(self, s, γ, hat_γ, av, z, d):
         self.s, self.γ, self.hat_γ, self.av, self.z, self.d = s, γ, hat_γ, av, z, d
@@ -247,26 +303,8 @@ class FINITO_basic_iterable(_Iterable):
         self.ctx.finito_init(self.F, self.g, gam, hat_γ, self._x0_dev, s, av, z)   # :76-84
         return FINITO_basic_state(s, gam, hat_γ, av, z, d_b)
 
-    def _next_batch(self, st):                                             # Finito_basic.jl:95-108
-        N, r = self.N, self.batch
-        if self.sweeping == 1:
-            return self.stream.sample_without_replacement(N, r)           # :97
-        if self.sweeping == 2:
-            st.idxr = st.idxr % st.d + 1                                   # :99  (first step uses batch 2)
-        elif self.sweeping == 3:
-            if st.idx == st.d:                                             # :101-106
-                st.inds = self.stream.randperm(st.d)
-                st.idx = 1
-            else:
-                st.idx += 1
-            st.idxr = int(st.inds[st.idx - 1]) + 1
-        return _static_batch(N, r, st.idxr - 1)
-
     def _step(self, st, n):                                                # Finito_basic.jl:109-118, n iterations
-        batches = [_localise(self, self._next_batch(st)) for _ in range(n)]
-        bptr = np.zeros(n + 1, np.int64)
-        np.cumsum([len(b) for b in batches], out=bptr[1:])
-        bidx = np.concatenate(batches) if batches else np.zeros(0, np.int64)
+        bptr, bidx = _next_batches_packed(self, st, n)
         self.ctx.finito_steps(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.s, st.av, st.z)
 
 
@@ -346,23 +384,28 @@ class FINITO_adaptive_iterable(_Iterable):
         self.ctx.synchronize()   # surfaces the degenerate-probe case (reference :78-85) as an error
         return FINITO_adaptive_state(s, meta, hg, av, z, self.N)
 
-    def _next_index(self, st):                                             # :104-116 (1-based idxr like the reference)
+    def _next_indices(self, st, n):                                        # :104-116 applied n times (0-based result)
         N = self.N
         if self.sweeping == 1:
-            st.idxr = int(self.stream.rand_indices(N, 1)[0]) + 1
+            idx = self.stream.rand_indices(N, n)
         elif self.sweeping == 2:
-            st.idxr = st.idxr % N + 1
-        elif self.sweeping == 3:
-            if st.idx == N:
-                st.ind = self.stream.randperm(N)
-                st.idx = 1
-            else:
-                st.idx += 1
-            st.idxr = int(st.ind[st.idx - 1]) + 1
-        return st.idxr - 1
+            idx = (st.idxr + np.arange(n, dtype=np.int64)) % N             # idxr is 1-based: the next 0-based index is idxr % N
+        else:
+            out, left = [], n
+            while left > 0:
+                if st.idx == N:                                            # a pass is complete: fresh randperm (:109-112)
+                    st.ind = self.stream.randperm(N)
+                    st.idx = 0
+                take = min(left, N - st.idx)
+                out.append(np.asarray(st.ind[st.idx:st.idx + take], dtype=np.int64))
+                st.idx += take
+                left -= take
+            idx = np.concatenate(out)
+        st.idxr = int(idx[-1]) + 1
+        return idx
 
     def _step(self, st, n):                                                # :118-150, n iterations in one launch
-        idx = np.fromiter((self._next_index(st) for _ in range(n)), dtype=np.int64, count=n)
+        idx = self._next_indices(st, n)
         done, trials = self.ctx.afinito_steps(self.F, self.g, self.α, self.tol_b, idx, st.s, st.meta, st.av, st.z, st.hat_γ_dev)
         st.trials += trials
         if done < n:                                                       # :121-124  @warn + return nothing
@@ -408,13 +451,8 @@ class Proshi_basic_iterable(_Iterable):
         self.ctx.proshi_init(self.F, self.g, gam, self._x0_dev, s, av, z, hg)   # :76-87
         return Proshi_basic_state(self, s, gam, float(hg.item()), av, z, -(-N // r) if N > 0 else 0)
 
-    _next_batch = FINITO_basic_iterable._next_batch                        # :95-107 is Finito's batch logic verbatim
-
     def _step(self, st, n):                                                # :109-121
-        batches = [self.F.localise(self._next_batch(st)) for _ in range(n)]
-        bptr = np.zeros(n + 1, np.int64)
-        np.cumsum([len(b) for b in batches], out=bptr[1:])
-        bidx = np.concatenate(batches) if batches else np.zeros(0, np.int64)
+        bptr, bidx = _next_batches_packed(self, st, n)
         self.ctx.proshi_steps(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.s, st.av, st.z)
 
 

@@ -254,6 +254,17 @@ CIAO_API int32_t ciao_synth_normal(ciao_ctx *ctx, int32_t dtype, void *out, int6
 CIAO_API int32_t ciao_synth_targets(ciao_ctx *ctx, const ciao_problem *p, const void *x_true, double noise, int32_t labels,
                            int64_t row0, uint64_t seed, void *b_out);
 
+/* ---- host-side helper: the batch draws of Finito / ProShI with sweeping = 1 ------------------------------------ */
+/* n consecutive `sample(1:N, r, replace=false)` (Finito_basic.jl:97, ProShI_basic.jl:97) from the injected
+ * counter-based index stream (splitmix64(seed), outputs pos, pos+1, ...: DESIGN.md "index streams"; Julia's own RNG is
+ * not reproducible outside Julia), written 0-based to the HOST array out_host[n*r]; *pos_out_host = the stream
+ * position after the draws.  Rule per batch: draw as many uniform candidates as are still missing, append, drop
+ * repeats keeping first occurrences, until r distinct indices are held.  Needs 2r <= N (the wrapper shuffles
+ * otherwise).  Pure host code, no ctx: it exists because a device batch takes 10-50 us and an interpreted host cannot
+ * draw batches at that rate. */
+CIAO_API int32_t ciao_sample_batches(uint64_t seed, uint64_t pos, int64_t N, int64_t r, int64_t n, int64_t *out_host,
+                            uint64_t *pos_out_host);
+
 #ifdef __cplusplus
 }
 #endif

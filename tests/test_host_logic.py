@@ -107,3 +107,65 @@ def test_operator_descriptions_validate():
         ops.LeastSquares(np.zeros((2, 3)), np.zeros(3))
     f = ops.LeastSquares(np.ones((1, 3)), [2.0], 6.0)
     assert f.A.shape == (1, 3) and f.b.shape == (1,) and f.lam == 6.0
+
+
+# ---- batch selection for n iterations at a time (solvers._next_batches_packed, sampling.sample_batches) -----------------
+@pytest.mark.parametrize("N,r,n", [(50, 20, 40), (1000, 500, 6), (1000, 37, 200), (200_000, 256, 50), (10, 1, 30), (7, 5, 10),
+                                    (100, 50, 20), (4, 2, 50), (3, 3, 4)])
+def test_sample_batches_equals_separate_draws(ciao, N, r, n):
+    """n batches in one call (the library's host helper) == n calls of the interpreted rule: same indices, same stream
+    position afterwards -- with heavy collisions (2r = N), r = 1, and the shuffle branch (2r > N)."""
+    a, b = ciao.IndexStream(5), ciao.IndexStream(5)
+    a.rand_indices(N, 3), b.rand_indices(N, 3)
+    A = np.array(a.sample_batches(N, r, n))
+    B = np.stack([b.sample_without_replacement(N, r) for _ in range(n)])
+    assert np.array_equal(A, B) and a.pos == b.pos
+    assert all(len(set(row.tolist())) == r for row in A) and A.min() >= 0 and A.max() < N
+    assert np.array_equal(a.rand_indices(N, 5), b.rand_indices(N, 5))
+
+
+class _FakeF:
+    N = N_total = 23
+    cyclic = None
+
+
+class _FakeIt:
+    def __init__(self, sweeping, stream, N=23, batch=4):
+        self.sweeping, self.stream, self.N, self.batch, self.F = sweeping, stream, N, batch, _FakeF()
+
+
+class _St:
+    def __init__(self, d):
+        self.d, self.idxr, self.idx, self.inds = d, 1, 0, np.arange(d, dtype=np.int64)   # Finito_basic.jl:37-40
+
+
+def _one_step_reference(it, st):
+    """Finito_basic.jl:95-108, literally, one iteration (1-based idxr as in the reference)."""
+    if it.sweeping == 2:
+        st.idxr = st.idxr % st.d + 1
+    else:
+        if st.idx == st.d:
+            st.inds = it.stream.randperm(st.d)
+            st.idx = 1
+        else:
+            st.idx += 1
+        st.idxr = int(st.inds[st.idx - 1]) + 1
+    lo = it.batch * (st.idxr - 1)
+    return np.arange(lo, min(lo + it.batch, it.N), dtype=np.int64)
+
+
+@pytest.mark.parametrize("sweeping", [2, 3])
+@pytest.mark.parametrize("chunks", [[1] * 20, [7, 1, 13, 2], [23]])
+def test_static_batch_sequences_in_chunks(ciao, sweeping, chunks):
+    """Cyclic (first step = batch 2) and shuffled (first pass = identity order, fresh randperm per pass) batch choice:
+    n iterations at a time give the batches of n single iterations, across pass boundaries, ragged last batch included."""
+    from ciaoalgorithms_jl_amd import solvers as S
+    d = -(-23 // 4)
+    it_a, st_a = _FakeIt(sweeping, ciao.IndexStream(3)), _St(d)
+    it_b, st_b = _FakeIt(sweeping, ciao.IndexStream(3)), _St(d)
+    for n in chunks:
+        bptr, bidx = S._next_batches_packed(it_a, st_a, n)
+        ref = [_one_step_reference(it_b, st_b) for _ in range(n)]
+        assert np.array_equal(bptr, np.concatenate([[0], np.cumsum([len(x) for x in ref])]))
+        assert np.array_equal(bidx, np.concatenate(ref))
+        assert st_a.idxr == st_b.idxr
