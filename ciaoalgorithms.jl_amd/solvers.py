@@ -341,11 +341,10 @@ class FINITO_LFinito_iterable(_Iterable):
             if r == 1 and self.sweeping != 3 and self.F.N == self.N:
                 bptr = np.arange(N + 1, dtype=np.int64)                    # identity order, one sample per batch
                 bidx = np.arange(N, dtype=np.int64)
+            elif self.F.N == self.F.N_total and self.F.cyclic is None:
+                bptr, bidx = _static_batches_packed(N, r, st.inds)
             else:
-                batches = [_localise(self, _static_batch(N, r, int(j))) for j in st.inds]
-                bptr = np.zeros(len(batches) + 1, np.int64)
-                np.cumsum([len(b) for b in batches], out=bptr[1:])
-                bidx = np.concatenate(batches) if batches else np.zeros(0, np.int64)
+                bptr, bidx = _pack_batches([_localise(self, _static_batch(N, r, int(j))) for j in st.inds])
             self.ctx.lfinito_iterate(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.av, st.z, st.z_full)
 
 
