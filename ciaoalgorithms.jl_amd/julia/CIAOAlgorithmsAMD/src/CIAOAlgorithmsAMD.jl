@@ -415,15 +415,23 @@ function Base.iterate(iter::FINITO_iterable{R}, state::FINITO_state{R}) where {R
                     context().h, p, g, dptr(state.γ), Float64(state.hat_γ), length(batches), bptr, dptr(bidx),
                     dptr(state.av), dptr(state.z), dptr(state.z_full)))
     else                                                           # Finito_basic.jl:91-121
-        batch = next_batch!(iter, state)
-        bptr = Int64[0, length(batch)]
-        bidx = to_dev_idx(batch)
-        check(ccall((:ciao_finito_steps, libciao), Int32,
-                    (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-                    context().h, p, g, dptr(state.γ), Float64(state.hat_γ), 1, bptr, dptr(bidx),
-                    dptr(state.s), dptr(state.av), dptr(state.z)))
+        finito_steps!(iter, state, 1)
     end
     return state, state
+end
+
+# `n` consecutive reference iterations in ONE launch: the batch choices are made first, with the reference's own RNG calls
+# in the reference's order (next_batch! n times), then shipped together.  Base.iterate uses n = 1; the functor uses
+# large n, because one iteration is 0.5-50 us of device work and a launch per iteration would be launch-bound.
+function finito_steps!(iter::FINITO_iterable{R}, state::FINITO_state{R}, n::Int) where {R}
+    batches = [copy(next_batch!(iter, state)) for _ in 1:n]
+    bptr = Int64[0; cumsum(length.(batches))]
+    bidx = to_dev_idx(reduce(vcat, batches))
+    check(ccall((:ciao_finito_steps, libciao), Int32,
+                (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, Ref(cproblem(iter.F)), Ref(iter.g), dptr(state.γ), Float64(state.hat_γ), n, bptr, dptr(bidx),
+                dptr(state.s), dptr(state.av), dptr(state.z)))
+    return n
 end
 solution(state::FINITO_state) = state.z                            # Finito_basic.jl:123, Finito_LFinito.jl:105
 
@@ -440,17 +448,30 @@ function iterator(solver::Finito{R}, x0::AbstractArray{C}; F = nothing, g = Prox
                                          solver.minibatch[2], solver.α, solver.LFinito)
 end
 
+# n iterations of whichever Finito variant in as few launches as possible; returns how many were done
+steps!(iter::FINITO_iterable, state::FINITO_state, n::Int) =
+    iter.lfinito ? (foreach(_ -> iterate(iter, state), 1:n); n) : finito_steps!(iter, state, n)
+hatγ(state::FINITO_state) = state.hat_γ
+
 function (solver::Finito{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrComplex{R}}   # Finito.jl:66-133
-    disp(it, state) = @printf "%5d | %.3e  \n" it state.hat_γ
+    disp(it, state) = @printf "%5d | %.3e  \n" it hatγ(state)
     iter = iterator(solver, x0; kwargs...)
-    num_iters, state_final = nothing, nothing
-    for (it_, state_) in enumerate(Iterators.take(iter, solver.maxit))
-        solver.verbose && mod(it_, solver.freq) == 0 && disp(it_, state_)
-        num_iters, state_final = it_, state_
+    next = iterate(iter)
+    next === nothing && return solution(nothing), nothing      # MethodError, as in the reference (Finito.jl:132)
+    state, _ = next
+    num_iters = 1
+    solver.verbose && mod(num_iters, solver.freq) == 0 && disp(num_iters, state)
+    # nothing observes intermediate states unless verbose: issue the remaining iterations in large launches
+    while num_iters < solver.maxit
+        n = min(solver.maxit - num_iters, solver.verbose ? solver.freq - mod(num_iters, solver.freq) : 1 << 16)
+        done = steps!(iter, state, n)
+        num_iters += done
+        solver.verbose && mod(num_iters, solver.freq) == 0 && disp(num_iters, state)
+        done < n && break                                      # adaptive: the stepsize collapsed (Finito_adaptive.jl:121-124)
     end
-    solver.verbose && mod(num_iters, solver.freq) !== 0 && disp(num_iters, state_final)
+    solver.verbose && mod(num_iters, solver.freq) !== 0 && disp(num_iters, state)
     synchronize(context())
-    return reshape(Array(solution(state_final)), size(x0)), num_iters
+    return reshape(Array(solution(state)), size(x0)), num_iters
 end
 
 # ======================================================================================================================
@@ -482,9 +503,9 @@ function Base.iterate(iter::FINITO_adaptive_iterable{R}) where {R}      # Finito
     return state, state
 end
 
-function Base.iterate(iter::FINITO_adaptive_iterable{R}, state::FINITO_adaptive_state{R}) where {R}
+function next_index!(iter::FINITO_adaptive_iterable, state::FINITO_adaptive_state)   # Finito_adaptive.jl:104-116
     N = iter.N
-    if iter.sweeping == 1                                               # :104-116
+    if iter.sweeping == 1
         state.idxr = rand(1:N)
     elseif iter.sweeping == 2
         state.idxr = mod(state.idxr, N) + 1
@@ -496,18 +517,27 @@ function Base.iterate(iter::FINITO_adaptive_iterable{R}, state::FINITO_adaptive_
         end
         state.idxr = state.ind[state.idx]
     end
+    return state.idxr
+end
+
+# n iterations in one launch (index choices first, in the reference's order); returns how many completed
+function afinito_steps!(iter::FINITO_adaptive_iterable{R}, state::FINITO_adaptive_state{R}, n::Int) where {R}
+    idx = to_dev_idx([next_index!(iter, state) for _ in 1:n])
     done, trials = Ref{Int64}(0), Ref{Int64}(0)
-    idx = to_dev_idx([state.idxr])
     check(ccall((:ciao_afinito_steps, libciao), Int32,
                 (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Float64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int64}, Ref{Int64}),
-                context().h, Ref(cproblem(iter.F)), Ref(iter.g), Float64(iter.α), Float64(iter.tol_b), 1, dptr(idx),
+                context().h, Ref(cproblem(iter.F)), Ref(iter.g), Float64(iter.α), Float64(iter.tol_b), n, dptr(idx),
                 dptr(state.s), dptr(state.meta), dptr(state.av), dptr(state.z), dptr(state.hat_γ), done, trials))
-    if done[] < 1                                                       # :121-124
-        @warn "parameter `γ` became too small"
-        return nothing
-    end
+    done[] < n && @warn "parameter `γ` became too small"            # :121-124
+    return Int(done[])
+end
+
+function Base.iterate(iter::FINITO_adaptive_iterable{R}, state::FINITO_adaptive_state{R}) where {R}
+    afinito_steps!(iter, state, 1) < 1 && return nothing
     return state, state
 end
+steps!(iter::FINITO_adaptive_iterable, state::FINITO_adaptive_state, n::Int) = afinito_steps!(iter, state, n)
+hatγ(state::FINITO_adaptive_state) = Array(state.hat_γ)[1]
 solution(state::FINITO_adaptive_state) = state.z                        # Finito_adaptive.jl:155
 
 # ======================================================================================================================
@@ -592,14 +622,18 @@ function Base.iterate(iter::Proshi_basic_iterable{R}) where {R}          # ProSh
     return state, state
 end
 
-function Base.iterate(iter::Proshi_basic_iterable{R}, state::Proshi_basic_state{R}) where {R}   # :91-124
-    batch = next_batch!(iter, state)                                     # :95-107 is Finito's batch logic verbatim
-    bptr = Int64[0, length(batch)]
-    bidx = to_dev_idx(batch)
+function proshi_steps!(iter::Proshi_basic_iterable{R}, state::Proshi_basic_state{R}, n::Int) where {R}   # :91-124, n times
+    batches = [copy(next_batch!(iter, state)) for _ in 1:n]             # :95-107 is Finito's batch logic verbatim
+    bptr = Int64[0; cumsum(length.(batches))]
+    bidx = to_dev_idx(reduce(vcat, batches))
     check(ccall((:ciao_proshi_steps, libciao), Int32,
                 (Ptr{Cvoid}, Ref{CiaoSepQuad}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-                context().h, Ref(csepquad(iter.F)), Ref(iter.g), dptr(state.γ), Float64(state.hat_γ), 1, bptr, dptr(bidx),
+                context().h, Ref(csepquad(iter.F)), Ref(iter.g), dptr(state.γ), Float64(state.hat_γ), n, bptr, dptr(bidx),
                 dptr(state.s), dptr(state.av), dptr(state.z)))
+    return n
+end
+function Base.iterate(iter::Proshi_basic_iterable{R}, state::Proshi_basic_state{R}) where {R}
+    proshi_steps!(iter, state, 1)
     return state, state
 end
 
@@ -620,10 +654,14 @@ end
 function (solver::Proshi{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrComplex{R}}   # ProShI.jl:42-83
     disp(it, state) = @printf "%5d | %.3e  \n" it state.hat_γ
     iter = iterator(solver, x0; kwargs...)
-    num_iters, state_final = nothing, nothing
-    for (it_, state_) in enumerate(Iterators.take(iter, solver.maxit))
-        solver.verbose && mod(it_, solver.freq) == 0 && disp(it_, state_)
-        num_iters, state_final = it_, state_
+    next = iterate(iter)
+    next === nothing && return solution(nothing), nothing
+    state_final, _ = next
+    num_iters = 1
+    while num_iters < solver.maxit                                        # chunked exactly as the Finito functor above
+        n = min(solver.maxit - num_iters, solver.verbose ? solver.freq - mod(num_iters, solver.freq) : 1 << 16)
+        num_iters += proshi_steps!(iter, state_final, n)
+        solver.verbose && mod(num_iters, solver.freq) == 0 && disp(num_iters, state_final)
     end
     solver.verbose && mod(num_iters, solver.freq) !== 0 && disp(num_iters, state_final)
     sol = Array(solution(state_final))                                    # d x N (column i = agent i), as the reference's vector of x_i
