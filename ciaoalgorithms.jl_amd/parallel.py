@@ -69,11 +69,20 @@ class AllReduceHook:
         self.group = group
         self.calls = 0
         self.bytes = 0
+        self._views = {}      # (ptr, count, dtype) -> tensor view of the library's buffer (it is reused call after call)
+        self._backend = None
 
     def __call__(self, buf: int, count: int, dtype: int, stream: int) -> int:
         dist = self.dist
-        t = _wrap(buf, count, dtype, self.device)
-        backend = dist.get_backend(self.group)
+        key = (buf, count, dtype)
+        t = self._views.get(key)
+        if t is None:
+            if len(self._views) > 64:
+                self._views.clear()
+            t = self._views[key] = _wrap(buf, count, dtype, self.device)
+        if self._backend is None:
+            self._backend = dist.get_backend(self.group)
+        backend = self._backend
         if self.device.type == "cuda" and backend != "nccl":
             if stream:
                 torch.cuda.ExternalStream(stream, device=self.device).synchronize()
