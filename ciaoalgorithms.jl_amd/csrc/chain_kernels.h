@@ -46,6 +46,7 @@ struct ChainArgs {
     T *av, *z, *zf, *w;
     int64_t N;             // local rows (index validation)
     int *errflag;          // device word set to 1 on an out-of-range index
+    long long *dbg;        // CIAO_CHAIN_DBG & 8 builds only: [wave][6] cycle sums (option "chain_dbg_ptr")
 };
 
 template <typename T>
@@ -60,7 +61,8 @@ struct VecOfC<double> {
 };
 
 #ifndef CIAO_CHAIN_DBG
-#define CIAO_CHAIN_DBG 0   // timing experiments only (tools/chain_probe.sh): 1 = no ring refill, 2 = no cross-wave exchange, 4 = no element-wise update
+#define CIAO_CHAIN_DBG 0   // timing experiments only (tools/chain_probe.sh): 1 = no ring refill, 2 = no cross-wave exchange, 4 = no element-wise update,
+                           // 8 = s_memtime stamps at five points of every step, summed per wave into ChainArgs::dbg (tools/chain_stamps.py)
 #endif
 
 constexpr int CHAIN_NT = 256;
@@ -523,6 +525,19 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
 
     int par = 0;
     int64_t inb = 0;
+#if (CIAO_CHAIN_DBG & 8)
+    // cycle stamps: T0 after the barrier, T1 dot product known, T2 update + refill issued, T3 next dot reduced in-wave,
+    // T4 partial written and LDS idle (about to enter the barrier).  sums[k] += T(k+1) - T(k), sums[4] += T0' - T4.
+    unsigned long long stamp_sum[5] = {0, 0, 0, 0, 0}, stamp_prev = 0, stamp_steps = 0;
+#define CIAO_STAMP(k)                                                     \
+    do {                                                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        if (stamp_prev) stamp_sum[k] += now_ - stamp_prev;                \
+        stamp_prev = now_;                                                \
+    } while (0)
+#else
+#define CIAO_STAMP(k) do { } while (0)
+#endif
     for (int64_t base = 0; base < a.nsteps; base += CH) {
         const int nch = (int)((a.nsteps - base) < CH ? (a.nsteps - base) : CH);
 
@@ -611,6 +626,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                     }
                 d1 = wave_allsum(d1);
                 if (TWO) d2 = wave_allsum(d2);
+                CIAO_STAMP(2);   // T3: closes [T2, T3] = prefetch of the next step's inputs + dot + in-wave reduction
                 if (lane == 0) {
                     red[par][wib][0] = d1;
                     if (TWO) red[par][wib][1] = d2;
@@ -627,9 +643,16 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                 }
                 if (!(CIAO_CHAIN_DBG & 2)) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                CIAO_STAMP(3);   // T4: closes [T3, T4] = partial written, LDS idle
                 __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue
+                CIAO_STAMP(4);   // T0: closes [T4, T0] = waiting for the other waves
                 d1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
                 if (TWO) d2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+#if (CIAO_CHAIN_DBG & 8)
+                asm volatile("" : "+v"(d1));   // the sum is formed HERE, before the stamp
+                ++stamp_steps;
+#endif
+                CIAO_STAMP(0);   // T1: closes [T0, T1] = read the four partials and add them
                 }
                 par ^= 1;
 
@@ -715,10 +738,22 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
 
                 if (++inb == a.batch) inb = 0;
                 if (!(CIAO_CHAIN_DBG & 1)) refill(u, row_n);   // after this step's table stores (program order); the look-ahead entry always exists
+#if (CIAO_CHAIN_DBG & 8)
+#pragma unroll
+                for (int j = 0; j < J; ++j) asm volatile("" : "+v"(p[j]));   // the update is done HERE
+#endif
+                CIAO_STAMP(1);   // T2: closes [T1, T2] = link function + element-wise update + prox + DMA issue
             }
         }
     }
     wait_vmcnt<0>();   // nothing may still be writing LDS when the workgroup retires
+#if (CIAO_CHAIN_DBG & 8)
+    if (a.dbg && lane == 0) {
+        for (int k = 0; k < 5; ++k) a.dbg[wib * 6 + k] = (long long)stamp_sum[k];
+        a.dbg[wib * 6 + 5] = (long long)stamp_steps;
+    }
+#endif
+#undef CIAO_STAMP
 
 #pragma unroll
     for (int j = 0; j < J; ++j) {

@@ -45,6 +45,7 @@ struct ciao_ctx {
     int64_t chain_no_dma = 0;       // testing: route chains through the register-ring kernel instead of the LDS-DMA one
     int chain_last_dma = 0;
     bool chain_last_masked = false;
+    long long *chain_dbg = nullptr;   // timing builds only (CIAO_CHAIN_DBG & 8): device buffer for cycle stamps
     int64_t force_generic = 0;      // testing: route every rows launch through the generic kernel
 
     std::string last_kernel;
