@@ -748,13 +748,16 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
 // Block = COLS columns x SLICES slices of the partial rows (512 threads); COLS*sizeof(T) = 128 B, one L2 line per
 // partial row, so the d/COLS blocks spread the (grid x d) partial matrix over many CUs.
 constexpr int FIN_THREADS = 512;
+#ifndef CIAO_FIN_BYTES
+#define CIAO_FIN_BYTES 128   // bytes of one partial row that a finalize block covers (tuning: -DCIAO_FIN_BYTES=64)
+#endif
 
 template <typename T>
 __global__ void __launch_bounds__(FIN_THREADS)
     finalize_kernel(const T *__restrict__ partial, int64_t pstride, int nparts, const T *__restrict__ pextra,
                     int64_t d, T *raw_out, Epilogue<T> ep)
 {
-    constexpr int COLS = 128 / sizeof(T);
+    constexpr int COLS = CIAO_FIN_BYTES / sizeof(T);
     constexpr int SLICES = FIN_THREADS / COLS;
     __shared__ T lds[SLICES][COLS];
     __shared__ T lds_extra;
