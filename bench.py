@@ -101,7 +101,11 @@ def main():
     L_max = (lam_f if not logistic else 0.25) * 1.3                      # ||a_i||^2 <= ~1.3 for d = 1024
     gamma = 1.0 / (7.0 * L_max) if not logistic else 1.0 / (10.0 * L_max)   # test_lasso.jl:164 / test_logistic_l1.jl:126
     if world > 1 or force_dist:
-        ctx.set_allreduce(AllReduceHook(dev))
+        if os.environ.get("CIAO_BENCH_COLLECTIVE", "torch") == "rccl":   # the library calls ncclAllReduce itself
+            from ciaoalgorithms_jl_amd.parallel import RcclComm
+            ctx.set_rccl(RcclComm(rank, world, dev.index))
+        else:                                                            # default: torch.distributed (backend nccl = RCCL)
+            ctx.set_allreduce(AllReduceHook(dev))
     xa = torch.zeros(d, dtype=tdt, device=dev)                           # x0 = 0 (test_lasso.jl:60)
     xb = torch.empty_like(xa)
     av = torch.empty_like(xa)

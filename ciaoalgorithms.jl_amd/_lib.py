@@ -57,6 +57,7 @@ SIGNATURES = {
     "ciao_ctx_set_stream": (_i32, [_vp, _vp]),
     "ciao_ctx_synchronize": (_i32, [_vp]),
     "ciao_ctx_set_allreduce": (_i32, [_vp, ALLREDUCE_FN, _vp]),
+    "ciao_ctx_set_rccl": (_i32, [_vp, _vp, C.c_char_p]),
     "ciao_ctx_set_option": (_i32, [_vp, C.c_char_p, _i64]),
     "ciao_ctx_timing_enable": (_i32, [_vp, _i32]),
     "ciao_ctx_timing_read": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i64)]),

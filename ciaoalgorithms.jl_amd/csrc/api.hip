@@ -4,6 +4,7 @@
 // BEFORE anything is launched), builds the kernel argument structs and enqueues the kernels on the ctx's stream.
 // Nothing here computes on the CPU: if the HIP runtime or the device is missing the calls fail with CIAO_ERR_HIP.
 
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -685,6 +686,52 @@ int32_t ciao_ctx_set_allreduce(ciao_ctx *ctx, ciao_allreduce_fn fn, void *user)
     CIAO_REQUIRE(ctx, "ctx is NULL");
     ctx->hook = fn;
     ctx->hook_user = user;
+    return CIAO_OK;
+}
+
+// the library's own all-reduce hook: RCCL called directly (no host-language callback per reduction)
+static int32_t rccl_hook(void *user, void *buf, int64_t count, int32_t dtype, void *stream)
+{
+    ciao_ctx *ctx = static_cast<ciao_ctx *>(user);
+    const int nccl_type = (dtype == CIAO_F64) ? 8 : 7;   // ncclFloat64 / ncclFloat32 (rccl.h)
+    const int r = ctx->rccl_allreduce(buf, buf, (size_t)count, nccl_type, /*ncclSum*/ 0, ctx->rccl_comm, (hipStream_t)stream);
+    if (r != 0) {
+        set_error("ncclAllReduce failed with %d (%s)", r, ctx->rccl_errstr ? ctx->rccl_errstr(r) : "?");
+        return r;
+    }
+    return 0;
+}
+
+int32_t ciao_ctx_set_rccl(ciao_ctx *ctx, void *comm, const char *librccl_path)
+{
+    CIAO_REQUIRE(ctx, "ctx is NULL");
+    if (!comm) {
+        if (ctx->hook == rccl_hook) {
+            ctx->hook = nullptr;
+            ctx->hook_user = nullptr;
+        }
+        ctx->rccl_comm = nullptr;
+        return CIAO_OK;
+    }
+    const char *path = librccl_path ? librccl_path : "librccl.so";
+    void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);   // the same handle again if the host has loaded it already
+    if (!h) {
+        set_error("cannot load RCCL from '%s': %s", path, dlerror());
+        return CIAO_ERR_ARG;
+    }
+    void *f = dlsym(h, "ncclAllReduce");
+    if (!f) {
+        set_error("'%s' has no ncclAllReduce", path);
+        dlclose(h);
+        return CIAO_ERR_ARG;
+    }
+    if (ctx->rccl_lib && ctx->rccl_lib != h) dlclose(ctx->rccl_lib);
+    ctx->rccl_lib = h;
+    ctx->rccl_allreduce = reinterpret_cast<int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)>(f);
+    ctx->rccl_errstr = reinterpret_cast<const char *(*)(int)>(dlsym(h, "ncclGetErrorString"));
+    ctx->rccl_comm = comm;
+    ctx->hook = rccl_hook;
+    ctx->hook_user = ctx;
     return CIAO_OK;
 }
 

@@ -32,6 +32,12 @@ struct ciao_ctx {
     double *scal = nullptr;    // small device scratch for scalar reductions (4096 doubles)
     int *errflag = nullptr;    // sticky device error word (out-of-range index)
 
+    // native RCCL all-reduce (ciao_ctx_set_rccl): resolved with dlopen so that nothing links against RCCL
+    void *rccl_comm = nullptr;
+    void *rccl_lib = nullptr;
+    int (*rccl_allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*rccl_errstr)(int) = nullptr;
+
     // tuning
     int64_t sweep_blocks_per_cu = 0;   // 0 = choose from the row size (rows_launch.inc)
     int64_t sweep_multi = 1;           // short rows (<= 4 KiB): several rows per wave per iteration (rows_multi_kernel)

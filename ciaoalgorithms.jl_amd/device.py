@@ -213,6 +213,17 @@ class Context:
         self._hook_keepalive = cb
         L.check(self.lib.ciao_ctx_set_allreduce(self._h, cb, None))
 
+    def set_rccl(self, comm):
+        """Native all-reduce: `comm` is a parallel.RcclComm (or None to clear).  The library then calls ncclAllReduce itself on
+        its stream -- no Python callback per reduction (include/ciao_hip.h: ciao_ctx_set_rccl)."""
+        if comm is None:
+            self._rccl_keepalive = None
+            L.check(self.lib.ciao_ctx_set_rccl(self._h, None, None))
+            return
+        self._rccl_keepalive = comm
+        self._hook_keepalive = None
+        L.check(self.lib.ciao_ctx_set_rccl(self._h, comm.handle, comm.lib_path.encode()))
+
     # -- helpers -------------------------------------------------------------------------------------------------------
     def _vec(self, t: torch.Tensor, p: PackedF, name: str, n: int | None = None):
         n = p.d if n is None else n

@@ -101,6 +101,52 @@ class AllReduceHook:
         return 0
 
 
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]   # rccl.h: NCCL_UNIQUE_ID_BYTES
+
+
+def default_rccl_path() -> str:
+    """The RCCL this process already uses: the one bundled with torch, else the ROCm one."""
+    import os
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else "librccl.so"
+
+
+class RcclComm:
+    """An RCCL communicator of our own (one rank per process / GPU), for Context.set_rccl: the d-vector all-reduce is then
+    issued by libciao_hip.so itself on its stream.  The unique id travels through the existing torch.distributed group
+    (any backend); nothing else of torch is involved.  `handle` is the ncclComm_t."""
+
+    def __init__(self, rank: int, world: int, device: int, group=None, lib_path: str | None = None):
+        import torch.distributed as dist
+        self.lib_path = lib_path or default_rccl_path()
+        self._lib = C.CDLL(self.lib_path, mode=C.RTLD_LOCAL)
+        self._lib.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+        self._lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+        self._lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        self._lib.ncclGetErrorString.restype = C.c_char_p
+        uid = _NcclUniqueId()
+        if rank == 0:
+            self._check(self._lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        if world > 1:
+            box = [C.string_at(C.addressof(uid), 128) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            C.memmove(C.addressof(uid), box[0], 128)
+        torch.cuda.set_device(device)
+        comm = C.c_void_p()
+        self._check(self._lib.ncclCommInitRank(C.byref(comm), world, uid, rank), "ncclCommInitRank")
+        self.handle, self.rank, self.world = comm, rank, world
+
+    def _check(self, r, what):
+        if r != 0:
+            raise RuntimeError(f"{what} failed: {self._lib.ncclGetErrorString(r).decode()}")
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self._lib.ncclCommDestroy(self.handle)
+            self.handle = C.c_void_p()
+
+
 def init_process_group_from_env(backend: str | None = None):
     """torchrun-style rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK from the environment)."""
     import os

@@ -108,6 +108,11 @@ CIAO_API int32_t ciao_ctx_destroy(ciao_ctx *ctx);
 CIAO_API int32_t ciao_ctx_set_stream(ciao_ctx *ctx, void *stream);
 CIAO_API int32_t ciao_ctx_synchronize(ciao_ctx *ctx);
 CIAO_API int32_t ciao_ctx_set_allreduce(ciao_ctx *ctx, ciao_allreduce_fn fn, void *user); /* fn = NULL: single GPU */
+/* The same without a host callback: `comm` is an ncclComm_t of RCCL spanning the ranks that share the rows; the library
+ * then calls ncclAllReduce(buf, buf, count, ncclFloat|ncclDouble, ncclSum, comm, stream) itself wherever the hook would
+ * be called.  RCCL is resolved at run time from `librccl_path` (NULL = "librccl.so"), so single-GPU hosts need no RCCL;
+ * pass the library the communicator was created with.  comm = NULL removes it.  Replaces any hook set before. */
+CIAO_API int32_t ciao_ctx_set_rccl(ciao_ctx *ctx, void *comm, const char *librccl_path);
 /* Tuning knobs (performance only, never results-changing beyond summation order); returns CIAO_ERR_ARG for unknown keys:
  *   "sweep_blocks_per_cu", "sweep_grid", "sweep_prefetch", "sweep_multi", "force_generic"   grid / variant of the rows kernels
  *   "chain_max_batch"      Finito / LFinito batches up to this size run as one sequential chain (-1 = measured crossover)

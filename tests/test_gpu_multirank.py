@@ -107,3 +107,66 @@ def test_two_ranks_on_one_gpu():
         p.join(timeout=60)
     for rank, ok in res:
         assert all(v is True for v in ok.values()), f"rank {rank}: {ok}"
+
+
+def _rccl_worker(q):
+    """One rank, a communicator of our own, the library calling ncclAllReduce itself (ciao_ctx_set_rccl)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import torch
+        import ciao_loader
+        ciao_loader.load()
+        from ciaoalgorithms_jl_amd import _lib as L
+        from ciaoalgorithms_jl_amd.device import Context, PackedF, ProxG
+        from ciaoalgorithms_jl_amd.parallel import RcclComm
+        from ciaoalgorithms_jl_amd.solvers import Finito
+        from ciaoalgorithms_jl_amd.sampling import IndexStream
+        from oracle import oracle as O
+        from oracle import ref_solvers as RS
+        import problems as P
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        ok = {}
+        ctx = Context(0)
+        comm = RcclComm(0, 1, 0)
+        ctx.set_rccl(comm)
+        N, d = 300, 1024
+        A, b, x = P.synthetic("ls", N, d, np.float64, seed=3)
+        F = PackedF(L.LOSS_LS, torch.from_numpy(A).to(dev), torch.from_numpy(b).to(dev), float(N))
+        g = ProxG(L.PROX_L1, lam=0.01)
+        og, op = O.Prox("l1", lam=0.01), O.Problem("ls", A, b, float(N))
+        xd = torch.from_numpy(x).to(dev)
+        av, y = torch.empty_like(xd), torch.empty_like(xd)
+        ctx.proxgrad_step(F, g, 0.05 / N, xd, av, y)
+        rav = O.full_pass(op, x)
+        ok["av"] = bool(np.abs(av.cpu().numpy() - rav).max() <= 1e-10 * np.abs(rav).max())
+        Li = float(N) * np.sum(A * A, axis=1)
+        xs, _ = Finito(np.float64, maxit=6, sweeping=2, minibatch=(True, 64))(np.zeros(d), F=F, g=g, L=Li, N=N, ctx=ctx, stream=IndexStream(0))
+        xr, _ = RS.finito(op, og, np.zeros(d), maxit=6, sweeping=2, batch=64, lfinito=False, L=Li, stream=IndexStream(0))
+        ok["finito"] = bool(np.abs(xs - xr).max() <= 1e-9 * max(np.abs(xr).max(), 1e-30) + 1e-13)
+        try:   # with a communicator set the problem counts as row-sharded: the sequential chains refuse it
+            ctx.svrg_inner(F, g, 0.1, np.zeros(3, np.int64), av, y, xd, torch.empty_like(xd))
+            ok["chain_refused"] = False
+        except L.CiaoError:
+            ok["chain_refused"] = True
+        ctx.set_rccl(None)
+        ctx.svrg_inner(F, g, 0.1 / N, np.zeros(3, np.int64), av, y, xd, torch.empty_like(xd))   # accepted again
+        ctx.synchronize()
+        ctx.close()
+        comm.close()
+        q.put(ok)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put({"exception": repr(e) + traceback.format_exc()})
+
+
+def test_native_rccl_allreduce_one_rank():
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    p = mpc.Process(target=_rccl_worker, args=(q,))
+    p.start()
+    ok = q.get(timeout=300)
+    p.join(timeout=60)
+    assert all(v is True for v in ok.values()), ok
