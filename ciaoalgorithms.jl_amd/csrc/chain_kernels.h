@@ -389,19 +389,24 @@ __device__ __forceinline__ void drain_vmcnt_visible()
     asm volatile("" ::: "memory");
 }
 
-template <int J>
-struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at ~0.3 us per step, within 64 KiB of LDS per ring
-    static constexpr int value = J <= 2 ? 8 : (J <= 4 ? 4 : 2);   // 64 KiB of LDS per ring at most
+template <int J, bool TABLE>   // J = row bytes / 4096
+struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at 0.4-0.9 us per step, within 128 KiB of LDS for the rings:
+                    // with a table ring beside the row ring 64 KiB each, without one the row ring takes it all
+    static constexpr int value = TABLE ? (J <= 2 ? 8 : (J <= 4 ? 4 : 2)) : (J <= 4 ? 8 : 4);
 };
 
-template <typename T, int J, int ALG, int LOSS, bool MASKED>
-__global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
+// NT threads (256 or 512): 32 KiB rows are shared by eight waves instead of four (a step costs ~0.38 us + ~0.06 us per
+// 16-byte chunk a thread owns, but eight waves also pay more for the exchange: chain_launch.inc has the measurements).
+template <typename T, int J, int ALG, int LOSS, bool MASKED, int NT>
+__global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
 {
+    constexpr int NW = NT / WAVE;
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
     using V = typename VecOfC<T>::type;
     constexpr int VEC = 16 / sizeof(T);
-    constexpr int DEPTH = DmaDepth<J>::value;
-    constexpr int CH = CHAIN_CHUNK;
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
+    constexpr int DEPTH = DmaDepth<J * NT / 256, HAS_TABLE>::value;   // by row bytes (J*NT*16), whatever the thread count
+    constexpr int CH = CHAIN_CHUNK;
     constexpr bool SVRG_ANY = (ALG == CA_SVRG || ALG == CA_SVRGC);
     constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
     constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO || ALG == CA_SVRGC);   // s_g staging
@@ -413,7 +418,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
     // dependent path.  It costs one step of DMA lead, hence only with DEPTH >= 4.
     constexpr bool PIPE = DEPTH >= 4;
     constexpr int WAIT_N = (PIPE ? DEPTH - 2 : DEPTH - 1) * OPS_PER_STEP;
-    constexpr int ROW_BYTES = J * CHAIN_NT * 16;
+    constexpr int ROW_BYTES = J * NT * 16;
     static_assert(CH % DEPTH == 0 && DEPTH % 2 == 0, "ring slots must line up with chunk starts; ping-pong needs even DEPTH");
 
     // one dynamic LDS block, carved by hand (16-byte aligned pieces):
@@ -431,7 +436,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
     int *s_stale = reinterpret_cast<int *>(cur);
     cur += (HAS_TABLE ? CH : 0) * sizeof(int);
     cur += (16 - (reinterpret_cast<uintptr_t>(cur) & 15)) & 15;
-    T(*red)[CHAIN_NW][2] = reinterpret_cast<T(*)[CHAIN_NW][2]>(cur);
+    T(*red)[NW][2] = reinterpret_cast<T(*)[NW][2]>(cur);
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -447,7 +452,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
     int64_t cl[J];   // chunk to address: own chunk, or 0 when dead
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const int64_t c = tid + (int64_t)j * CHAIN_NT;
+        const int64_t c = tid + (int64_t)j * NT;
         ok[j] = !MASKED || c < nchunks;
         cl[j] = ok[j] ? c : 0;
     }
@@ -489,12 +494,12 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
         const unsigned char *ap = reinterpret_cast<const unsigned char *>(a.A + r * a.ld);
 #pragma unroll
         for (int j = 0; j < J; ++j)
-            glds16(ap + cl[j] * 16, ringA_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
+            glds16(ap + cl[j] * 16, ringA_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
         if (HAS_TABLE) {
             const unsigned char *sp = reinterpret_cast<const unsigned char *>(a.table + r * d);
 #pragma unroll
             for (int j = 0; j < J; ++j)
-                glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
+                glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
         }
     };
 
@@ -509,8 +514,8 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
     auto fetch = [&](StepIn &x, int u, int s) {   // plain LDS reads; the caller has retired slot u's DMA
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            x.ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
-            if (HAS_TABLE) x.sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
+            x.ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * NW + wib) * 64 + lane) * 16);
+            if (HAS_TABLE) x.sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * NW + wib) * 64 + lane) * 16);
             if (MASKED && !ok[j]) {
                 x.ar[j] = V(T(0));
                 if (HAS_TABLE) x.sr[j] = V(T(0));
@@ -547,7 +552,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
         if (tid < DEPTH && base > 0) hist = s_row[CH + tid];
         __syncthreads();
         if (tid < DEPTH) s_row[tid] = hist;
-        for (int e = tid; e < nch + DEPTH; e += CHAIN_NT) {
+        for (int e = tid; e < nch + DEPTH; e += NT) {
             int64_t st = base + e;
             if (st > a.nsteps - 1) st = a.nsteps - 1;
             int64_t r = a.idx[st];
@@ -563,7 +568,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
         }
         __syncthreads();
         if (HAS_TABLE) {
-            for (int e = tid; e < nch; e += CHAIN_NT) {
+            for (int e = tid; e < nch; e += NT) {
                 const int64_t r = s_row[DEPTH + e];
                 bool st = false;
 #pragma unroll
@@ -648,6 +653,10 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
                 CIAO_STAMP(4);   // T0: closes [T4, T0] = waiting for the other waves
                 d1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
                 if (TWO) d2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+                if (NW == 8) {   // fixed association order: two groups of four
+                    d1 += (red[par][4][0] + red[par][5][0]) + (red[par][6][0] + red[par][7][0]);
+                    if (TWO) d2 += (red[par][4][1] + red[par][5][1]) + (red[par][6][1] + red[par][7][1]);
+                }
 #if (CIAO_CHAIN_DBG & 8)
                 asm volatile("" : "+v"(d1));   // the sum is formed HERE, before the stamp
                 ++stamp_steps;
@@ -769,15 +778,16 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_dma_kernel(ChainArgs<T> a)
     }
 }
 
-template <typename T, int J, int ALG>
+template <typename T, int J, int ALG, int NT>
 constexpr size_t chain_dma_lds_bytes()
 {
-    constexpr int DEPTH = DmaDepth<J>::value;
+    constexpr int NW = NT / WAVE;
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
+    constexpr int DEPTH = DmaDepth<J * NT / 256, HAS_TABLE>::value;
     constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO || ALG == CA_SVRGC);
-    return (size_t)DEPTH * J * CHAIN_NT * 16 * (HAS_TABLE ? 2 : 1) + (CHAIN_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
+    return (size_t)DEPTH * J * NT * 16 * (HAS_TABLE ? 2 : 1) + (CHAIN_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
            CHAIN_CHUNK * sizeof(T) * (PER_SAMPLE_GAM ? 2 : 1) + (HAS_TABLE ? CHAIN_CHUNK * sizeof(int) : 0) + 16 +
-           2 * CHAIN_NW * 2 * sizeof(T);
+           2 * NW * 2 * sizeof(T);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1029,7 +1039,7 @@ constexpr int AF_CHUNK = 512;
 template <typename T, int J>
 constexpr size_t afinito_dma_lds_bytes()
 {
-    constexpr int DEPTH = DmaDepth<J>::value;
+    constexpr int DEPTH = DmaDepth<J, true>::value;
     return (size_t)2 * DEPTH * J * CHAIN_NT * 16 + (size_t)DEPTH * CHAIN_NW * 256 + (AF_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
            AF_CHUNK * sizeof(T) + AF_CHUNK * sizeof(int) + 16 + 2 * CHAIN_NW * 2 * sizeof(T);
 }
@@ -1039,7 +1049,7 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
 {
     using V = typename VecOfC<T>::type;
     constexpr int VEC = 16 / sizeof(T);
-    constexpr int DEPTH = DmaDepth<J>::value;
+    constexpr int DEPTH = DmaDepth<J, true>::value;
     constexpr int CH = AF_CHUNK;
     constexpr int OPS_PER_STEP = (MASKED ? 2 * J : 3 * J) + 1;   // MASKED: predicated table stores are not counted (chain_dma_kernel)
     constexpr bool PIPE = DEPTH >= 4;
