@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <new>
 #include <vector>
 
 #include "ciao_ctx.h"
@@ -625,7 +626,11 @@ int32_t ciao_ctx_create(int32_t device, void *stream, ciao_ctx **out)
     CIAO_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     CIAO_HIP(hipGetDeviceProperties(&prop, device));
-    ciao_ctx *ctx = new ciao_ctx();
+    ciao_ctx *ctx = new (std::nothrow) ciao_ctx();
+    if (!ctx) {
+        set_error("out of host memory");
+        return CIAO_ERR_ALLOC;
+    }
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
     ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -931,11 +936,12 @@ int32_t ciao_hat_gamma(ciao_ctx *ctx, int32_t dtype, int64_t N, const void *gam,
     else
         hipLaunchKernelGGL((invsum_kernel<float>), dim3(nb), dim3(256), 0, ctx->stream, N, (const float *)gam, ctx->scal);
     CIAO_HIP(hipGetLastError());
-    std::vector<double> part(nb);
-    CIAO_HIP(hipMemcpyAsync(part.data(), ctx->scal, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    double part_buf[256];
+    double *const part_data = part_buf;
+    CIAO_HIP(hipMemcpyAsync(part_data, ctx->scal, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CIAO_HIP(hipStreamSynchronize(ctx->stream));
     double s = 0.0;
-    for (int i = 0; i < nb; ++i) s += part[i];
+    for (int i = 0; i < nb; ++i) s += part_data[i];
     if (ctx->hook) {
         CIAO_HIP(hipMemcpyAsync(ctx->scal, &s, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         const int32_t hs = ctx->hook(ctx->hook_user, ctx->scal, 1, CIAO_F64, (void *)ctx->stream);
@@ -1121,7 +1127,13 @@ int32_t ciao_sample_batches(uint64_t seed, uint64_t pos, int64_t N, int64_t r, i
     // a probe touches one cache line and nothing is cleared between batches (a stale tag reads as an empty slot)
     uint64_t cap = 16;
     while (cap < (uint64_t)(2 * r)) cap <<= 1;
-    std::vector<uint64_t> slots(cap, 0);
+    std::vector<uint64_t> slots;
+    try {
+        slots.assign(cap, 0);
+    } catch (...) {   // nothing may unwind through the C ABI
+        set_error("out of host memory (%llu hash slots)", (unsigned long long)cap);
+        return CIAO_ERR_ALLOC;
+    }
     uint32_t tag = 0;
     for (int64_t t = 0; t < n; ++t) {
         if (++tag == 0) {   // 2^32 batches later the tags would repeat: start over with clean slots
