@@ -118,6 +118,45 @@ function pack_g(::Type{R}, g, d::Int) where {R}
     throw(ArgumentError("g is not a family the device path supports (Zero, NormL1, IndBox)"))
 end
 
+# ---- L1 plugin API on packed operators (the ProximalOperators.jl calling convention, device arrays) ---------------------
+# gradient!(y, F, i, x): y = ∇f_i(x), returns f_i(x)            call sites SVRG_basic.jl:60,74,75,89; SAGA_basic.jl:43,56
+function gradient!(y::ROCArray{R,1}, F::PackedF{R}, i::Integer, x::ROCArray{R,1}) where {R}
+    fval = ROCArray{R}(undef, 1)
+    check(ccall((:ciao_gradient, libciao), Int32, (Ptr{Cvoid}, Ref{CiaoProblem}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, Ref(cproblem(F)), i - 1, dptr(x), dptr(y), dptr(fval)))
+    return Array(fval)[1]
+end
+# prox!(y, g, x, γ): y = prox_{γ g}(x) for a packed g = pack_g(R, g, d)[1]         call sites SVRG_basic.jl:80; SAGA_basic.jl:48,64
+function prox!(y::ROCArray{R,1}, g::CiaoProxDesc, x::ROCArray{R,1}, γ::Real) where {R}
+    check(ccall((:ciao_prox, libciao), Int32, (Ptr{Cvoid}, Int32, Int64, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Ptr{Cvoid}),
+                context().h, dtype_code(R), length(x), Ref(g), dptr(x), Float64(γ), dptr(y)))
+    return y
+end
+# av = (1/N) Σ ∇f_i(x): the full-gradient sweep on its own (SVRG_basic.jl:58-63), and fused with a prox step
+function full_gradient!(av::ROCArray{R,1}, F::PackedF{R}, x::ROCArray{R,1}) where {R}
+    check(ccall((:ciao_full_gradient, libciao), Int32, (Ptr{Cvoid}, Ref{CiaoProblem}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, Ref(cproblem(F)), dptr(x), dptr(av)))
+    return av
+end
+function proxgrad_step!(y::ROCArray{R,1}, av::ROCArray{R,1}, F::PackedF{R}, g::CiaoProxDesc, x::ROCArray{R,1}, γ::Real) where {R}
+    check(ccall((:ciao_proxgrad_step, libciao), Int32, (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, Ref(cproblem(F)), Ref(g), Float64(γ), dptr(x), dptr(av), dptr(y)))
+    return y
+end
+# (1/N) Σ f_i(x) + g(x): what test/test_lasso.jl:45 computes on the host
+function objective(F::PackedF{R}, g::CiaoProxDesc, x::ROCArray{R,1}) where {R}
+    out = Ref{Float64}(0.0)
+    check(ccall((:ciao_objective, libciao), Int32, (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Ref{Float64}),
+                context().h, Ref(cproblem(F)), Ref(g), dptr(x), out))
+    return out[]
+end
+# multi-GPU: hand an RCCL communicator (ncclComm_t) to the context; tuning knobs
+set_rccl!(comm::Ptr{Cvoid}, lib::AbstractString = "librccl.so") =
+    check(ccall((:ciao_ctx_set_rccl, libciao), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Cstring), context().h, comm, lib))
+set_option!(key::AbstractString, value::Integer) =
+    check(ccall((:ciao_ctx_set_option, libciao), Int32, (Ptr{Cvoid}, Cstring, Int64), context().h, key, value))
+last_kernel() = unsafe_string(ccall((:ciao_ctx_last_kernel, libciao), Cstring, (Ptr{Cvoid},), context().h))
+
 # The reference draws from Julia's global RNG inside Base.iterate; here the draws are made on the host with the SAME
 # calls (so a Julia user keeps the reference's sample stream) and shipped as 0-based Int64 device arrays.
 to_dev_idx(idx::AbstractVector{<:Integer}) = ROCArray(Int64.(idx) .- 1)
