@@ -354,3 +354,43 @@ class TestSharing:
         F, g, L, x0, sum_star, N = self._problem(ops)
         with pytest.raises(TypeError):
             S.Proshi(self.T, maxit=3)(x0, F=[ops.Quadratic(np.ones((2, 2)), np.ones(2))] * N, g=g, L=L, N=N)   # dense Q
+
+
+# ======================================================================================================================
+# the same solvers on row lengths outside the wave-per-row shapes, against the CPU restatement of the iterables
+# ======================================================================================================================
+@pytest.mark.parametrize("d", [1000, 1024, 1536])
+def test_solvers_follow_the_oracle_on_odd_row_lengths(api, ciao, ctx, d):
+    """SVRG, SAGA, Finito (single samples as a chain, batches one workgroup per row), LFinito and adaptive Finito through
+    the public functors at d = 1000 / 1536 (masked kernels) and 1024 (exact shape), same index streams as the oracle's
+    iterables: the iterates agree to fp64 rounding accumulated over a few thousand dependent updates."""
+    import torch
+    from oracle import oracle as O
+    from oracle import ref_solvers as RS
+    from ciaoalgorithms_jl_amd.device import PackedF, ProxG
+    import ciaoalgorithms_jl_amd._lib as L
+    S, ops = api
+    N = 400
+    A, b, _ = P.synthetic("ls", N, d, np.float64, seed=d)
+    x0 = np.zeros(d)
+    Li = float(N) * np.sum(A * A, axis=1)
+    F = PackedF.least_squares(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda(), float(N))
+    g, og, op = ProxG(L.PROX_L1, lam=0.01), O.Prox("l1", lam=0.01), O.Problem("ls", A, b, float(N))
+    gamma = 1.0 / (7 * Li.max())
+
+    def same(x, xr, what, rel=1e-8):
+        err = np.abs(np.asarray(x) - xr).max()
+        assert err <= rel * max(np.abs(xr).max(), 1e-30) + 1e-13, f"{what} (d={d}): {err:.3e}"
+
+    x, it = S.SVRG(np.float64, γ=gamma, maxit=4)(x0, F=F, g=g, N=N, ctx=ctx, stream=ciao.IndexStream(1))
+    xr, itr = RS.svrg(op, og, x0, maxit=4, gamma=gamma, stream=ciao.IndexStream(1))
+    assert it == itr
+    same(x, xr, "SVRG")
+    x, it = S.SAGA(np.float64, γ=1.0 / (3 * Li.max()), maxit=3000)(x0, F=F, g=g, N=N, ctx=ctx, stream=ciao.IndexStream(2))
+    xr, _ = RS.saga(op, og, x0, maxit=3000, gamma=1.0 / (3 * Li.max()), stream=ciao.IndexStream(2))
+    same(x, xr, "SAGA")
+    for sweeping, batch, lf, maxit in ((1, 1, False, 2000), (1, 32, False, 60), (3, 50, False, 40), (2, 32, True, 5), (3, 1, True, 3)):
+        solver = S.Finito(np.float64, sweeping=sweeping, minibatch=(batch > 1, batch), LFinito=lf, maxit=maxit)
+        x, it = solver(x0, F=F, g=g, L=Li, N=N, ctx=ctx, stream=ciao.IndexStream(3))
+        xr, _ = RS.finito(op, og, x0, maxit=maxit, sweeping=sweeping, batch=batch, lfinito=lf, L=Li, stream=ciao.IndexStream(3))
+        same(x, xr, f"Finito sweeping={sweeping} batch={batch} LFinito={lf}")
