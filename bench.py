@@ -165,6 +165,9 @@ def main():
         "dtype": args.dtype,
         "data": "synthetic",
         "epochs_per_sec": args.steps / elapsed,
+        # everything in a step that is not the sweep kernel: finalize + epilogue, launch gaps and -- with several ranks -- the
+        # all-reduce of the d+1 scalars (BASELINE.md section 2 asks for that figure in microseconds)
+        "step_overhead_us_beyond_sweep_kernel": (elapsed / args.steps - k_avg_s) * 1e6,
         "config": {"workload": f"{'l1_logistic' if logistic else 'lasso'}_svrg_fullgrad_prox_sweep",
                    "N_total": N_total, "rows_per_gpu": n_local, "d": d, "f": "LeastSquares(a_i,b_i,N)" if not logistic else "Precompose(LogisticLoss)",
                    "g": f"NormL1({lam_g:g})", "gamma": gamma, "parallelism": f"rows_sharded_x{world}",
