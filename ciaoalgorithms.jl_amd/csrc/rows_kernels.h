@@ -346,11 +346,17 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
 //     MASKED the last chunk group is predicated, so any 16-byte aligned row of up to J*4096 bytes, J <= 16, runs here
 //     (d = 1000, 1536, 3000 ...; also d = 4096 fp64) instead of on the scalar generic kernel.
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int J, int MODE, bool MASKED>
+// (3) VEC = 1 (one element per "chunk" instead of 16 bytes): rows with no alignment at all -- odd d, odd row strides --
+//     of up to 4096 elements.  Narrower loads (256 / 512 B per wave-instruction) but still one pass over the row.
+template <typename T, int N>
+struct ChunkOf {
+    typedef T type __attribute__((ext_vector_type(N)));
+};
+
+template <typename T, int J, int MODE, bool MASKED, int VEC>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
 {
-    using V = typename VecOf<T>::type;
-    constexpr int VEC = VecOf<T>::N;
+    using V = typename ChunkOf<T, VEC>::type;
     constexpr bool TWO = (MODE == RM_GRAD2);
     constexpr bool TABLE = (MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH);
     constexpr bool TREAD = (MODE == RM_FINITO_BATCH);

@@ -67,7 +67,7 @@ def dev(a):
 
 
 SHAPES = [(1, 1), (6, 3), (8, 5), (37, 50), (200, 64), (129, 128), (300, 256), (64, 1024), (33, 1000), (16, 2048), (5, 4096),
-          (40, 1536), (12, 3000), (9, 8192), (700, 1100)]
+          (40, 1536), (12, 3000), (9, 8192), (700, 1100), (25, 1001), (7, 3001), (300, 257)]
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -165,11 +165,18 @@ def test_full_gradient_padded_rows_and_prefetch_variants(ctx, dtype):
     ctx.set_option("sweep_prefetch", -1)
     # the two pipelining flavours assign the same rows to the same waves: identical summation order
     assert np.array_equal(outs[0], outs[1])
-    op2, dp2 = make("logistic", A, b, 1.0, dtype, pad=3)    # ld = 259: unaligned rows -> generic path
+    op2, dp2 = make("logistic", A, b, 1.0, dtype, pad=3)    # ld = 259: rows with no 16-byte alignment -> element-wise chunks
     av = torch.empty(256, dtype=dev(x).dtype, device="cuda")
     ctx.full_gradient(dp2, dev(x), av)
-    assert "rows_generic_kernel" in ctx.last_kernel()
+    assert "rows_split_kernel" in ctx.last_kernel() and "scalar" in ctx.last_kernel(), ctx.last_kernel()
     close(av, ref, dtype, scale=4, what="unaligned rows")
+    ctx.set_option("force_generic", 1)
+    try:
+        ctx.full_gradient(dp2, dev(x), av)
+        assert "rows_generic_kernel" in ctx.last_kernel()
+    finally:
+        ctx.set_option("force_generic", 0)
+    close(av, ref, dtype, scale=4, what="unaligned rows, generic kernel")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -258,7 +265,7 @@ def test_sweep_is_bitwise_reproducible(ctx):
 # ----------------------------------------------------------------------------------------------------------------------
 # d*sizeof(T) a multiple of 4096 B selects the LDS-DMA chain (f64: 512, 1024, 2048, 4096; f32: 1024, 2048, 4096);
 # everything else (and every shape again with chain_no_dma=1) runs the register-ring chain
-CHAIN_SHAPES = [(6, 3), (8, 5), (50, 50), (40, 256), (30, 300), (12, 512), (64, 1024), (20, 1500), (9, 2048), (10, 4096)]
+CHAIN_SHAPES = [(6, 3), (8, 5), (50, 50), (40, 256), (30, 300), (12, 512), (64, 1024), (20, 1500), (9, 2048), (10, 4096), (15, 1001)]
 
 
 @pytest.fixture(params=[0, 1], ids=["dma", "regring"])
@@ -468,7 +475,8 @@ def _batches(stream, N, r, nit, mode):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape,r", [((6, 3), 1), ((8, 5), 2), ((8, 5), 3), ((50, 50), 7), ((40, 256), 1), ((64, 1024), 16),
-                                     ((300, 64), 100), ((20, 1500), 4), ((10, 4096), 3), ((33, 2048), 1), ((1500, 1024), 700)])
+                                     ((300, 64), 100), ((20, 1500), 4), ((10, 4096), 3), ((33, 2048), 1), ((1500, 1024), 700),
+                                     ((60, 1001), 7), ((400, 259), 300)])
 @pytest.mark.parametrize("path", ["chain", "block_per_row", "wave_per_row"])
 def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, path):
     """The three routes of a batch: the sequential chain kernel; batch-parallel with one workgroup per row (whole-4-KiB rows
@@ -518,7 +526,7 @@ def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, path):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape,r", [((6, 3), 1), ((8, 5), 2), ((8, 5), 3), ((50, 50), 7), ((64, 1024), 16), ((300, 64), 100),
-                                     ((20, 1500), 1), ((17, 2048), 2), ((1300, 1024), 600)])
+                                     ((20, 1500), 1), ((17, 2048), 2), ((1300, 1024), 600), ((50, 1001), 6)])
 @pytest.mark.parametrize("path", ["chain", "block_per_row", "wave_per_row"])
 def test_lfinito_iterations(ctx, ciao, chain_variant, dtype, shape, r, path):
     import torch
