@@ -265,7 +265,7 @@ def test_sweep_is_bitwise_reproducible(ctx):
 # ----------------------------------------------------------------------------------------------------------------------
 # d*sizeof(T) a multiple of 4096 B selects the LDS-DMA chain (f64: 512, 1024, 2048, 4096; f32: 1024, 2048, 4096);
 # everything else (and every shape again with chain_no_dma=1) runs the register-ring chain
-CHAIN_SHAPES = [(6, 3), (8, 5), (50, 50), (40, 256), (30, 300), (12, 512), (64, 1024), (20, 1500), (9, 2048), (10, 4096), (15, 1001)]
+CHAIN_SHAPES = [(6, 3), (8, 5), (50, 50), (40, 256), (30, 300), (12, 512), (64, 1024), (20, 1500), (9, 2048), (10, 4096), (15, 1001), (11, 1501)]
 
 
 @pytest.fixture(params=[0, 1], ids=["dma", "regring"])
