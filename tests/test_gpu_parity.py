@@ -800,3 +800,58 @@ def test_argument_validation(ctx):
         ctx.gradient(dp, 10, dev(x0), av)                                                  # sample index out of range
     with pytest.raises(CiaoError):
         ctx.set_option("no_such_option", 1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# kernel-selection boundaries: row lengths on either side of every dispatch threshold
+# ----------------------------------------------------------------------------------------------------------------------
+BOUNDARY_D = [63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 1023, 1025, 2047, 2049, 4095, 4097, 8191, 8192, 8193, 16383, 16384, 16385]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d", BOUNDARY_D)
+def test_row_length_boundaries(ctx, ciao, dtype, d):
+    """Sweep, SAGA / Finito table init and a Finito batch on row lengths around every threshold of the dispatch (wave-per-row
+    shapes, 16-byte chunks, element-wise chunks, 4096-element and 64 KiB limits, generic kernel): whichever kernel is chosen,
+    the result is the oracle's."""
+    import torch
+    from oracle import oracle as O
+    from ciaoalgorithms_jl_amd._lib import CiaoError
+    rowb = d * np.dtype(dtype).itemsize
+    covered = (rowb % 16 == 0 and rowb <= 65536) or (256 <= d <= 4096) or 2 * rowb <= 144 * 1024
+    N = 23
+    A, b, x0 = P.synthetic("ls", N, d, dtype, seed=d)
+    op, dp = make("ls", A, b, float(N), dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.02)
+    tdt = dev(x0).dtype
+    av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+    if not covered:   # rows beyond every kernel's coverage are refused with a message, not mis-computed
+        with pytest.raises(CiaoError, match="outside the kernels' coverage"):
+            ctx.full_gradient(dp, dev(x0), av)
+        return
+    ctx.full_gradient(dp, dev(x0), av)
+    k_sweep = ctx.last_kernel()
+    close(av, O.full_pass(op, x0), dtype, scale=8, what=f"sweep d={d} ({k_sweep})")
+    table = torch.empty((N, d), dtype=tdt, device="cuda")
+    gamma = 0.5 / N
+    ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
+    rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
+    close(table, rt, dtype, scale=8, what=f"saga_init table d={d} ({ctx.last_kernel()})")
+    close(av, rav, dtype, scale=20, what="saga_init av")
+    Li = float(N) * np.sum(A.astype(np.float64) ** 2, axis=1)
+    gam = (0.999 * N / Li).astype(dtype)
+    dgam = dev(gam)
+    hg = ctx.hat_gamma(dgam)
+    rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
+    ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
+    close(table, rt, dtype, scale=8, what=f"finito_init table d={d}")
+    ctx.set_option("chain_max_batch", 0)
+    try:
+        batch = np.array([3, 19, 0, 7, 11, 22, 5], dtype=np.int64)
+        ctx.finito_steps(dp, dg, dgam, hg, np.array([0, 7], np.int64), batch, table, av, z)
+    finally:
+        ctx.set_option("chain_max_batch", -1)
+    O.finito_steps(op, og, gam, rhg, [batch], rt, rav, rz)
+    close(table, rt, dtype, scale=50, what=f"finito batch table d={d} ({ctx.last_kernel()})")
+    close(z, rz, dtype, scale=200, what="finito batch z")
+    ctx.synchronize()
