@@ -855,3 +855,38 @@ def test_row_length_boundaries(ctx, ciao, dtype, d):
     close(table, rt, dtype, scale=50, what=f"finito batch table d={d} ({ctx.last_kernel()})")
     close(z, rz, dtype, scale=200, what="finito batch z")
     ctx.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d", [255, 257, 511, 513, 1023, 1025, 2047, 2049, 3071, 4095, 4096, 4097])
+def test_chain_row_length_boundaries(ctx, ciao, dtype, d):
+    """SVRG inner cycle and SAGA steps on row lengths around the chain kernels' thresholds (LDS-DMA exact / masked, register
+    ring E = 1 / 4 / 8 / 16, and the refusal beyond 4096 elements)."""
+    import torch
+    from oracle import oracle as O
+    from ciaoalgorithms_jl_amd._lib import CiaoError
+    N = 12
+    A, b, x0 = P.synthetic("ls", N, d, dtype, seed=d)
+    op, dp = make("ls", A, b, float(N), dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.01)
+    tdt = dev(x0).dtype
+    av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+    ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+    rav, rz, rzf, rw = O.svrg_init(op, x0)
+    idx = ciao.IndexStream(d).rand_indices(N, 60)
+    gamma = 0.05 / N
+    if d > 4096:
+        with pytest.raises(CiaoError, match="sequential chain kernels cover"):
+            ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
+        return
+    ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
+    O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
+    close(w, rw, dtype, scale=200, what=f"svrg_inner w d={d} ({ctx.last_kernel()})")
+    table = torch.empty((N, d), dtype=tdt, device="cuda")
+    ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
+    rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
+    ctx.saga_steps(dp, dg, gamma, False, idx, table, av, z)
+    O.saga_steps(op, og, dtype(gamma), False, idx, rt, rav, rz)
+    close(z, rz, dtype, scale=200, what=f"saga z d={d} ({ctx.last_kernel()})")
+    close(table, rt, dtype, scale=200, what="saga table")
+    ctx.synchronize()
