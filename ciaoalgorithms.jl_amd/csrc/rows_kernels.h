@@ -490,6 +490,195 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Rows shorter than a wave's reach (d <= 256 elements): SEVERAL ROWS PER WAVE (rows_small_kernel).
+// The full sweeps over a dense matrix (no index list, ld == d) see G consecutive rows as one contiguous stretch of G*d
+// elements; a wave loads it coalesced (lane l takes elements l, l+64, ...: SMALL_I of them), so element (l, i) always
+// belongs to the same row-in-group and the same column, whatever the group.  Per group: products a*x go to the wave's
+// private LDS area, Q lanes per row add up the row's d products and combine by shuffles, one of them evaluates the link function, and every element picks up its row's scalar again through LDS.  Accumulators
+// stay in registers per (lane, i); columns are combined once, at the end.  Covers GRAD, SAGA_INIT and FINITO_INIT.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SMALL_I = 16;
+constexpr int SMALL_GE = WAVE * SMALL_I;   // elements of one wave-iteration
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
+{
+    static_assert(MODE == RM_GRAD || MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT, "contiguous full sweeps only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char small_raw[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int d = (int)a.d;
+    // per wave: prod[SMALL_GE] | s1[64] | gg[64];  after the sweep the first ROWS_WAVES*d elements of the block's area hold
+    // the per-wave column sums
+    T *base = reinterpret_cast<T *>(small_raw);
+    T *prod = base + (size_t)wib * (SMALL_GE + 2 * WAVE);
+    T *s1s = prod + SMALL_GE;
+    T *ggs = s1s + WAVE;
+    int G = SMALL_GE / d;
+    if (G > WAVE) G = WAVE;
+    const int used = G * d;
+    const T s2 = (a.loss == CIAO_LOSS_LS) ? a.lam : (a.loss == CIAO_LOSS_LOGISTIC ? T(1) : T(0));
+    // the dot product of row r is shared by Q = 2^qs adjacent lanes (r*Q .. r*Q+Q-1) when the group has few rows
+    int qs = 0;
+    while ((2 << qs) * G <= WAVE) ++qs;
+    const int Q = 1 << qs;
+    const int myrow = lane >> qs, myq = lane & (Q - 1);
+
+    bool live[SMALL_I];
+    int rrow[SMALL_I];
+    T xcol[SMALL_I], acc[SMALL_I];
+#pragma unroll
+    for (int i = 0; i < SMALL_I; ++i) {
+        const int e = lane + WAVE * i;
+        live[i] = e < used;
+        rrow[i] = live[i] ? e / d : 0;
+        xcol[i] = live[i] ? a.x1[e - rrow[i] * d] : T(0);
+        acc[i] = T(0);
+    }
+    T ex = T(0);
+    s1s[lane] = T(0);   // rows of a short last group are never written: their (unused, times-zero) scalars must be finite
+    ggs[lane] = T(1);
+    const int64_t ngroups = (a.nrows + G - 1) / G;
+    const int64_t nwaves = (int64_t)gridDim.x * ROWS_WAVES;
+    // the elements of group g (rows g*G ...): one coalesced element-wise load per (lane, i), zero beyond the matrix
+    // ... and the scalars (b_i, gamma_i) of the row a lane works on in the same breath: a load issued later, between the phases, would
+    // make the compiler's in-order vmcnt wait drain the prefetch of the next group as well
+    auto fetch = [&](T(&v)[SMALL_I], T &bi, T &gi, int64_t g) {
+        const int64_t left = a.nrows - g * G;
+        const int nrg = left < G ? (int)left : G;
+        const int usedg = nrg * d;
+        const int64_t rb = a.row0 + g * G;
+        const T *gp = a.A ? a.A + rb * (int64_t)d : nullptr;
+        // branch-free: dead elements read the group's last live element and are zeroed by a select (a predicated load per
+        // element costs an exec-mask branch each; the loop was instruction-bound at ~1500 instructions per group)
+        const int lastg = usedg - 1;
+#pragma unroll
+        for (int i = 0; i < SMALL_I; ++i) {
+            const int e = lane + WAVE * i;
+            const int ec = e < usedg ? e : lastg;
+#ifdef CIAO_SMALL_PLAIN
+            const T val = gp ? gp[ec] : T(0);
+#else
+            const T val = gp ? __builtin_nontemporal_load(&gp[ec]) : T(0);
+#endif
+            v[i] = e < usedg ? val : T(0);
+        }
+        // volatile: hipcc otherwise sinks these two loads down to their use, behind the prefetch
+        bi = (a.b && myrow < nrg) ? *reinterpret_cast<const volatile T *>(a.b + rb + myrow) : T(0);
+        gi = (MODE == RM_FINITO_INIT && a.gam && myrow < nrg) ? *reinterpret_cast<const volatile T *>(a.gam + rb + myrow) : a.gam_uniform;
+    };
+    T av[SMALL_I], avn[SMALL_I];
+    T bcur = T(0), gcur = T(1), bnext = T(0), gnext = T(1);
+    int64_t g = (int64_t)blockIdx.x * ROWS_WAVES + wib;
+    if (g < ngroups) fetch(av, bcur, gcur, g);
+    for (; g < ngroups; g += nwaves) {
+        const int64_t row_b = a.row0 + g * G;
+        const int64_t left = a.nrows - g * G;
+        const int nr = left < G ? (int)left : G;
+        const int usedg = nr * d;
+#pragma unroll
+        for (int i = 0; i < SMALL_I; ++i) prod[lane + WAVE * i] = av[i] * xcol[i];   // unconditional: dead slots are never read
+        // the next group's elements travel while this one is reduced (one group in flight per wave is too little to cover
+        // the HBM latency at two waves per SIMD)
+        const bool more = g + nwaves < ngroups;
+        if (more) fetch(avn, bnext, gnext, g + nwaves);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes have landed (no other wave touches them)
+        {
+            // lane (r, q) adds elements q, q+Q, ... of row r (two interleaved partial sums keep two LDS reads in flight),
+            // then the Q partials are combined by xor-shuffles inside the aligned group of Q lanes
+            const bool rowlive = myrow < nr;
+            const T *pr = prod + (rowlive ? myrow : 0) * d;
+            T d0 = T(0), d1 = T(0);
+            int k = myq;
+            for (; k + Q < d; k += 2 * Q) {
+                d0 += pr[k];
+                d1 += pr[k + Q];
+            }
+            if (k < d) d0 += pr[k];
+            T dot = d0 + d1;
+            for (int m = Q >> 1; m > 0; m >>= 1) dot += __shfl_xor(dot, m, WAVE);
+            if (rowlive && myq == 0) {
+                const int64_t row = row_b + myrow;
+                const T bi = bcur;
+                const GradCoef<T> gc = grad_coef(a.loss, dot, bi, a.lam);
+                s1s[myrow] = gc.s1;
+                if (MODE == RM_FINITO_INIT) ggs[myrow] = gcur;
+                if (MODE == RM_GRAD) {
+                    if (a.want_fval) ex += loss_value(a.loss, dot, bi, a.lam);
+                    if (a.rowdot_out) a.rowdot_out[row] = dot;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        T *tp = (MODE == RM_GRAD) ? nullptr : a.table + row_b * (int64_t)d;
+#pragma unroll
+        for (int i = 0; i < SMALL_I; ++i) {
+            const int e = lane + WAVE * i;
+            if (MODE == RM_GRAD) {
+                // unconditional: dead elements carry a = 0 and a (finite) scalar of an earlier group, i.e. add zero
+                acc[i] += (s1s[rrow[i]] * s2) * av[i];               // coef() * a, as the wave-per-row kernels
+                continue;
+            }
+            if (!(live[i] && e < usedg)) continue;
+            const T s1 = s1s[rrow[i]];
+            if (MODE == RM_SAGA_INIT) {
+                const T gv = (av[i] * s1) * s2;                       // GradCoef::elem
+                __builtin_nontemporal_store(gv, &tp[e]);
+                acc[i] += gv;
+            } else {
+                const T gi = ggs[rrow[i]];
+                const T tv = xcol[i] - (gi * a.invN) * ((av[i] * s1) * s2);
+                __builtin_nontemporal_store(tv, &tp[e]);
+                acc[i] += tv * (T(1) / gi);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // s1s / ggs are rewritten by the next group
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < SMALL_I; ++i) av[i] = avn[i];
+            bcur = bnext;
+            gcur = gnext;
+        }
+    }
+
+    // columns: element (lane, i) -> prod[e]; lane c then adds rows 0..G-1 of column c in row order
+#pragma unroll
+    for (int i = 0; i < SMALL_I; ++i)
+        if (live[i]) prod[lane + WAVE * i] = acc[i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    T colsum[(256 + WAVE - 1) / WAVE];
+#pragma unroll
+    for (int q = 0; q < (256 + WAVE - 1) / WAVE; ++q) {
+        const int c = lane + WAVE * q;
+        T sacc = T(0);
+        if (c < d)
+            for (int r = 0; r < G; ++r) sacc += prod[r * d + c];
+        colsum[q] = sacc;
+    }
+    ex = wave_allsum(ex);
+    __syncthreads();   // every wave is done with its private area; reuse the block's area for the per-wave column sums
+    __shared__ T red_extra_small[ROWS_WAVES];
+#pragma unroll
+    for (int q = 0; q < (256 + WAVE - 1) / WAVE; ++q) {
+        const int c = lane + WAVE * q;
+        if (c < d) base[wib * d + c] = colsum[q];
+    }
+    if (lane == 0) red_extra_small[wib] = ex;
+    __syncthreads();
+    T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
+    for (int c = threadIdx.x; c < d; c += ROWS_BLOCK) {
+        T sacc = base[c];
+        for (int w = 1; w < ROWS_WAVES; ++w) sacc += base[w * d + c];
+        pout[c] = sacc;
+    }
+    if (threadIdx.x == 0) {
+        T e2 = T(0);
+        for (int w = 0; w < ROWS_WAVES; ++w) e2 += red_extra_small[w];
+        a.pextra[blockIdx.x] = e2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Short-row variant of the gradient sweeps (GRAD / GRAD2): R rows per wave per iteration.
 // The chip streams fastest with about 8 KiB of loads in flight per wave at one block per CU (tools/tune_sweep.py); a
 // 4 KiB (d=1024 fp32) or shorter row leaves a wave with too little in flight and too much per-row latency (dot ->
