@@ -80,6 +80,9 @@ def main():
         ctx.set_option("split_blocks_per_cu", min(args.blocks_per_cu, 16))
     if args.grid is not None:
         ctx.set_option("sweep_grid", args.grid)
+    for kv in os.environ.get("CIAO_OPTS", "").split(","):   # any other tuning knob: CIAO_OPTS=key=value,key=value
+        if "=" in kv:
+            ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
     # ---- synthetic problem, generated on the device, keyed by the GLOBAL (row, col): SURVEY.md section 8d ------------
     n_local, d = args.rows_per_gpu, args.d

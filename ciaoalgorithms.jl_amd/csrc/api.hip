@@ -753,6 +753,9 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
         ctx->split_max_rows = value;
     } else if (!strcmp(key, "chain_dbg_ptr")) {   // timing builds (tools/chain_stamps.py): device int64[24]
         ctx->chain_dbg = reinterpret_cast<long long *>((uintptr_t)value);
+    } else if (!strcmp(key, "small_i")) {
+        CIAO_REQUIRE(value == 0 || value == 8 || value == 16, "small_i must be 0, 8 or 16");
+        ctx->small_i = value;
     } else if (!strcmp(key, "split_all")) {
         ctx->split_all = value != 0;
     } else if (!strcmp(key, "split_blocks_per_cu")) {

@@ -42,6 +42,7 @@ struct ciao_ctx {
     int64_t sweep_blocks_per_cu = 0;   // 0 = choose from the row size (rows_launch.inc)
     int64_t sweep_multi = 1;           // short rows (<= 4 KiB): several rows per wave per iteration (rows_multi_kernel)
     int64_t split_max_rows = -1;       // batches up to this many rows run one workgroup per row (rows_split_kernel); -1 = automatic
+    int64_t small_i = 0;               // rows_small_kernel: elements per lane and iteration, 8 or 16 (0 = automatic)
     int64_t split_all = 0;             // tuning experiment: workgroup-per-row kernel for every mode and size
     int64_t split_blocks_per_cu = 0;   // its grid cap in blocks per CU (0 = automatic)
     int64_t sweep_grid = 0;            // testing: absolute grid override for the rows kernels (0 = automatic)

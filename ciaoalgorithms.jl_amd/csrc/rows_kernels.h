@@ -497,12 +497,12 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
 // private LDS area, Q lanes per row add up the row's d products and combine by shuffles, one of them evaluates the link function, and every element picks up its row's scalar again through LDS.  Accumulators
 // stay in registers per (lane, i); columns are combined once, at the end.  Covers GRAD, SAGA_INIT and FINITO_INIT.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int SMALL_I = 16;
-constexpr int SMALL_GE = WAVE * SMALL_I;   // elements of one wave-iteration
+// SMALL_I elements per lane and wave-iteration (8 or 16): the smaller group halves the registers and doubles the waves per CU
 
-template <typename T, int MODE>
+template <typename T, int MODE, int SMALL_I>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
 {
+    constexpr int SMALL_GE = WAVE * SMALL_I;   // elements of one wave-iteration
     static_assert(MODE == RM_GRAD || MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT, "contiguous full sweeps only");
     extern __shared__ __attribute__((aligned(16))) unsigned char small_raw[];
     const int lane = threadIdx.x & (WAVE - 1);

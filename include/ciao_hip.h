@@ -119,6 +119,7 @@ CIAO_API int32_t ciao_ctx_set_rccl(ciao_ctx *ctx, void *comm, const char *librcc
  *   "split_max_rows"       batches up to this size run one workgroup per row instead of one wave per row (-1 = 16384)
  *   "split_blocks_per_cu"  grid cap of that kernel (0 = automatic)
  *   "split_all"            experiment: that kernel for every mode and size (tools/tune_split.py)
+ *   "small_i"              rows_small_kernel (rows under 1 KiB): elements per lane and iteration, 8 or 16 (0 = automatic)
  *   "chain_no_dma", "svrg_cache_rowdots"                                                    chain kernel variants */
 CIAO_API int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value);
 /* Kernel timing for bench.py's roofline line: when enabled, every launch of the dominant streaming kernel of an entry
