@@ -890,3 +890,48 @@ def test_chain_row_length_boundaries(ctx, ciao, dtype, d):
     close(z, rz, dtype, scale=200, what=f"saga z d={d} ({ctx.last_kernel()})")
     close(table, rt, dtype, scale=200, what="saga table")
     ctx.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("small_i", [8, 16])
+@pytest.mark.parametrize("shape", [(333, 50), (97, 200), (1000, 7), (41, 255)])
+def test_small_row_kernel_group_sizes(ctx, ciao, dtype, small_i, shape):
+    """rows_small_kernel with 8 and 16 elements per lane (both exist for both types; the automatic choice uses one of each):
+    sweep, SAGA init and Finito init against the oracle, row counts that are not multiples of the rows per group."""
+    import torch
+    from oracle import oracle as O
+    N, d = shape
+    A, b, x0 = P.synthetic("logistic" if d == 200 else "ls", N, d, dtype, seed=N)
+    loss = "logistic" if d == 200 else "ls"
+    lam_f = 1.0 if loss == "logistic" else float(N)
+    op, dp = make(loss, A, b, lam_f, dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.02)
+    tdt = dev(x0).dtype
+    av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+    table = torch.empty((N, d), dtype=tdt, device="cuda")
+    ctx.set_option("small_i", small_i)
+    try:
+        ctx.full_gradient(dp, dev(x0), av)
+        rowb = d * np.dtype(dtype).itemsize
+        if rowb % 16 == 0 and rowb >= 1024:   # whole 16-byte chunks of at least 1 KiB: a workgroup per row instead
+            assert "rows_split_kernel" in ctx.last_kernel(), ctx.last_kernel()
+        else:
+            assert "rows_small_kernel" in ctx.last_kernel() and f"I{small_i}" in ctx.last_kernel(), ctx.last_kernel()
+        close(av, O.full_pass(op, x0), dtype, scale=8, what=f"sweep ({ctx.last_kernel()})")
+        gamma = 0.5 / N
+        ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
+        rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
+        close(table, rt, dtype, scale=8, what="saga_init table")
+        close(av, rav, dtype, scale=20, what="saga_init av")
+        Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1)
+        gam = (0.999 * N / Li).astype(dtype)
+        dgam = dev(gam)
+        hg = ctx.hat_gamma(dgam)
+        rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
+        ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
+        close(table, rt, dtype, scale=8, what="finito_init table")
+        close(av, rav, dtype, scale=50, what="finito_init av")
+        close(z, rz, dtype, scale=50, what="finito_init z")
+    finally:
+        ctx.set_option("small_i", 0)
+    ctx.synchronize()
