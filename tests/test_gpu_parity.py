@@ -935,3 +935,63 @@ def test_small_row_kernel_group_sizes(ctx, ciao, dtype, small_i, shape):
     finally:
         ctx.set_option("small_i", 0)
     ctx.synchronize()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# seeded random shapes: row counts, row lengths and row strides nobody picked by hand
+# ----------------------------------------------------------------------------------------------------------------------
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        N = int(rng.choice([1, 2, 3, 5, 17, 63, 64, 65, 130, 257, 600, 1500]))
+        d = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 1100), rng.integers(1100, 2600)]))
+        pad = int(rng.choice([0, 0, 0, 1, 2, 4, 7]))
+        dtype = [np.float64, np.float32][int(rng.integers(0, 2))]
+        loss = ["ls", "logistic"][int(rng.integers(0, 2))]
+        out.append((N, d, pad, dtype, loss))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_cases(48, 2024), ids=lambda c: f"N{c[0]}-d{c[1]}-pad{c[2]}-{'f64' if c[3] == np.float64 else 'f32'}-{c[4]}")
+def test_random_shapes(ctx, ciao, case):
+    """Sweep, both table inits, a Finito batch (batch-parallel) and a short SAGA chain on seeded random (N, d, row stride,
+    type, loss): every combination lands on some kernel, and that kernel agrees with the oracle."""
+    import torch
+    from oracle import oracle as O
+    N, d, pad, dtype, loss = case
+    A, b, x0 = P.synthetic(loss, N, d, dtype, seed=N * 7919 + d)
+    lam_f = float(N) if loss == "ls" else 1.0
+    op, dp = make(loss, A, b, lam_f, dtype, pad=pad)
+    og, dg = make_g("l1", dtype, d, lam=0.02)
+    tdt = dev(x0).dtype
+    av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+    table = torch.empty((N, d), dtype=tdt, device="cuda")
+    ctx.full_gradient(dp, dev(x0), av)
+    close(av, O.full_pass(op, x0), dtype, scale=8, what=f"sweep ({ctx.last_kernel()})")
+    gamma = 0.5 / max(lam_f, 1.0)
+    ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
+    rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
+    close(table, rt, dtype, scale=8, what=f"saga_init table ({ctx.last_kernel()})")
+    idx = ciao.IndexStream(N + d).rand_indices(N, 25)
+    ctx.saga_steps(dp, dg, gamma, False, idx, table, av, z)
+    O.saga_steps(op, og, dtype(gamma), False, idx, rt, rav, rz)
+    close(z, rz, dtype, scale=200, what=f"saga z ({ctx.last_kernel()})")
+    Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1) + 1e-12
+    gam = (0.999 * N / Li).astype(dtype)
+    dgam = dev(gam)
+    hg = ctx.hat_gamma(dgam)
+    rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
+    ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
+    close(table, rt, dtype, scale=8, what=f"finito_init table ({ctx.last_kernel()})")
+    r = min(N, 9)
+    batch = ciao.IndexStream(d).sample_without_replacement(N, r)
+    ctx.set_option("chain_max_batch", 0)
+    try:
+        ctx.finito_steps(dp, dg, dgam, hg, np.array([0, r], np.int64), batch, table, av, z)
+    finally:
+        ctx.set_option("chain_max_batch", -1)
+    O.finito_steps(op, og, gam, rhg, [batch], rt, rav, rz)
+    close(table, rt, dtype, scale=50, what=f"finito batch table ({ctx.last_kernel()})")
+    close(z, rz, dtype, scale=300, what="finito batch z")
+    ctx.synchronize()
