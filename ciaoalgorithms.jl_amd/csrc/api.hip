@@ -313,6 +313,8 @@ static bool batch_as_chain(const ciao_ctx *ctx, const ciao_problem *p, int64_t r
         const int64_t rowb = p->d * (int64_t)sizeof(T);
         if (rowb % 4096 == 0 && rowb <= 32768 && rowb != 12288 && rowb != 20480 && rowb != 24576 && rowb != 28672)
             lim = rowb == 4096 ? 14 : (rowb == 8192 ? 12 : (rowb == 16384 ? 8 : 4));
+        else if (rowb < 1024)
+            lim = 28;   // rows under 1 KiB: chain steps 0.3-0.5 us against ~14 us per batch on the scalar generic kernel
         else
             lim = 14;
     }
