@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
 // ------------------------------------------------------------------------------------------------------------------
 // SMALL_I elements per lane and wave-iteration (8 or 16): the smaller group halves the registers and doubles the waves per CU
 
-template <typename T, int MODE, int SMALL_I>
+template <typename T, int MODE, int SMALL_I, bool PADDED>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
 {
     constexpr int SMALL_GE = WAVE * SMALL_I;   // elements of one wave-iteration
@@ -524,15 +524,21 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
     const int Q = 1 << qs;
     const int myrow = lane >> qs, myq = lane & (Q - 1);
 
+    // PADDED (row stride ld > d): element (r, c) of the group sits r*ld + c elements after the group's first; with
+    // ld == d that is the element's own number e, the loads are perfectly contiguous and no offset table is kept (its 16
+    // registers cost the fp64 variant half its bandwidth: 4.5 -> 2.4 TB/s)
+    const int ld = PADDED ? (int)a.ld : d;
     bool live[SMALL_I];
-    int rrow[SMALL_I];
+    int rrow[SMALL_I], aoff[PADDED ? SMALL_I : 1];
     T xcol[SMALL_I], acc[SMALL_I];
 #pragma unroll
     for (int i = 0; i < SMALL_I; ++i) {
         const int e = lane + WAVE * i;
         live[i] = e < used;
         rrow[i] = live[i] ? e / d : 0;
-        xcol[i] = live[i] ? a.x1[e - rrow[i] * d] : T(0);
+        const int c = live[i] ? e - rrow[i] * d : 0;
+        if (PADDED) aoff[i] = rrow[i] * ld + c;
+        xcol[i] = live[i] ? a.x1[c] : T(0);
         acc[i] = T(0);
     }
     T ex = T(0);
@@ -546,22 +552,20 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
     auto fetch = [&](T(&v)[SMALL_I], T &bi, T &gi, int64_t g) {
         const int64_t left = a.nrows - g * G;
         const int nrg = left < G ? (int)left : G;
-        const int usedg = nrg * d;
         const int64_t rb = a.row0 + g * G;
-        const T *gp = a.A ? a.A + rb * (int64_t)d : nullptr;
-        // branch-free: dead elements read the group's last live element and are zeroed by a select (a predicated load per
+        const T *gp = a.A ? a.A + rb * (int64_t)ld : nullptr;
+        // branch-free: dead elements read the group's first element and are zeroed by a select (a predicated load per
         // element costs an exec-mask branch each; the loop was instruction-bound at ~1500 instructions per group)
-        const int lastg = usedg - 1;
 #pragma unroll
         for (int i = 0; i < SMALL_I; ++i) {
-            const int e = lane + WAVE * i;
-            const int ec = e < usedg ? e : lastg;
+            const bool on = live[i] && rrow[i] < nrg;
+            const int ec = on ? (PADDED ? aoff[i] : lane + WAVE * i) : 0;
 #ifdef CIAO_SMALL_PLAIN
             const T val = gp ? gp[ec] : T(0);
 #else
             const T val = gp ? __builtin_nontemporal_load(&gp[ec]) : T(0);
 #endif
-            v[i] = e < usedg ? val : T(0);
+            v[i] = on ? val : T(0);
         }
         // volatile: hipcc otherwise sinks these two loads down to their use, behind the prefetch
         bi = (a.b && myrow < nrg) ? *reinterpret_cast<const volatile T *>(a.b + rb + myrow) : T(0);
@@ -575,7 +579,6 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
         const int64_t row_b = a.row0 + g * G;
         const int64_t left = a.nrows - g * G;
         const int nr = left < G ? (int)left : G;
-        const int usedg = nr * d;
 #pragma unroll
         for (int i = 0; i < SMALL_I; ++i) prod[lane + WAVE * i] = av[i] * xcol[i];   // unconditional: dead slots are never read
         // the next group's elements travel while this one is reduced (one group in flight per wave is too little to cover
@@ -619,7 +622,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
                 acc[i] += (s1s[rrow[i]] * s2) * av[i];               // coef() * a, as the wave-per-row kernels
                 continue;
             }
-            if (!(live[i] && e < usedg)) continue;
+            if (!(live[i] && rrow[i] < nr)) continue;
             const T s1 = s1s[rrow[i]];
             if (MODE == RM_SAGA_INIT) {
                 const T gv = (av[i] * s1) * s2;                       // GradCoef::elem
