@@ -305,7 +305,7 @@ template <typename T>
 static bool batch_as_chain(const ciao_ctx *ctx, const ciao_problem *p, int64_t r)
 {
     if (ctx->hook) return false;                       // sharded batches need the all-reduce between kernels
-    if (p->d > 16 * CHAIN_NT) return false;            // the chain keeps d/256 elements per thread in registers
+    if (p->d > 32 * CHAIN_NT) return false;            // the chain keeps d/256 elements per thread in registers
     int64_t lim = ctx->chain_max_batch;
     if (lim < 0) {
         // whole-4-KiB rows: rows_split_kernel batches cost ~6.5 us up to r = 64, LDS-DMA chain steps 0.47 / 0.55 / 0.8 / 1.5 us at

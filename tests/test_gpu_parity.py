@@ -858,10 +858,10 @@ def test_row_length_boundaries(ctx, ciao, dtype, d):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("d", [255, 257, 511, 513, 1023, 1025, 2047, 2049, 3071, 4095, 4096, 4097])
+@pytest.mark.parametrize("d", [255, 257, 511, 513, 1023, 1025, 2047, 2049, 3071, 4095, 4096, 4097, 6000, 8192, 8193])
 def test_chain_row_length_boundaries(ctx, ciao, dtype, d):
     """SVRG inner cycle and SAGA steps on row lengths around the chain kernels' thresholds (LDS-DMA exact / masked, register
-    ring E = 1 / 4 / 8 / 16, and the refusal beyond 4096 elements)."""
+    ring E = 1 / 4 / 8 / 16 / 32, and the refusal beyond 8192 elements)."""
     import torch
     from oracle import oracle as O
     from ciaoalgorithms_jl_amd._lib import CiaoError
@@ -875,7 +875,7 @@ def test_chain_row_length_boundaries(ctx, ciao, dtype, d):
     rav, rz, rzf, rw = O.svrg_init(op, x0)
     idx = ciao.IndexStream(d).rand_indices(N, 60)
     gamma = 0.05 / N
-    if d > 4096:
+    if d > 8192:
         with pytest.raises(CiaoError, match="sequential chain kernels cover"):
             ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
         return
