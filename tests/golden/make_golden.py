@@ -63,16 +63,32 @@ def run_case(name, loss, A, b, lam_f, L, lam_g, x0, seed):
 
 
 def main():
-    A, y, L, lam, x0, x_star = P.logistic_fixture(np.float64)
-    run_case("logistic_l1_reference_fixture_f64", "logistic", A, y, 1.0, L, lam, x0, seed=1)
-    A, b, L, lam, x0, x_star, f_star = P.lasso_known_answer(dtype=np.float64)
-    run_case("lasso_known_answer_f64", "ls", A, b, float(A.shape[0]), L, lam, x0, seed=2)
-    A, b, L, lam, x0, x_star, f_star = P.lasso_known_answer(dtype=np.float32)
-    run_case("lasso_known_answer_f32", "ls", A, b, float(A.shape[0]), L, lam, x0, seed=2)
-    # a BASELINE-shaped (d = 1024) instance, small N: exercises the fast sweep and the LDS-DMA chains
-    A, b, x = P.synthetic("ls", 16, 1024, np.float64, seed=3)
-    L = 16.0 * np.sum(A * A, axis=1)
-    run_case("lasso_d1024_f64", "ls", A, b, 16.0, L, 0.01, np.zeros(1024), seed=3)
+    only = set(sys.argv[1:])   # optional: names of the cases to (re)generate; default all
+    want = lambda name: not only or name in only  # noqa: E731
+    if want("logistic_l1_reference_fixture_f64"):
+        A, y, L, lam, x0, x_star = P.logistic_fixture(np.float64)
+        run_case("logistic_l1_reference_fixture_f64", "logistic", A, y, 1.0, L, lam, x0, seed=1)
+    if want("lasso_known_answer_f64"):
+        A, b, L, lam, x0, x_star, f_star = P.lasso_known_answer(dtype=np.float64)
+        run_case("lasso_known_answer_f64", "ls", A, b, float(A.shape[0]), L, lam, x0, seed=2)
+    if want("lasso_known_answer_f32"):
+        A, b, L, lam, x0, x_star, f_star = P.lasso_known_answer(dtype=np.float32)
+        run_case("lasso_known_answer_f32", "ls", A, b, float(A.shape[0]), L, lam, x0, seed=2)
+    if want("lasso_d1024_f64"):
+        # a BASELINE-shaped (d = 1024) instance, small N: exercises the fast sweep and the LDS-DMA chains
+        A, b, x = P.synthetic("ls", 16, 1024, np.float64, seed=3)
+        L = 16.0 * np.sum(A * A, axis=1)
+        run_case("lasso_d1024_f64", "ls", A, b, 16.0, L, 0.01, np.zeros(1024), seed=3)
+    if want("lasso_d1000_f64"):
+        # a row length outside the wave-per-row shapes: the masked workgroup-per-row kernel and the masked LDS-DMA chains
+        A, b, x = P.synthetic("ls", 12, 1000, np.float64, seed=4)
+        L = 12.0 * np.sum(A * A, axis=1)
+        run_case("lasso_d1000_f64", "ls", A, b, 12.0, L, 0.01, np.zeros(1000), seed=4)
+    if want("logistic_d50_f32"):
+        # rows of 200 bytes: several rows per wave in the sweeps, tiny-row chains
+        A, y, x = P.synthetic("logistic", 40, 50, np.float32, seed=5)
+        L = (0.25 * np.sum(A.astype(np.float64) ** 2, axis=1)).astype(np.float32)
+        run_case("logistic_d50_f32", "logistic", A, y, 1.0, L, 0.01, np.zeros(50, np.float32), seed=5)
 
 
 if __name__ == "__main__":
