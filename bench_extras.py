@@ -107,6 +107,25 @@ def run(ctx, dev, quick=False):
     del F, table
     torch.cuda.empty_cache()
 
+    # ---- the sweep on row lengths outside the wave-per-row shapes: workgroup per row (masked), several rows per wave ------------
+    for d_odd, tdt, tag in ((1000, torch.float64, "f64"), (50, torch.float64, "f64"), (3000, torch.float32, "f32")):
+        Nn = (2_000_000 if d_odd >= 1000 else 8_000_000) // scale
+        Fo = _problem(ctx, dev, Nn, d_odd, tdt, False)
+        xo = torch.zeros(d_odd, dtype=tdt, device=dev)
+        avo = torch.empty_like(xo)
+        ctx.full_gradient(Fo, xo, avo)
+        ctx.timing_enable(True)
+        ctx.timing_read()
+        for _ in range(5):
+            ctx.full_gradient(Fo, xo, avo)
+        ms, n = ctx.timing_read()
+        ctx.timing_enable(False)
+        es = 8 if tdt == torch.float64 else 4
+        out[f"sweep_{tag}_d{d_odd}"] = {"kernel_ms": ms / max(n, 1), "alg_GBps": Nn * (d_odd * es + es) / (ms / max(n, 1) * 1e-3) / 1e9, "N": Nn,
+                                        "kernel": ctx.last_kernel()}
+        del Fo
+        torch.cuda.empty_cache()
+
     # ---- adaptive Finito steps, Lasso d=1024 fp64 ------------------------------------------------------
     N, d = 200_000 // scale, 1024
     F = _problem(ctx, dev, N, d, torch.float64, False)
