@@ -55,7 +55,7 @@ def run(ctx, dev, quick=False):
     # one full SVRG epoch with m = N (inner chain + tail + sweep)
     if not quick:
         idxN = ctx._idx(st.rand_indices(N, N))
-        t = _timed(ctx, lambda: ctx.svrg_iterate(F, g, gamma, idxN, False, av, z, zf, w))
+        t = _timed(ctx, lambda: ctx.svrg_iterate(F, g, gamma, idxN, False, av, z, zf, w, reuse_rowdots=True))
         out["svrg_epoch_m=N_f64_N1M_d1024"] = {"epochs_per_s": 1.0 / t, "seconds": t}
     del F, idx
     torch.cuda.empty_cache()

@@ -10,7 +10,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libciao_hip.so")
+# CIAO_HIP_LIB selects another build of the same sources: the experiment builds of tools/exp_build.sh (timing macros), which
+# live under build/<name>/ and never replace the product library.  ciao_build_flags() tells the two apart.
+LIB_PATH = os.environ.get("CIAO_HIP_LIB") or os.path.join(_HERE, "libciao_hip.so")
+ABI_VERSION = 2
 
 OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_ALLOC, ERR_HOOK = 0, -1, -2, -3, -4, -5
 F32, F64 = 0, 1
@@ -52,12 +55,14 @@ _PP, _GP, _SP = C.POINTER(Problem), C.POINTER(ProxDesc), C.POINTER(SepQuad)
 SIGNATURES = {
     "ciao_abi_version": (_i32, []),
     "ciao_last_error": (C.c_char_p, []),
+    "ciao_build_flags": (C.c_char_p, []),
     "ciao_ctx_create": (_i32, [_i32, _vp, C.POINTER(_vp)]),
     "ciao_ctx_destroy": (_i32, [_vp]),
     "ciao_ctx_set_stream": (_i32, [_vp, _vp]),
     "ciao_ctx_synchronize": (_i32, [_vp]),
     "ciao_ctx_set_allreduce": (_i32, [_vp, ALLREDUCE_FN, _vp]),
     "ciao_ctx_set_rccl": (_i32, [_vp, _vp, C.c_char_p]),
+    "ciao_ctx_set_monitor": (_i32, [_vp, _GP, _vp]),
     "ciao_ctx_set_option": (_i32, [_vp, C.c_char_p, _i64]),
     "ciao_ctx_timing_enable": (_i32, [_vp, _i32]),
     "ciao_ctx_timing_read": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i64)]),
@@ -69,7 +74,7 @@ SIGNATURES = {
     "ciao_objective": (_i32, [_vp, _PP, _GP, _vp, C.POINTER(_f64)]),
     "ciao_svrg_init": (_i32, [_vp, _PP, _vp, _vp, _vp, _vp, _vp]),
     "ciao_svrg_inner": (_i32, [_vp, _PP, _GP, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "ciao_svrg_iterate": (_i32, [_vp, _PP, _GP, _f64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "ciao_svrg_iterate": (_i32, [_vp, _PP, _GP, _f64, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ciao_saga_init": (_i32, [_vp, _PP, _GP, _f64, _vp, _vp, _vp, _vp]),
     "ciao_saga_steps": (_i32, [_vp, _PP, _GP, _f64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "ciao_hat_gamma": (_i32, [_vp, _i32, _i64, _vp, C.POINTER(_f64)]),
@@ -104,6 +109,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.ciao_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {lib.ciao_abi_version()}, this binding needs {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 

@@ -180,6 +180,29 @@ static int32_t prox_launch(ciao_ctx *ctx, int64_t d, const ciao_prox_desc *g, co
     return CIAO_OK;
 }
 
+// ---- objective monitor (ciao_ctx_set_monitor) ------------------------------------------------------
+// While a monitor is set, every FULL pass over the rows (mode GRAD, no index list) also sums the values f_i(x) the
+// reference's gradient! returns and discards: they ride on the same sweep as the extra reduced scalar (all-reduced with the
+// d-vector on a row-sharded problem), the epilogue leaves (1/N) sum_i f_i(x) in obj[1], and one small launch adds g(x).
+template <typename T>
+static void monitor_begin(const ciao_ctx *ctx, const ciao_problem *p, RowsArgs<T> &a, Epilogue<T> &e)
+{
+    if (!ctx->monitor) return;
+    a.want_fval = 1;
+    e.obj_out = ctx->monitor;
+    e.obj_scale = 1.0 / (double)p->N_total;
+}
+
+template <typename T>
+static int32_t monitor_end(ciao_ctx *ctx, int64_t d, const void *x)
+{
+    if (!ctx->monitor) return CIAO_OK;
+    hipLaunchKernelGGL((gvalue_kernel<T>), dim3(1), dim3(256), 0, ctx->stream, d, make_prox<T>(ctx->monitor_has_g ? &ctx->monitor_g : nullptr),
+                       (const T *)x, ctx->monitor + 2, ctx->monitor);
+    CIAO_HIP(hipGetLastError());
+    return CIAO_OK;
+}
+
 // ---- typed implementations -------------------------------------------------------------------------------------------
 template <typename T>
 static int32_t full_gradient_t(ciao_ctx *ctx, const ciao_problem *p, const void *x, void *av, bool keep_rowdots = false)
@@ -197,7 +220,9 @@ static int32_t full_gradient_t(ciao_ctx *ctx, const ciao_problem *p, const void 
     Epilogue<T> e = epi_zero<T>();
     e.c_sum = a.invN;   // av = sum / N
     e.av_out = (T *)av;
-    return launch_rows<T>(ctx, RM_GRAD, a, e);
+    monitor_begin<T>(ctx, p, a, e);
+    CIAO_TRY(launch_rows<T>(ctx, RM_GRAD, a, e));
+    return monitor_end<T>(ctx, p->d, x);
 }
 
 template <typename T>
@@ -215,7 +240,13 @@ static int32_t proxgrad_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
     e.p1 = T(1);
     e.pw = (const T *)x;
     e.g = make_prox<T>(g);
-    return launch_rows<T>(ctx, RM_GRAD, a, e);
+    if (y == x && ctx->monitor) {   // the monitor reads x after the sweep: keep a copy when the step overwrites it
+        CIAO_TRY(ensure(ctx, &ctx->monx, &ctx->monx_bytes, (size_t)p->d * sizeof(T)));
+        CIAO_HIP(hipMemcpyAsync(ctx->monx, x, (size_t)p->d * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    monitor_begin<T>(ctx, p, a, e);
+    CIAO_TRY(launch_rows<T>(ctx, RM_GRAD, a, e));
+    return monitor_end<T>(ctx, p->d, (y == x && ctx->monitor) ? ctx->monx : x);
 }
 
 template <typename T>
@@ -240,9 +271,9 @@ static int32_t svrg_inner_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_pro
 
 template <typename T>
 static int32_t svrg_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
-                              const int64_t *idx, int32_t plus, void *av, void *z, void *z_full, void *w)
+                              const int64_t *idx, int32_t plus, int32_t reuse_rowdots, void *av, void *z, void *z_full, void *w)
 {
-    CIAO_TRY(svrg_inner_t<T>(ctx, p, g, gamma, m, idx, av, z, z_full, w, true));
+    CIAO_TRY(svrg_inner_t<T>(ctx, p, g, gamma, m, idx, av, z, z_full, w, reuse_rowdots != 0));
     ctx->rowdot_A = nullptr;   // z_full is about to change
     hipLaunchKernelGGL((svrg_tail_kernel<T>), dim3((unsigned)((p->d + 255) / 256)), dim3(256), 0, ctx->stream, p->d, (T)m,
                        (int)plus, (T *)z, (T *)z_full, (T *)w);
@@ -380,7 +411,9 @@ static int32_t lfinito_init_t(ciao_ctx *ctx, const ciao_problem *p, double hat_g
     e.c_u = T(1);
     e.u = (const T *)x0;
     e.av_out = (T *)av;
+    monitor_begin<T>(ctx, p, a, e);
     CIAO_TRY(launch_rows<T>(ctx, RM_GRAD, a, e));
+    CIAO_TRY(monitor_end<T>(ctx, p->d, x0));
     const size_t bytes = (size_t)p->d * sizeof(T);
     CIAO_HIP(hipMemcpyAsync(z, av, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     CIAO_HIP(hipMemcpyAsync(z_full, av, bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -403,7 +436,9 @@ static int32_t lfinito_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const cia
         e.c_u = T(1);
         e.u = (const T *)z_full;
         e.av_out = (T *)av;
+        monitor_begin<T>(ctx, p, a, e);
         CIAO_TRY(launch_rows<T>(ctx, RM_GRAD, a, e));
+        CIAO_TRY(monitor_end<T>(ctx, p->d, z_full));
     }
     int64_t t = 0;
     bool z_ready = false;
@@ -595,7 +630,8 @@ static int32_t objective_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox
     a.x1 = (const T *)x;
     a.want_fval = 1;
     CIAO_TRY(launch_rows_raw<T>(ctx, RM_GRAD, a));
-    hipLaunchKernelGGL((gvalue_kernel<T>), dim3(1), dim3(256), 0, ctx->stream, p->d, make_prox<T>(g), (const T *)x, ctx->scal);
+    hipLaunchKernelGGL((gvalue_kernel<T>), dim3(1), dim3(256), 0, ctx->stream, p->d, make_prox<T>(g), (const T *)x, ctx->scal,
+                       (double *)nullptr);
     CIAO_HIP(hipGetLastError());
     T fsum;
     double gval;
@@ -618,6 +654,11 @@ int32_t ciao_abi_version(void) { return CIAO_ABI_VERSION; }
 
 const char *ciao_last_error(void) { return g_err; }
 
+#ifndef CIAO_BUILD_FLAGS
+#define CIAO_BUILD_FLAGS ""
+#endif
+const char *ciao_build_flags(void) { return CIAO_BUILD_FLAGS; }
+
 int32_t ciao_ctx_create(int32_t device, void *stream, ciao_ctx **out)
 {
     CIAO_REQUIRE(out, "out is NULL");
@@ -625,7 +666,7 @@ int32_t ciao_ctx_create(int32_t device, void *stream, ciao_ctx **out)
     int ndev = 0;
     CIAO_HIP(hipGetDeviceCount(&ndev));
     CIAO_REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
-    CIAO_HIP(hipSetDevice(device));
+    DeviceGuard dg(device);   // allocate on `device`, leave the caller's current device as it was
     hipDeviceProp_t prop;
     CIAO_HIP(hipGetDeviceProperties(&prop, device));
     ciao_ctx *ctx = new (std::nothrow) ciao_ctx();
@@ -650,11 +691,13 @@ int32_t ciao_ctx_create(int32_t device, void *stream, ciao_ctx **out)
 int32_t ciao_ctx_destroy(ciao_ctx *ctx)
 {
     if (!ctx) return CIAO_OK;
+    DeviceGuard dg(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->partial) (void)hipFree(ctx->partial);
     if (ctx->pextra) (void)hipFree(ctx->pextra);
     if (ctx->sumbuf) (void)hipFree(ctx->sumbuf);
     if (ctx->rowdot) (void)hipFree(ctx->rowdot);
+    if (ctx->monx) (void)hipFree(ctx->monx);
     if (ctx->scal) (void)hipFree(ctx->scal);
     if (ctx->errflag) (void)hipFree(ctx->errflag);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -664,6 +707,7 @@ int32_t ciao_ctx_destroy(ciao_ctx *ctx)
 
 int32_t ciao_ctx_set_stream(ciao_ctx *ctx, void *stream)
 {
+    CIAO_ENTER(ctx);
     CIAO_REQUIRE(ctx, "ctx is NULL");
     ctx->stream = (hipStream_t)stream;
     return CIAO_OK;
@@ -671,6 +715,7 @@ int32_t ciao_ctx_set_stream(ciao_ctx *ctx, void *stream)
 
 int32_t ciao_ctx_synchronize(ciao_ctx *ctx)
 {
+    CIAO_ENTER(ctx);
     CIAO_REQUIRE(ctx, "ctx is NULL");
     int flag = 0;
     CIAO_HIP(hipMemcpyAsync(&flag, ctx->errflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -690,6 +735,7 @@ int32_t ciao_ctx_synchronize(ciao_ctx *ctx)
 
 int32_t ciao_ctx_set_allreduce(ciao_ctx *ctx, ciao_allreduce_fn fn, void *user)
 {
+    CIAO_ENTER(ctx);
     CIAO_REQUIRE(ctx, "ctx is NULL");
     ctx->hook = fn;
     ctx->hook_user = user;
@@ -711,6 +757,7 @@ static int32_t rccl_hook(void *user, void *buf, int64_t count, int32_t dtype, vo
 
 int32_t ciao_ctx_set_rccl(ciao_ctx *ctx, void *comm, const char *librccl_path)
 {
+    CIAO_ENTER(ctx);
     CIAO_REQUIRE(ctx, "ctx is NULL");
     if (!comm) {
         if (ctx->hook == rccl_hook) {
@@ -742,8 +789,19 @@ int32_t ciao_ctx_set_rccl(ciao_ctx *ctx, void *comm, const char *librccl_path)
     return CIAO_OK;
 }
 
+int32_t ciao_ctx_set_monitor(ciao_ctx *ctx, const ciao_prox_desc *g, double *obj_dev)
+{
+    CIAO_ENTER(ctx);
+    CIAO_TRY(check_prox(g));
+    ctx->monitor = obj_dev;
+    ctx->monitor_has_g = (g != nullptr);
+    if (g) ctx->monitor_g = *g;
+    return CIAO_OK;
+}
+
 int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
 {
+    CIAO_ENTER(ctx);
     CIAO_REQUIRE(ctx && key, "ctx or key is NULL");
     if (!strcmp(key, "sweep_blocks_per_cu")) {
         CIAO_REQUIRE(value >= 0 && value <= 16, "sweep_blocks_per_cu must be in 0..16 (0 = automatic)");
@@ -787,6 +845,7 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
 
 int32_t ciao_ctx_timing_enable(ciao_ctx *ctx, int32_t enable)
 {
+    CIAO_ENTER(ctx);
     CIAO_REQUIRE(ctx, "ctx is NULL");
     ctx->timing = enable != 0;
     return CIAO_OK;
@@ -794,6 +853,7 @@ int32_t ciao_ctx_timing_enable(ciao_ctx *ctx, int32_t enable)
 
 int32_t ciao_ctx_timing_read(ciao_ctx *ctx, double *total_ms_host, int64_t *launches_host)
 {
+    CIAO_ENTER(ctx);
     CIAO_REQUIRE(ctx && total_ms_host && launches_host, "NULL argument");
     CIAO_HIP(hipStreamSynchronize(ctx->stream));
     double tot = 0.0;
@@ -812,6 +872,7 @@ const char *ciao_ctx_last_kernel(ciao_ctx *ctx) { return ctx ? ctx->last_kernel.
 
 int32_t ciao_gradient(ciao_ctx *ctx, const ciao_problem *p, int64_t i, const void *x, void *y, void *fval)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_REQUIRE(x && y, "x or y is NULL");
     CIAO_REQUIRE(i >= 0 && i < p->N, "sample index %lld outside [0, %lld)", (long long)i, (long long)p->N);
@@ -829,6 +890,7 @@ int32_t ciao_gradient(ciao_ctx *ctx, const ciao_problem *p, int64_t i, const voi
 
 int32_t ciao_prox(ciao_ctx *ctx, int32_t dtype, int64_t d, const ciao_prox_desc *g, const void *x, double gamma, void *y)
 {
+    CIAO_ENTER(ctx);
     CIAO_REQUIRE(ctx, "ctx is NULL");
     ctx->rowdot_A = nullptr;
     CIAO_REQUIRE(dtype == CIAO_F32 || dtype == CIAO_F64, "bad dtype %d", dtype);
@@ -841,6 +903,7 @@ int32_t ciao_prox(ciao_ctx *ctx, int32_t dtype, int64_t d, const ciao_prox_desc 
 
 int32_t ciao_full_gradient(ciao_ctx *ctx, const ciao_problem *p, const void *x, void *av)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_REQUIRE(x && av, "x or av is NULL");
     return DISPATCH(p->dtype, full_gradient_t, ctx, p, x, av);
@@ -849,6 +912,7 @@ int32_t ciao_full_gradient(ciao_ctx *ctx, const ciao_problem *p, const void *x, 
 int32_t ciao_proxgrad_step(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, const void *x,
                            void *av, void *y)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(x && av && y, "x, av or y is NULL");
@@ -858,6 +922,7 @@ int32_t ciao_proxgrad_step(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox
 
 int32_t ciao_objective(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *x, double *obj_host)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(x && obj_host, "x or obj_host is NULL");
@@ -866,6 +931,7 @@ int32_t ciao_objective(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_des
 
 int32_t ciao_svrg_init(ciao_ctx *ctx, const ciao_problem *p, const void *x0, void *av, void *z, void *z_full, void *w)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_REQUIRE(x0 && av && z && z_full && w, "NULL state vector");
     const size_t bytes = (size_t)p->d * (p->dtype == CIAO_F64 ? 8 : 4);
@@ -880,9 +946,10 @@ int32_t ciao_svrg_init(ciao_ctx *ctx, const ciao_problem *p, const void *x0, voi
 int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
                         const int64_t *idx, const void *av, void *z, const void *z_full, void *w)
 {
-    const void *keep = ctx ? ctx->rowdot_A : nullptr;
+    CIAO_ENTER(ctx);
+    const void *keep = ctx->rowdot_A;
     CIAO_TRY(check_problem(ctx, p));
-    ctx->rowdot_A = keep;   // z_full is read-only here
+    ctx->rowdot_A = keep;   // z_full is read-only here: a following ciao_svrg_iterate may still reuse the row dots
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(m >= 0 && (m == 0 || idx), "m < 0 or idx is NULL");
     CIAO_REQUIRE(m == 0 || p->N > 0, "cannot sample from an empty problem");
@@ -893,23 +960,27 @@ int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_de
 }
 
 int32_t ciao_svrg_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
-                          const int64_t *idx, int32_t plus, void *av, void *z, void *z_full, void *w)
+                          const int64_t *idx, int32_t plus, int32_t reuse_rowdots, void *av, void *z, void *z_full, void *w)
 {
-    const void *keep = ctx ? ctx->rowdot_A : nullptr;
+    CIAO_ENTER(ctx);
+    const void *keep = ctx->rowdot_A;
     CIAO_TRY(check_problem(ctx, p));
-    ctx->rowdot_A = keep;   // valid iff the previous call on this ctx was svrg_init / svrg_iterate / svrg_inner
+    // the a_i'z_full of the last full pass are used only when the CALLER vouches that A and z_full still hold what that
+    // pass read (reuse_rowdots) AND the previous call on this ctx was svrg_init / svrg_iterate / svrg_inner on these buffers
+    ctx->rowdot_A = reuse_rowdots ? keep : nullptr;
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(m >= 1 && idx, "m < 1 or idx is NULL");
     CIAO_REQUIRE(p->N > 0, "cannot sample from an empty problem");
     CIAO_REQUIRE(av && z && z_full && w, "NULL state vector");
     CIAO_REQUIRE(gamma > 0, "gamma must be > 0");
     CIAO_REQUIRE(!ctx->hook, "the SVRG inner cycle is a sequential chain: replicas only, not valid on a row-sharded problem");
-    return DISPATCH(p->dtype, svrg_iterate_t, ctx, p, g, gamma, m, idx, plus, av, z, z_full, w);
+    return DISPATCH(p->dtype, svrg_iterate_t, ctx, p, g, gamma, m, idx, plus, reuse_rowdots, av, z, z_full, w);
 }
 
 int32_t ciao_saga_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, const void *x0,
                        void *table, void *av, void *z)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(x0 && av && z && (table || p->N == 0), "NULL state vector / table");
@@ -920,6 +991,7 @@ int32_t ciao_saga_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_des
 int32_t ciao_saga_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int32_t sag,
                         int64_t nsteps, const int64_t *idx, void *table, void *av, void *z)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(nsteps >= 0 && (nsteps == 0 || idx), "nsteps < 0 or idx is NULL");
@@ -932,6 +1004,7 @@ int32_t ciao_saga_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_de
 
 int32_t ciao_hat_gamma(ciao_ctx *ctx, int32_t dtype, int64_t N, const void *gam, double *hat_gamma_host)
 {
+    CIAO_ENTER(ctx);
     CIAO_REQUIRE(ctx && hat_gamma_host, "ctx or output is NULL");
     CIAO_REQUIRE(dtype == CIAO_F32 || dtype == CIAO_F64, "bad dtype %d", dtype);
     CIAO_REQUIRE(N >= 0 && (N == 0 || gam), "N < 0 or gam is NULL");
@@ -964,6 +1037,7 @@ int32_t ciao_hat_gamma(ciao_ctx *ctx, int32_t dtype, int64_t N, const void *gam,
 int32_t ciao_finito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
                          const void *x0, void *table, void *av, void *z)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(x0 && av && z && ((table && gam) || p->N == 0), "NULL state vector / table / gam");
@@ -974,6 +1048,7 @@ int32_t ciao_finito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_d
 int32_t ciao_finito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
                           int64_t nit, const int64_t *bptr_host, const int64_t *bidx, void *table, void *av, void *z)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(nit >= 0 && (nit == 0 || (bptr_host && (bidx || bptr_host[nit] == bptr_host[0]))), "nit < 0 or NULL batch arrays");
@@ -986,6 +1061,7 @@ int32_t ciao_finito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
 int32_t ciao_lfinito_init(ciao_ctx *ctx, const ciao_problem *p, double hat_gamma, const void *x0, void *av, void *z,
                           void *z_full)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_REQUIRE(x0 && av && z && z_full, "NULL state vector");
     CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
@@ -995,6 +1071,7 @@ int32_t ciao_lfinito_init(ciao_ctx *ctx, const ciao_problem *p, double hat_gamma
 int32_t ciao_lfinito_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
                              int64_t nb, const int64_t *bptr_host, const int64_t *bidx, void *av, void *z, void *z_full)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(nb >= 0 && (nb == 0 || (bptr_host && (bidx || bptr_host[nb] == bptr_host[0]))), "nb < 0 or NULL batch arrays");
@@ -1006,6 +1083,7 @@ int32_t ciao_lfinito_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_pr
 int32_t ciao_afinito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha, const void *x0,
                           void *table, void *meta, void *av, void *z, void *hat_gamma_dev)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(x0 && av && z && hat_gamma_dev && ((table && meta) || p->N == 0), "NULL state vector / table / meta");
@@ -1020,6 +1098,7 @@ int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox
                            int64_t nsteps, const int64_t *idx, void *table, void *meta, void *av, void *z, void *hat_gamma_dev,
                            int64_t *done_host, int64_t *trials_host)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(nsteps >= 0 && (nsteps == 0 || idx), "nsteps < 0 or idx is NULL");
@@ -1039,6 +1118,7 @@ int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox
 int32_t ciao_proshi_init(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_desc *g, const void *gam, const void *x0,
                          void *table, void *av, void *z, void *hat_gamma_dev)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_sepquad(ctx, f));
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(x0 && av && z && hat_gamma_dev && ((table && gam) || f->N == 0), "NULL state vector / table / gam");
@@ -1048,6 +1128,7 @@ int32_t ciao_proshi_init(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_d
 int32_t ciao_proshi_steps(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_desc *g, const void *gam, double hat_gamma,
                           int64_t nit, const int64_t *bptr_host, const int64_t *bidx, void *table, void *av, void *z)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_sepquad(ctx, f));
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(nit >= 0 && (nit == 0 || (bptr_host && (bidx || bptr_host[nit] == bptr_host[0]))), "nit < 0 or NULL batch arrays");
@@ -1058,6 +1139,7 @@ int32_t ciao_proshi_steps(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_
 
 int32_t ciao_proshi_solution(ciao_ctx *ctx, const ciao_sepquad *f, const void *gam, const void *z, void *table)
 {
+    CIAO_ENTER(ctx);
     CIAO_TRY(check_sepquad(ctx, f));
     CIAO_REQUIRE((table && gam && z) || f->N == 0, "NULL argument");
     if (f->N == 0) return CIAO_OK;
@@ -1076,6 +1158,7 @@ int32_t ciao_proshi_solution(ciao_ctx *ctx, const ciao_sepquad *f, const void *g
 int32_t ciao_synth_normal(ciao_ctx *ctx, int32_t dtype, void *out, int64_t nrows, int64_t d, int64_t ld, int64_t row0,
                           uint64_t seed, double scale)
 {
+    CIAO_ENTER(ctx);
     CIAO_REQUIRE(ctx && (out || nrows == 0), "ctx or out is NULL");
     CIAO_REQUIRE(dtype == CIAO_F32 || dtype == CIAO_F64, "bad dtype %d", dtype);
     CIAO_REQUIRE(nrows >= 0 && d >= 1 && ld >= d, "bad shape");
@@ -1096,6 +1179,7 @@ int32_t ciao_synth_normal(ciao_ctx *ctx, int32_t dtype, void *out, int64_t nrows
 int32_t ciao_synth_targets(ciao_ctx *ctx, const ciao_problem *p, const void *x_true, double noise, int32_t labels,
                            int64_t row0, uint64_t seed, void *b_out)
 {
+    CIAO_ENTER(ctx);
     CIAO_REQUIRE(ctx && p && x_true && (b_out || p->N == 0), "NULL argument");
     CIAO_REQUIRE(p->dtype == CIAO_F32 || p->dtype == CIAO_F64, "bad dtype");
     CIAO_REQUIRE(p->N >= 0 && p->d >= 1 && p->ld >= p->d && (p->A || p->N == 0), "bad problem shape");

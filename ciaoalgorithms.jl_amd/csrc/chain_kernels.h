@@ -1372,7 +1372,7 @@ __global__ void __launch_bounds__(256) svrg_tail_kernel(int64_t d, T m, int plus
 
 // g(x) = lam*||x||_1 partial sums are tiny: one block
 template <typename T>
-__global__ void __launch_bounds__(256) gvalue_kernel(int64_t d, ProxD<T> g, const T *x, double *out)
+__global__ void __launch_bounds__(256) gvalue_kernel(int64_t d, ProxD<T> g, const T *x, double *out, double *obj)
 {
     __shared__ double s[256];
     double acc = 0.0;
@@ -1383,7 +1383,10 @@ __global__ void __launch_bounds__(256) gvalue_kernel(int64_t d, ProxD<T> g, cons
         if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = s[0];
+    if (threadIdx.x == 0) {
+        *out = s[0];
+        if (obj) obj[0] = obj[1] + s[0];   // monitor: F = (1/N) sum f_i (left in obj[1] by the sweep's epilogue) + g
+    }
 }
 
 // sum_i 1/gam_i  (two-pass deterministic): per-block partials, summed by finalize on the host side of the call

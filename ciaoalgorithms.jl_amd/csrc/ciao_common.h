@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define CIAO_BENCH_API 1
 #include "../../include/ciao_hip.h"
 
 namespace ciao {
@@ -203,6 +204,8 @@ struct Epilogue {
                      // 2 (ProShI init): hat_gamma = extra is the prox parameter;  both: *hg_out = hat_gamma
     T *hg_out;
     int zmode;       // 0: z = prox(..) ; 1 (ProShI, ProShI_basic.jl:84-86, :119-121): z = (prox_{tau g}(a) - a) / tau
+    double *obj_out; // objective monitor (full passes with want_fval): obj_out[1] = extra * obj_scale = (1/N) sum_i f_i(x)
+    double obj_scale;
 };
 
 template <typename T>
@@ -210,6 +213,7 @@ __device__ __forceinline__ void epilogue_apply(const Epilogue<T> &e, int64_t k, 
 {
     const T hgx = e.inv_extra == 1 ? T(1) / extra : (e.inv_extra == 2 ? extra : T(1));
     if (e.inv_extra && e.hg_out && k == 0) *e.hg_out = hgx;
+    if (e.obj_out && k == 0) e.obj_out[1] = (double)extra * e.obj_scale;
     T a = (e.inv_extra == 1 ? e.c_sum * hgx : e.c_sum) * sum;
     if (e.acc_in) a += e.c_acc * e.acc_in[k];
     T cu = e.uv_extra ? e.c_u * extra : e.c_u;

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#define CIAO_BENCH_API 1
 #include "../../include/ciao_hip.h"
 
 struct ciao_ctx {
@@ -29,6 +30,11 @@ struct ciao_ctx {
     size_t rowdot_bytes = 0;
     const void *rowdot_A = nullptr, *rowdot_x = nullptr;   // which (data matrix, z_full vector) the cache belongs to
     int64_t rowdot_N = -1;
+    double *monitor = nullptr;         // ciao_ctx_set_monitor: device double[3] {F, (1/N) sum f_i, g} of the last full pass, or NULL
+    bool monitor_has_g = false;
+    ciao_prox_desc monitor_g{};
+    void *monx = nullptr;              // copy of x for the monitor when a step overwrites x in place
+    size_t monx_bytes = 0;
     double *scal = nullptr;    // small device scratch for scalar reductions (4096 doubles)
     int *errflag = nullptr;    // sticky device error word (out-of-range index)
 
@@ -89,5 +95,27 @@ int32_t hip_fail(hipError_t e, const char *what);
     } while (0)
 
 int32_t ensure(ciao_ctx *ctx, void **buf, size_t *have, size_t need);
+
+// Every extern "C" entry point runs with the ctx's device current and restores the caller's device on the way out: a host
+// that holds several contexts (one per GPU) and switches devices between calls must not get workspace allocations or
+// launches on the wrong GPU.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+#define CIAO_ENTER(ctx)                     \
+    CIAO_REQUIRE((ctx), "ctx is NULL");     \
+    ::ciao::DeviceGuard _ciao_dg((ctx)->device)
 
 }  // namespace ciao

@@ -213,6 +213,17 @@ class Context:
         self._hook_keepalive = cb
         L.check(self.lib.ciao_ctx_set_allreduce(self._h, cb, None))
 
+    def set_monitor(self, g: "ProxG | None", obj: "torch.Tensor | None"):
+        """Objective monitor (include/ciao_hip.h: ciao_ctx_set_monitor): `obj` is a device float64[3] that every full pass
+        fills with {F(x), (1/N) sum f_i(x), g(x)}; obj=None switches it off."""
+        if obj is None:
+            self._monitor_keepalive = None
+            L.check(self.lib.ciao_ctx_set_monitor(self._h, None, None))
+            return
+        assert obj.is_cuda and obj.dtype == torch.float64 and obj.is_contiguous() and obj.numel() >= 3
+        self._monitor_keepalive = (g, obj)
+        L.check(self.lib.ciao_ctx_set_monitor(self._h, g.ref if g is not None else None, _ptr(obj)))
+
     def set_rccl(self, comm):
         """Native all-reduce: `comm` is a parallel.RcclComm (or None to clear).  The library then calls ncclAllReduce itself on
         its stream -- no Python callback per reduction (include/ciao_hip.h: ciao_ctx_set_rccl)."""
@@ -236,7 +247,12 @@ class Context:
         if isinstance(idx, torch.Tensor):
             assert idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous()
             return idx
-        return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(f"cuda:{self.device}", non_blocking=False)
+        t = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(f"cuda:{self.device}", non_blocking=False)
+        # The (synchronous) upload ran on torch's current stream; the kernels that read `t` run on the ctx's stream and may
+        # still be running when the caller drops `t`: tell the caching allocator, or it hands the block out again too early.
+        if self.stream is not None:
+            t.record_stream(self.stream)
+        return t
 
     # -- L1 plugin API ----------------------------------------------------------------------------------------------
     def gradient(self, p: PackedF, i: int, x, y, fval=None):
@@ -270,11 +286,14 @@ class Context:
                                          self._vec(z, p, "z"), self._vec(z_full, p, "z_full"), self._vec(w, p, "w")))
         return idx
 
-    def svrg_iterate(self, p, g, gamma, idx, plus, av, z, z_full, w):
+    def svrg_iterate(self, p, g, gamma, idx, plus, av, z, z_full, w, reuse_rowdots: bool = False):
+        """reuse_rowdots=True: the caller vouches that A, b and z_full are exactly what the previous svrg_init /
+        svrg_iterate on this context left (include/ciao_hip.h: ciao_svrg_iterate); the inner cycle then reuses the
+        a_i'z_full of that full pass.  The default never reads anything cached."""
         idx = self._idx(idx)
         L.check(self.lib.ciao_svrg_iterate(self._h, p.ref, g.ref, float(gamma), idx.numel(), _ptr(idx), 1 if plus else 0,
-                                           self._vec(av, p, "av"), self._vec(z, p, "z"), self._vec(z_full, p, "z_full"),
-                                           self._vec(w, p, "w")))
+                                           1 if reuse_rowdots else 0, self._vec(av, p, "av"), self._vec(z, p, "z"),
+                                           self._vec(z_full, p, "z_full"), self._vec(w, p, "w")))
         return idx
 
     # -- SAGA / SAG ----------------------------------------------------------------------------------------------------

@@ -157,6 +157,15 @@ set_option!(key::AbstractString, value::Integer) =
     check(ccall((:ciao_ctx_set_option, libciao), Int32, (Ptr{Cvoid}, Cstring, Int64), context().h, key, value))
 last_kernel() = unsafe_string(ccall((:ciao_ctx_last_kernel, libciao), Cstring, (Ptr{Cvoid},), context().h))
 
+# Objective monitor (SURVEY.md 8f rank 4): `obj` is a ROCArray{Float64}(undef, 3) that every full pass fills with
+# {F(x), (1/N) Σ f_i(x), g(x)}; `set_monitor!(nothing)` switches it off.
+set_monitor!(g::CiaoProxDesc, obj::ROCArray{Float64,1}) =
+    check(ccall((:ciao_ctx_set_monitor, libciao), Int32, (Ptr{Cvoid}, Ref{CiaoProxDesc}, Ptr{Cvoid}), context().h, Ref(g), dptr(obj)))
+set_monitor!(::Nothing) =
+    check(ccall((:ciao_ctx_set_monitor, libciao), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), context().h, C_NULL, C_NULL))
+build_flags() = unsafe_string(ccall((:ciao_build_flags, libciao), Cstring, ()))
+const TRUST_SVRG_STATE = Ref(false)
+
 # The reference draws from Julia's global RNG inside Base.iterate; here the draws are made on the host with the SAME
 # calls (so a Julia user keeps the reference's sample stream) and shipped as 0-based Int64 device arrays.
 to_dev_idx(idx::AbstractVector{<:Integer}) = ROCArray(Int64.(idx) .- 1)
@@ -215,10 +224,13 @@ end
 function Base.iterate(iter::SVRG_basic_iterable{R}, state::SVRG_basic_state{R}) where {R}   # SVRG_basic.jl:71-96
     idx = to_dev_idx(rand(1:iter.N, state.m))                                               # :73
     p, g = Ref(cproblem(iter.F)), Ref(iter.g)
+    # reuse_rowdots: a Julia array has no in-place version counter, and `solution(state) === state.z_full` hands the
+    # vector to user code, so the wrapper vouches for the cached a_i'z_full only when the user says the state is untouched
+    # (TRUST_SVRG_STATE[] = true; include/ciao_hip.h: ciao_svrg_iterate).  The default recomputes both dot products.
     check(ccall((:ciao_svrg_iterate, libciao), Int32,
-                (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Int64, Ptr{Cvoid}, Int32,
+                (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Int64, Ptr{Cvoid}, Int32, Int32,
                  Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-                context().h, p, g, Float64(state.γ), state.m, dptr(idx), Int32(iter.plus),
+                context().h, p, g, Float64(state.γ), state.m, dptr(idx), Int32(iter.plus), Int32(TRUST_SVRG_STATE[]),
                 dptr(state.av), dptr(state.z), dptr(state.z_full), dptr(state.w)))
     iter.plus && (state.m *= 2)                                                             # :93
     return state, state

@@ -15,6 +15,19 @@ Differences forced by the device boundary (documented in DESIGN.md):
     test/test_lasso.jl:185), and the solver returns it as a numpy array when x0 was a numpy array;
   * adaptive Finito (Finito_adaptive.jl) keeps its per-sample scalars in an N x 4 device
     array instead of an N x d gradient table (grad f_i = c_i a_i for the packable families).
+
+State ownership rule (SVRG).  The SVRG inner cycle may reuse the row dots a_i'z_full that the previous full pass computed
+(one dot product per update instead of two).  That is only valid while A, b and z_full are untouched between two
+iterations, and `state.z_full` IS the tensor `solution(state)` returns.  The iterable therefore records torch's in-place
+version counters of those tensors after every call and vouches for the state (`reuse_rowdots`) only when they have not
+moved; any torch in-place edit (warm restart, projection, rescaling A) makes the next epoch recompute.  Writes that
+bypass torch (a raw pointer handed to another library) are not seen: call `state.invalidate()` after those.
+
+Objective monitor / stopping.  The reference has `stop(state) = false` (SVRG.jl:55,70) and
+its tests compute the cost outside (test_lasso.jl:45-47).  Here `solver(x0; ..., stop=callable)` ends the loop at the first
+yielded state for which `stop(state)` is true (IterationTools.halt semantics), and `state.objective` is
+(1/N) sum f_i(x) + g(x): for SVRG and LFinito it rides on the full pass the iteration makes anyway (the values
+`gradient!` returns and the reference discards), taken at z_full; for the other iterables it costs one extra sweep.
 """
 from __future__ import annotations
 
@@ -76,6 +89,32 @@ class _Iterable:
         self.stream = stream if stream is not None else IndexStream(0)
         self._state = None
         self._started = False
+        self.monitor = False      # set by the functor when `verbose` or a `stop` callback wants objective values
+        self._obj = None          # device float64[3]: {F, (1/N) sum f_i, g} of the last full pass
+
+    # objective monitor: the ctx may be shared between iterables, so it is armed around each call that makes a full pass
+    def _monitor_on(self):
+        if not self.monitor:
+            return
+        if self._obj is None:
+            self._obj = torch.full((3,), float("nan"), dtype=torch.float64, device=self._x0_dev.device)
+        self.ctx.set_monitor(self.g, self._obj)
+
+    def _monitor_off(self):
+        if self.monitor:
+            self.ctx.set_monitor(None, None)
+
+    def objective(self, state):
+        """(1/N) sum_i f_i(x) + g(x).  With the monitor armed, SVRG / LFinito read what their own full pass left (x = z_full);
+        otherwise one extra sweep at solution(state)."""
+        if self.monitor and self._obj is not None and self._rides_on_full_pass:
+            self.ctx.synchronize()
+            return float(self._obj[0].item())
+        if isinstance(state, Proshi_basic_state):
+            raise NotImplementedError("objective of a sharing problem (1/N) sum f_i(x_i) + g(sum x_i) is not on the device path")
+        return self.ctx.objective(self.F, self.g, solution(state))
+
+    _rides_on_full_pass = False
 
     def _new(self):
         return torch.empty(self.d, dtype=self.R, device=self._x0_dev.device)
@@ -104,11 +143,25 @@ class _Iterable:
 # ======================================================================================================================
 # SVRG  (SVRG_basic.jl)
 # ======================================================================================================================
-class SVRG_basic_state:
+class _State:
+    _it = None
+
+    @property
+    def objective(self):
+        """(1/N) sum_i f_i(x) + g(x) -- see the module docstring (objective monitor)."""
+        return self._it.objective(self)
+
+
+class SVRG_basic_state(_State):
     def __init__(self, γ, m, av, z, z_full, w):
         self.γ, self.m, self.av, self.z, self.z_full, self.w = γ, m, av, z, z_full, w
+        self._tok = None   # torch version counters of (z_full, A, b) after the library last wrote the state
 
     gamma = property(lambda self: self.γ)
+
+    def invalidate(self):
+        """Forget that the library knows a_i'z_full: call after editing z_full / A / b behind torch's back."""
+        self._tok = None
 
 
 class SVRG_basic_iterable(_Iterable):
@@ -136,13 +189,29 @@ class SVRG_basic_iterable(_Iterable):
         else:
             γ = self.γ
         av, z, z_full, w = self._new(), self._new(), self._new(), self._new()
+        self._monitor_on()
         self.ctx.svrg_init(self.F, self._x0_dev, av, z, z_full, w)         # :57-66
-        return SVRG_basic_state(float(γ), int(m), av, z, z_full, w)
+        self._monitor_off()
+        st = SVRG_basic_state(float(γ), int(m), av, z, z_full, w)
+        st._it = self
+        st._tok = self._versions(st)
+        return st
+
+    _rides_on_full_pass = True
+
+    def _versions(self, st):
+        """torch's in-place version counters of everything the cached a_i'z_full depend on (module docstring)."""
+        return (st.z_full._version, st.z_full.data_ptr(),
+                -1 if self.F.A is None else self.F.A._version, -1 if self.F.b is None else self.F.b._version)
 
     def _step(self, st, n):                                                # SVRG_basic.jl:71-96
         for _ in range(n):
             idx = self.stream.rand_indices(self.N, st.m)                   # :73
-            self.ctx.svrg_iterate(self.F, self.g, st.γ, idx, self.plus, st.av, st.z, st.z_full, st.w)
+            fresh = st._tok is not None and st._tok == self._versions(st)
+            self._monitor_on()
+            self.ctx.svrg_iterate(self.F, self.g, st.γ, idx, self.plus, st.av, st.z, st.z_full, st.w, reuse_rowdots=fresh)
+            self._monitor_off()
+            st._tok = self._versions(st)
             if self.plus:
                 st.m *= 2                                                  # :93
 
@@ -150,7 +219,7 @@ class SVRG_basic_iterable(_Iterable):
 # ======================================================================================================================
 # SAGA / SAG  (SAGA_basic.jl)
 # ======================================================================================================================
-class SAGA_basic_state:
+class SAGA_basic_state(_State):
     def __init__(self, s, γ, av, z):
         self.s, self.γ, self.av, self.z, self.ind = s, γ, av, z, 0
 
@@ -176,7 +245,9 @@ class SAGA_basic_iterable(_Iterable):
         s = torch.empty((self.N, self.d), dtype=self.R, device=self._x0_dev.device)   # N x d table, 288 GB HBM budget
         av, z = self._new(), self._new()
         self.ctx.saga_init(self.F, self.g, γ, self._x0_dev, s, av, z)      # :41-48
-        return SAGA_basic_state(s, float(γ), av, z)
+        st = SAGA_basic_state(s, float(γ), av, z)
+        st._it = self
+        return st
 
     def _step(self, st, n):                                                # SAGA_basic.jl:53-68, n consecutive calls
         idx = self.stream.rand_indices(self.N, n)                          # :55 (one draw per iteration)
@@ -275,7 +346,7 @@ def _next_batches_packed(it, st, n):
     return _pack_batches([_localise(it, _static_batch(N, r, int(j))) for j in js])
 
 
-class FINITO_basic_state:
+class FINITO_basic_state(_State):
     def __init__(self, s, γ, hat_γ, av, z, d):
         self.s, self.γ, self.hat_γ, self.av, self.z, self.d = s, γ, hat_γ, av, z, d
         self.ind = None
@@ -301,14 +372,16 @@ class FINITO_basic_iterable(_Iterable):
         s = torch.empty((self.F.N, self.d), dtype=self.R, device=self._x0_dev.device)
         av, z = self._new(), self._new()
         self.ctx.finito_init(self.F, self.g, gam, hat_γ, self._x0_dev, s, av, z)   # :76-84
-        return FINITO_basic_state(s, gam, hat_γ, av, z, d_b)
+        st = FINITO_basic_state(s, gam, hat_γ, av, z, d_b)
+        st._it = self
+        return st
 
     def _step(self, st, n):                                                # Finito_basic.jl:109-118, n iterations
         bptr, bidx = _next_batches_packed(self, st, n)
         self.ctx.finito_steps(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.s, st.av, st.z)
 
 
-class FINITO_LFinito_state:
+class FINITO_LFinito_state(_State):
     def __init__(self, γ, hat_γ, av, d, z, z_full):
         self.γ, self.hat_γ, self.av, self.d, self.z, self.z_full = γ, hat_γ, av, d, z, z_full
         self.inds = np.arange(d, dtype=np.int64)
@@ -330,8 +403,14 @@ class FINITO_LFinito_iterable(_Iterable):
             return None
         hat_γ = self.ctx.hat_gamma(gam)                                    # :66
         av, z, z_full = self._new(), self._new(), self._new()
+        self._monitor_on()
         self.ctx.lfinito_init(self.F, hat_γ, self._x0_dev, av, z, z_full)  # :67-72
-        return FINITO_LFinito_state(gam, hat_γ, av, -(-N // r) if N > 0 else 0, z, z_full)
+        self._monitor_off()
+        st = FINITO_LFinito_state(gam, hat_γ, av, -(-N // r) if N > 0 else 0, z, z_full)
+        st._it = self
+        return st
+
+    _rides_on_full_pass = True
 
     def _step(self, st, n):                                                # Finito_LFinito.jl:78-103
         N, r = self.N, self.batch
@@ -345,10 +424,12 @@ class FINITO_LFinito_iterable(_Iterable):
                 bptr, bidx = _static_batches_packed(N, r, st.inds)
             else:
                 bptr, bidx = _pack_batches([_localise(self, _static_batch(N, r, int(j))) for j in st.inds])
+            self._monitor_on()
             self.ctx.lfinito_iterate(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.av, st.z, st.z_full)
+            self._monitor_off()
 
 
-class FINITO_adaptive_state:
+class FINITO_adaptive_state(_State):
     """Finito_adaptive.jl:13-29.  For the row-structured f_i of this path grad f_i = c_i a_i, so the reference's N x d
     gradient table `∇f` is the column c_i of `meta` (N x 4 copies x 4: c_i, f_i(x_i), γ_i, a_i'x_i); γ and fi_x are views."""
 
@@ -381,7 +462,9 @@ class FINITO_adaptive_iterable(_Iterable):
         av, z = self._new(), self._new()
         self.ctx.afinito_init(self.F, self.g, self.α, self._x0_dev, s, meta, av, z, hg)
         self.ctx.synchronize()   # surfaces the degenerate-probe case (reference :78-85) as an error
-        return FINITO_adaptive_state(s, meta, hg, av, z, self.N)
+        st = FINITO_adaptive_state(s, meta, hg, av, z, self.N)
+        st._it = self
+        return st
 
     def _next_indices(self, st, n):                                        # :104-116 applied n times (0-based result)
         N = self.N
@@ -415,7 +498,7 @@ class FINITO_adaptive_iterable(_Iterable):
 # ======================================================================================================================
 # ProShI  (src/algorithms/ProShI/ProShI_basic.jl) -- sharing problems: the solution is the whole N x d table
 # ======================================================================================================================
-class Proshi_basic_state:
+class Proshi_basic_state(_State):
     def __init__(self, it, s, γ, hat_γ, av, z, d):
         self._it, self.s, self.γ, self.hat_γ, self.av, self.z, self.d = it, s, γ, hat_γ, av, z, d
         self.idxr, self.idx, self.inds = 1, 0, np.arange(d, dtype=np.int64)   # ProShI_basic.jl:37-39
@@ -436,6 +519,7 @@ class Proshi_basic_iterable(_Iterable):
         self.g = pack_g(g, self.d, self.R, self._x0_dev.device)
         self.stream = stream if stream is not None else IndexStream(0)
         self._state, self._started = None, False
+        self.monitor, self._obj = False, None
         self.L, self.γ, self.sweeping, self.batch, self.α = L, γ, int(sweeping), int(batch), α
 
     def _init(self):                                                       # ProShI_basic.jl:44-89
@@ -472,14 +556,19 @@ def solution(state):
 # L3: solver structs + functors + iterator()
 # ======================================================================================================================
 class _Solver:
-    _chunk = 1 << 20   # iterations per device launch in the functor's fast path
+    _chunk = 1 << 20        # iterations per device launch in the functor's fast path ...
+    _chunk_samples = 1 << 24   # ... capped so that one chunk's batch indices stay within 128 MiB (host scratch + HBM)
 
-    def _drive(self, it, maxit, disp):
-        """The functor's loop (SVRG.jl:69-83): take(iter, maxit), optional printing, return (solution, num_iters).
+    def _drive(self, it, maxit, disp, stop=None, check_every=1):
+        """The functor's loop (SVRG.jl:69-83): take(halt(iter, stop), maxit), optional printing, return (solution, num_iters).
 
-        Nothing observes the intermediate states unless `verbose`, so iterations that are one device step each
-        (SAGA, Finito) are issued `chunk` at a time; the yielded-state semantics of `iterator(...)` are unchanged.
+        The reference's `stop(state) = false` (SVRG.jl:55); a callable `stop` ends the loop at the first yielded state for
+        which it is true (IterationTools.halt yields that state and then stops).  `check_every=k` evaluates it only at every
+        k-th state, so that iterables whose iteration is one device step (SAGA, Finito) still run k steps per launch.
+        Nothing observes the intermediate states unless `verbose` / `stop`, so those iterations are issued `chunk` at a
+        time; the yielded-state semantics of `iterator(...)` are unchanged.
         """
+        it.monitor = bool(self.verbose or stop is not None)
         it_obj = iter(it)
         num_iters, state = 0, None
         try:
@@ -490,11 +579,18 @@ class _Solver:
         if state is not None:
             if self.verbose and num_iters % self.freq == 0:
                 disp(num_iters, state)
-            while num_iters < maxit:
+            halted = stop is not None and check_every == 1 and bool(stop(state))
+            while num_iters < maxit and not halted:
                 n = maxit - num_iters
                 if self.verbose:
                     n = min(n, self.freq - num_iters % self.freq)
-                n = min(n, self._chunk if it._chunkable else 1)
+                if stop is not None:
+                    n = min(n, check_every - num_iters % check_every)
+                chunk = self._chunk
+                r = getattr(it, "batch", 1)
+                if r > 1:
+                    chunk = max(1, min(chunk, self._chunk_samples // r))
+                n = min(n, chunk if it._chunkable else 1)
                 done = it._step(state, n)
                 done = n if done is None else done
                 num_iters += done
@@ -502,6 +598,8 @@ class _Solver:
                     disp(num_iters, state)
                 if done < n:   # the iterable ended early (adaptive Finito: stepsize collapsed, Finito_adaptive.jl:121-124)
                     break
+                if stop is not None and num_iters % check_every == 0:
+                    halted = bool(stop(state))
             if self.verbose and num_iters % self.freq != 0:
                 disp(num_iters, state)
         sol = solution(state)
@@ -509,6 +607,22 @@ class _Solver:
         if isinstance(state, Proshi_basic_state):   # Array{Array{R,1}}: one x_i per agent (test_sharing.jl:45)
             return ([row for row in sol.cpu().numpy()] if it._numpy else sol), num_iters
         return (sol.cpu().numpy().reshape(np.shape(it.x0)) if it._numpy else sol), num_iters
+
+
+def _split_drive_kw(kw):
+    """Functor keywords that steer the loop rather than the iterable: stop=callable(state)->bool, check_every=k."""
+    return kw.pop("stop", None), int(kw.pop("check_every", 1))
+
+
+def _disp(fmt_attr):
+    """`@printf("%5d | %.3e\n", it, γ)` of the reference (SVRG.jl:56); with the monitor armed the objective is appended."""
+    def show(k, st):
+        line = "%5d | %.3e  " % (k, getattr(st, fmt_attr))
+        it = st._it
+        if it is not None and it.monitor and not isinstance(st, Proshi_basic_state):
+            line += "| F = %.9e" % st.objective
+        print(line)
+    return show
 
 
 SVRG_basic_iterable._chunkable = False
@@ -538,7 +652,8 @@ class SVRG(_Solver):
         if self.plus and self.maxit > 25:                                  # :61-65
             maxit = 25
             warnings.warn("exponential number of inner updates...reverted to 25 maximum iterations")
-        return self._drive(self._iterable(x0, **kw), maxit, lambda it, st: print("%5d | %.3e  " % (it, st.γ)))
+        stop, every = _split_drive_kw(kw)
+        return self._drive(self._iterable(x0, **kw), maxit, _disp("γ"), stop, every)
 
 
 class SAGA(_Solver):
@@ -555,7 +670,8 @@ class SAGA(_Solver):
         return SAGA_basic_iterable(self.R, F, g, x0, N, L, self.γ, self.SAG_flag, ctx=ctx, stream=stream)
 
     def __call__(self, x0, **kw):                                          # SAGA.jl:44-73
-        return self._drive(self._iterable(x0, **kw), self.maxit, lambda it, st: print("%5d | %.3e  " % (it, st.γ)))
+        stop, every = _split_drive_kw(kw)
+        return self._drive(self._iterable(x0, **kw), self.maxit, _disp("γ"), stop, every)
 
 
 def SAG(R=np.float64, **kw):
@@ -592,7 +708,8 @@ class Finito(_Solver):
                                      ctx=ctx, stream=stream)
 
     def __call__(self, x0, **kw):                                          # Finito.jl:66-133
-        return self._drive(self._iterable(x0, **kw), self.maxit, lambda it, st: print("%5d | %.3e  " % (it, st.hat_γ)))
+        stop, every = _split_drive_kw(kw)
+        return self._drive(self._iterable(x0, **kw), self.maxit, _disp("hat_γ"), stop, every)
 
 
 class Proshi(_Solver):
@@ -614,7 +731,8 @@ class Proshi(_Solver):
                                      stream=stream)
 
     def __call__(self, x0, **kw):                                          # ProShI.jl:42-83
-        return self._drive(self._iterable(x0, **kw), self.maxit, lambda it, st: print("%5d | %.3e  " % (it, st.hat_γ)))
+        stop, every = _split_drive_kw(kw)
+        return self._drive(self._iterable(x0, **kw), self.maxit, _disp("hat_γ"), stop, every)
 
 
 Proshi_basic_iterable._chunkable = True

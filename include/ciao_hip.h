@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CIAO_ABI_VERSION 1
+#define CIAO_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define CIAO_API __attribute__((visibility("default")))
@@ -102,6 +102,9 @@ typedef int32_t (*ciao_allreduce_fn)(void *user, void *buf, int64_t count, int32
 /* ---- library / context ------------------------------------------------------------------------------------- */
 CIAO_API int32_t ciao_abi_version(void);
 CIAO_API const char *ciao_last_error(void);
+/* The extra compiler flags this library was built with: "" for the product build.  Experiment builds (timing macros, some
+ * of which give wrong results; tools/exp_build.sh) report theirs here and are never written over the product library. */
+CIAO_API const char *ciao_build_flags(void);
 /* device >= 0; stream = hipStream_t to enqueue on (NULL = the device's default stream). */
 CIAO_API int32_t ciao_ctx_create(int32_t device, void *stream, ciao_ctx **out);
 CIAO_API int32_t ciao_ctx_destroy(ciao_ctx *ctx);
@@ -113,6 +116,15 @@ CIAO_API int32_t ciao_ctx_set_allreduce(ciao_ctx *ctx, ciao_allreduce_fn fn, voi
  * be called.  RCCL is resolved at run time from `librccl_path` (NULL = "librccl.so"), so single-GPU hosts need no RCCL;
  * pass the library the communicator was created with.  comm = NULL removes it.  Replaces any hook set before. */
 CIAO_API int32_t ciao_ctx_set_rccl(ciao_ctx *ctx, void *comm, const char *librccl_path);
+/* Objective monitor (the step after the path; the reference has stop(state) = false, SVRG/SVRG.jl:55,70,
+ * and computes the cost outside, test/test_lasso.jl:45-47).  obj_dev = device double[3], or NULL to switch it off.  While
+ * set, every full pass over the rows -- ciao_full_gradient, ciao_proxgrad_step, ciao_svrg_init, the tail pass of
+ * ciao_svrg_iterate (at the new z_full = the solution), ciao_lfinito_init, the full pass of ciao_lfinito_iterate (at
+ * z_full) -- also leaves, for the point x the pass was taken at,
+ *     obj_dev[1] = (1/N_total) sum_i f_i(x)    obj_dev[2] = g(x)    obj_dev[0] = obj_dev[1] + obj_dev[2]
+ * where the f_i(x) are the values `gradient!` returns and the reference discards: they ride on the same sweep (no extra
+ * pass over A; all-reduced with the d-vector on a row-sharded problem).  g (may be NULL = Zero) is copied. */
+CIAO_API int32_t ciao_ctx_set_monitor(ciao_ctx *ctx, const ciao_prox_desc *g, double *obj_dev);
 /* Tuning knobs (performance only, never results-changing beyond summation order); returns CIAO_ERR_ARG for unknown keys:
  *   "sweep_blocks_per_cu", "sweep_grid", "sweep_prefetch", "sweep_multi", "force_generic"   grid / variant of the rows kernels
  *   "chain_max_batch"      Finito / LFinito batches up to this size run as one sequential chain (-1 = measured crossover)
@@ -120,7 +132,8 @@ CIAO_API int32_t ciao_ctx_set_rccl(ciao_ctx *ctx, void *comm, const char *librcc
  *   "split_blocks_per_cu"  grid cap of that kernel (0 = automatic)
  *   "split_all"            experiment: that kernel for every mode and size (tools/tune_split.py)
  *   "small_i"              rows_small_kernel (rows under 1 KiB): elements per lane and iteration, 8 or 16 (0 = automatic)
- *   "chain_no_dma", "svrg_cache_rowdots"                                                    chain kernel variants */
+ *   "chain_no_dma"                                                                          chain kernel variant
+ *   "svrg_cache_rowdots"   0: the SVRG full pass does not store a_i'z_full at all (see ciao_svrg_iterate) */
 CIAO_API int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value);
 /* Kernel timing for bench.py's roofline line: when enabled, every launch of the dominant streaming kernel of an entry
  * point (rows_fast_kernel / rows_generic_kernel) is bracketed by HIP events on the ctx's stream.  _read synchronises,
@@ -164,13 +177,16 @@ CIAO_API int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const cia
                         const int64_t *idx, const void *av, void *z, const void *z_full, void *w);
 /* Base.iterate(iter, state), :71-96 = inner cycle + tail (z_full = z/m; basic: w = z_full; z = 0) + full pass.
  * (`state.m *= 2` of SVRG++ is host bookkeeping; pass the current m.)
- * The full pass also stores a_i'z_full per row in the ctx workspace; when the NEXT call on this ctx is again
- * ciao_svrg_iterate (or ciao_svrg_inner) with the same A and z_full pointers, the inner cycle reads those N scalars
- * instead of recomputing the second dot product.  Between such calls the state vectors belong to
- * the library: do not overwrite z_full from outside (any other ciao_* call drops the cache; option
- * "svrg_cache_rowdots" = 0 disables it). */
+ * The full pass also stores a_i'z_full per row in the ctx workspace (N scalars).  With reuse_rowdots != 0 the CALLER
+ * vouches that A and z_full still hold exactly what the previous ciao_svrg_init / ciao_svrg_iterate on this ctx left in
+ * them (nothing wrote to either from outside, not even in place); the inner cycle then reads those N scalars instead of
+ * recomputing the second dot product of every step (0.39 vs 0.50 us per update at d = 1024 fp64).
+ * The library additionally requires that the previous call on this ctx was one of those two (or ciao_svrg_inner) with
+ * the same A, z_full and N; anything else recomputes.  With reuse_rowdots == 0 nothing cached is ever read: the safe
+ * choice for a host that hands the state vectors to user code between calls.  The host mirrors track this themselves
+ * (solvers.py: torch's in-place version counters of z_full, A and b). */
 CIAO_API int32_t ciao_svrg_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
-                          const int64_t *idx, int32_t plus, void *av, void *z, void *z_full, void *w);
+                          const int64_t *idx, int32_t plus, int32_t reuse_rowdots, void *av, void *z, void *z_full, void *w);
 
 /* ---- SAGA / SAG  (SAGA_SAG/SAGA_basic.jl) ------------------------------------------------------------------- */
 /* Base.iterate(iter), :41-48: table[i] = grad f_i(x0); av = sum/N; z = prox_{gamma g}((1-gamma) x0). */
@@ -252,6 +268,13 @@ CIAO_API int32_t ciao_proshi_steps(ciao_ctx *ctx, const ciao_sepquad *f, const c
 /* solution(state), :127-132: table_i += gam_i z for every agent, IN PLACE (as the reference does). */
 CIAO_API int32_t ciao_proshi_solution(ciao_ctx *ctx, const ciao_sepquad *f, const void *gam, const void *z, void *table);
 
+/* ==================================================================================================================
+ * Everything above is the drop-in surface: the entry points a reference-side binding needs for this path.
+ * The declarations below are NOT part of it.  They are helpers the benchmark, the tests and the Python host mirror use
+ * (synthetic data generated on the device; the host-side batch sampler of the injected index stream) and are only
+ * visible with CIAO_BENCH_API defined.
+ * ================================================================================================================== */
+#ifdef CIAO_BENCH_API
 /* ---- synthetic data (bench / tests): counter-based generator, reproducible per (seed, row, col) ------------- */
 /* out[i*ld + k] = scale * N(0,1) for rows row0 .. row0+nrows, keyed by the GLOBAL (row, col). */
 CIAO_API int32_t ciao_synth_normal(ciao_ctx *ctx, int32_t dtype, void *out, int64_t nrows, int64_t d, int64_t ld,
@@ -270,6 +293,8 @@ CIAO_API int32_t ciao_synth_targets(ciao_ctx *ctx, const ciao_problem *p, const 
  * draw batches at that rate. */
 CIAO_API int32_t ciao_sample_batches(uint64_t seed, uint64_t pos, int64_t N, int64_t r, int64_t n, int64_t *out_host,
                             uint64_t *pos_out_host);
+
+#endif /* CIAO_BENCH_API */
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """GPU runs: dump the observed error / stated tolerance of every parity comparison (max per call site)."""
+    try:
+        import problems as P
+    except Exception:
+        return
+    if not P.PARITY_LOG:
+        return
+    import json
+    worst = {}
+    for rec in P.PARITY_LOG:
+        key = f"{rec['test']}:{rec['line']}:{rec['dtype']}"
+        if key not in worst or rec["ratio"] > worst[key]["ratio"]:
+            worst[key] = rec
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_observed.json"), "w") as fh:
+        json.dump(sorted(worst.values(), key=lambda r: (r["test"], r["line"], r["dtype"])), fh, indent=1)
+
+
 @pytest.fixture(scope="session")
 def ciao():
     """The product package, loaded under its importable alias."""

@@ -82,3 +82,7 @@ def sharing_fixture(dtype=np.float64):
     L = np.array([abs(dd[0, 0]) + eta, 0.0 + eta, 0.0 + eta])
     return (dd.astype(dtype), np.ones((N, n), dtype), eta, -2.0, 2.0, L.astype(dtype), np.ones(n, dtype), np.zeros(n, dtype),
             np.array([-5.136781609195401, -0.9333333333333327]))
+
+
+# every GPU-vs-oracle comparison of tests/test_gpu_parity.py appends {test, line, what, dtype, ratio, scale} here
+PARITY_LOG = []

@@ -12,9 +12,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "ciao_hip.h")
 
 
-def declared_symbols():
-    src = open(HEADER).read()
+def _symbols(src):
     return sorted(set(re.findall(r"CIAO_API\s+[\w\s\*]+?\b(ciao_\w+)\s*\(", src)))
+
+
+def declared_symbols():
+    """Every entry point the header declares, the CIAO_BENCH_API section included."""
+    return _symbols(open(HEADER).read())
+
+
+def surface_symbols():
+    """The drop-in surface only: what the header shows WITHOUT CIAO_BENCH_API."""
+    src = open(HEADER).read()
+    i0, i1 = src.index("#ifdef CIAO_BENCH_API"), src.index("#endif /* CIAO_BENCH_API */")
+    return _symbols(src[:i0] + src[i1:])
+
+
+def test_bench_helpers_are_outside_the_drop_in_surface():
+    """ciao_synth_* and ciao_sample_batches serve bench.py / the tests / the host mirror's sampler, not the reference's path:
+    a binding that includes the header as is does not see them."""
+    extra = sorted(set(declared_symbols()) - set(surface_symbols()))
+    assert extra == ["ciao_sample_batches", "ciao_synth_normal", "ciao_synth_targets"]
+    for name in surface_symbols():
+        assert not name.startswith("ciao_synth") and name != "ciao_sample_batches"
+
+
+def test_product_library_is_a_clean_build(ciao):
+    """Experiment builds (tools/exp_build.sh: timing macros, some with WRONG results) report their flags; the product
+    library must report none."""
+    lib = ciao._lib.load()
+    assert "CIAO_HIP_LIB" not in os.environ, "tests must run against the product library"
+    assert lib.ciao_build_flags() == b""
 
 
 def test_header_declares_the_expected_entry_points():
@@ -30,7 +58,7 @@ def test_library_exports_every_declared_symbol(ciao):
     lib = ciao._lib.load()
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} is declared in include/ciao_hip.h but not exported by libciao_hip.so"
-    assert lib.ciao_abi_version() == 1
+    assert lib.ciao_abi_version() == 2
 
 
 def test_ctypes_table_matches_header(ciao):
@@ -65,7 +93,7 @@ def test_struct_layouts_match_the_header(ciao, tmp_path):
 def test_header_is_plain_c(tmp_path):
     """The boundary must be consumable from C (and therefore from Julia's ccall): compile the header as C11, pedantic."""
     src = tmp_path / "inc.c"
-    src.write_text('#include "ciao_hip.h"\nint main(void){return CIAO_ABI_VERSION - 1;}\n')
+    src.write_text('#define CIAO_BENCH_API 1\n#include "ciao_hip.h"\nint main(void){return CIAO_ABI_VERSION - 2;}\n')
     subprocess.run(["gcc", "-std=c11", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                     "-o", str(tmp_path / "inc.o")], check=True)
 

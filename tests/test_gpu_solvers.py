@@ -394,3 +394,42 @@ def test_solvers_follow_the_oracle_on_odd_row_lengths(api, ciao, ctx, d):
         x, it = solver(x0, F=F, g=g, L=Li, N=N, ctx=ctx, stream=ciao.IndexStream(3))
         xr, _ = RS.finito(op, og, x0, maxit=maxit, sweeping=sweeping, batch=batch, lfinito=lf, L=Li, stream=ciao.IndexStream(3))
         same(x, xr, f"Finito sweeping={sweeping} batch={batch} LFinito={lf}")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# stopping / objective monitor (reference: stop(state) = false, SVRG/SVRG.jl:55,70)
+# ----------------------------------------------------------------------------------------------------------------------
+def test_stop_callback_and_state_objective(api, ctx, capsys):
+    """`solver(x0; ..., stop=f)` ends at the first yielded state with f(state) true (IterationTools.halt); state.objective is
+    the cost the reference's tests compute outside the solver (test_lasso.jl:45-47)."""
+    S, ops = api
+    T = np.float64
+    F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+    seen = []
+
+    def stop(state):
+        seen.append(state.objective)
+        return seen[-1] - f_star < 1e-6
+
+    for mk in (lambda: S.SVRG(T, γ=1 / (7 * L.max()), maxit=1000),
+               lambda: S.Finito(T, LFinito=True, sweeping=2, maxit=1000),
+               lambda: S.Finito(T, sweeping=2, maxit=100000),
+               lambda: S.SAGA(T, maxit=100000)):
+        seen.clear()
+        x, it = mk()(x0, F=F, g=g, L=L, N=N, ctx=ctx, stop=stop)
+        assert 1 < it < mk().maxit, "the callback must end the loop early"
+        assert len(seen) == it and seen[-1] - f_star < 1e-6 and all(v - f_star >= 1e-6 for v in seen[:-1])
+        assert cost(x) - f_star < 1e-4
+    # the monitored value is the cost at the monitored point: for SVRG that is z_full = the solution itself
+    seen.clear()
+    x, it = S.SVRG(T, γ=1 / (7 * L.max()), maxit=1000)(x0, F=F, g=g, L=L, N=N, ctx=ctx, stop=stop)
+    assert abs(seen[-1] - cost(x)) <= 1e-12 * max(1.0, abs(seen[-1]))
+    # check_every: the callback sees every k-th state only
+    seen.clear()
+    x, it = S.SAGA(T, maxit=5000)(x0, F=F, g=g, L=L, N=N, ctx=ctx, stop=lambda st: seen.append(1) or False, check_every=50)
+    assert it == 5000 and len(seen) == 5000 // 50
+    # verbose prints the reference's line plus the objective
+    S.SVRG(T, γ=1 / (7 * L.max()), maxit=20, verbose=True, freq=10)(x0, F=F, g=g, L=L, N=N, ctx=ctx)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 2 and all("| F = " in ln for ln in out)
+    assert float(out[1].split("F =")[1]) <= float(out[0].split("F =")[1])
