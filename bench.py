@@ -8,11 +8,25 @@ and the next step starts from x+ (a proximal-gradient iteration, so no step can 
 
 Workload at N=1: Lasso (f_i = LeastSquares(a_i', b_i, N), g = NormL1) with N = 10M rows, d = 1024, fp64 (81.92 GB of A):
 the configuration BASELINE.json's metric is quoted on.  With --gpus P every rank holds its own 10M-row shard (weak
-scaling; P = 8 is BASELINE config #4, N = 80M) and the d-vector sum is all-reduced with RCCL once per step.
+scaling; P = 8 is BASELINE config #4, N = 80M) and the d-vector sum is all-reduced over xGMI once per step.
 
-Prints ONE JSON line (rank 0).  `value` = sample-gradient(+prox) updates per second over all ranks, inputs resident in
-HBM before the timed region.  `roofline` is for the dominant kernel (rows_fast_kernel), timed with HIP events on the
-stream it is launched on; `cpu_baseline` is the single-threaded CPU oracle on a bounded sample of the same rows.
+Launching.  `python bench.py --gpus P` with P > 1 and no WORLD_SIZE in the environment starts the P ranks ITSELF: the
+parent process (which never touches the GPU and does not even import torch) spawns P fresh children with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, waits for them, relays rank 0's JSON line and exits
+non-zero if any child failed.  Under `python -m torch.distributed.run --nproc-per-node P bench.py --gpus P` (WORLD_SIZE
+set) each process is one rank.  Either way: one process per GPU.
+
+The collective is RCCL over xGMI.  Default: the library calls ncclAllReduce itself on its stream (ciao_ctx_set_rccl; no
+host callback per reduction).  CIAO_BENCH_COLLECTIVE=torch routes it through torch.distributed (backend "nccl" = RCCL)
+instead; CIAO_BENCH_BACKEND=gloo exists only to rehearse several ranks on ONE GPU (host-staged).  `config.collective`
+reports what actually ran.
+
+Prints ONE JSON line (rank 0).  `value` = sample-gradient(+prox) evaluations of the SWEEP per second over all ranks,
+inputs resident in HBM before the timed region.  An *update* in SURVEY.md section 8d's sense is one step of the
+sequential SVRG / SAGA inner loops; those are latency-bound dependent chains and are reported separately at top level
+(`svrg_updates_per_sec`, `saga_updates_per_sec`, `svrg_epochs_per_sec_N10M`), each with its own roofline fraction.
+`roofline` is for the dominant kernel (the rows sweep), timed with HIP events on the stream it is launched on;
+`cpu_baseline` is the single-threaded CPU oracle on a bounded sample of the same rows.
 """
 import argparse
 import json
@@ -27,7 +41,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -43,27 +57,138 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary timings (sequential chains, table kernels; N=1 only)")
-    return ap.parse_args()
+    ap.add_argument("--no-chains", action="store_true", help="skip the top-level SVRG / SAGA chain figures (N=1 only)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work at all: rendezvous, barrier and the JSON relay only (CPU test of the launcher)")
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse()
+# ======================================================================================================================
+# parent: spawn one fresh process per GPU (never touches the GPU itself)
+# ======================================================================================================================
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    import subprocess
+    world = args.gpus
+    env0 = dict(os.environ)
+    env0["WORLD_SIZE"] = str(world)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0.setdefault("MASTER_PORT", str(_free_port()))
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    env0["CIAO_BENCH_SPAWNED"] = "1"
+    procs = []
+    for r in range(world):
+        env = dict(env0)
+        env["RANK"] = env["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out0 = ""
+    deadline = time.time() + float(os.environ.get("CIAO_BENCH_TIMEOUT", "1500"))
+    failed = None
+    try:
+        # rank 0's line is short: read it when the process ends; poll the others so that one dead rank cannot hang the rest
+        pending = set(range(world))
+        while pending and failed is None:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is not None:
+                    pending.discard(r)
+                    if r == 0:
+                        out0 = procs[0].stdout.read()
+                    if rc != 0:
+                        failed = (r, rc)
+                        break
+            if time.time() > deadline:
+                failed = (-1, 124)
+            time.sleep(0.05)
+    finally:
+        for p in procs:           # exactly the processes started here, by PID
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:
+                pass
+    if failed is not None:
+        print(f"[bench] rank {failed[0]} failed with exit code {failed[1]}; no result line", file=sys.stderr)
+        sys.stdout.write(out0)
+        return failed[1] if failed[1] not in (0, None) else 1
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if not lines:
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+# ======================================================================================================================
+# one rank
+# ======================================================================================================================
+def dry_rank(args):
+    """The launcher's plumbing without a GPU: process group (gloo), barrier, MAX over ranks, rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "sweep_sample_gradients_per_sec", "value": None, "unit": "sample-gradients/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "max_rank_seconds": float(el.item()),
+                          "config": {"workload": "launcher_dry_run", "collective": "gloo(dry run)" if world > 1 else "none"}}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def _timed_events(torch, stream, fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def run_rank(args):
     import numpy as np
     import torch
     import ciao_loader
     ciao_loader.load()
     from ciaoalgorithms_jl_amd import _lib as L
     from ciaoalgorithms_jl_amd.device import Context, PackedF, ProxG
-    from ciaoalgorithms_jl_amd.parallel import AllReduceHook, init_process_group_from_env, shard_rows
+    from ciaoalgorithms_jl_amd.parallel import AllReduceHook, RcclComm, init_process_group_from_env, shard_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = 0
     dist = None
-    force_dist = os.environ.get("CIAO_BENCH_FORCE_DIST") == "1"   # exercise the RCCL hook even with one rank
+    force_dist = os.environ.get("CIAO_BENCH_FORCE_DIST") == "1"   # exercise the collective path even with one rank
+    backend = os.environ.get("CIAO_BENCH_BACKEND", "nccl")        # "nccl" IS RCCL on ROCm; gloo = one-GPU rehearsal only
     if world > 1 or force_dist:
         import torch.distributed as dist
-        # RCCL ("nccl") is the product path; CIAO_BENCH_BACKEND=gloo exists only to rehearse several ranks on ONE GPU
-        rank, world, local = init_process_group_from_env(os.environ.get("CIAO_BENCH_BACKEND", "nccl"))
+        if backend == "nccl" and world > torch.cuda.device_count():
+            print(f"[bench] {world} ranks need {world} GPUs (found {torch.cuda.device_count()}); RCCL takes one rank per device. "
+                  f"CIAO_BENCH_BACKEND=gloo rehearses several ranks on one GPU.", file=sys.stderr)
+            return 2
+        rank, world, local = init_process_group_from_env(backend)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:
@@ -103,12 +228,25 @@ def main():
     g = ProxG(L.PROX_L1, lam=lam_g)
     L_max = (lam_f if not logistic else 0.25) * 1.3                      # ||a_i||^2 <= ~1.3 for d = 1024
     gamma = 1.0 / (7.0 * L_max) if not logistic else 1.0 / (10.0 * L_max)   # test_lasso.jl:164 / test_logistic_l1.jl:126
+
+    # ---- the collective: what is installed is what `config.collective` reports -----------------------------------------
+    collective, rccl_ranks, comm, hook = "none", None, None, None
     if world > 1 or force_dist:
-        if os.environ.get("CIAO_BENCH_COLLECTIVE", "torch") == "rccl":   # the library calls ncclAllReduce itself
-            from ciaoalgorithms_jl_amd.parallel import RcclComm
-            ctx.set_rccl(RcclComm(rank, world, dev.index))
-        else:                                                            # default: torch.distributed (backend nccl = RCCL)
-            ctx.set_allreduce(AllReduceHook(dev))
+        want = os.environ.get("CIAO_BENCH_COLLECTIVE", "rccl" if backend == "nccl" else "torch")
+        if want == "rccl" and backend == "nccl":
+            try:
+                comm = RcclComm(rank, world, dev.index)
+                ctx.set_rccl(comm)
+                rccl_ranks = comm.count()
+                collective = "rccl ncclAllReduce(d+1) per step, issued by the library on its stream"
+            except Exception as e:   # a box whose RCCL cannot be loaded natively still gets a (truthfully labelled) number
+                print(f"[bench] native RCCL path unavailable ({e!r}); falling back to torch.distributed", file=sys.stderr)
+                comm = None
+        if comm is None:
+            hook = AllReduceHook(dev)
+            ctx.set_allreduce(hook)
+            collective = (f"torch.distributed all_reduce(d+1) per step, backend {dist.get_backend()}"
+                          + (" (= RCCL)" if dist.get_backend() == "nccl" else " (host-staged: one-GPU rehearsal, not xGMI)"))
     xa = torch.zeros(d, dtype=tdt, device=dev)                           # x0 = 0 (test_lasso.jl:60)
     xb = torch.empty_like(xa)
     av = torch.empty_like(xa)
@@ -142,22 +280,49 @@ def main():
     ctx.synchronize()
     kernel_name = ctx.last_kernel()
 
+    # ---- the collective alone: K all-reduces of d+1 scalars back to back on the compute stream ---------------------------
+    allreduce_us = None
+    if world > 1 or force_dist:
+        buf = torch.zeros(d + 1, dtype=tdt, device=dev)
+        reps = 200
+        try:
+            if comm is not None:
+                fn = lambda: comm.all_reduce(buf, ctx.stream)
+            else:
+                fn = lambda: hook(buf.data_ptr(), d + 1, L.F64 if es == 8 else L.F32, ctx.stream.cuda_stream if ctx.stream else 0)
+            for _ in range(10):
+                fn()
+            fence()
+            allreduce_us = _timed_events(torch, ctx.stream or torch.cuda.current_stream(), fn, reps) * 1e6
+            fence()
+        except Exception as e:
+            print(f"[bench] all-reduce microbenchmark failed: {e!r}", file=sys.stderr)
+
     units = float(N_total) * args.steps                                  # sample-gradients processed by all ranks
     value = units / elapsed
     alg_bytes = n_local * (d * es + es)                                  # per launch: rows + b_i  
     k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
     achieved = alg_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
-    traffic = None
+    # HBM traffic per launch from the PMC counters: NOT measured in this run (a counter pass cannot share a run with the
+    # timed region); it is the committed value of an earlier `rocprofv3 --pmc` pass of this same command
+    traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            traffic = json.load(fh).get(f"{args.loss}_{args.dtype}_N{n_local}_d{d}")
+            tj = json.load(fh)
+        traffic = tj.get(f"{args.loss}_{args.dtype}_N{n_local}_d{d}")
+        if traffic is not None and tj.get("kernel") and tj["kernel"].split(" grid")[0] != kernel_name.split(" grid")[0]:
+            traffic = None   # the dominant kernel has changed since the counter pass: do not present a stale figure
+        traffic_src = {"file": "profiles/pmc_traffic.json", "measured_at": tj.get("measured_at"), "static": True} if traffic else None
     except Exception:
         traffic = None
 
     out = {
-        "metric": "sample_gradient_prox_updates_per_sec",
+        "metric": "sweep_sample_gradients_per_sec",
+        "metric_definition": "sample-gradient(+fused prox) evaluations per second of the SVRG full-gradient + prox sweep "
+                             "(SURVEY.md 8a row S4; BASELINE.md's roofline row).  One SVRG/SAGA inner-loop *update* (SURVEY.md "
+                             "8d) is a step of a dependent chain: see svrg_updates_per_sec / saga_updates_per_sec.",
         "value": value,
-        "unit": "updates/s",
+        "unit": "sample-gradients/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -167,16 +332,19 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "epochs_per_sec": args.steps / elapsed,
+        "sweeps_per_sec": args.steps / elapsed,
         # everything in a step that is not the sweep kernel: finalize + epilogue, launch gaps and -- with several ranks -- the
         # all-reduce of the d+1 scalars (BASELINE.md section 2 asks for that figure in microseconds)
         "step_overhead_us_beyond_sweep_kernel": (elapsed / args.steps - k_avg_s) * 1e6,
+        "allreduce_us_per_step": allreduce_us,
+        "rccl_ranks": rccl_ranks,
         "config": {"workload": f"{'l1_logistic' if logistic else 'lasso'}_svrg_fullgrad_prox_sweep",
                    "N_total": N_total, "rows_per_gpu": n_local, "d": d, "f": "LeastSquares(a_i,b_i,N)" if not logistic else "Precompose(LogisticLoss)",
                    "g": f"NormL1({lam_g:g})", "gamma": gamma, "parallelism": f"rows_sharded_x{world}",
-                   "collective": "rccl_allreduce(d+1)/step" if (world > 1 or force_dist) else "none"},
+                   "collective": collective, "launcher": "bench.py spawned the ranks" if os.environ.get("CIAO_BENCH_SPAWNED") else
+                   ("external launcher (WORLD_SIZE set)" if world > 1 else "single process")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name,
                      "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_n, "algorithmic_bytes_per_launch": alg_bytes},
     }
 
@@ -198,13 +366,21 @@ def main():
             t2 = time.perf_counter()
             _, nt = O.full_pass_omp(op, x_h)
             t_omp = time.perf_counter() - t2
-            out["cpu_baseline"] = {"value": n_s * reps / t_cpu, "unit": "updates/s", "cores": 1, "kind": "port",
+            out["cpu_baseline"] = {"value": n_s * reps / t_cpu, "unit": "sample-gradients/s", "cores": 1, "kind": "port",
                                    "sample": f"first {n_s} rows of the same A (d={d}, {args.dtype}), {reps} sequential full passes, "
                                              f"{t_cpu:.1f} s; oracle/ciao_oracle.c orc_full_pass (SVRG_basic.jl:87-92 restated)",
                                    "all_cores": {"value": n_s / t_omp, "cores": int(nt), "kind": "openmp sweep (not the reference's shape)"},
                                    "host_cores": os.cpu_count()}
+            del A_h, b_h, op
         except Exception as e:  # the baseline must never cost us the bench line
-            out["cpu_baseline"] = {"value": None, "unit": "updates/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+            out["cpu_baseline"] = {"value": None, "unit": "sample-gradients/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+
+    # ---- the updates SURVEY.md 8d defines: sequential SVRG / SAGA chains at the metric's own size (N=1 only) -------------
+    if rank == 0 and world == 1 and not args.no_chains:
+        try:
+            out.update(chain_figures(ctx, dev, F, g, gamma, A, b, n_local, d, args, L, np, torch))
+        except Exception as e:
+            out["chain_figures_error"] = repr(e)
 
     if not args.no_extras and world == 1 and rank == 0:
         try:
@@ -218,10 +394,98 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def chain_figures(ctx, dev, F, g, gamma, A, b, N, d, args, L, np, torch):
+    """One REAL SVRG outer iteration (SVRG_basic.jl:71-96: m = N dependent updates + the full pass) on the resident
+    problem, and SAGA steps at BASELINE config #3's size (N rows x d fp32 + the N x d gradient table).  Each figure carries
+    the bandwidth bound it is measured against (S3 d*s+8, G3 3*d*s+8 bytes per update); the chains are
+    dependent (step k+1 reads the iterate step k wrote), so the bound is not reachable by construction."""
+    from ciaoalgorithms_jl_amd.device import PackedF, ProxG
+    from ciaoalgorithms_jl_amd.sampling import IndexStream
+    res = {}
+    tdt = A.dtype
+    es = 8 if tdt == torch.float64 else 4
+    st = IndexStream(0)
+    x0 = torch.zeros(d, dtype=tdt, device=dev)
+    av, z, zf, w = (torch.empty_like(x0) for _ in range(4))
+    ctx.svrg_init(F, x0, av, z, zf, w)
+    idx = ctx._idx(st.rand_indices(N, N))
+    ctx.svrg_iterate(F, g, gamma, idx[:4096], False, av, z, zf, w)                 # warm (code objects, workspace)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.svrg_iterate(F, g, gamma, idx, False, av, z, zf, w, reuse_rowdots=True)      # ONE epoch, m = N
+    ctx.synchronize()
+    t_epoch = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    ctx.full_gradient(F, zf, av)
+    ctx.synchronize()
+    t_sweep = time.perf_counter() - t1
+    t_chain = max(t_epoch - t_sweep, 1e-9)
+    upd = N / t_chain
+    bound = HBM_PEAK_GBS * 1e9 / (d * es + 8)
+    res["svrg_updates_per_sec"] = {"value": upd, "us_per_update": 1e6 / upd, "m": N, "N": N, "d": d, "dtype": args.dtype,
+                                   "what": "SVRG inner cycle (SVRG_basic.jl:73-82), one dependent chain on one workgroup",
+                                   "roofline": {"bound": "hbm", "bytes_per_update": d * es + 8, "bound_updates_per_sec": bound,
+                                                "achieved": upd * (d * es + 8) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": upd / bound, "note": "latency-bound dependent chain (SURVEY.md section 7)"}}
+    ep_bytes = N * (d * es + 8) + N * (d * es + es)
+    res[f"svrg_epochs_per_sec_N{N // 1_000_000}M" if N % 1_000_000 == 0 else f"svrg_epochs_per_sec_N{N}"] = {
+        "value": 1.0 / t_epoch, "seconds_per_epoch": t_epoch, "m": N, "inner_cycle_s": t_chain, "full_pass_s": t_sweep,
+        "what": "one SVRG outer iteration = m = N updates + tail + full-gradient sweep (SVRG_basic.jl:71-96), measured once",
+        "roofline": {"bound": "hbm", "bytes_per_epoch": ep_bytes, "achieved": ep_bytes / t_epoch / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": ep_bytes / t_epoch / 1e9 / HBM_PEAK_GBS}}
+    del idx
+    # ---- SAGA at config #3: l1-logistic, fp32, N x d data + N x d table -------------------------------------------------
+    if d * 4 * N * 2 + (A.numel() * A.element_size() if A.dtype != torch.float32 else 0) < 250e9:
+        A32 = torch.empty((N, d), dtype=torch.float32, device=dev)
+        y32 = torch.empty((N,), dtype=torch.float32, device=dev)
+        ctx.synth_normal(A32, 0, seed=1, scale=1.0 / np.sqrt(d))
+        rng = np.random.default_rng(1)
+        xt = torch.from_numpy(rng.standard_normal(d) * (rng.random(d) < 0.05)).to(dev, torch.float32)
+        Fs = PackedF(L.LOSS_LOGISTIC, A32, y32, 1.0)
+        ctx.synth_targets(Fs, xt, noise=0.1, labels=True, seed=1, b_out=y32)
+        gs = ProxG(L.PROX_L1, lam=1.0 / N)
+        gam = 1.0 / (3 * 0.25 * 1.3)
+        table = torch.empty((N, d), dtype=torch.float32, device=dev)
+        x1 = torch.ones(d, dtype=torch.float32, device=dev)
+        sav, sz = torch.empty_like(x1), torch.empty_like(x1)
+        ctx.saga_init(Fs, gs, gam, x1, table, sav, sz)
+        k = 400_000
+        sidx = ctx._idx(st.rand_indices(N, k))
+        ctx.saga_steps(Fs, gs, gam, False, sidx[:4096], table, sav, sz)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        ctx.saga_steps(Fs, gs, gam, False, sidx, table, sav, sz)
+        ctx.synchronize()
+        ts = time.perf_counter() - t0
+        upd = k / ts
+        bound = HBM_PEAK_GBS * 1e9 / (3 * d * 4 + 8)
+        res["saga_updates_per_sec"] = {"value": upd, "us_per_update": 1e6 / upd, "steps": k, "N": N, "d": d, "dtype": "f32",
+                                       "what": "SAGA step (SAGA_basic.jl:53-68) at BASELINE config #3 (l1-logistic, table in HBM)",
+                                       "kernel": ctx.last_kernel(),
+                                       "roofline": {"bound": "hbm", "bytes_per_update": 3 * d * 4 + 8, "bound_updates_per_sec": bound,
+                                                    "achieved": upd * (3 * d * 4 + 8) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                    "frac": upd / bound, "note": "latency-bound dependent chain (SURVEY.md section 7)"}}
+        del A32, y32, table, Fs, sidx
+        torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)          # parent: no torch, no HIP, no GPU
+    if args.dry_run:
+        return dry_rank(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -80,12 +80,15 @@ SIGNATURES = {
     "ciao_hat_gamma": (_i32, [_vp, _i32, _i64, _vp, C.POINTER(_f64)]),
     "ciao_finito_init": (_i32, [_vp, _PP, _GP, _vp, _f64, _vp, _vp, _vp, _vp]),
     "ciao_finito_steps": (_i32, [_vp, _PP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ciao_finito_steps_blocks": (_i32, [_vp, _PP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ciao_lfinito_init": (_i32, [_vp, _PP, _f64, _vp, _vp, _vp, _vp]),
     "ciao_lfinito_iterate": (_i32, [_vp, _PP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ciao_lfinito_iterate_blocks": (_i32, [_vp, _PP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ciao_afinito_init": (_i32, [_vp, _PP, _GP, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ciao_afinito_steps": (_i32, [_vp, _PP, _GP, _f64, _f64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "ciao_proshi_init": (_i32, [_vp, _SP, _GP, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ciao_proshi_steps": (_i32, [_vp, _SP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ciao_proshi_steps_blocks": (_i32, [_vp, _SP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ciao_proshi_solution": (_i32, [_vp, _SP, _vp, _vp, _vp]),
     "ciao_synth_normal": (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _i64, C.c_uint64, _f64]),
     "ciao_synth_targets": (_i32, [_vp, _PP, _vp, _f64, _i32, _i64, C.c_uint64, _vp]),

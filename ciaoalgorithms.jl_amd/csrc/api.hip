@@ -329,6 +329,40 @@ static int32_t finito_init_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_pr
     return launch_rows<T>(ctx, RM_FINITO_INIT, a, e);
 }
 
+// Where the batches of a call come from: index lists (bidx[bptr[t] .. bptr[t+1]), device int64) or contiguous row blocks
+// (first[t] .. first[t]+len[t]: the static batches of Finito_basic.jl:52-58, no index array at all).
+struct BatchSrc {
+    const int64_t *bptr = nullptr, *bidx = nullptr;    // index lists
+    const int64_t *first = nullptr, *len = nullptr;    // row blocks (host arrays)
+    bool blocks() const { return first != nullptr; }
+    int64_t size(int64_t t) const { return blocks() ? len[t] : bptr[t + 1] - bptr[t]; }
+    const int64_t *idx(int64_t t) const { return blocks() ? nullptr : bidx + bptr[t]; }
+    int64_t row0(int64_t t) const { return blocks() ? first[t] : 0; }
+};
+
+// Row blocks that run as a sequential chain need their indices spelled out on the device: first[t] .. first[t]+r-1 for
+// t in [t0, t1), r each, into the ctx's index workspace (host-built, one upload per run; pageable memory, so the copy is
+// complete when hipMemcpyAsync returns and the host buffer may go).
+static int32_t block_indices(ciao_ctx *ctx, const BatchSrc &src, int64_t t0, int64_t t1, int64_t r, const int64_t **out)
+{
+    const size_t n = (size_t)((t1 - t0) * r);
+    CIAO_TRY(ensure(ctx, &ctx->idxbuf, &ctx->idxbuf_bytes, n * sizeof(int64_t)));
+    std::vector<int64_t> h;
+    try {
+        h.resize(n);
+    } catch (...) {
+        set_error("out of host memory (%zu block indices)", n);
+        return CIAO_ERR_ALLOC;
+    }
+    size_t k = 0;
+    for (int64_t t = t0; t < t1; ++t)
+        for (int64_t q = 0; q < r; ++q) h[k++] = src.first[t] + q;
+    CIAO_HIP(hipMemcpyAsync(ctx->idxbuf, h.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    CIAO_HIP(hipStreamSynchronize(ctx->stream));   // h goes out of scope: be certain the staging copy has consumed it
+    *out = (const int64_t *)ctx->idxbuf;
+    return CIAO_OK;
+}
+
 // Batches of r samples: r dependent chain steps in one persistent workgroup, or one batch-parallel rows launch?
 // "chain_max_batch" >= 0 fixes the crossover; -1 (default) derives it from measurements on MI355X: a batch-parallel step
 // costs ~10 us of launches + latency whatever r (tools/finito_batch_time.py), a chain step 0.45-1.5 us growing with the row.
@@ -354,20 +388,21 @@ static bool batch_as_chain(const ciao_ctx *ctx, const ciao_problem *p, int64_t r
 
 template <typename T>
 static int32_t finito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
-                              int64_t nit, const int64_t *bptr, const int64_t *bidx, void *table, void *av, void *z)
+                              int64_t nit, const BatchSrc &src, void *table, void *av, void *z)
 {
     int64_t t = 0;
     while (t < nit) {
-        const int64_t r = bptr[t + 1] - bptr[t];
+        const int64_t r = src.size(t);
         // on a row-sharded problem a batch may have no member on this rank: it still joins the all-reduce with a zero sum
         CIAO_REQUIRE(r >= 1 || (ctx->hook && r == 0), "Finito batch %lld is empty", (long long)t);
         // a run of consecutive batches of the same size
         int64_t t1 = t + 1;
-        while (t1 < nit && bptr[t1 + 1] - bptr[t1] == r) ++t1;
+        while (t1 < nit && src.size(t1) == r) ++t1;
         if (batch_as_chain<T>(ctx, p, r)) {
             ChainArgs<T> a = chain_args<T>(p, g);
             a.nsteps = (t1 - t) * r;
-            a.idx = bidx + bptr[t];
+            a.idx = src.idx(t);
+            if (src.blocks()) CIAO_TRY(block_indices(ctx, src, t, t1, r, &a.idx));
             a.batch = r;
             a.gam = (const T *)gam;
             a.hat_gamma = (T)hat_gamma;
@@ -376,10 +411,11 @@ static int32_t finito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_p
             a.z = (T *)z;
             CIAO_TRY(launch_chain<T>(ctx, CA_FINITO, a));
         } else {
-            for (int64_t tt = t; tt < t1; ++tt) {
+            auto one = [&](int64_t tt) -> int32_t {
                 RowsArgs<T> a = rows_args<T>(p);
                 a.nrows = r;
-                a.idx = bidx + bptr[tt];
+                a.idx = src.idx(tt);
+                a.row0 = src.row0(tt);
                 a.x1 = (const T *)z;
                 a.table = (T *)table;
                 a.gam = (const T *)gam;
@@ -392,7 +428,44 @@ static int32_t finito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_p
                 e.z_out = (T *)z;   // z = prox_{hat_gamma g}(av)
                 e.tau = (T)hat_gamma;
                 e.g = make_prox<T>(g);
-                CIAO_TRY(launch_rows<T>(ctx, RM_FINITO_BATCH, a, e));
+                return launch_rows<T>(ctx, RM_FINITO_BATCH, a, e);
+            };
+            if (ctx->graph_batches && !ctx->hook && t1 - t > 4) {
+                // EXPERIMENT (option "graph_batches"): the run of batches as one captured graph, timed by events around its
+                // launch -- what the batches cost when the host's launch rate is out of the picture
+                CIAO_TRY(one(t));   // eager: sizes the workspace (no allocation may happen while capturing)
+                const bool tsave = ctx->timing;
+                ctx->timing = false;
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                CIAO_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                int32_t st = CIAO_OK;
+                for (int64_t tt = t + 1; tt < t1 && st == CIAO_OK; ++tt) st = one(tt);
+                hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+                ctx->timing = tsave;
+                if (st != CIAO_OK || ce != hipSuccess) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    return st != CIAO_OK ? st : hip_fail(ce, "hipStreamEndCapture");
+                }
+                CIAO_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                hipEvent_t e0, e1;
+                CIAO_HIP(hipEventCreate(&e0));
+                CIAO_HIP(hipEventCreate(&e1));
+                CIAO_HIP(hipEventRecord(e0, ctx->stream));
+                CIAO_HIP(hipGraphLaunch(exec, ctx->stream));
+                CIAO_HIP(hipEventRecord(e1, ctx->stream));
+                CIAO_HIP(hipStreamSynchronize(ctx->stream));
+                float ms = 0.f;
+                CIAO_HIP(hipEventElapsedTime(&ms, e0, e1));
+                char buf[96];
+                snprintf(buf, sizeof buf, " graph_us_per_batch=%.3f batches=%lld", ms * 1e3 / (double)(t1 - t - 1), (long long)(t1 - t - 1));
+                ctx->last_kernel += buf;
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+                (void)hipGraphExecDestroy(exec);
+                (void)hipGraphDestroy(graph);
+            } else {
+                for (int64_t tt = t; tt < t1; ++tt) CIAO_TRY(one(tt));
             }
         }
         t = t1;
@@ -422,8 +495,7 @@ static int32_t lfinito_init_t(ciao_ctx *ctx, const ciao_problem *p, double hat_g
 
 template <typename T>
 static int32_t lfinito_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam,
-                                 double hat_gamma, int64_t nb, const int64_t *bptr, const int64_t *bidx, void *av, void *z,
-                                 void *z_full)
+                                 double hat_gamma, int64_t nb, const BatchSrc &src, void *av, void *z, void *z_full)
 {
     const T hg = (T)hat_gamma;
     // z_full = prox_{hg g}(av)                                   Finito_LFinito.jl:83
@@ -443,14 +515,15 @@ static int32_t lfinito_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const cia
     int64_t t = 0;
     bool z_ready = false;
     while (t < nb) {
-        const int64_t r = bptr[t + 1] - bptr[t];
+        const int64_t r = src.size(t);
         CIAO_REQUIRE(r >= 1 || (ctx->hook && r == 0), "LFinito batch %lld is empty", (long long)t);
         int64_t t1 = t + 1;
-        while (t1 < nb && bptr[t1 + 1] - bptr[t1] == r) ++t1;
+        while (t1 < nb && src.size(t1) == r) ++t1;
         if (batch_as_chain<T>(ctx, p, r)) {
             ChainArgs<T> a = chain_args<T>(p, g);
             a.nsteps = (t1 - t) * r;
-            a.idx = bidx + bptr[t];
+            a.idx = src.idx(t);
+            if (src.blocks()) CIAO_TRY(block_indices(ctx, src, t, t1, r, &a.idx));
             a.batch = r;
             a.gam = (const T *)gam;
             a.hat_gamma = hg;
@@ -465,7 +538,8 @@ static int32_t lfinito_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const cia
                 if (!z_ready) CIAO_TRY(prox_launch<T>(ctx, p->d, g, (const T *)av, hg, T(1), (T *)z));
                 RowsArgs<T> a = rows_args<T>(p);
                 a.nrows = r;
-                a.idx = bidx + bptr[tt];
+                a.idx = src.idx(tt);
+                a.row0 = src.row0(tt);
                 a.x1 = (const T *)z_full;   // acc += (coef(z_full) - coef(z)) a_i
                 a.x2 = (const T *)z;
                 a.gam = (const T *)gam;
@@ -576,6 +650,7 @@ static int32_t proshi_init_t(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_pr
     a.x = (const T *)x0;
     a.nrows = f->N;
     a.idx = nullptr;
+    a.row0 = 0;
     Epilogue<T> e = epi_zero<T>();
     e.c_sum = T(1);            // av = sum_i s_i
     e.inv_extra = 2;           // hat_gamma = sum_i gam_i
@@ -589,15 +664,16 @@ static int32_t proshi_init_t(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_pr
 
 template <typename T>
 static int32_t proshi_steps_t(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_desc *g, const void *gam, double hat_gamma,
-                              int64_t nit, const int64_t *bptr, const int64_t *bidx, void *table, void *av, void *z)
+                              int64_t nit, const BatchSrc &src, void *table, void *av, void *z)
 {
     for (int64_t t = 0; t < nit; ++t) {
-        const int64_t r = bptr[t + 1] - bptr[t];
+        const int64_t r = src.size(t);
         CIAO_REQUIRE(r >= 1 || (ctx->hook && r == 0), "ProShI batch %lld is empty", (long long)t);
         ProshiArgs<T> a = proshi_args<T>(f, gam, table);
         a.x = (const T *)z;
         a.nrows = r;
-        a.idx = bidx + bptr[t];
+        a.idx = src.idx(t);
+        a.row0 = src.row0(t);
         Epilogue<T> e = epi_zero<T>();
         e.c_acc = T(1);        // av += sum_{i in batch} (s_i_new - s_i_old)
         e.acc_in = (const T *)av;
@@ -698,6 +774,7 @@ int32_t ciao_ctx_destroy(ciao_ctx *ctx)
     if (ctx->sumbuf) (void)hipFree(ctx->sumbuf);
     if (ctx->rowdot) (void)hipFree(ctx->rowdot);
     if (ctx->monx) (void)hipFree(ctx->monx);
+    if (ctx->idxbuf) (void)hipFree(ctx->idxbuf);
     if (ctx->scal) (void)hipFree(ctx->scal);
     if (ctx->errflag) (void)hipFree(ctx->errflag);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -834,6 +911,8 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
         ctx->rowdot_A = nullptr;
     } else if (!strcmp(key, "chain_no_dma")) {
         ctx->chain_no_dma = value != 0;
+    } else if (!strcmp(key, "graph_batches")) {
+        ctx->graph_batches = value != 0;
     } else if (!strcmp(key, "force_generic")) {
         ctx->force_generic = value != 0;
     } else {
@@ -1045,6 +1124,18 @@ int32_t ciao_finito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_d
     return DISPATCH(p->dtype, finito_init_t, ctx, p, g, gam, hat_gamma, x0, table, av, z);
 }
 
+// validation of a call's row blocks: inside [0, N), non-negative lengths (empty only on a row-sharded problem)
+static int32_t check_blocks(const ciao_ctx *ctx, int64_t N, int64_t n, const int64_t *first_host, const int64_t *len_host, const char *what)
+{
+    CIAO_REQUIRE(n >= 0 && (n == 0 || (first_host && len_host)), "%s: n < 0 or NULL block arrays", what);
+    for (int64_t t = 0; t < n; ++t) {
+        CIAO_REQUIRE(len_host[t] >= 1 || (ctx->hook && len_host[t] == 0), "%s: batch %lld is empty", what, (long long)t);
+        CIAO_REQUIRE(first_host[t] >= 0 && first_host[t] + len_host[t] <= N, "%s: batch %lld = rows [%lld, %lld) leaves [0, %lld)", what,
+                     (long long)t, (long long)first_host[t], (long long)(first_host[t] + len_host[t]), (long long)N);
+    }
+    return CIAO_OK;
+}
+
 int32_t ciao_finito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
                           int64_t nit, const int64_t *bptr_host, const int64_t *bidx, void *table, void *av, void *z)
 {
@@ -1055,7 +1146,26 @@ int32_t ciao_finito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
     CIAO_REQUIRE(nit == 0 || p->N > 0, "cannot sample from an empty problem");
     CIAO_REQUIRE(table && av && z && gam, "NULL state vector / table / gam");
     CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
-    return DISPATCH(p->dtype, finito_steps_t, ctx, p, g, gam, hat_gamma, nit, bptr_host, bidx, table, av, z);
+    BatchSrc src;
+    src.bptr = bptr_host;
+    src.bidx = bidx;
+    return DISPATCH(p->dtype, finito_steps_t, ctx, p, g, gam, hat_gamma, nit, src, table, av, z);
+}
+
+int32_t ciao_finito_steps_blocks(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
+                                 int64_t nit, const int64_t *first_host, const int64_t *len_host, void *table, void *av, void *z)
+{
+    CIAO_ENTER(ctx);
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_blocks(ctx, p->N, nit, first_host, len_host, "ciao_finito_steps_blocks"));
+    CIAO_REQUIRE(nit == 0 || p->N > 0 || ctx->hook, "cannot take batches from an empty problem");
+    CIAO_REQUIRE(table && av && z && gam, "NULL state vector / table / gam");
+    CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
+    BatchSrc src;
+    src.first = first_host;
+    src.len = len_host;
+    return DISPATCH(p->dtype, finito_steps_t, ctx, p, g, gam, hat_gamma, nit, src, table, av, z);
 }
 
 int32_t ciao_lfinito_init(ciao_ctx *ctx, const ciao_problem *p, double hat_gamma, const void *x0, void *av, void *z,
@@ -1077,7 +1187,25 @@ int32_t ciao_lfinito_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_pr
     CIAO_REQUIRE(nb >= 0 && (nb == 0 || (bptr_host && (bidx || bptr_host[nb] == bptr_host[0]))), "nb < 0 or NULL batch arrays");
     CIAO_REQUIRE(av && z && z_full && gam, "NULL state vector / gam");
     CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
-    return DISPATCH(p->dtype, lfinito_iterate_t, ctx, p, g, gam, hat_gamma, nb, bptr_host, bidx, av, z, z_full);
+    BatchSrc src;
+    src.bptr = bptr_host;
+    src.bidx = bidx;
+    return DISPATCH(p->dtype, lfinito_iterate_t, ctx, p, g, gam, hat_gamma, nb, src, av, z, z_full);
+}
+
+int32_t ciao_lfinito_iterate_blocks(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
+                                    int64_t nb, const int64_t *first_host, const int64_t *len_host, void *av, void *z, void *z_full)
+{
+    CIAO_ENTER(ctx);
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_blocks(ctx, p->N, nb, first_host, len_host, "ciao_lfinito_iterate_blocks"));
+    CIAO_REQUIRE(av && z && z_full && gam, "NULL state vector / gam");
+    CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
+    BatchSrc src;
+    src.first = first_host;
+    src.len = len_host;
+    return DISPATCH(p->dtype, lfinito_iterate_t, ctx, p, g, gam, hat_gamma, nb, src, av, z, z_full);
 }
 
 int32_t ciao_afinito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha, const void *x0,
@@ -1134,7 +1262,25 @@ int32_t ciao_proshi_steps(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_
     CIAO_REQUIRE(nit >= 0 && (nit == 0 || (bptr_host && (bidx || bptr_host[nit] == bptr_host[0]))), "nit < 0 or NULL batch arrays");
     CIAO_REQUIRE(table && gam && av && z, "NULL state vector / table / gam");
     CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
-    return DISPATCH(f->dtype, proshi_steps_t, ctx, f, g, gam, hat_gamma, nit, bptr_host, bidx, table, av, z);
+    BatchSrc src;
+    src.bptr = bptr_host;
+    src.bidx = bidx;
+    return DISPATCH(f->dtype, proshi_steps_t, ctx, f, g, gam, hat_gamma, nit, src, table, av, z);
+}
+
+int32_t ciao_proshi_steps_blocks(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_desc *g, const void *gam, double hat_gamma,
+                                 int64_t nit, const int64_t *first_host, const int64_t *len_host, void *table, void *av, void *z)
+{
+    CIAO_ENTER(ctx);
+    CIAO_TRY(check_sepquad(ctx, f));
+    CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_blocks(ctx, f->N, nit, first_host, len_host, "ciao_proshi_steps_blocks"));
+    CIAO_REQUIRE(table && gam && av && z, "NULL state vector / table / gam");
+    CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
+    BatchSrc src;
+    src.first = first_host;
+    src.len = len_host;
+    return DISPATCH(f->dtype, proshi_steps_t, ctx, f, g, gam, hat_gamma, nit, src, table, av, z);
 }
 
 int32_t ciao_proshi_solution(ciao_ctx *ctx, const ciao_sepquad *f, const void *gam, const void *z, void *table)

@@ -208,26 +208,34 @@ struct Epilogue {
     double obj_scale;
 };
 
+// operands already in registers (the caller requested them before its reduction): acc_in[k], u[k], v[k], pw[k]
 template <typename T>
-__device__ __forceinline__ void epilogue_apply(const Epilogue<T> &e, int64_t k, T sum, T extra)
+__device__ __forceinline__ void epilogue_apply_pre(const Epilogue<T> &e, int64_t k, T sum, T extra, T acc_k, T u_k, T v_k, T pw_k)
 {
     const T hgx = e.inv_extra == 1 ? T(1) / extra : (e.inv_extra == 2 ? extra : T(1));
     if (e.inv_extra && e.hg_out && k == 0) *e.hg_out = hgx;
     if (e.obj_out && k == 0) e.obj_out[1] = (double)extra * e.obj_scale;
     T a = (e.inv_extra == 1 ? e.c_sum * hgx : e.c_sum) * sum;
-    if (e.acc_in) a += e.c_acc * e.acc_in[k];
+    if (e.acc_in) a += e.c_acc * acc_k;
     T cu = e.uv_extra ? e.c_u * extra : e.c_u;
     T cv = e.uv_extra ? e.c_v * extra : e.c_v;
-    if (e.u) a += cu * e.u[k];
-    if (e.v) a += cv * e.v[k];
+    if (e.u) a += cu * u_k;
+    if (e.v) a += cv * v_k;
     if (e.av_out) e.av_out[k] = a;
     if (e.z_out) {
         T t = e.p0 * a;
-        if (e.pw) t += e.p1 * e.pw[k];
+        if (e.pw) t += e.p1 * pw_k;
         const T tau = e.inv_extra ? hgx : e.tau;
         const T pz = prox_elem(e.g, t, tau, k);
         e.z_out[k] = e.zmode == 1 ? (pz - t) / tau : pz;
     }
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_apply(const Epilogue<T> &e, int64_t k, T sum, T extra)
+{
+    epilogue_apply_pre(e, k, sum, extra, e.acc_in ? e.acc_in[k] : T(0), e.u ? e.u[k] : T(0), e.v ? e.v[k] : T(0),
+                       e.pw ? e.pw[k] : T(0));
 }
 
 }  // namespace ciao

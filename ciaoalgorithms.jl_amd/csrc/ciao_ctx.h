@@ -35,6 +35,8 @@ struct ciao_ctx {
     ciao_prox_desc monitor_g{};
     void *monx = nullptr;              // copy of x for the monitor when a step overwrites x in place
     size_t monx_bytes = 0;
+    void *idxbuf = nullptr;            // spelled-out indices of row-block batches that run as a sequential chain
+    size_t idxbuf_bytes = 0;
     double *scal = nullptr;    // small device scratch for scalar reductions (4096 doubles)
     int *errflag = nullptr;    // sticky device error word (out-of-range index)
 
@@ -59,6 +61,7 @@ struct ciao_ctx {
     int chain_last_dma = 0;
     bool chain_last_masked = false;
     long long *chain_dbg = nullptr;   // timing builds only (CIAO_CHAIN_DBG & 8): device buffer for cycle stamps
+    int64_t graph_batches = 0;      // experiment: capture runs of batch-parallel Finito batches as one graph (api.hip)
     int64_t force_generic = 0;      // testing: route every rows launch through the generic kernel
 
     std::string last_kernel;

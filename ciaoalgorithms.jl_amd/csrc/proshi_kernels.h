@@ -19,7 +19,8 @@ struct ProshiArgs {
     const T *x;            // INIT: x0 ; STEP: z
     T *table;              // N x d
     int64_t nrows;
-    const int64_t *idx;    // STEP: batch members; INIT: nullptr (all rows)
+    const int64_t *idx;    // STEP: batch members, or nullptr = the contiguous rows row0 .. row0+nrows; INIT: nullptr (all rows)
+    int64_t row0;
     T *partial;
     int64_t pstride;
     T *pextra;
@@ -52,7 +53,7 @@ __global__ void __launch_bounds__(PROSHI_NW *WAVE) proshi_rows_kernel(ProshiArgs
 
     T extra = T(0);
     for (int64_t u = (int64_t)blockIdx.x * PROSHI_NW + wib; u < a.nrows; u += nwaves) {
-        int64_t row = a.idx ? a.idx[u] : u;
+        int64_t row = a.idx ? a.idx[u] : a.row0 + u;
         if ((uint64_t)row >= (uint64_t)a.N) {
             if (lane == 0) *a.errflag = 1;
             row = 0;
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(256) proshi_vec_kernel(ProshiArgs<T> a)
     }
     T extra = T(0);
     for (int64_t u = blockIdx.x; u < a.nrows; u += gridDim.x) {
-        int64_t row = a.idx ? a.idx[u] : u;
+        int64_t row = a.idx ? a.idx[u] : a.row0 + u;
         if ((uint64_t)row >= (uint64_t)a.N) {
             if (tid == 0) *a.errflag = 1;
             row = 0;

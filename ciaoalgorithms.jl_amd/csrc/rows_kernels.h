@@ -81,13 +81,36 @@ struct RowsWaves {
     static constexpr int value = raw < 1 ? 1 : (raw > 8 ? 8 : raw);
 };
 
-// table rows are written once per visit and not re-read by this kernel: non-temporal stores (CIAO_PLAIN_STORES: timing
-// experiment with default-policy stores)
-#ifdef CIAO_PLAIN_STORES
-#define TSTORE(val, ptr) (*(ptr) = (val))
-#else
-#define TSTORE(val, ptr) __builtin_nontemporal_store((val), (ptr))
+// Store flavours (16-byte chunks).  Table rows are written once per visit and not re-read by this kernel; the per-block
+// partials are read by the NEXT kernel (finalize), on other XCDs.  CIAO_TSTORE / CIAO_PSTORE pick the cache policy of the two
+// (experiment builds, tools/exp_build.sh): 0 = non-temporal, 1 = default policy, 2 = sc1 (write-through: the bytes leave the
+// XCD's L2 during the kernel instead of at its end-of-kernel release, MI355X_MICROARCH.md "publish-large").
+#ifndef CIAO_TSTORE
+#define CIAO_TSTORE 0
 #endif
+#ifndef CIAO_PSTORE
+#define CIAO_PSTORE 1
+#endif
+template <int FLAVOUR, typename V>
+__device__ __forceinline__ void store16(V val, V *ptr)
+{
+    if constexpr (sizeof(V) != 16) {   // element-wise chunks (rows with no 16-byte structure): non-temporal or default only
+        if constexpr (FLAVOUR == 1)
+            *ptr = val;
+        else
+            __builtin_nontemporal_store(val, ptr);
+    } else if constexpr (FLAVOUR == 0) {
+        __builtin_nontemporal_store(val, ptr);
+    } else if constexpr (FLAVOUR == 1) {
+        *ptr = val;
+    } else {
+        // hipcc does not count asm stores (nothing here waits on them; the hardware retires them before the kernel ends);
+        // s_nop 1: the data registers may not be overwritten before the store has read them (cdna_hip_programming.md 5.7)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(val) : "memory");
+    }
+}
+#define TSTORE(val, ptr) store16<CIAO_TSTORE>((val), (ptr))
+#define PSTORE(val, ptr) store16<CIAO_PSTORE>((val), (ptr))
 
 template <typename T, int K, int MODE, int PF>
 __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>::value)) rows_fast_kernel(RowsArgs<T> a)
@@ -330,8 +353,6 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
     }
 }
 
-#undef TSTORE
-
 // ------------------------------------------------------------------------------------------------------------------
 // ONE WORKGROUP per row (rows_split_kernel).  Two jobs:
 //
@@ -452,7 +473,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) gv[v] = g1.elem(x.ar[j][v]);
                 acc[j] += gv;
-                if (ok[j]) __builtin_nontemporal_store(gv, &x.sp[tid + j * ROWS_BLOCK]);
+                if (ok[j]) TSTORE(gv, &x.sp[tid + j * ROWS_BLOCK]);
             }
         } else {                                      // Finito_basic.jl:77-83 (init) / :110-117 (batch)
             const T cg = x.gi * a.invN;
@@ -468,7 +489,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
                     else
                         acc[j][v] += (tv[v] - x.sr[j][v]) * rr;
                 }
-                if (ok[j]) __builtin_nontemporal_store(tv, &x.sp[tid + j * ROWS_BLOCK]);
+                if (ok[j]) TSTORE(tv, &x.sp[tid + j * ROWS_BLOCK]);
             }
         }
     };
@@ -485,7 +506,12 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
     V *pout = reinterpret_cast<V *>(a.partial + (int64_t)blockIdx.x * a.pstride);
 #pragma unroll
     for (int j = 0; j < J; ++j)
-        if (ok[j]) pout[tid + j * ROWS_BLOCK] = acc[j];
+        if (ok[j]) {
+            if constexpr (VEC * sizeof(T) == 16)
+                PSTORE(acc[j], &pout[tid + j * ROWS_BLOCK]);
+            else
+                pout[tid + j * ROWS_BLOCK] = acc[j];
+        }
     if (tid == 0) a.pextra[blockIdx.x] = extra;   // extra is workgroup-uniform
 }
 
@@ -941,13 +967,19 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// finalize: sum the per-block partials in a fixed order and apply the epilogue.  Block = (64 columns) x (16 slices).
+// finalize: sum the per-block partials in a fixed order and apply the epilogue.
+// A batch step is rows kernel -> finalize -> next rows kernel, so for batches of a few hundred rows this kernel is half of
+// the step (rocprofv3, r = 256, d = 4096 fp32: rows 6.4 us, finalize 5.0 us with the first version of this kernel, which
+// made two dependent rounds of 4-byte loads and fetched the epilogue's operands only after the reduction).  Now:
+//   - a block covers one 128-byte line of every partial row (8 lanes x 16 B) with 32 slices of partial rows, so with up to
+//     256 partials every thread has ALL its loads (<= 8 x 16 B) in flight at once: one memory round trip;
+//   - the epilogue's own operands (acc_in, u, v, pw) are requested before the partials, not after the reduction;
+//   - the order of the additions is fixed (per thread: pairwise over its loads; then 4 groups of 8 slices; then the 4 group
+//     sums pairwise), so results are bitwise reproducible run to run.
 // ------------------------------------------------------------------------------------------------------------------
-// Block = COLS columns x SLICES slices of the partial rows (512 threads); COLS*sizeof(T) = 128 B, one L2 line per
-// partial row, so the d/COLS blocks spread the (grid x d) partial matrix over many CUs.
-constexpr int FIN_THREADS = 512;
+constexpr int FIN_THREADS = 256;
 #ifndef CIAO_FIN_BYTES
-#define CIAO_FIN_BYTES 128   // bytes of one partial row that a finalize block covers (tuning: -DCIAO_FIN_BYTES=64)
+#define CIAO_FIN_BYTES 128   // bytes of one partial row that a finalize block covers (one L2 line)
 #endif
 
 template <typename T>
@@ -955,65 +987,74 @@ __global__ void __launch_bounds__(FIN_THREADS)
     finalize_kernel(const T *__restrict__ partial, int64_t pstride, int nparts, const T *__restrict__ pextra,
                     int64_t d, T *raw_out, Epilogue<T> ep)
 {
+    constexpr int VEC = 16 / sizeof(T);
+    using V = typename ChunkOf<T, VEC>::type;
+    constexpr int LANES = CIAO_FIN_BYTES / 16;         // 16-byte chunks of the line
+    constexpr int SLICES = FIN_THREADS / LANES;        // 32
     constexpr int COLS = CIAO_FIN_BYTES / sizeof(T);
-    constexpr int SLICES = FIN_THREADS / COLS;
-    __shared__ T lds[SLICES][COLS];
+    constexpr int U = 8;                               // loads in flight per thread and round
+    __shared__ V lds[SLICES][LANES];
+    __shared__ V lds2[4][LANES];
     __shared__ T lds_extra;
-    const int tx = threadIdx.x % COLS;
-    const int ty = threadIdx.x / COLS;
-    const int64_t col = (int64_t)blockIdx.x * COLS + tx;
+    const int tx = threadIdx.x % LANES;
+    const int ty = threadIdx.x / LANES;
+    const int64_t col = (int64_t)blockIdx.x * COLS + tx * VEC;   // this thread's first column (rows are padded to pstride)
 
-    T s = T(0);
-    if (col < d) {
-        // eight loads in flight per thread (the partials sit in L2 / Infinity Cache: the cost is round trips, not bytes);
-        // the association order is fixed: four chains, combined pairwise
-        T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
-        int p = ty;
-        for (; p + 7 * SLICES < nparts; p += 8 * SLICES) {
-            T v[8];
+    // the epilogue's operands for the VEC columns this thread may own at the end: requested first
+    T pa[VEC], pu[VEC], pv[VEC], pp[VEC];
+    if (ty == 0 && !raw_out) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(p + u * SLICES) * pstride + col];
-            s0 += v[0];
-            s1 += v[1];
-            s2 += v[2];
-            s3 += v[3];
-            s0 += v[4];
-            s1 += v[5];
-            s2 += v[6];
-            s3 += v[7];
+        for (int v = 0; v < VEC; ++v) {
+            const bool in = col + v < d;
+            pa[v] = (ep.acc_in && in) ? ep.acc_in[col + v] : T(0);
+            pu[v] = (ep.u && in) ? ep.u[col + v] : T(0);
+            pv[v] = (ep.v && in) ? ep.v[col + v] : T(0);
+            pp[v] = (ep.pw && in) ? ep.pw[col + v] : T(0);
         }
-        {   // up to seven left: issue them together as well
-            T v[7];
+    }
+
+    V s = V(T(0));
+    if (col < pstride) {
+        const V *pp0 = reinterpret_cast<const V *>(partial + col);
+        const int64_t vstride = pstride / VEC;   // pstride is a multiple of 64 elements
+        for (int p0 = ty; p0 < nparts; p0 += U * SLICES) {
+            V v[U];
 #pragma unroll
-            for (int u = 0; u < 7; ++u) v[u] = (p + u * SLICES < nparts) ? partial[(int64_t)(p + u * SLICES) * pstride + col] : T(0);
-            s0 += v[0];
-            s1 += v[1];
-            s2 += v[2];
-            s3 += v[3];
-            s0 += v[4];
-            s1 += v[5];
-            s2 += v[6];
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * SLICES;
+                v[u] = p < nparts ? pp0[(int64_t)p * vstride] : V(T(0));
+            }
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
-        s = (s0 + s1) + (s2 + s3);
     }
     lds[ty][tx] = s;
-    if (threadIdx.x < WAVE) {   // wave 0: the extra scalar (all 64 lanes active)
+    if (threadIdx.x >= FIN_THREADS - WAVE) {   // last wave: the extra scalar (all 64 lanes active)
+        const int l = threadIdx.x & (WAVE - 1);
         T ex = T(0);
-        for (int p = threadIdx.x; p < nparts; p += WAVE) ex += pextra[p];
+        for (int p = l; p < nparts; p += WAVE) ex += pextra[p];
         ex = wave_allsum(ex);
-        if (threadIdx.x == 0) lds_extra = ex;
+        if (l == 0) lds_extra = ex;
     }
     __syncthreads();
-    if (ty == 0 && col < d) {
-        T tot = lds[0][tx];
+    if (ty < 4) {
+        V g = lds[ty * 8][tx];
 #pragma unroll
-        for (int y = 1; y < SLICES; ++y) tot += lds[y][tx];
+        for (int j = 1; j < 8; ++j) g += lds[ty * 8 + j][tx];
+        lds2[ty][tx] = g;
+    }
+    __syncthreads();
+    if (ty == 0) {
+        const V tot = (lds2[0][tx] + lds2[1][tx]) + (lds2[2][tx] + lds2[3][tx]);
         const T extra = lds_extra;
-        if (raw_out) {
-            raw_out[col] = tot;
-            if (col == 0) raw_out[d] = extra;
-        } else {
-            epilogue_apply(ep, col, tot, extra);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            if (col + v >= d) continue;
+            if (raw_out) {
+                raw_out[col + v] = tot[v];
+                if (col + v == 0) raw_out[d] = extra;
+            } else {
+                epilogue_apply_pre(ep, col + v, tot[v], extra, pa[v], pu[v], pv[v], pp[v]);
+            }
         }
     }
 }

@@ -83,6 +83,24 @@ class PackedF:
         sel = idx[(idx >= self.row0) & (idx < self.row0 + self.N)]
         return sel - self.row0
 
+    def local_blocks(self, lo, hi):
+        """Global row blocks [lo[t], hi[t]) -> (first, length) of the LOCAL rows this shard owns of each: again contiguous
+        blocks, under both ownership rules (block: clip to [row0, row0+N); cyclic: local row = i // world for i % world == rank)."""
+        import numpy as _np
+        lo = _np.asarray(lo, dtype=_np.int64)
+        hi = _np.asarray(hi, dtype=_np.int64)
+        if self.N == self.N_total and self.cyclic is None:
+            return lo, hi - lo
+        if self.cyclic is not None:
+            rank, world = self.cyclic
+            f = (lo - rank + world - 1) // world          # first local row whose global index is >= lo
+            e = (hi - rank + world - 1) // world          # first local row whose global index is >= hi
+            f = _np.maximum(f, 0)
+            return f, _np.maximum(e - f, 0)
+        f = _np.clip(lo, self.row0, self.row0 + self.N) - self.row0
+        e = _np.clip(hi, self.row0, self.row0 + self.N) - self.row0
+        return f, e - f
+
     def local_slice(self, vec):
         """The entries of a global N_total-vector (L, gamma) that belong to this shard's rows."""
         if self.N == self.N_total and self.cyclic is None:
@@ -130,6 +148,7 @@ class PackedSepQuad:
 
     localise = PackedF.localise
     local_slice = PackedF.local_slice
+    local_blocks = PackedF.local_blocks
 
 
 class ProxG:
@@ -327,6 +346,32 @@ class Context:
                                            self._vec(table, p, "table", p.N * p.d), self._vec(av, p, "av"),
                                            self._vec(z, p, "z")))
         return bidx
+
+    @staticmethod
+    def _blocks(first, length):
+        first = np.ascontiguousarray(first, dtype=np.int64)
+        length = np.ascontiguousarray(length, dtype=np.int64)
+        assert first.shape == length.shape and first.ndim == 1
+        return first, length
+
+    def finito_steps_blocks(self, p, g, gam, hat_gamma, first, length, table, av, z):
+        """Batches given as contiguous local row blocks [first[t], first[t] + length[t]) -- no index array (ciao_finito_steps_blocks)."""
+        first, length = self._blocks(first, length)
+        L.check(self.lib.ciao_finito_steps_blocks(self._h, p.ref, g.ref, self._vec(gam, p, "gam", p.N), float(hat_gamma), first.size,
+                                                  C.c_void_p(first.ctypes.data), C.c_void_p(length.ctypes.data),
+                                                  self._vec(table, p, "table", p.N * p.d), self._vec(av, p, "av"), self._vec(z, p, "z")))
+
+    def lfinito_iterate_blocks(self, p, g, gam, hat_gamma, first, length, av, z, z_full):
+        first, length = self._blocks(first, length)
+        L.check(self.lib.ciao_lfinito_iterate_blocks(self._h, p.ref, g.ref, self._vec(gam, p, "gam", p.N), float(hat_gamma), first.size,
+                                                     C.c_void_p(first.ctypes.data), C.c_void_p(length.ctypes.data),
+                                                     self._vec(av, p, "av"), self._vec(z, p, "z"), self._vec(z_full, p, "z_full")))
+
+    def proshi_steps_blocks(self, f, g, gam, hat_gamma, first, length, table, av, z):
+        first, length = self._blocks(first, length)
+        L.check(self.lib.ciao_proshi_steps_blocks(self._h, f.ref, g.ref, self._vec(gam, f, "gam", f.N), float(hat_gamma), first.size,
+                                                  C.c_void_p(first.ctypes.data), C.c_void_p(length.ctypes.data),
+                                                  self._vec(table, f, "table", f.N * f.d), self._vec(av, f, "av"), self._vec(z, f, "z")))
 
     def lfinito_init(self, p, hat_gamma, x0, av, z, z_full):
         L.check(self.lib.ciao_lfinito_init(self._h, p.ref, float(hat_gamma), self._vec(x0, p, "x0"), self._vec(av, p, "av"),

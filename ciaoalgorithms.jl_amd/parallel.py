@@ -124,6 +124,8 @@ class RcclComm:
         self._lib.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
         self._lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
         self._lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        self._lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         self._lib.ncclGetErrorString.restype = C.c_char_p
         uid = _NcclUniqueId()
         if rank == 0:
@@ -140,6 +142,21 @@ class RcclComm:
     def _check(self, r, what):
         if r != 0:
             raise RuntimeError(f"{what} failed: {self._lib.ncclGetErrorString(r).decode()}")
+
+    def count(self) -> int:
+        """ncclCommCount: the number of ranks RCCL itself says this communicator spans."""
+        n = C.c_int(0)
+        self._check(self._lib.ncclCommCount(self.handle, C.byref(n)), "ncclCommCount")
+        return int(n.value)
+
+    def all_reduce(self, t: torch.Tensor, stream=None):
+        """In-place sum of a float32/float64 device tensor on `stream` (a torch stream; None = the current one): the very call
+        libciao_hip.so makes for the d-vector sums (csrc/api.hip rccl_hook); used by bench.py to time the collective alone."""
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
+        s = stream if stream is not None else torch.cuda.current_stream(t.device)
+        self._check(self._lib.ncclAllReduce(C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), t.numel(),
+                                            8 if t.dtype == torch.float64 else 7, 0, self.handle, C.c_void_p(s.cuda_stream)),
+                    "ncclAllReduce")
 
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle.value:

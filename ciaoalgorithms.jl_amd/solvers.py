@@ -308,6 +308,15 @@ def _static_batches_packed(N, r, js):
     return bptr, bidx
 
 
+def _static_blocks(it, js):
+    """The static batches number js[0], js[1], ... (Finito_basic.jl:52-58) as this rank's contiguous LOCAL row blocks
+    (first, length): index-free, and arithmetic on whole arrays whatever the sharding."""
+    js = np.asarray(js, dtype=np.int64)
+    lo = it.batch * js
+    hi = np.minimum(lo + it.batch, it.N)
+    return it.F.local_blocks(lo, hi)
+
+
 def _next_static_numbers(it, st, n):
     """The 0-based static batch numbers of the next n iterations for sweeping 2 (cyclic, Finito_basic.jl:99: the first
     step uses batch 2) and 3 (a fresh randperm(d) whenever a pass is complete, :100-108; the first pass is the identity
@@ -377,6 +386,10 @@ class FINITO_basic_iterable(_Iterable):
         return st
 
     def _step(self, st, n):                                                # Finito_basic.jl:109-118, n iterations
+        if self.sweeping != 1:   # static batches are contiguous row blocks: no index array at all (:99-108)
+            first, length = _static_blocks(self, _next_static_numbers(self, st, n))
+            self.ctx.finito_steps_blocks(self.F, self.g, st.γ, st.hat_γ, first, length, st.s, st.av, st.z)
+            return
         bptr, bidx = _next_batches_packed(self, st, n)
         self.ctx.finito_steps(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.s, st.av, st.z)
 
@@ -413,19 +426,13 @@ class FINITO_LFinito_iterable(_Iterable):
     _rides_on_full_pass = True
 
     def _step(self, st, n):                                                # Finito_LFinito.jl:78-103
-        N, r = self.N, self.batch
         for _ in range(n):
             if self.sweeping == 3:
                 st.inds = self.stream.randperm(st.d)                       # :89
-            if r == 1 and self.sweeping != 3 and self.F.N == self.N:
-                bptr = np.arange(N + 1, dtype=np.int64)                    # identity order, one sample per batch
-                bidx = np.arange(N, dtype=np.int64)
-            elif self.F.N == self.F.N_total and self.F.cyclic is None:
-                bptr, bidx = _static_batches_packed(N, r, st.inds)
-            else:
-                bptr, bidx = _pack_batches([_localise(self, _static_batch(N, r, int(j))) for j in st.inds])
+            # the batches are always the static contiguous blocks (:44-49), visited in the order st.inds (:90)
+            first, length = _static_blocks(self, st.inds)
             self._monitor_on()
-            self.ctx.lfinito_iterate(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.av, st.z, st.z_full)
+            self.ctx.lfinito_iterate_blocks(self.F, self.g, st.γ, st.hat_γ, first, length, st.av, st.z, st.z_full)
             self._monitor_off()
 
 
@@ -535,6 +542,10 @@ class Proshi_basic_iterable(_Iterable):
         return Proshi_basic_state(self, s, gam, float(hg.item()), av, z, -(-N // r) if N > 0 else 0)
 
     def _step(self, st, n):                                                # :109-121
+        if self.sweeping != 1:   # static batches: contiguous blocks of agents (:50-57)
+            first, length = _static_blocks(self, _next_static_numbers(self, st, n))
+            self.ctx.proshi_steps_blocks(self.F, self.g, st.γ, st.hat_γ, first, length, st.s, st.av, st.z)
+            return
         bptr, bidx = _next_batches_packed(self, st, n)
         self.ctx.proshi_steps(self.F, self.g, st.γ, st.hat_γ, bptr, bidx, st.s, st.av, st.z)
 

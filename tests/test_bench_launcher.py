@@ -1,0 +1,72 @@
+"""bench.py's own launcher: `python bench.py --gpus N` without a launcher must start N ranks itself --
+fresh child processes, spawned before the parent has touched the GPU (the parent never imports torch) -- relay rank 0's
+JSON line and exit non-zero when a rank fails.  The CPU tests use --dry-run (rendezvous + barrier + relay, no GPU work);
+the GPU test runs the real step with two ranks sharing the one GPU of the test box (gloo rehearsal)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_direct_invocation_spawns_n_ranks(n):
+    r = _run(["--gpus", str(n), "--dry-run", "--steps", "4", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0's)"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == n and j["steps"] == 4 and j["warmup"] == 1 and j["dry_run"] is True
+    assert "gloo" in j["config"]["collective"]          # the line says what ran, not what the product path would use
+
+
+def test_rank_under_an_external_launcher_does_not_respawn():
+    """With WORLD_SIZE set (torch.distributed.run) the process IS a rank: world 1 here, so it just prints its line."""
+    r = _run(["--gpus", "1", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_a_failed_rank_fails_the_run():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs the GPU-less container: there the real (non-dry) ranks die at context creation")
+    r = _run(["--gpus", "2", "--steps", "1", "--rows-per-gpu", "100", "--no-cpu", "--no-extras"], {"CIAO_BENCH_BACKEND": "gloo"})
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no result line may be relayed from a failed run"
+    assert "failed with exit code" in r.stderr
+
+
+def test_parent_never_imports_torch():
+    """The parent must not be able to touch the GPU: the spawning path runs with torch made unimportable."""
+    code = ("import sys; sys.modules['torch'] = None; sys.argv = ['bench.py', '--gpus', '2', '--dry-run']; "
+            f"sys.path.insert(0, {ROOT!r}); import bench; rc = bench.main(); assert 'torch' not in "
+            "[m for m in sys.modules if sys.modules[m] is not None]; sys.exit(rc)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["n_gpus"] == 2
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_one_gpu_real_step():
+    """The real sweep, two ranks sharing GPU 0 (RCCL takes one rank per device, so the rehearsal collective is gloo): the
+    line must say n_gpus = 2, count both shards' rows, and name the collective that actually ran."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--rows-per-gpu", "200000", "--no-cpu", "--no-extras", "--no-chains"],
+             {"CIAO_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["N_total"] == 400000 and j["config"]["rows_per_gpu"] == 200000
+    assert "gloo" in j["config"]["collective"] and "rccl" not in j["config"]["collective"].lower().replace("(= rccl)", "")
+    assert j["rccl_ranks"] is None and j["allreduce_us_per_step"] is not None
+    assert j["value"] > 0 and j["roofline"]["kernel_launches"] == 3
+    assert j["config"]["launcher"] == "bench.py spawned the ranks"

@@ -169,3 +169,37 @@ def test_static_batch_sequences_in_chunks(ciao, sweeping, chunks):
         assert np.array_equal(bptr, np.concatenate([[0], np.cumsum([len(x) for x in ref])]))
         assert np.array_equal(bidx, np.concatenate(ref))
         assert st_a.idxr == st_b.idxr
+
+
+def test_local_blocks_agree_with_localise():
+    """A contiguous block of global rows is a contiguous block of LOCAL rows under both ownership rules (device.PackedF):
+    local_blocks (array arithmetic, feeds the index-free *_blocks entry points) against localise (explicit indices)."""
+    import ciao_loader
+    ciao_loader.load()
+    from ciaoalgorithms_jl_amd.device import PackedF
+
+    class Shard:   # the ownership fields of a PackedF, without a device
+        localise = PackedF.localise
+        local_blocks = PackedF.local_blocks
+
+        def __init__(self, N, N_total, row0=0, cyclic=None):
+            self.N, self.N_total, self.row0, self.cyclic = N, N_total, row0, cyclic
+
+    rng = np.random.default_rng(0)
+    N_total = 1003
+    for world in (1, 2, 3, 8):
+        for rank in range(world):
+            base, rem = divmod(N_total, world)
+            n = base + (1 if rank < rem else 0)
+            row0 = rank * base + min(rank, rem)
+            shards = [Shard(n, N_total, row0=row0)] if world > 1 else [Shard(N_total, N_total)]
+            if world > 1:
+                shards.append(Shard((N_total - rank + world - 1) // world, N_total, cyclic=(rank, world)))
+            lo = rng.integers(0, N_total, 200)
+            hi = np.minimum(lo + rng.integers(0, 300, 200), N_total)
+            for sh in shards:
+                first, length = sh.local_blocks(lo, hi)
+                for a, b, f, l in zip(lo, hi, first, length):
+                    want = sh.localise(np.arange(a, b, dtype=np.int64))
+                    assert l == want.size and (l == 0 or (f == want[0] and np.array_equal(want, np.arange(f, f + l)))), (world, rank, a, b)
+                    assert 0 <= f and f + l <= sh.N

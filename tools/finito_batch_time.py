@@ -10,7 +10,8 @@ from ciaoalgorithms_jl_amd import _lib as L
 from ciaoalgorithms_jl_amd.device import Context, PackedF, ProxG
 from ciaoalgorithms_jl_amd.sampling import IndexStream
 torch.cuda.set_device(0)
-ctx = Context(0)
+own = torch.cuda.Stream() if os.environ.get("CIAO_OWN_STREAM") else None   # a capturable (non-default) stream
+ctx = Context(0, stream=own)
 for kv in os.environ.get("CIAO_OPTS", "").split(","):
     if "=" in kv:
         k, v = kv.split("=")
@@ -27,6 +28,7 @@ hg = ctx.hat_gamma(gam)
 x0 = torch.zeros(d, dtype=dt, device="cuda")
 table = torch.empty((N, d), dtype=dt, device="cuda")
 av, z = torch.empty_like(x0), torch.empty_like(x0)
+torch.cuda.synchronize()
 ctx.finito_init(F, g, gam, hg, x0, table, av, z)
 st = IndexStream(0)
 out = []
@@ -38,6 +40,21 @@ for r in rs:
     t0 = time.perf_counter(); ctx.finito_steps(F, g, gam, hg, bptr, bidx, table, av, z); ctx.synchronize()
     t = time.perf_counter() - t0
     out.append(f"r={r}: {t / nit * 1e6:.2f} us/batch, {nit * r * (3 * d * 4 + 16) / t / 1e9:.0f} GB/s [{ctx.last_kernel()}]")
+    print(out[-1], flush=True)
+if os.environ.get("CIAO_BLOCKS"):   # static contiguous batches: index lists vs the index-free *_blocks entry point
+    for r in rs:
+        nit = max(8, min(2000, N // r))
+        first = (np.random.default_rng(0).permutation(N // r)[:nit] * r).astype(np.int64)
+        length = np.full(nit, r, np.int64)
+        bptr = np.arange(nit + 1, dtype=np.int64) * r
+        bidx = ctx._idx((first[:, None] + np.arange(r)[None, :]).reshape(-1))
+        for name, fn in (("index lists", lambda: ctx.finito_steps(F, g, gam, hg, bptr, bidx, table, av, z)),
+                         ("row blocks ", lambda: ctx.finito_steps_blocks(F, g, gam, hg, first, length, table, av, z))):
+            fn(); ctx.synchronize()
+            t0 = time.perf_counter(); fn(); ctx.synchronize()
+            t = time.perf_counter() - t0
+            out.append(f"static r={r} {name}: {t / nit * 1e6:.2f} us/batch [{ctx.last_kernel()}]")
+            print(out[-1], flush=True)
 if os.environ.get("CIAO_LFINITO"):
     zf = torch.empty_like(x0)
     ctx.lfinito_init(F, hg, x0, av, z, zf)
