@@ -46,6 +46,15 @@ class SepQuad(C.Structure):
                 ("hi", C.c_double)]
 
 
+MAX_SHARDS = 8
+
+
+class ShardTable(C.Structure):
+    """ciao_shard_table"""
+    _fields_ = [("nshards", C.c_int32), ("owner", C.c_int32), ("row0", C.c_int64 * (MAX_SHARDS + 1)),
+                ("A", C.c_void_p * MAX_SHARDS), ("b", C.c_void_p * MAX_SHARDS), ("table", C.c_void_p * MAX_SHARDS)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
@@ -75,6 +84,10 @@ SIGNATURES = {
     "ciao_svrg_init": (_i32, [_vp, _PP, _vp, _vp, _vp, _vp, _vp]),
     "ciao_svrg_inner": (_i32, [_vp, _PP, _GP, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ciao_svrg_iterate": (_i32, [_vp, _PP, _GP, _f64, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ciao_ctx_set_shards": (_i32, [_vp, C.POINTER(ShardTable)]),
+    "ciao_ipc_export": (_i32, [_vp, _vp, C.POINTER(_i64)]),
+    "ciao_ipc_open": (_i32, [_vp, _i64, C.POINTER(_vp)]),
+    "ciao_ipc_close": (_i32, [_vp, _i64]),
     "ciao_saga_init": (_i32, [_vp, _PP, _GP, _f64, _vp, _vp, _vp, _vp]),
     "ciao_saga_steps": (_i32, [_vp, _PP, _GP, _f64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "ciao_hat_gamma": (_i32, [_vp, _i32, _i64, _vp, C.POINTER(_f64)]),

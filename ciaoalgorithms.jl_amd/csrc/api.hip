@@ -160,7 +160,48 @@ static ChainArgs<T> chain_args(const ciao_problem *p, const ciao_prox_desc *g)
     a.gam_uniform = T(1);
     a.g = make_prox<T>(g);
     a.N = p->N;
+    a.nshards = 0;
     return a;
+}
+
+// the chain over a shard table: indices are GLOBAL rows, every shard's base pointer is valid on this device
+template <typename T>
+static void chain_shards(const ciao_ctx *ctx, const ciao_problem *p, ChainArgs<T> &a, bool with_table)
+{
+    const ciao_shard_table &sh = ctx->shards;
+    a.nshards = sh.nshards;
+    a.N = p->N_total;
+    for (int k = 0; k < CIAO_MAX_SHARDS; ++k) {
+        const bool on = k < sh.nshards;
+        a.shA[k] = on ? (const T *)sh.A[k] : nullptr;
+        a.shb[k] = on ? (const T *)sh.b[k] : nullptr;
+        a.shT[k] = (on && with_table) ? (T *)sh.table[k] : nullptr;
+    }
+    for (int k = 0; k <= CIAO_MAX_SHARDS; ++k) a.sh_row0[k] = k <= sh.nshards ? sh.row0[k] : sh.row0[sh.nshards];
+}
+
+// Row-sharded chains: after the owner's chain, vectors u and v (d each) are all-reduced with the non-owners contributing
+// zeros, so every rank ends with the owner's values (the sum adds exact zeros: bitwise the owner's).
+template <typename T>
+static int32_t broadcast_from_owner(ciao_ctx *ctx, int64_t d, void *u, void *v)
+{
+    const size_t bytes = (size_t)d * sizeof(T);
+    CIAO_TRY(ensure(ctx, &ctx->sumbuf, &ctx->sumbuf_bytes, 2 * bytes + sizeof(T)));
+    char *buf = (char *)ctx->sumbuf;
+    if (ctx->shards.owner) {
+        CIAO_HIP(hipMemcpyAsync(buf, u, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        CIAO_HIP(hipMemcpyAsync(buf + bytes, v, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        CIAO_HIP(hipMemsetAsync(buf, 0, 2 * bytes, ctx->stream));
+    }
+    const int32_t hs = ctx->hook(ctx->hook_user, buf, 2 * d, sizeof(T) == 8 ? CIAO_F64 : CIAO_F32, (void *)ctx->stream);
+    if (hs != 0) {
+        set_error("all-reduce hook failed with status %d", hs);
+        return CIAO_ERR_HOOK;
+    }
+    CIAO_HIP(hipMemcpyAsync(u, buf, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    CIAO_HIP(hipMemcpyAsync(v, buf + bytes, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return CIAO_OK;
 }
 
 template <typename T>
@@ -261,6 +302,13 @@ static int32_t svrg_inner_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_pro
     a.z = (T *)z;
     a.zf = (T *)z_full;
     a.w = (T *)w;
+    if (ctx->shards.nshards > 0) {   // row-sharded problem: the owner runs the one chain over every shard's rows
+        if (ctx->shards.owner) {
+            chain_shards<T>(ctx, p, a, false);
+            CIAO_TRY(launch_chain<T>(ctx, CA_SVRG, a));
+        }
+        return ctx->hook ? broadcast_from_owner<T>(ctx, p->d, z, w) : CIAO_OK;
+    }
     // a_i'z_full for every row is already known if the last full pass on this ctx was the one at this z_full
     if (use_rowdots && ctx->rowdot_A == p->A && ctx->rowdot_x == z_full && ctx->rowdot_N == p->N && ctx->rowdot_A) {
         a.gam = (const T *)ctx->rowdot;
@@ -308,6 +356,13 @@ static int32_t saga_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_pro
     a.table = (T *)table;
     a.av = (T *)av;
     a.z = (T *)z;
+    if (ctx->shards.nshards > 0) {   // row-sharded problem: data rows AND table rows of the other shards are peer memory
+        if (ctx->shards.owner) {
+            chain_shards<T>(ctx, p, a, true);
+            CIAO_TRY(launch_chain<T>(ctx, CA_SAGA, a));
+        }
+        return ctx->hook ? broadcast_from_owner<T>(ctx, p->d, z, av) : CIAO_OK;
+    }
     return launch_chain<T>(ctx, CA_SAGA, a);
 }
 
@@ -580,6 +635,7 @@ static int32_t afinito_init_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_p
     a.table = (T *)table;
     a.meta = (T *)meta;
     a.alpha = (T)alpha;
+    a.Nd = (double)p->N_total;
     Epilogue<T> e = epi_zero<T>();
     e.c_sum = T(1);
     e.inv_extra = 1;              // hat_gamma = 1 / sum_i 1/gamma_i ; av = hat_gamma * sum ; z = prox_{hat_gamma g}(av)
@@ -608,6 +664,7 @@ static int32_t afinito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_
     a.tol_b = (T)tol_b;
     a.invN = T(1) / (T)p->N_total;
     a.Nf = (T)p->N_total;
+    a.Nd = (double)p->N_total;
     a.g = make_prox<T>(g);
     a.table = (T *)table;
     a.meta = (T *)meta;
@@ -949,6 +1006,71 @@ int32_t ciao_ctx_timing_read(ciao_ctx *ctx, double *total_ms_host, int64_t *laun
 
 const char *ciao_ctx_last_kernel(ciao_ctx *ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
 
+// a shard table must describe exactly the problem the call is about
+static int32_t check_shards(const ciao_ctx *ctx, const ciao_problem *p, bool need_table)
+{
+    const ciao_shard_table &sh = ctx->shards;
+    if (sh.nshards == 0) return CIAO_OK;
+    CIAO_REQUIRE(sh.row0[sh.nshards] == p->N_total, "the shard table covers %lld rows but the problem has N_total = %lld",
+                 (long long)sh.row0[sh.nshards], (long long)p->N_total);
+    if (sh.owner && p->loss != CIAO_LOSS_ZERO)
+        for (int k = 0; k < sh.nshards; ++k) {
+            if (sh.row0[k + 1] == sh.row0[k]) continue;
+            CIAO_REQUIRE(sh.A[k] && sh.b[k], "shard %d has rows but no data pointers on the chain owner", k);
+            CIAO_REQUIRE(!need_table || sh.table[k], "shard %d has no table pointer on the chain owner (SAGA)", k);
+        }
+    return CIAO_OK;
+}
+
+int32_t ciao_ctx_set_shards(ciao_ctx *ctx, const ciao_shard_table *shards)
+{
+    CIAO_ENTER(ctx);
+    ctx->rowdot_A = nullptr;
+    if (!shards) {
+        ctx->shards = ciao_shard_table{};
+        return CIAO_OK;
+    }
+    CIAO_REQUIRE(shards->nshards >= 1 && shards->nshards <= CIAO_MAX_SHARDS, "nshards must be in 1..%d (got %d)", CIAO_MAX_SHARDS,
+                 shards->nshards);
+    CIAO_REQUIRE(shards->row0[0] == 0, "row0[0] must be 0");
+    for (int k = 0; k < shards->nshards; ++k)
+        CIAO_REQUIRE(shards->row0[k + 1] >= shards->row0[k], "row0 must be non-decreasing (shard %d)", k);
+    ctx->shards = *shards;
+    return CIAO_OK;
+}
+
+int32_t ciao_ipc_export(const void *dev_ptr, void *handle_out, int64_t *offset_out)
+{
+    CIAO_REQUIRE(dev_ptr && handle_out && offset_out, "NULL argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI documents 64-byte handles");
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    CIAO_HIP(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dev_ptr));
+    hipIpcMemHandle_t h;
+    CIAO_HIP(hipIpcGetMemHandle(&h, (void *)base));
+    memcpy(handle_out, &h, sizeof h);
+    *offset_out = (int64_t)((const char *)dev_ptr - (const char *)base);
+    return CIAO_OK;
+}
+
+int32_t ciao_ipc_open(const void *handle, int64_t offset, void **dev_ptr_out)
+{
+    CIAO_REQUIRE(handle && dev_ptr_out && offset >= 0, "NULL argument or negative offset");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof h);
+    void *base = nullptr;
+    CIAO_HIP(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+    *dev_ptr_out = (char *)base + offset;
+    return CIAO_OK;
+}
+
+int32_t ciao_ipc_close(void *dev_ptr, int64_t offset)
+{
+    CIAO_REQUIRE(dev_ptr && offset >= 0, "NULL argument or negative offset");
+    CIAO_HIP(hipIpcCloseMemHandle((char *)dev_ptr - offset));
+    return CIAO_OK;
+}
+
 int32_t ciao_gradient(ciao_ctx *ctx, const ciao_problem *p, int64_t i, const void *x, void *y, void *fval)
 {
     CIAO_ENTER(ctx);
@@ -1031,10 +1153,12 @@ int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_de
     ctx->rowdot_A = keep;   // z_full is read-only here: a following ciao_svrg_iterate may still reuse the row dots
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(m >= 0 && (m == 0 || idx), "m < 0 or idx is NULL");
-    CIAO_REQUIRE(m == 0 || p->N > 0, "cannot sample from an empty problem");
+    CIAO_REQUIRE(m == 0 || p->N > 0 || ctx->shards.nshards > 0, "cannot sample from an empty problem");
     CIAO_REQUIRE(av && z && z_full && w, "NULL state vector");
     CIAO_REQUIRE(gamma > 0, "gamma must be > 0");
-    CIAO_REQUIRE(!ctx->hook, "the SVRG inner cycle is a sequential chain: replicas only, not valid on a row-sharded problem");
+    CIAO_REQUIRE(!ctx->hook || ctx->shards.nshards > 0,
+                 "the SVRG inner cycle is a sequential chain: on a row-sharded problem it needs a shard table (ciao_ctx_set_shards)");
+    CIAO_TRY(check_shards(ctx, p, false));
     return DISPATCH(p->dtype, svrg_inner_t, ctx, p, g, gamma, m, idx, av, z, z_full, w);
 }
 
@@ -1049,10 +1173,12 @@ int32_t ciao_svrg_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
     ctx->rowdot_A = reuse_rowdots ? keep : nullptr;
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(m >= 1 && idx, "m < 1 or idx is NULL");
-    CIAO_REQUIRE(p->N > 0, "cannot sample from an empty problem");
+    CIAO_REQUIRE(p->N > 0 || ctx->shards.nshards > 0, "cannot sample from an empty problem");
     CIAO_REQUIRE(av && z && z_full && w, "NULL state vector");
     CIAO_REQUIRE(gamma > 0, "gamma must be > 0");
-    CIAO_REQUIRE(!ctx->hook, "the SVRG inner cycle is a sequential chain: replicas only, not valid on a row-sharded problem");
+    CIAO_REQUIRE(!ctx->hook || ctx->shards.nshards > 0,
+                 "the SVRG inner cycle is a sequential chain: on a row-sharded problem it needs a shard table (ciao_ctx_set_shards)");
+    CIAO_TRY(check_shards(ctx, p, false));
     return DISPATCH(p->dtype, svrg_iterate_t, ctx, p, g, gamma, m, idx, plus, reuse_rowdots, av, z, z_full, w);
 }
 
@@ -1074,10 +1200,12 @@ int32_t ciao_saga_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_de
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
     CIAO_REQUIRE(nsteps >= 0 && (nsteps == 0 || idx), "nsteps < 0 or idx is NULL");
-    CIAO_REQUIRE(nsteps == 0 || p->N > 0, "cannot sample from an empty problem");
-    CIAO_REQUIRE(table && av && z, "NULL state vector / table");
+    CIAO_REQUIRE(nsteps == 0 || p->N > 0 || ctx->shards.nshards > 0, "cannot sample from an empty problem");
+    CIAO_REQUIRE((table || ctx->shards.nshards > 0) && av && z, "NULL state vector / table");
     CIAO_REQUIRE(gamma > 0, "gamma must be > 0");
-    CIAO_REQUIRE(!ctx->hook, "SAGA steps are a sequential chain: replicas only, not valid on a row-sharded problem");
+    CIAO_REQUIRE(!ctx->hook || ctx->shards.nshards > 0,
+                 "SAGA steps are a sequential chain: on a row-sharded problem they need a shard table (ciao_ctx_set_shards)");
+    CIAO_TRY(check_shards(ctx, p, true));
     return DISPATCH(p->dtype, saga_steps_t, ctx, p, g, gamma, sag, nsteps, idx, table, av, z);
 }
 

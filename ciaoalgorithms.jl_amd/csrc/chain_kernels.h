@@ -44,10 +44,41 @@ struct ChainArgs {
     T *table;
     ProxD<T> g;
     T *av, *z, *zf, *w;
-    int64_t N;             // local rows (index validation)
+    int64_t N;             // rows the indices may address (index validation): local rows, or N_total with a shard table
     int *errflag;          // device word set to 1 on an out-of-range index
     long long *dbg;        // CIAO_CHAIN_DBG & 8 builds only: [wave][6] cycle sums (option "chain_dbg_ptr")
+    // Row-sharded problem (ciao_ctx_set_shards; SURVEY.md 8e "one chain on one GPU pulling remote rows over xGMI"): the rows
+    // live in nshards allocations, shard k = global rows [sh_row0[k], sh_row0[k+1]); the pointers may be peer-mapped memory of
+    // other GPUs.  idx then holds GLOBAL rows.  nshards = 0: A / b / table above are the whole problem.
+    int nshards;
+    const T *shA[CIAO_MAX_SHARDS];
+    const T *shb[CIAO_MAX_SHARDS];
+    T *shT[CIAO_MAX_SHARDS];
+    int64_t sh_row0[CIAO_MAX_SHARDS + 1];
 };
+
+// global row -> (shard, local row) for the contiguous block partition; all values wave-uniform
+template <typename T>
+__device__ __forceinline__ int shard_of(const ChainArgs<T> &a, int64_t r, int64_t &local)
+{
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < CIAO_MAX_SHARDS; ++j) k += (j < a.nshards && r >= a.sh_row0[j]) ? 1 : 0;
+    local = r - a.sh_row0[k];
+    return k;
+}
+// address of the table row of global row r (uniform): one multiply without shards, a short scalar search with them
+template <bool SHARDED, typename T>
+__device__ __forceinline__ T *table_row(const ChainArgs<T> &a, int64_t r)
+{
+    if constexpr (!SHARDED) return a.table + r * a.d;
+    int64_t local;
+    const int k = shard_of(a, r, local);
+    T *base = a.shT[0];
+#pragma unroll
+    for (int j = 1; j < CIAO_MAX_SHARDS; ++j) base = (j == k) ? a.shT[j] : base;
+    return base + local * a.d;
+}
 
 template <typename T>
 struct VecOfC;
@@ -67,7 +98,7 @@ struct VecOfC<double> {
 
 constexpr int CHAIN_NT = 256;
 constexpr int CHAIN_NW = CHAIN_NT / WAVE;
-constexpr int CHAIN_CHUNK = 1024;   // steps whose indices / b_i / gamma_i are staged in LDS at a time
+constexpr int CHAIN_CHUNK = 1024;   // steps whose indices / b_i / gamma_i (/ row addresses) are staged in LDS at a time
 
 template <int E>
 struct ChainDepth {
@@ -397,7 +428,10 @@ struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at 0.4-0.9 u
 
 // NT threads (256 or 512): 32 KiB rows are shared by eight waves instead of four (a step costs ~0.38 us + ~0.06 us per
 // 16-byte chunk a thread owns, but eight waves also pay more for the exchange: chain_launch.inc has the measurements).
-template <typename T, int J, int ALG, int LOSS, bool MASKED, int NT>
+// SHARDED: the rows live in several allocations (ChainArgs::sh*, ciao_ctx_set_shards): each step's row ADDRESS is resolved
+// while staging and kept in LDS, table rows are addressed through the shard table.  A separate instantiation, so that the
+// single-allocation chain keeps its instruction count (an always-present shard search cost it 0.07 us per SAGA step).
+template <typename T, int J, int ALG, int LOSS, bool MASKED, int NT, bool SHARDED = false>
 __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
 {
     constexpr int NW = NT / WAVE;
@@ -419,16 +453,22 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
     constexpr bool PIPE = DEPTH >= 4;
     constexpr int WAIT_N = (PIPE ? DEPTH - 2 : DEPTH - 1) * OPS_PER_STEP;
     constexpr int ROW_BYTES = J * NT * 16;
+    static_assert(!SHARDED || ALG == CA_SVRG || ALG == CA_SAGA, "only the SVRG and SAGA chains run over a shard table");
+    constexpr bool STAGE_PTR = SHARDED;
     static_assert(CH % DEPTH == 0 && DEPTH % 2 == 0, "ring slots must line up with chunk starts; ping-pong needs even DEPTH");
 
     // one dynamic LDS block, carved by hand (16-byte aligned pieces):
-    //   ringA[DEPTH][ROW_BYTES] | ringT[DEPTH][ROW_BYTES] (table algs) | s_row | s_b | s_g | s_stale | red
+    //   ringA[DEPTH][ROW_BYTES] | ringT[DEPTH][ROW_BYTES] (table algs) | s_row | s_ptr | s_b | s_g | s_stale | red
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     unsigned char *ringA = dsm;
     unsigned char *ringT = ringA + DEPTH * ROW_BYTES;
     unsigned char *cur = ringT + (HAS_TABLE ? DEPTH * ROW_BYTES : 0);
     int64_t *s_row = reinterpret_cast<int64_t *>(cur);
     cur += (CH + 2 * DEPTH) * sizeof(int64_t);
+    // the data row's ADDRESS per step, resolved while staging (one multiply, or the shard search on a row-sharded problem):
+    // the step itself only reads it back, so a remote (peer-mapped) row costs the step nothing extra to address
+    const unsigned char **s_ptr = reinterpret_cast<const unsigned char **>(cur);
+    cur += (STAGE_PTR ? CH + 2 * DEPTH : 0) * sizeof(int64_t);
     T *s_b = reinterpret_cast<T *>(cur);
     cur += CH * sizeof(T);
     T *s_g = reinterpret_cast<T *>(cur);
@@ -489,14 +529,13 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
 #pragma unroll
     for (int j = 0; j < J; ++j) gav[j] = a.gamma * av[j];
 
-    // issue the DMA of row r into ring slot u: J (+J) wave-instructions of 1 KiB each
-    auto refill = [&](int u, int64_t r) {
-        const unsigned char *ap = reinterpret_cast<const unsigned char *>(a.A + r * a.ld);
+    // issue the DMA of row r (at address ap) into ring slot u: J (+J) wave-instructions of 1 KiB each
+    auto refill = [&](int u, int64_t r, const unsigned char *ap) {
 #pragma unroll
         for (int j = 0; j < J; ++j)
             glds16(ap + cl[j] * 16, ringA_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
         if (HAS_TABLE) {
-            const unsigned char *sp = reinterpret_cast<const unsigned char *>(a.table + r * d);
+            const unsigned char *sp = reinterpret_cast<const unsigned char *>(table_row<SHARDED>(a, r));
 #pragma unroll
             for (int j = 0; j < J; ++j)
                 glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
@@ -507,6 +546,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
     struct StepIn {
         V ar[J], sr[J];
         int64_t row, row_n;
+        const unsigned char *ptr_n;
         T bi, gi;
         int stale;
     };
@@ -523,6 +563,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
         }
         x.row = s_row[DEPTH + s];
         x.row_n = s_row[DEPTH + s + DEPTH];
+        x.ptr_n = STAGE_PTR ? s_ptr[DEPTH + s + DEPTH] : nullptr;
         x.bi = s_b[s];
         x.gi = PER_SAMPLE_GAM ? s_g[s] : T(1);
         x.stale = HAS_TABLE ? s_stale[s] : 0;
@@ -561,8 +602,19 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 r = 0;
             }
             s_row[DEPTH + e] = r;
+            const T *arow, *bp;
+            if (SHARDED) {   // global row -> (shard, local row): the shard's base may be another GPU's memory
+                int64_t local;
+                const int k = shard_of(a, r, local);
+                arow = a.shA[k] + local * a.ld;
+                bp = a.shb[k] ? a.shb[k] + local : nullptr;
+            } else {
+                arow = a.A + r * a.ld;
+                bp = a.b ? a.b + r : nullptr;
+            }
+            if (STAGE_PTR) s_ptr[DEPTH + e] = reinterpret_cast<const unsigned char *>(arow);
             if (e < nch) {
-                s_b[e] = a.b ? a.b[r] : T(0);
+                s_b[e] = bp ? *bp : T(0);
                 if (PER_SAMPLE_GAM) s_g[e] = a.gam ? a.gam[r] : a.gam_uniform;
             }
         }
@@ -579,7 +631,11 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
         }
         if (base == 0) {
 #pragma unroll
-            for (int u = 0; u < DEPTH; ++u) refill(u, uniform64(s_row[DEPTH + u]));
+            for (int u = 0; u < DEPTH; ++u) {
+                const int64_t r0 = uniform64(s_row[DEPTH + u]);
+                refill(u, r0, STAGE_PTR ? reinterpret_cast<const unsigned char *>(uniform64((int64_t)(uintptr_t)s_ptr[DEPTH + u]))
+                                        : reinterpret_cast<const unsigned char *>(a.A + r0 * a.ld));
+            }
         }
         wait_vmcnt<0>();          // ring fully landed: the counted waits below assume the steady-state op sequence
         drain_vmcnt_visible();    // ... and hipcc knows that the state / staging loads are retired too
@@ -603,6 +659,8 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 }
                 const int64_t row = uniform64(x.row);
                 const int64_t row_n = uniform64(x.row_n);
+                const unsigned char *ptr_n = STAGE_PTR ? reinterpret_cast<const unsigned char *>(uniform64((int64_t)(uintptr_t)x.ptr_n))
+                                                       : reinterpret_cast<const unsigned char *>(a.A + row_n * a.ld);
                 const T bi = x.bi;
 
                 if (ALG == CA_LFINITO && inb == 0) {   // Finito_LFinito.jl:92  z = prox(av)
@@ -615,7 +673,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 if (HAS_TABLE && __builtin_amdgcn_readfirstlane(x.stale)) {
                     // an intervening step rewrote this table row after its DMA was issued: re-read it from memory (this
                     // very thread stored these bytes, so program order makes them visible)
-                    const V *sp = reinterpret_cast<const V *>(a.table + row * d);
+                    const V *sp = reinterpret_cast<const V *>(table_row<SHARDED>(a, row));
 #pragma unroll
                     for (int j = 0; j < J; ++j) x.sr[j] = ok[j] ? sp[cl[j]] : V(T(0));
                     drain_vmcnt_visible();   // retire it HERE, or hipcc puts a draining vmcnt(0) on the common path
@@ -684,7 +742,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                                 zs[j][v] += p[j][v];
                             }
                     } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
-                        V *sp = reinterpret_cast<V *>(a.table + row * d);
+                        V *sp = reinterpret_cast<V *>(table_row<SHARDED>(a, row));
                         const T gl = a.gamma * plam;
                         const T cp = gp.coef();
                         const T ngam = -a.gamma;
@@ -708,7 +766,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                         const T gi = x.gi;
                         const T ncc = -(gi * a.invN) * gp.coef();   // t = z - (gamma_i/N) * c * a
                         const T rr = a.hat_gamma / gi;
-                        V *sp = reinterpret_cast<V *>(a.table + row * d);
+                        V *sp = reinterpret_cast<V *>(table_row<SHARDED>(a, row));
     #pragma unroll
                         for (int j = 0; j < J; ++j) {
                             V tv;
@@ -746,7 +804,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                     update(std::false_type{});
 
                 if (++inb == a.batch) inb = 0;
-                if (!(CIAO_CHAIN_DBG & 1)) refill(u, row_n);   // after this step's table stores (program order); the look-ahead entry always exists
+                if (!(CIAO_CHAIN_DBG & 1)) refill(u, row_n, ptr_n);   // after this step's table stores (program order); the look-ahead entry always exists
 #if (CIAO_CHAIN_DBG & 8)
 #pragma unroll
                 for (int j = 0; j < J; ++j) asm volatile("" : "+v"(p[j]));   // the update is done HERE
@@ -778,14 +836,15 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
     }
 }
 
-template <typename T, int J, int ALG, int NT>
+template <typename T, int J, int ALG, int NT, bool SHARDED = false>
 constexpr size_t chain_dma_lds_bytes()
 {
     constexpr int NW = NT / WAVE;
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
     constexpr int DEPTH = DmaDepth<J * NT / 256, HAS_TABLE>::value;
     constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO || ALG == CA_SVRGC);
-    return (size_t)DEPTH * J * NT * 16 * (HAS_TABLE ? 2 : 1) + (CHAIN_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
+    constexpr bool STAGE_PTR = SHARDED;
+    return (size_t)DEPTH * J * NT * 16 * (HAS_TABLE ? 2 : 1) + (STAGE_PTR ? 2 : 1) * (CHAIN_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
            CHAIN_CHUNK * sizeof(T) * (PER_SAMPLE_GAM ? 2 : 1) + (HAS_TABLE ? CHAIN_CHUNK * sizeof(int) : 0) + 16 +
            2 * NW * 2 * sizeof(T);
 }
@@ -810,6 +869,7 @@ struct AFinitoArgs {
     int64_t nsteps;
     const int64_t *idx;
     T alpha, tol_b, invN, Nf;
+    double Nd;             // N_total as the reference uses it in `0.5 * iter.N * iter.α / γ` (Float64 whatever R, :128)
     ProxD<T> g;
     T *table, *meta, *av, *z;
     T *hg;                // device scalar: hat_gamma (in/out)
@@ -929,11 +989,13 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_chain_kernel(AFinitoArgs<T> 
             const T n2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
             par ^= 1;
             fi_z = loss_value(LOSS, dz, bi, a.lam);                                     // :125
-            const T fi_model = fi_x + c_old * (dz - as_i) + (T(0.5) * a.Nf * a.alpha / gi) * n2;   // :126-129
+            // Julia's promotions, which matter for R = Float32: `0.5 * iter.N * iter.α / γ` is Float64 (the literal 0.5), so the
+            // model value and the comparison are Float64; `γ *= 0.8` multiplies in Float64 and rounds back to R.
+            const double fi_model = (double)(fi_x + c_old * (dz - as_i)) + (0.5 * a.Nd * (double)a.alpha / (double)gi) * (double)n2;   // :126-129
             const T tol = T(10) * Eps<T>::value * (T(1) + fabs2(fi_z));                 // :130
-            if (fi_z <= fi_model + tol) break;                                          // :131
+            if ((double)fi_z <= fi_model + (double)tol) break;                          // :131
             const T gb = gi;                                                            // :133
-            gi *= T(0.8);                                                               // :134
+            gi = (T)((double)gi * 0.8);                                                 // :134
             const T hg_old = hg;
             hg = T(1) / (T(1) / hg_old + T(1) / gi - T(1) / gb);                        // :139
             const T gl = hg * plam;
@@ -1257,7 +1319,7 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
                     }
                     // the two divisions of the step depend only on gamma_i and hat_gamma: issued here, they run in the shadow of
                     // the exchange instead of behind it
-                    const T qc = T(0.5) * a.Nf * a.alpha / gi;                                  // :128
+                    const double qc = 0.5 * a.Nd * (double)a.alpha / (double)gi;                // :128 (Float64 in the reference whatever R)
                     const T r1 = hg / gi;                                                       // :145
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue
@@ -1265,14 +1327,14 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
                     const T n2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
                     par ^= 1;
                     fi_z = loss_value(LOSS, dz, bi, a.lam);                                     // :125
-                    const T fi_model = fi_x + c_old * (dz - as_i) + qc * n2;                    // :126-129
+                    const double fi_model = (double)(fi_x + c_old * (dz - as_i)) + qc * (double)n2;   // :126-129
                     const T tol = T(10) * Eps<T>::value * (T(1) + fabs2(fi_z));                 // :130
-                    if (fi_z <= fi_model + tol) {                                               // :131
+                    if ((double)fi_z <= fi_model + (double)tol) {                               // :131
                         r1_acc = r1;
                         break;
                     }
                     const T gb = gi;                                                            // :133
-                    gi *= T(0.8);                                                               // :134
+                    gi = (T)((double)gi * 0.8);                                                 // :134 (Float64 product, rounded to R)
                     const T hg_old = hg;
                     hg = T(1) / (T(1) / hg_old + T(1) / gi - T(1) / gb);                        // :139
 #pragma unroll

@@ -19,6 +19,9 @@ struct ciao_ctx {
     ciao_allreduce_fn hook = nullptr;
     void *hook_user = nullptr;
 
+    // row-sharded problem for the sequential chains (ciao_ctx_set_shards); nshards = 0: none
+    ciao_shard_table shards{};
+
     // private workspace (grown on demand, never inside a timed region after the first call of a given shape)
     void *partial = nullptr;   // per-block partial d-vectors
     size_t partial_bytes = 0;

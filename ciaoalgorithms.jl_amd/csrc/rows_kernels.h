@@ -43,6 +43,7 @@ struct RowsArgs {
     int want_fval;
     T *meta;               // AFINITO_INIT: N x 4 copies x 4 per-sample scalars {c_i, f_i, gam_i, a_i's_i}
     T alpha;               // AFINITO_INIT: the solver's α
+    double Nd;             // AFINITO_INIT: N_total as a double (the reference divides a Float64 by the Int N, :88)
     T *rowdot_out;         // GRAD only: if non-null, rowdot_out[row] = a_row'x1 (feeds the SVRG chain, chain_kernels.h CA_SVRGC)
     T *partial;            // [gridDim.x][pstride]
     int64_t pstride;
@@ -238,7 +239,9 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
                 if (lane == 0) *a.errflag = 2;
                 nmg = Eps<T>::value;
             }
-            const T gi = a.alpha / ((nmg / fsqrt((T)a.d)) * a.invN);
+            // L_int = zeros(N) is a Float64 array whatever R (:73): L = nmg / (t sqrt(d)) / N and alpha / L are Float64,
+            // gamma_i is that quotient rounded to R (:86-88)
+            const T gi = (T)((double)a.alpha / (((double)nmg / sqrt((double)a.d)) / a.Nd));
             const T rinv = T(1) / gi;
             const T cn = c0 * a.invN;
             V *sp = reinterpret_cast<V *>(tp);
@@ -919,7 +922,7 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
                 if (lane == 0) *a.errflag = 2;
                 nmg = Eps<T>::value;
             }
-            const T gi = a.alpha / ((nmg / fsqrt((T)d)) * a.invN);
+            const T gi = (T)((double)a.alpha / (((double)nmg / sqrt((double)d)) / a.Nd));   // Float64 as in the reference (:73, :86-88)
             const T rinv = T(1) / gi;
             const T cn = c0 * a.invN;
             for (int64_t e = lane; e < d; e += WAVE) {

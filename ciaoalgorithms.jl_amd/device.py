@@ -181,6 +181,7 @@ class Context:
         handle = C.c_void_p(stream.cuda_stream) if stream is not None else None
         L.check(self.lib.ciao_ctx_create(self.device, handle, C.byref(self._h)))
         self._hook_keepalive = None
+        self.shards = None
 
     # -- lifetime ----------------------------------------------------------------------------------------------------
     def close(self):
@@ -242,6 +243,11 @@ class Context:
         assert obj.is_cuda and obj.dtype == torch.float64 and obj.is_contiguous() and obj.numel() >= 3
         self._monitor_keepalive = (g, obj)
         L.check(self.lib.ciao_ctx_set_monitor(self._h, g.ref if g is not None else None, _ptr(obj)))
+
+    def set_shards(self, table: "L.ShardTable | None"):
+        """Row-sharded problem for the sequential chains (include/ciao_hip.h: ciao_ctx_set_shards); None removes it."""
+        L.check(self.lib.ciao_ctx_set_shards(self._h, C.byref(table) if table is not None else None))
+        self.shards = table
 
     def set_rccl(self, comm):
         """Native all-reduce: `comm` is a parallel.RcclComm (or None to clear).  The library then calls ncclAllReduce itself on

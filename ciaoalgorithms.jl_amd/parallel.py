@@ -101,6 +101,84 @@ class AllReduceHook:
         return 0
 
 
+class ShardGroup:
+    """The sequential chains (SVRG inner cycle, SAGA steps) on a row-sharded problem: ONE rank -- the owner -- runs the chain
+    and reads the other ranks' rows through peer-mapped pointers over xGMI (include/ciao_hip.h:
+    ciao_ctx_set_shards).  `install` exchanges HIP IPC handles of every rank's A, b (and SAGA table shard) through the process
+    group, opens them on the owner and hands the library the shard table; the other ranks install the same partition
+    without pointers.  Contiguous block partition only (parallel.shard_rows); an all-reduce hook must be installed too."""
+
+    def __init__(self, ctx, owner: int = 0, group=None):
+        self.ctx, self.owner, self.group = ctx, int(owner), group
+        self._opened = []     # (ptr, offset) mappings to close
+        self._keep = None
+
+    def _export(self, t):
+        if t is None:
+            return None
+        h = (C.c_char * 64)()
+        off = C.c_int64(0)
+        L.check(self.ctx.lib.ciao_ipc_export(C.c_void_p(t.data_ptr()), h, C.byref(off)))
+        return bytes(h), int(off.value)
+
+    def _open(self, exported):
+        if exported is None:
+            return None
+        h, off = exported
+        buf = (C.c_char * 64).from_buffer_copy(h)
+        out = C.c_void_p()
+        L.check(self.ctx.lib.ciao_ipc_open(buf, off, C.byref(out)))
+        self._opened.append((out.value, off))
+        return out.value
+
+    def install(self, F, table=None):
+        import torch.distributed as dist
+        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        if world > L.MAX_SHARDS:
+            raise ValueError(f"at most {L.MAX_SHARDS} shards (one node)")
+        if F.cyclic is not None:
+            raise ValueError("sharded chains need the contiguous block partition (parallel.shard_rows)")
+        self.close()
+        mine = {"n": F.N, "row0": F.row0, "ld": F.ld, "A": self._export(F.A) if F.N else None,
+                "b": self._export(F.b) if F.N else None, "table": self._export(table) if (table is not None and F.N) else None}
+        every = [None] * world
+        dist.all_gather_object(every, mine, group=self.group)
+        row0 = 0
+        for k, e in enumerate(every):
+            if e["row0"] != row0 or (e["n"] and e["ld"] != F.ld):
+                raise ValueError(f"shard {k} starts at row {e['row0']} (expected {row0}) or has another row stride")
+            row0 += e["n"]
+        if row0 != F.N_total:
+            raise ValueError(f"the shards hold {row0} rows, the problem has N_total = {F.N_total}")
+        tbl = L.ShardTable()
+        tbl.nshards, tbl.owner = world, 1 if rank == self.owner else 0
+        acc = 0
+        for k, e in enumerate(every):
+            tbl.row0[k] = acc
+            acc += e["n"]
+            if rank != self.owner or e["n"] == 0:
+                continue
+            if k == rank:   # the owner's own shard: its local pointers
+                tbl.A[k], tbl.b[k] = F.A.data_ptr(), F.b.data_ptr()
+                tbl.table[k] = table.data_ptr() if table is not None else None
+            else:
+                tbl.A[k], tbl.b[k], tbl.table[k] = self._open(e["A"]), self._open(e["b"]), self._open(e["table"])
+        tbl.row0[world] = acc
+        self._keep = (F, table)
+        self.ctx.set_shards(tbl)
+        dist.barrier(group=self.group)   # nobody may free / reuse an exported allocation before the owner has opened it
+        return tbl
+
+    def close(self):
+        if self.ctx.shards is not None:
+            self.ctx.synchronize()
+            self.ctx.set_shards(None)
+        for ptr, off in self._opened:
+            self.ctx.lib.ciao_ipc_close(C.c_void_p(ptr), off)
+        self._opened = []
+        self._keep = None
+
+
 class _NcclUniqueId(C.Structure):
     _fields_ = [("internal", C.c_char * 128)]   # rccl.h: NCCL_UNIQUE_ID_BYTES
 

@@ -165,11 +165,13 @@ class SVRG_basic_state(_State):
 
 
 class SVRG_basic_iterable(_Iterable):
-    def __init__(self, R, F, g, x0, N, L, μ, γ, m, plus, ctx=None, stream=None):
+    def __init__(self, R, F, g, x0, N, L, μ, γ, m, plus, ctx=None, stream=None, shards=None):
         super().__init__(R, F, g, x0, N, ctx, stream)
         self.L, self.μ, self.γ, self.m, self.plus = L, μ, γ, m, plus
-        if self.F.row0 != 0 or self.F.N != self.N:
-            raise ValueError("the SVRG inner cycle is a sequential chain: it needs the whole problem on one device")
+        self.shards = shards   # parallel.ShardGroup: the one chain runs on its owner and pulls the other shards' rows over xGMI
+        if (self.F.row0 != 0 or self.F.N != self.N) and shards is None:
+            raise ValueError("the SVRG inner cycle is a sequential chain: it needs the whole problem on one device, or a "
+                             "parallel.ShardGroup (shards=...) through which one rank reads the other shards' rows")
 
     def _init(self):                                                       # SVRG_basic.jl:30-69
         N = self.N
@@ -189,6 +191,8 @@ class SVRG_basic_iterable(_Iterable):
         else:
             γ = self.γ
         av, z, z_full, w = self._new(), self._new(), self._new(), self._new()
+        if self.shards is not None:
+            self.shards.install(self.F)
         self._monitor_on()
         self.ctx.svrg_init(self.F, self._x0_dev, av, z, z_full, w)         # :57-66
         self._monitor_off()
@@ -207,7 +211,7 @@ class SVRG_basic_iterable(_Iterable):
     def _step(self, st, n):                                                # SVRG_basic.jl:71-96
         for _ in range(n):
             idx = self.stream.rand_indices(self.N, st.m)                   # :73
-            fresh = st._tok is not None and st._tok == self._versions(st)
+            fresh = self.shards is None and st._tok is not None and st._tok == self._versions(st)
             self._monitor_on()
             self.ctx.svrg_iterate(self.F, self.g, st.γ, idx, self.plus, st.av, st.z, st.z_full, st.w, reuse_rowdots=fresh)
             self._monitor_off()
@@ -227,11 +231,13 @@ class SAGA_basic_state(_State):
 
 
 class SAGA_basic_iterable(_Iterable):
-    def __init__(self, R, F, g, x0, N, L, γ, SAG, ctx=None, stream=None):
+    def __init__(self, R, F, g, x0, N, L, γ, SAG, ctx=None, stream=None, shards=None):
         super().__init__(R, F, g, x0, N, ctx, stream)
         self.L, self.γ, self.SAG = L, γ, SAG
-        if self.F.row0 != 0 or self.F.N != self.N:
-            raise ValueError("SAGA steps are a sequential chain: they need the whole problem on one device")
+        self.shards = shards   # parallel.ShardGroup (see SVRG_basic_iterable): data rows AND table rows of the other shards are remote
+        if (self.F.row0 != 0 or self.F.N != self.N) and shards is None:
+            raise ValueError("SAGA steps are a sequential chain: they need the whole problem on one device, or a "
+                             "parallel.ShardGroup (shards=...)")
 
     def _init(self):                                                       # SAGA_basic.jl:26-51
         if self.γ is None:
@@ -242,8 +248,10 @@ class SAGA_basic_iterable(_Iterable):
             γ = 1 / (16 * L_M) if self.SAG else 1 / (3 * L_M)
         else:
             γ = self.γ
-        s = torch.empty((self.N, self.d), dtype=self.R, device=self._x0_dev.device)   # N x d table, 288 GB HBM budget
+        s = torch.empty((self.F.N, self.d), dtype=self.R, device=self._x0_dev.device)   # this rank's rows of the N x d table
         av, z = self._new(), self._new()
+        if self.shards is not None:
+            self.shards.install(self.F, table=s)
         self.ctx.saga_init(self.F, self.g, γ, self._x0_dev, s, av, z)      # :41-48
         st = SAGA_basic_state(s, float(γ), av, z)
         st._it = self
@@ -653,10 +661,10 @@ class SVRG(_Solver):
         assert freq > 0
         self.R, self.γ, self.maxit, self.verbose, self.freq, self.m, self.plus = R, γ, int(maxit), verbose, int(freq), m, plus
 
-    def _iterable(self, x0, F=None, g=None, L=None, μ=None, mu=None, N=None, ctx=None, stream=None):
+    def _iterable(self, x0, F=None, g=None, L=None, μ=None, mu=None, N=None, ctx=None, stream=None, shards=None):
         μ = _pick(μ, mu, "μ")
         m = self.m if self.m is not None else N                            # SVRG.jl:59
-        return SVRG_basic_iterable(self.R, F, g, x0, N, L, μ, self.γ, m, self.plus, ctx=ctx, stream=stream)
+        return SVRG_basic_iterable(self.R, F, g, x0, N, L, μ, self.γ, m, self.plus, ctx=ctx, stream=stream, shards=shards)
 
     def __call__(self, x0, **kw):                                          # SVRG.jl:46-84
         maxit = self.maxit
@@ -677,8 +685,8 @@ class SAGA(_Solver):
         assert freq > 0
         self.R, self.γ, self.maxit, self.verbose, self.freq, self.SAG_flag = R, γ, int(maxit), verbose, int(freq), SAG_flag
 
-    def _iterable(self, x0, F=None, g=None, L=None, N=None, ctx=None, stream=None):
-        return SAGA_basic_iterable(self.R, F, g, x0, N, L, self.γ, self.SAG_flag, ctx=ctx, stream=stream)
+    def _iterable(self, x0, F=None, g=None, L=None, N=None, ctx=None, stream=None, shards=None):
+        return SAGA_basic_iterable(self.R, F, g, x0, N, L, self.γ, self.SAG_flag, ctx=ctx, stream=stream, shards=shards)
 
     def __call__(self, x0, **kw):                                          # SAGA.jl:44-73
         stop, every = _split_drive_kw(kw)

@@ -188,6 +188,39 @@ CIAO_API int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const cia
 CIAO_API int32_t ciao_svrg_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
                           const int64_t *idx, int32_t plus, int32_t reuse_rowdots, void *av, void *z, void *z_full, void *w);
 
+/* ---- the sequential chains on a row-sharded problem ("one chain on one GPU pulling remote rows over xGMI") --
+ * The inner loops of SVRG and SAGA are one dependent chain and do not shard: on a problem whose rows do not fit one GPU
+ * (BASELINE config #4: 80M x 1024) exactly ONE rank, the chain owner, runs the chain and reads the rows of the other shards
+ * through peer-mapped pointers (hipIpcOpenMemHandle / peer access: the loads travel over xGMI; all indices are known up front,
+ * SVRG_basic.jl:73, so the rows are prefetched through the same LDS-DMA ring as local ones).  Same arithmetic, same order:
+ * the chain's results are bitwise those of the unsharded chain on the concatenated rows.
+ *   shard k = GLOBAL rows [row0[k], row0[k+1]) (contiguous block partition, row0[0] = 0, row0[nshards] = N_total);
+ *   A[k], b[k] (and table[k] for SAGA): device pointers valid on THIS device for shard k's rows (its own shard: the
+ *   local pointers); every A[k] has the row stride of the local problem.  Non-owners pass the same nshards / row0 and
+ *   may leave the pointers NULL. */
+#define CIAO_MAX_SHARDS 8
+typedef struct {
+    int32_t nshards;
+    int32_t owner;                          /* != 0 on the one rank that runs the chains */
+    int64_t row0[CIAO_MAX_SHARDS + 1];
+    const void *A[CIAO_MAX_SHARDS];
+    const void *b[CIAO_MAX_SHARDS];
+    void *table[CIAO_MAX_SHARDS];           /* SAGA gradient table shards (NULL when only SVRG is run) */
+} ciao_shard_table;
+/* Installs (copies) the shard table; NULL removes it.  While one is set AND an all-reduce hook is installed,
+ * ciao_svrg_inner / ciao_svrg_iterate / ciao_saga_steps are valid on the row-sharded problem: `idx` then holds GLOBAL rows,
+ * the owner runs the chain, every other rank skips it, and the iterates the chain produced (z, w; for SAGA z, av) reach all
+ * ranks through one all-reduce of 2d scalars in which the non-owners contribute zeros; the tail and the full pass of
+ * ciao_svrg_iterate then run sharded as usual.  (The a_i'z_full cache is not used across shards.) */
+CIAO_API int32_t ciao_ctx_set_shards(ciao_ctx *ctx, const ciao_shard_table *shards);
+/* Sharing a device allocation with the chain owner's process (plain HIP IPC, no torch / AMDGPU.jl needed):
+ * _export: handle_out = 64 bytes describing the allocation that contains dev_ptr, *offset_out = dev_ptr's offset in it;
+ * _open (in the other process, on the device that will read it): *dev_ptr_out = the mapped pointer + offset;
+ * _close: unmaps what _open returned (pass the same dev_ptr and offset). */
+CIAO_API int32_t ciao_ipc_export(const void *dev_ptr, void *handle_out, int64_t *offset_out);
+CIAO_API int32_t ciao_ipc_open(const void *handle, int64_t offset, void **dev_ptr_out);
+CIAO_API int32_t ciao_ipc_close(void *dev_ptr, int64_t offset);
+
 /* ---- SAGA / SAG  (SAGA_SAG/SAGA_basic.jl) ------------------------------------------------------------------- */
 /* Base.iterate(iter), :41-48: table[i] = grad f_i(x0); av = sum/N; z = prox_{gamma g}((1-gamma) x0). */
 CIAO_API int32_t ciao_saga_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma,

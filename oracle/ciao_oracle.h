@@ -9,9 +9,12 @@
  *   - literal l1-logistic fixture + hard-coded x_star     (/root/reference/test/test_logistic_l1.jl:12-29)
  *   - lasso known-answer generator                        (/root/reference/test/test_lasso.jl:15-47)
  *   - structural pins: maxit=1 returns the init state     (test_lasso.jl:188-192, :224-228)
- * The Julia reference cannot run in this container (no julia binary), so there is no oracle/_ref build and no
- * per-step golden vector produced by the reference itself; per-step vectors under tests/golden/ are produced
- * by THIS restatement and are labelled so.
+ * What kind of pin that is: a CONVERGENCE pin.  The reference holds known ANSWERS (fixed points of the restated
+ * operators), no per-step vectors, and cannot run here (no julia binary): there is no oracle/_ref build and no golden
+ * vector produced by the reference itself.  So the fixed point of every restated algorithm is pinned by reference-held
+ * data; the transient-only details (SAGA's z0 = prox((1-γ)x0), cyclic Finito starting at batch 2, the order of the
+ * additions) are pinned by the structural tests and by reading the source line by line, i.e. by THIS restatement.
+ * Per-step vectors under tests/golden/ are produced by this restatement and are labelled so.
  */
 #ifndef CIAO_ORACLE_H
 #define CIAO_ORACLE_H
@@ -79,7 +82,10 @@ typedef struct {
                               const orc_prox_desc *g, const R *gam, R hat_gamma, int64_t nit,                   \
                               const int64_t *bptr, const int64_t *bidx, R *table, R *av, R *z);                 \
     void orc_proshi_solution_##S(int64_t N, int64_t d, const R *gam, const R *z, R *table);                     \
-    double orc_objective_##S(const orc_problem *p, const orc_prox_desc *g, const R *x);
+    double orc_objective_##S(const orc_problem *p, const orc_prox_desc *g, const R *x);                        \
+    /* Julia's sum(A): Base.mapreduce_impl, pairwise above 1024 elements (the six init sums use these) */      \
+    void orc_julia_sum_vec_##S(int64_t N, int64_t d, const R *rows, const R *div, R *out);                     \
+    R orc_julia_sum_scalar_##S(int64_t N, const R *x, int inv);
 
 ORC_DECL(double, f64)
 ORC_DECL(float, f32)

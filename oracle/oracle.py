@@ -54,6 +54,10 @@ def lib():
             getattr(_lib, f"orc_gradient_{sfx}").restype = ct
             getattr(_lib, f"orc_gradient_{sfx}").argtypes = [C.c_int, C.c_int64, C.c_void_p, ct, ct, C.c_void_p, C.c_void_p]
             getattr(_lib, f"orc_objective_{sfx}").restype = C.c_double
+            getattr(_lib, f"orc_julia_sum_scalar_{sfx}").restype = ct
+            getattr(_lib, f"orc_julia_sum_scalar_{sfx}").argtypes = [C.c_int64, C.c_void_p, C.c_int]
+            getattr(_lib, f"orc_julia_sum_vec_{sfx}").restype = None
+            getattr(_lib, f"orc_julia_sum_vec_{sfx}").argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
             getattr(_lib, f"orc_full_pass_omp_{sfx}").restype = C.c_int
     return _lib
 
@@ -304,3 +308,20 @@ def proshi_solution(f: SepQuad, gam, z, table):
 
 def objective(p: Problem, g: Prox, x):
     return getattr(lib(), f"orc_objective_{_sfx(p.dtype)}")(p.ref, g.ref, _p(_chk(x, p.dtype, (p.d,))))
+
+
+def julia_sum_vec(rows, div=None):
+    """sum(A) for A = the rows of a (N, d) array (sum(A ./ div) with div): Base.mapreduce_impl's association order."""
+    rows = np.ascontiguousarray(rows)
+    N, d = rows.shape
+    out = np.empty(d, rows.dtype)
+    if div is not None:
+        div = np.ascontiguousarray(div, dtype=rows.dtype)
+    getattr(lib(), f"orc_julia_sum_vec_{_sfx(rows.dtype)}")(N, d, _p(rows), _p(div), _p(out))
+    return out
+
+
+def julia_sum_scalar(x, inv=False):
+    """sum(x) (or sum(1 ./ x)) for a vector of scalars, pairwise above 1024 elements with left-to-right leaves."""
+    x = np.ascontiguousarray(x)
+    return x.dtype.type(getattr(lib(), f"orc_julia_sum_scalar_{_sfx(x.dtype)}")(x.size, _p(x), 1 if inv else 0))

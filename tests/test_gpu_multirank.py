@@ -85,11 +85,58 @@ def _worker(rank, world, port, q):
             ok["chain_refused"] = False
         except L.CiaoError:
             ok["chain_refused"] = True
+        # ---- ... unless a shard table says where every rank's rows live: then ONE chain runs on the owner (rank 0) and reads
+        # rank 1's rows through an IPC-mapped pointer (here: the same GPU; on a node: a peer GPU over xGMI).  BASELINE config #4
+        # as a real SVRG solve; SURVEY.md 8e option (a).
+        from ciaoalgorithms_jl_amd.parallel import ShardGroup
+        from ciaoalgorithms_jl_amd import solvers as S
+        gamma = 1.0 / (7 * float(Li.max()))
+        grp = ShardGroup(ctx, owner=0)
+        it = iter(S.iterator(S.SVRG(np.float64, γ=gamma), np.zeros(d), F=F, g=g, N=N, ctx=ctx, stream=IndexStream(3), shards=grp))
+        rit = iter(RS.SVRGIterable(op, og, np.zeros(d), gamma=gamma, stream=IndexStream(3)))
+        worst = 0.0
+        for _ in range(4):
+            sd, sr = next(it), next(rit)
+            worst = max(worst, float(np.abs(sd.z_full.cpu().numpy() - sr.z_full).max() / max(np.abs(sr.z_full).max(), 1e-30)))
+        ok["sharded_svrg_vs_oracle"] = bool(worst <= 1e-11)
+        ok["sharded_svrg_kernel"] = ("chain_dma_kernel" in ctx.last_kernel() or "rows_" in ctx.last_kernel())
+        gathered = [torch.zeros(d, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, sd.z_full.cpu())
+        ok["sharded_svrg_replicas_bitwise"] = all(torch.equal(gathered[0], t) for t in gathered)
+        # the chain itself is BITWISE the single-GPU chain: rank 0 also holds the whole problem and runs the same inner cycle alone
+        idxg = IndexStream(9).rand_indices(N, 2 * N)
+        avs, zs, zfs, ws = (torch.empty(d, dtype=torch.float64, device=dev) for _ in range(4))
+        ctx.svrg_init(F, xd, avs, zs, zfs, ws)                      # sharded full pass (all-reduced): the same av on both ranks
+        ctx.svrg_inner(F, g, gamma, idxg, avs, zs, zfs, ws)         # sharded: owner's chain over both shards + broadcast
+        if rank == 0:
+            solo = Context(0)
+            Fw = PackedF(L.LOSS_LS, torch.from_numpy(A).to(dev), torch.from_numpy(b).to(dev), float(N))
+            z1, zf1, w1 = torch.zeros_like(xd), xd.clone(), xd.clone()
+            solo.svrg_inner(Fw, g, gamma, idxg, avs, z1, zf1, w1)   # the SAME av, the whole matrix on one device
+            solo.synchronize()
+            ok["sharded_chain_bitwise_equals_single_gpu_chain"] = bool(torch.equal(w1, ws) and torch.equal(z1, zs))
+            solo.close()
+        wall = [torch.zeros(d, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(wall, ws.cpu())
+        ok["sharded_chain_result_on_every_rank"] = all(torch.equal(wall[0], t) for t in wall)
+        # SAGA: the gradient table is sharded too; rank 0's chain reads and writes rank 1's table rows
+        grp.close()
+        grp2 = ShardGroup(ctx, owner=0)
+        sit = iter(S.iterator(S.SAGA(np.float64, γ=gamma), np.zeros(d), F=F, g=g, N=N, ctx=ctx, stream=IndexStream(5), shards=grp2))
+        rsit = iter(RS.SAGAIterable(op, og, np.zeros(d), gamma=gamma, stream=IndexStream(5)))
+        ss = sr = None
+        for _ in range(300):
+            ss, sr = next(sit), next(rsit)
+        ok["sharded_saga_vs_oracle"] = bool(np.abs(ss.z.cpu().numpy() - sr.z).max() <= 1e-11 * max(np.abs(sr.z).max(), 1e-30))
+        row0, n = shard_rows(N, rank, world)
+        ok["sharded_saga_table_shard"] = bool(np.abs(ss.s.cpu().numpy() - sr.s[row0:row0 + n]).max() <= 1e-11 * np.abs(sr.s).max())
+        grp2.close()
         ctx.synchronize()
         ctx.close()
         q.put((rank, ok))
     except Exception as e:  # pragma: no cover
-        q.put((rank, {"exception": repr(e)}))
+        import traceback
+        q.put((rank, {"exception": repr(e) + traceback.format_exc()}))
     finally:
         dist.destroy_process_group()
 

@@ -1,12 +1,22 @@
 """GPU parity tests proper: every C-ABI entry point of libciao_hip.so against the CPU oracle on the same seeded
 inputs (sizes the oracle finishes in seconds), through the ctypes binding (the same ABI a Julia ccall binds).
 
-Tolerances (stated, per north_star "matching the CPU reference to a stated fp64 tolerance"):
-    fp64: 1e-10 relative to the infinity norm of the reference vector (+1e-12 absolute)
-    fp32: 2e-4  relative (+1e-6 absolute)
+Stated tolerance (north_star: "iterates matching the CPU reference to a stated fp64 tolerance"), in units of the
+rounding unit of the real type R (eps = 2.2e-16 for fp64, 1.2e-7 for fp32):
+
+        | device - oracle |_inf  <=  scale * eps(R) * | oracle |_inf
+
+with `scale` written at every comparison.  The scales are not guesses: every comparison logs its observed error in
+these units (gpurun_out/parity_observed.json, written by conftest.py at the end of a GPU run; the committed copy is
+profiles/r02_parity_observed.json) and tools/retune_scales.py sets each `scale=` to 10x the largest value observed at
+that call site over both dtypes, rounded up to 1-2-5 (floor 8).  What to expect (DESIGN.md section 5 has the law):
+one sweep over N rows is a sum of N terms in a fixed tree order against the oracle's sequential order, 2-20 eps
+observed; a dependent chain grows about linearly in the number of steps (a few hundred eps after 3 000 SVRG steps).
 Bitwise equality is not attainable: the reference sums sequentially (SVRG_basic.jl:59-63) while the device sums
 in a fixed tree order; the device result is bitwise reproducible run to run (tested below).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -14,23 +24,23 @@ import problems as P
 
 pytestmark = pytest.mark.gpu
 
-TOL = {np.float64: (1e-10, 1e-12), np.float32: (2e-4, 1e-6)}
+EPS = {np.float64: float(np.finfo(np.float64).eps), np.float32: float(np.finfo(np.float32).eps)}
+CALIBRATE = os.environ.get("CIAO_PARITY_CALIBRATE") == "1"   # log only (tools/retune_scales.py reads the log)
 
 
-def close(dev, ref, dtype, scale=1.0, what=""):
+def close(dev, ref, dtype, scale=8, what=""):
     dev = dev.detach().cpu().numpy() if hasattr(dev, "detach") else np.asarray(dev)
     ref = np.asarray(ref)
-    rel, ab = TOL[dtype]
-    unit = rel * max(np.abs(ref).max(initial=0.0), 1e-30) + ab      # the stated tolerance at scale = 1
+    unit = EPS[dtype] * max(np.abs(ref).max(initial=0.0), 1e-30)     # one rounding unit at the size of the reference
     bound = scale * unit
     err = np.abs(dev.astype(np.float64) - ref.astype(np.float64)).max(initial=0.0)
-    # every comparison is logged as (error / stated unit, scale allowed): conftest.py writes gpurun_out/parity_observed.json
-    # at session end, which is what the scale= factors in this file were set from (<= 10x the largest ratio observed)
+    # every comparison is logged as (error in eps units, scale allowed); conftest.py writes gpurun_out/parity_observed.json
     import inspect
     fr = inspect.stack()[1]
     P.PARITY_LOG.append({"test": fr.function, "line": fr.lineno, "what": what, "dtype": np.dtype(dtype).name,
                          "ratio": float(err / unit), "scale": float(scale)})
-    assert err <= bound, f"{what}: max abs err {err:.3e} > {bound:.3e}"
+    if not CALIBRATE:
+        assert err <= bound, f"{what}: max abs err {err:.3e} = {err / unit:.1f} eps > {scale} eps ({bound:.3e})"
 
 
 def make(loss, A, b, lam_f, dtype, pad=0):
@@ -92,8 +102,8 @@ def test_gradient_single_sample(ctx, dtype, loss):
     for i in (0, 4, 8):
         ctx.gradient(dp, i, dev(x), y, fv)
         gy, f = O.gradient(op.loss, A[i], b[i], 9.0, x)
-        close(y, gy, dtype, what=f"gradient i={i}")
-        close(fv, [f], dtype, scale=10, what="f_i value")
+        close(y, gy, dtype, scale=1000, what=f"gradient i={i}")
+        close(fv, [f], dtype, scale=2000, what="f_i value")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -130,8 +140,8 @@ def test_full_gradient(ctx, dtype, loss, shape):
     ref = O.full_pass(op, x)
     ref64 = O.full_pass(O.Problem(loss, A.astype(np.float64), b.astype(np.float64), float(N)), x.astype(np.float64))
     # judge against the fp64 oracle so that the fp32 oracle's own sequential-sum error does not enter
-    close(av, ref64, dtype, what=f"full_gradient {ctx.last_kernel()}")
-    close(av, ref, dtype, scale=4, what="full_gradient vs same-precision oracle")
+    close(av, ref64, dtype, scale=100, what=f"full_gradient {ctx.last_kernel()}")
+    close(av, ref, dtype, scale=200, what="full_gradient vs same-precision oracle")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -150,7 +160,7 @@ def test_full_gradient_generic_equals_fast(ctx, dtype):
         assert "rows_generic_kernel" in ctx.last_kernel()
     finally:
         ctx.set_option("force_generic", 0)
-    close(av2, av1.cpu().numpy(), dtype, what="generic vs fast")
+    close(av2, av1.cpu().numpy(), dtype, scale=20, what="generic vs fast")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -167,7 +177,7 @@ def test_full_gradient_padded_rows_and_prefetch_variants(ctx, dtype):
         av = torch.empty(256, dtype=dev(x).dtype, device="cuda")
         ctx.full_gradient(dp, dev(x), av)
         assert "rows_fast_kernel" in ctx.last_kernel() or "rows_multi_kernel" in ctx.last_kernel()
-        close(av, ref, dtype, scale=4, what=f"padded rows prefetch={pf}")
+        close(av, ref, dtype, scale=100, what=f"padded rows prefetch={pf}")
         outs.append(av.cpu().numpy())
     ctx.set_option("sweep_prefetch", -1)
     # the two pipelining flavours assign the same rows to the same waves: identical summation order
@@ -176,14 +186,14 @@ def test_full_gradient_padded_rows_and_prefetch_variants(ctx, dtype):
     av = torch.empty(256, dtype=dev(x).dtype, device="cuda")
     ctx.full_gradient(dp2, dev(x), av)
     assert "rows_split_kernel" in ctx.last_kernel() and "scalar" in ctx.last_kernel(), ctx.last_kernel()
-    close(av, ref, dtype, scale=4, what="unaligned rows")
+    close(av, ref, dtype, scale=100, what="unaligned rows")
     ctx.set_option("force_generic", 1)
     try:
         ctx.full_gradient(dp2, dev(x), av)
         assert "rows_generic_kernel" in ctx.last_kernel()
     finally:
         ctx.set_option("force_generic", 0)
-    close(av, ref, dtype, scale=4, what="unaligned rows, generic kernel")
+    close(av, ref, dtype, scale=100, what="unaligned rows, generic kernel")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -206,8 +216,8 @@ def test_multi_row_sweep_matches_single_row_sweep(ctx, dtype, d):
     if d * np.dtype(dtype).itemsize in (2048, 4096):
         assert "rows_multi_kernel" in outs[1][1] and "rows_fast_kernel" in outs[0][1]
     ref = O.full_pass(op, x)
-    close(outs[1][0], ref, dtype, scale=4, what="multi-row sweep")
-    close(outs[0][0], ref, dtype, scale=4, what="single-row sweep")
+    close(outs[1][0], ref, dtype, scale=100, what="multi-row sweep")
+    close(outs[0][0], ref, dtype, scale=100, what="single-row sweep")
 
 
 def test_full_gradient_empty_problem(ctx):
@@ -248,8 +258,8 @@ def test_proxgrad_step_and_objective(ctx, dtype, gk):
         ctx.proxgrad_step(dp, dg, gamma, dev(x), av, y)
         rav = O.full_pass(op, x)
         ry = O.prox(og, (x - dtype(gamma) * rav).astype(dtype), dtype(gamma))
-        close(av, rav, dtype, scale=4, what="proxgrad av")
-        close(y, ry, dtype, scale=8, what="proxgrad y")
+        close(av, rav, dtype, scale=100, what="proxgrad av")
+        close(y, ry, dtype, scale=10, what="proxgrad y")
         obj = ctx.objective(dp, dg, dev(x))
         robj = O.objective(op, og, x)
         assert abs(obj - robj) <= (1e-9 if dtype == np.float64 else 2e-4) * max(1.0, abs(robj))
@@ -281,7 +291,7 @@ def test_objective_monitor_rides_on_the_full_pass(ctx, ciao, dtype, shape):
             assert abs(o[0] - ref) <= rtol * max(1.0, abs(ref)), (o, ref)
             assert abs(o[0] - (o[1] + o[2])) <= 1e-15 * max(1.0, abs(o[0]))
             assert abs(o[2] - 0.02 * np.abs(x.astype(np.float64)).sum()) <= (1e-12 if dtype == np.float64 else 1e-6) * max(1.0, o[2])
-            close(av, O.full_pass(op, x), dtype, scale=4, what="the gradient is unchanged by the monitor")
+            close(av, O.full_pass(op, x), dtype, scale=100, what="the gradient is unchanged by the monitor")
             # prox-gradient step IN PLACE: the monitored point is the x the pass read, not the y it wrote
             xin = dev(x).clone()
             ctx.proxgrad_step(dp, dg, 0.01, xin, av, xin)
@@ -363,16 +373,16 @@ def test_svrg_epochs(ctx, ciao, chain_variant, dtype, loss, shape):
     av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
     ctx.svrg_init(dp, dev(x0), av, z, zf, w)
     rav, rz, rzf, rw = O.svrg_init(op, x0)
-    close(av, rav, dtype, scale=4, what="svrg_init av")
+    close(av, rav, dtype, scale=100, what="svrg_init av")
     assert np.array_equal(zf.cpu().numpy(), x0) and np.array_equal(w.cpu().numpy(), x0) and not z.any().item()
     m = 2 * N
     for ep in range(3):
         idx = st.rand_indices(N, m)
         ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w)
         O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
-        close(zf, rzf, dtype, scale=50, what=f"svrg epoch {ep} z_full ({ctx.last_kernel()})")
-        close(w, rw, dtype, scale=50, what=f"svrg epoch {ep} w")
-        close(av, rav, dtype, scale=50, what=f"svrg epoch {ep} av")
+        close(zf, rzf, dtype, scale=1000, what=f"svrg epoch {ep} z_full ({ctx.last_kernel()})")
+        close(w, rw, dtype, scale=1000, what=f"svrg epoch {ep} w")
+        close(av, rav, dtype, scale=200, what=f"svrg epoch {ep} av")
         assert not z.any().item()
     ctx.synchronize()
 
@@ -404,8 +414,8 @@ def test_chain_path_selection(ctx, ciao, dtype, d, expect):
     name = expect.format(t="f64" if es == 8 else "f32", j=j, jj=j)
     assert name in ctx.last_kernel(), ctx.last_kernel()
     O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
-    close(w, rw, dtype, scale=500, what=f"svrg_inner w ({ctx.last_kernel()})")
-    close(z, rz, dtype, scale=500 * 30, what="svrg_inner z (sum of 3000 iterates)")
+    close(w, rw, dtype, scale=5000, what=f"svrg_inner w ({ctx.last_kernel()})")
+    close(z, rz, dtype, scale=5000, what="svrg_inner z (sum of 3000 iterates)")
     ctx.synchronize()
 
 
@@ -429,14 +439,14 @@ def test_svrg_plus_and_inner_only(ctx, ciao, dtype):
         ctx.svrg_iterate(dp, dg, gamma, idx, True, av, z, zf, w)
         O.svrg_iterate(op, og, dtype(gamma), idx, True, rav, rz, rzf, rw)
         m *= 2
-        close(zf, rzf, dtype, scale=50, what=f"svrg++ epoch {ep} z_full")
-        close(w, rw, dtype, scale=50, what=f"svrg++ epoch {ep} w")
+        close(zf, rzf, dtype, scale=100, what=f"svrg++ epoch {ep} z_full")
+        close(w, rw, dtype, scale=200, what=f"svrg++ epoch {ep} w")
     # inner cycle alone accumulates into z
     idx = st.rand_indices(N, 17)
     ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
     O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
-    close(z, rz, dtype, scale=50, what="svrg_inner z")
-    close(w, rw, dtype, scale=50, what="svrg_inner w")
+    close(z, rz, dtype, scale=100, what="svrg_inner z")
+    close(w, rw, dtype, scale=200, what="svrg_inner w")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -465,8 +475,8 @@ def test_svrg_rowdot_cache(ctx, ciao, dtype):
     for ep in range(3):
         O.svrg_iterate(op, og, dtype(gamma), st.rand_indices(N, 2 * N), False, rav, rz, rzf, rw)
     for reuse in (True, False):
-        close(outs[reuse][0], rzf, dtype, scale=100, what=f"svrg z_full reuse={reuse}")
-        close(outs[reuse][1], rw, dtype, scale=100, what=f"svrg w reuse={reuse}")
+        close(outs[reuse][0], rzf, dtype, scale=2000, what=f"svrg z_full reuse={reuse}")
+        close(outs[reuse][1], rw, dtype, scale=2000, what=f"svrg w reuse={reuse}")
     # (b) z_full edited IN PLACE between two iterates (same pointer): without the flag nothing cached is read
     av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
     ctx.svrg_init(dp, dev(x0), av, z, zf, w)
@@ -483,7 +493,7 @@ def test_svrg_rowdot_cache(ctx, ciao, dtype):
     idx = ciao.IndexStream(5).rand_indices(N, N)
     ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w)              # ... and does not vouch for the old row dots
     O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
-    close(zf, rzf, dtype, scale=100, what="svrg after an in-place z_full edit (reuse_rowdots=0)")
+    close(zf, rzf, dtype, scale=500, what="svrg after an in-place z_full edit (reuse_rowdots=0)")
     # (c) another entry point in between: the library drops the cache even if the caller (wrongly) vouches
     av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
     ctx.svrg_init(dp, dev(x0), av, z, zf, w)
@@ -495,7 +505,7 @@ def test_svrg_rowdot_cache(ctx, ciao, dtype):
     rav[:] = O.full_pass(op, x1)
     ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w, reuse_rowdots=True)
     O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
-    close(zf, rzf, dtype, scale=100, what="svrg after external z_full change")
+    close(zf, rzf, dtype, scale=500, what="svrg after external z_full change")
     ctx.synchronize()
 
 
@@ -518,7 +528,7 @@ def test_svrg_state_edit_between_epochs_through_the_iterable(ctx, ciao, dtype):
     rav, rz, rzf, rw = O.svrg_init(op, x0)
     ref_stream = ciao.IndexStream(9)
     O.svrg_iterate(op, og, dtype(gamma), ref_stream.rand_indices(N, N), False, rav, rz, rzf, rw)
-    close(st.z_full, rzf, dtype, scale=100, what="epoch 1")
+    close(st.z_full, rzf, dtype, scale=500, what="epoch 1")
     st.z_full.mul_(0.25)                                # user edits the solution tensor in place
     st.w.copy_(st.z_full)
     ctx.full_gradient(dp, st.z_full, st.av)
@@ -527,10 +537,110 @@ def test_svrg_state_edit_between_epochs_through_the_iterable(ctx, ciao, dtype):
     rav[:] = O.full_pass(op, rzf)
     st = next(states)
     O.svrg_iterate(op, og, dtype(gamma), ref_stream.rand_indices(N, N), False, rav, rz, rzf, rw)
-    close(st.z_full, rzf, dtype, scale=100, what="epoch after an in-place edit of state.z_full")
+    close(st.z_full, rzf, dtype, scale=500, what="epoch after an in-place edit of state.z_full")
     st = next(states)                                   # untouched state again: reuse is back on and still right
     O.svrg_iterate(op, og, dtype(gamma), ref_stream.rand_indices(N, N), False, rav, rz, rzf, rw)
-    close(st.z_full, rzf, dtype, scale=100, what="epoch after that")
+    close(st.z_full, rzf, dtype, scale=1000, what="epoch after that")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d", [1024, 1000, 4096])
+def test_chain_over_a_shard_table_is_bitwise_the_unsharded_chain(ctx, ciao, dtype, d):
+    """ciao_ctx_set_shards: the rows of the problem live in several allocations (here three slices of one matrix, uneven, one
+    of them empty; on a node: the other GPUs' HBM, peer-mapped) and the one chain addresses each step's row through the
+    shard table.  Same kernel, same arithmetic, same order -> SVRG inner cycle and SAGA steps bitwise equal to the unsharded
+    run, including the table rows written through the shard pointers."""
+    import torch
+    import ciaoalgorithms_jl_amd._lib as L
+    N = 600
+    A, b, x0 = P.synthetic("logistic", N, d, dtype, seed=41)
+    op, dp = make("logistic", A, b, 1.0, dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.01)
+    tdt = dev(x0).dtype
+    cuts = [0, 217, 217, 480, N]                        # shard 1 is empty
+    idx = ciao.IndexStream(6).rand_indices(N, 1500)
+    idx[10:13] = idx[10]                                # table-row hazards inside the prefetch window, across the staging too
+
+    def shard_table(table=None):
+        t = L.ShardTable()
+        t.nshards, t.owner = len(cuts) - 1, 1
+        for k in range(len(cuts) - 1):
+            t.row0[k] = cuts[k]
+            t.A[k] = dp.A[cuts[k]:].data_ptr() if cuts[k] < N else None
+            t.b[k] = dp.b[cuts[k]:].data_ptr() if cuts[k] < N else None
+            t.table[k] = table[cuts[k]:].data_ptr() if (table is not None and cuts[k] < N) else None
+        t.row0[len(cuts) - 1] = N
+        return t
+
+    outs = []
+    for sharded in (False, True):
+        av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+        ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+        table = torch.empty((N, d), dtype=tdt, device="cuda")
+        sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+        ctx.saga_init(dp, dg, 0.3, dev(x0), table, sav, sz)
+        if sharded:
+            ctx.set_shards(shard_table(table))
+        try:
+            ctx.svrg_inner(dp, dg, 0.4, idx, av, z, zf, w)
+            k1 = ctx.last_kernel()
+            ctx.saga_steps(dp, dg, 0.3, False, idx, table, sav, sz)
+            k2 = ctx.last_kernel()
+            ctx.synchronize()
+        finally:
+            ctx.set_shards(None)
+        assert "chain_dma_kernel" in k1 and "chain_dma_kernel" in k2
+        outs.append([t.cpu().numpy() for t in (w, z, sz, sav, table)])
+    for u, v in zip(*outs):
+        assert np.array_equal(u, v)
+    rav, rz, rzf, rw = O_svrg_state(op, x0)
+    from oracle import oracle as O
+    O.svrg_inner(op, og, dtype(0.4), idx, rav, rz, rzf, rw)
+    close(outs[1][0], rw, dtype, scale=20000, what="sharded svrg_inner w vs oracle")
+
+
+def O_svrg_state(op, x0):
+    from oracle import oracle as O
+    return O.svrg_init(op, x0)
+
+
+def test_shard_table_is_validated(ctx, ciao):
+    import torch
+    import ciaoalgorithms_jl_amd._lib as L
+    A, b, x0 = P.synthetic("ls", 40, 1024, np.float64)
+    _, dp = make("ls", A, b, 40.0, np.float64)
+    _, dg = make_g("zero", np.float64, 1024)
+    t = L.ShardTable()
+    t.nshards, t.owner = 2, 1
+    t.row0[0], t.row0[1], t.row0[2] = 0, 10, 39        # covers 39 rows, the problem has 40
+    t.A[0], t.b[0], t.A[1], t.b[1] = dp.A.data_ptr(), dp.b.data_ptr(), dp.A[10:].data_ptr(), dp.b[10:].data_ptr()
+    v = [torch.zeros(1024, dtype=torch.float64, device="cuda") for _ in range(4)]
+    ctx.set_shards(t)
+    try:
+        with pytest.raises(ciao._lib.CiaoError, match="shard table covers"):
+            ctx.svrg_inner(dp, dg, 0.1, np.zeros(3, np.int64), *v)
+    finally:
+        ctx.set_shards(None)
+    bad = L.ShardTable()
+    bad.nshards = 9
+    with pytest.raises(ciao._lib.CiaoError):
+        ctx.set_shards(bad)
+    ctx.set_shards(None)
+    # rows that are not whole 16-byte chunks cannot take the LDS-DMA kernel: refused, never silently unsharded
+    A2, b2, _ = P.synthetic("ls", 40, 1001, np.float64)
+    _, dp2 = make("ls", A2, b2, 40.0, np.float64)
+    _, dg2 = make_g("zero", np.float64, 1001)
+    t2 = L.ShardTable()
+    t2.nshards, t2.owner = 1, 1
+    t2.row0[0], t2.row0[1] = 0, 40
+    t2.A[0], t2.b[0] = dp2.A.data_ptr(), dp2.b.data_ptr()
+    v2 = [torch.zeros(1001, dtype=torch.float64, device="cuda") for _ in range(4)]
+    ctx.set_shards(t2)
+    try:
+        with pytest.raises(ciao._lib.CiaoError, match="shard table needs rows"):
+            ctx.svrg_inner(dp2, dg2, 0.1, np.zeros(3, np.int64), *v2)
+    finally:
+        ctx.set_shards(None)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -557,9 +667,9 @@ def test_saga_steps(ctx, ciao, chain_variant, dtype, sag, shape):
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
     ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
     rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
-    close(table, rt, dtype, scale=4, what="saga_init table")
-    close(av, rav, dtype, scale=4, what="saga_init av")
-    close(z, rz, dtype, scale=4, what="saga_init z  (= prox((1-gamma) x0))")
+    close(table, rt, dtype, scale=50, what="saga_init table")
+    close(av, rav, dtype, scale=50, what="saga_init av")
+    close(z, rz, dtype, scale=10, what="saga_init z  (= prox((1-gamma) x0))")
     st = ciao.IndexStream(21)
     for chunk in (1, 2, 4 * N, 7):
         idx = st.rand_indices(N, chunk)
@@ -567,11 +677,11 @@ def test_saga_steps(ctx, ciao, chain_variant, dtype, sag, shape):
             idx[:] = idx[0]   # the same row seven times in a row
         ctx.saga_steps(dp, dg, gamma, sag, idx, table, av, z)
         O.saga_steps(op, og, dtype(gamma), sag, idx, rt, rav, rz)
-        close(z, rz, dtype, scale=100, what=f"saga z after chunk {chunk} ({ctx.last_kernel()})")
-        close(av, rav, dtype, scale=100, what=f"saga av after chunk {chunk}")
-        close(table, rt, dtype, scale=100, what=f"saga table after chunk {chunk}")
+        close(z, rz, dtype, scale=200, what=f"saga z after chunk {chunk} ({ctx.last_kernel()})")
+        close(av, rav, dtype, scale=200, what=f"saga av after chunk {chunk}")
+        close(table, rt, dtype, scale=500, what=f"saga table after chunk {chunk}")
     # invariant av == (1/N) sum_i s_i  
-    close(av, table.double().mean(dim=0).cpu().numpy(), dtype, scale=100, what="av invariant")
+    close(av, table.double().mean(dim=0).cpu().numpy(), dtype, scale=200, what="av invariant")
     ctx.synchronize()
 
 
@@ -616,9 +726,9 @@ def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, path):
     rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
     assert abs(hg - float(rhg)) <= (1e-12 if dtype == np.float64 else 1e-5) * abs(float(rhg))
     ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
-    close(table, rt, dtype, scale=4, what="finito_init table")
-    close(av, rav, dtype, scale=20, what="finito_init av")
-    close(z, rz, dtype, scale=20, what="finito_init z")
+    close(table, rt, dtype, scale=20, what="finito_init table")
+    close(av, rav, dtype, scale=100, what="finito_init av")
+    close(z, rz, dtype, scale=100, what="finito_init z")
     ctx.set_option("chain_max_batch", 64 if path == "chain" else 0)
     ctx.set_option("split_max_rows", 0 if path == "wave_per_row" else -1)
     try:
@@ -629,15 +739,15 @@ def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, path):
             np.cumsum([len(x) for x in batches], out=bptr[1:])
             ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(batches), table, av, z)
             O.finito_steps(op, og, gam, rhg, batches, rt, rav, rz)
-            close(z, rz, dtype, scale=200, what=f"finito z {mode} ({ctx.last_kernel()})")
-            close(av, rav, dtype, scale=200, what=f"finito av {mode}")
-            close(table, rt, dtype, scale=200, what=f"finito table {mode}")
+            close(z, rz, dtype, scale=20000, what=f"finito z {mode} ({ctx.last_kernel()})")
+            close(av, rav, dtype, scale=20000, what=f"finito av {mode}")
+            close(table, rt, dtype, scale=20000, what=f"finito table {mode}")
     finally:
         ctx.set_option("chain_max_batch", -1)
         ctx.set_option("split_max_rows", -1)
     # invariant av == hat_gamma * sum_i s_i / gamma_i   (row F3)
     inv = (table.double() / dgam.double()[:, None]).sum(dim=0).cpu().numpy() * hg
-    close(av, inv, dtype, scale=200, what="finito av invariant")
+    close(av, inv, dtype, scale=100, what="finito av invariant")
     ctx.synchronize()
 
 
@@ -662,7 +772,7 @@ def test_lfinito_iterations(ctx, ciao, chain_variant, dtype, shape, r, path):
     hg = ctx.hat_gamma(dgam)
     rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
     ctx.lfinito_init(dp, hg, dev(x0), av, z, zf)
-    close(av, rav, dtype, scale=20, what="lfinito_init av")
+    close(av, rav, dtype, scale=200, what="lfinito_init av")
     assert torch.equal(z, av) and torch.equal(zf, av)
     nb = -(-N // r)
     static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in range(nb)]
@@ -677,9 +787,9 @@ def test_lfinito_iterations(ctx, ciao, chain_variant, dtype, shape, r, path):
             np.cumsum([len(x) for x in batches], out=bptr[1:])
             ctx.lfinito_iterate(dp, dg, dgam, hg, bptr, np.concatenate(batches), av, z, zf)
             O.lfinito_iterate(op, og, gam, rhg, batches, rav, rz, rzf)
-            close(zf, rzf, dtype, scale=200, what=f"lfinito z_full it {it}")
-            close(z, rz, dtype, scale=200, what=f"lfinito z it {it} ({ctx.last_kernel()})")
-            close(av, rav, dtype, scale=200, what=f"lfinito av it {it}")
+            close(zf, rzf, dtype, scale=5000, what=f"lfinito z_full it {it}")
+            close(z, rz, dtype, scale=10000, what=f"lfinito z it {it} ({ctx.last_kernel()})")
+            close(av, rav, dtype, scale=10000, what=f"lfinito av it {it}")
     finally:
         ctx.set_option("chain_max_batch", -1)
         ctx.set_option("split_max_rows", -1)
@@ -789,11 +899,11 @@ def test_adaptive_finito_steps(ctx, ciao, dtype, shape):
     ctx.synchronize()
     rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(alpha), x0)
     S = 50 if dtype == np.float64 else 10
-    close(meta[:, 2], rgam, dtype, scale=S, what="adaptive init gamma_i")
-    close(meta[:, 1], rfi, dtype, scale=S, what="adaptive init f_i(x0)")
-    close(hg, [rhg], dtype, scale=S, what="adaptive init hat_gamma")
-    close(av, rav, dtype, scale=S, what="adaptive init av")
-    close(z, rz, dtype, scale=S, what="adaptive init z")
+    close(meta[:, 2], rgam, dtype, scale=20000, what="adaptive init gamma_i")
+    close(meta[:, 1], rfi, dtype, scale=500, what="adaptive init f_i(x0)")
+    close(hg, [rhg], dtype, scale=50, what="adaptive init hat_gamma")
+    close(av, rav, dtype, scale=100, what="adaptive init av")
+    close(z, rz, dtype, scale=100, what="adaptive init z")
     assert torch.equal(table, dev(x0).expand(N, d))
     st = ciao.IndexStream(4)
     idx = st.rand_indices(N, 3 * N)
@@ -814,29 +924,35 @@ def test_adaptive_finito_steps(ctx, ciao, dtype, shape):
     if dtype == np.float64:
         assert trials == rtrials, "same backtracking decisions in fp64"
     S = 2000 if dtype == np.float64 else 200
-    # In fp32 a backtracking test  f_i(z) <= model + tol  that sits on the boundary can legitimately flip between two
-    # correct implementations (a stepsize then differs by the factor 0.8), so the iterate comparison is only meaningful
-    # when both took the same decisions; the state invariant below is checked unconditionally.
+    # fp32: device and oracle now keep the reference's Float64 promotions in the backtracking test and in `γ *= 0.8`
+    # (Finito_adaptive.jl:128-136), so they take the same decisions unless a test f_i(z) <= model + tol sits on the boundary
+    # to within the rounding of the two dot products (different summation orders).  That may flip a decision (a stepsize then
+    # differs by the factor 0.8, the trajectories part and later decisions differ too), but it must stay the rare exception:
+    # the trial counts may differ by at most 2 %, and every case is logged (gpurun_out/parity_observed.json, "trial flips":
+    # observed 0 for eight of the nine shapes, 8 of 1229 = 0.65 % at (200, 2048)).
+    P.PARITY_LOG.append({"test": "test_adaptive_finito_steps", "line": 0, "what": f"trial flips {shape}", "dtype": np.dtype(dtype).name,
+                         "ratio": float(abs(trials - rtrials)), "scale": float(max(1, rtrials // 50))})
+    assert abs(trials - rtrials) <= max(1, rtrials // 50), (trials, rtrials)
     if trials == rtrials:
-        close(z, rz, dtype, scale=S, what=f"adaptive z ({ctx.last_kernel()})")
-        close(av, rav, dtype, scale=S, what="adaptive av")
-        close(hg, [rhg], dtype, scale=S, what="adaptive hat_gamma")
-        close(meta[:, 2], rgam, dtype, scale=S, what="adaptive gamma_i")
-        close(table, rt, dtype, scale=S, what="adaptive table")
+        close(z, rz, dtype, scale=1000, what=f"adaptive z ({ctx.last_kernel()})")
+        close(av, rav, dtype, scale=1000, what="adaptive av")
+        close(hg, [rhg], dtype, scale=100, what="adaptive hat_gamma")
+        close(meta[:, 2], rgam, dtype, scale=5000, what="adaptive gamma_i")
+        close(table, rt, dtype, scale=1000, what="adaptive table")
         # grad f_i = c_i a_i: the oracle's full gradient table against the device's N scalars
         gdev = meta[:, 0:1].double().cpu().numpy() * A.astype(np.float64)
-        close(gdev, rg, dtype, scale=S, what="adaptive gradient table (c_i a_i)")
+        close(gdev, rg, dtype, scale=500, what="adaptive gradient table (c_i a_i)")
     # invariant of the algorithm (Finito_adaptive.jl:93 and every update after it):
     #   av == hat_gamma * (sum_i x_i/gamma_i - (1/N) sum_i grad f_i),   hat_gamma == 1 / sum_i 1/gamma_i
     md = meta.double()
     hgd = float(hg.item())
     assert abs(hgd - 1.0 / float((1.0 / md[:, 2]).sum())) <= (1e-10 if dtype == np.float64 else 2e-4) * hgd
     inv = hgd * ((table.double() / md[:, 2:3]).sum(dim=0) - (md[:, 0:1] * dev(A).double()).sum(dim=0) / N)
-    close(av, inv.cpu().numpy(), dtype, scale=S, what="adaptive invariant av")
+    close(av, inv.cpu().numpy(), dtype, scale=500, what="adaptive invariant av")
     # the stored scalars are consistent with the stored points: a_i'x_i, c_i = coef(a_i'x_i), f_i(x_i)
     dots = (dev(A).double() * table.double()).sum(dim=1)
-    close(md[:, 3], dots.cpu().numpy(), dtype, scale=S, what="adaptive a_i'x_i")
-    close(md[:, 0], (lam_f * (dots - dev(b).double())).cpu().numpy(), dtype, scale=S, what="adaptive c_i")
+    close(md[:, 3], dots.cpu().numpy(), dtype, scale=20, what="adaptive a_i'x_i")
+    close(md[:, 0], (lam_f * (dots - dev(b).double())).cpu().numpy(), dtype, scale=20, what="adaptive c_i")
     ctx.synchronize()
 
 
@@ -869,10 +985,10 @@ def test_adaptive_finito_variants(ctx, ciao, kind, gkind, no_dma):
         ctx.set_option("chain_no_dma", 0)
     rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(alpha), dtype(tol_b), idx, rt, rg, rgam, rfi, rhg, rav, rz)
     assert done == rdone == len(idx) and trials == rtrials
-    close(z, rz, dtype, scale=5000, what=f"adaptive z ({ctx.last_kernel()})")
-    close(av, rav, dtype, scale=5000, what="adaptive av")
-    close(hg, [rhg], dtype, scale=5000, what="adaptive hat_gamma")
-    close(table, rt, dtype, scale=5000, what="adaptive table")
+    close(z, rz, dtype, scale=100000, what=f"adaptive z ({ctx.last_kernel()})")
+    close(av, rav, dtype, scale=100000, what="adaptive av")
+    close(hg, [rhg], dtype, scale=100, what="adaptive hat_gamma")
+    close(table, rt, dtype, scale=100000, what="adaptive table")
     assert torch.equal(meta4[:, 0], meta4[:, 1]) and torch.equal(meta4[:, 0], meta4[:, 2]) and torch.equal(meta4[:, 0], meta4[:, 3])
     ctx.synchronize()
 
@@ -937,10 +1053,10 @@ def test_proshi_steps(ctx, ciao, dtype, shape, r, generic):
     finally:
         ctx.set_option("force_generic", 0)
     rt, rav, rz, rhg = O.proshi_init(of, og, gam, x0)
-    close(table, rt, dtype, scale=4, what="proshi init table")
-    close(hg, [rhg], dtype, scale=4, what="proshi hat_gamma")
-    close(av, rav, dtype, scale=20, what="proshi init av")
-    close(z, rz, dtype, scale=200, what="proshi init z")
+    close(table, rt, dtype, scale=10, what="proshi init table")
+    close(hg, [rhg], dtype, scale=1000, what="proshi hat_gamma")
+    close(av, rav, dtype, scale=100, what="proshi init av")
+    close(z, rz, dtype, scale=1000, what="proshi init z")
     st = ciao.IndexStream(2)
     batches = [st.sample_without_replacement(N, r) for _ in range(12)]
     bptr = np.arange(len(batches) + 1, dtype=np.int64) * r
@@ -951,12 +1067,12 @@ def test_proshi_steps(ctx, ciao, dtype, shape, r, generic):
         ctx.set_option("force_generic", 0)
     O.proshi_steps(of, og, gam, rhg, batches, rt, rav, rz)
     S = 500 if dtype == np.float64 else 100
-    close(table, rt, dtype, scale=S, what=f"proshi table ({ctx.last_kernel()})")
-    close(av, rav, dtype, scale=S, what="proshi av")
-    close(z, rz, dtype, scale=10 * S, what="proshi z")
-    close(av, table.double().sum(dim=0).cpu().numpy(), dtype, scale=S, what="invariant av == sum_i s_i")
+    close(table, rt, dtype, scale=1000, what=f"proshi table ({ctx.last_kernel()})")
+    close(av, rav, dtype, scale=200, what="proshi av")
+    close(z, rz, dtype, scale=20000, what="proshi z")
+    close(av, table.double().sum(dim=0).cpu().numpy(), dtype, scale=50, what="invariant av == sum_i s_i")
     ctx.proshi_solution(df, dev(gam), z, table)
-    close(table, O.proshi_solution(of, gam, rz, rt), dtype, scale=10 * S, what="proshi solution")
+    close(table, O.proshi_solution(of, gam, rz, rt), dtype, scale=1000, what="proshi solution")
     ctx.synchronize()
 
 
@@ -1025,20 +1141,20 @@ def test_row_length_boundaries(ctx, ciao, dtype, d):
         return
     ctx.full_gradient(dp, dev(x0), av)
     k_sweep = ctx.last_kernel()
-    close(av, O.full_pass(op, x0), dtype, scale=8, what=f"sweep d={d} ({k_sweep})")
+    close(av, O.full_pass(op, x0), dtype, scale=100, what=f"sweep d={d} ({k_sweep})")
     table = torch.empty((N, d), dtype=tdt, device="cuda")
     gamma = 0.5 / N
     ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
     rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
-    close(table, rt, dtype, scale=8, what=f"saga_init table d={d} ({ctx.last_kernel()})")
-    close(av, rav, dtype, scale=20, what="saga_init av")
+    close(table, rt, dtype, scale=200, what=f"saga_init table d={d} ({ctx.last_kernel()})")
+    close(av, rav, dtype, scale=100, what="saga_init av")
     Li = float(N) * np.sum(A.astype(np.float64) ** 2, axis=1)
     gam = (0.999 * N / Li).astype(dtype)
     dgam = dev(gam)
     hg = ctx.hat_gamma(dgam)
     rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
     ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
-    close(table, rt, dtype, scale=8, what=f"finito_init table d={d}")
+    close(table, rt, dtype, scale=10, what=f"finito_init table d={d}")
     ctx.set_option("chain_max_batch", 0)
     try:
         batch = np.array([3, 19, 0, 7, 11, 22, 5], dtype=np.int64)
@@ -1047,7 +1163,7 @@ def test_row_length_boundaries(ctx, ciao, dtype, d):
         ctx.set_option("chain_max_batch", -1)
     O.finito_steps(op, og, gam, rhg, [batch], rt, rav, rz)
     close(table, rt, dtype, scale=50, what=f"finito batch table d={d} ({ctx.last_kernel()})")
-    close(z, rz, dtype, scale=200, what="finito batch z")
+    close(z, rz, dtype, scale=50, what="finito batch z")
     ctx.synchronize()
 
 
@@ -1075,13 +1191,13 @@ def test_chain_row_length_boundaries(ctx, ciao, dtype, d):
         return
     ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
     O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
-    close(w, rw, dtype, scale=200, what=f"svrg_inner w d={d} ({ctx.last_kernel()})")
+    close(w, rw, dtype, scale=500, what=f"svrg_inner w d={d} ({ctx.last_kernel()})")
     table = torch.empty((N, d), dtype=tdt, device="cuda")
     ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
     rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
     ctx.saga_steps(dp, dg, gamma, False, idx, table, av, z)
     O.saga_steps(op, og, dtype(gamma), False, idx, rt, rav, rz)
-    close(z, rz, dtype, scale=200, what=f"saga z d={d} ({ctx.last_kernel()})")
+    close(z, rz, dtype, scale=20, what=f"saga z d={d} ({ctx.last_kernel()})")
     close(table, rt, dtype, scale=200, what="saga table")
     ctx.synchronize()
 
@@ -1111,19 +1227,19 @@ def test_small_row_kernel_group_sizes(ctx, ciao, dtype, small_i, shape):
             assert "rows_split_kernel" in ctx.last_kernel(), ctx.last_kernel()
         else:
             assert "rows_small_kernel" in ctx.last_kernel() and f"I{small_i}" in ctx.last_kernel(), ctx.last_kernel()
-        close(av, O.full_pass(op, x0), dtype, scale=8, what=f"sweep ({ctx.last_kernel()})")
+        close(av, O.full_pass(op, x0), dtype, scale=100, what=f"sweep ({ctx.last_kernel()})")
         gamma = 0.5 / N
         ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
         rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
-        close(table, rt, dtype, scale=8, what="saga_init table")
-        close(av, rav, dtype, scale=20, what="saga_init av")
+        close(table, rt, dtype, scale=50, what="saga_init table")
+        close(av, rav, dtype, scale=50, what="saga_init av")
         Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1)
         gam = (0.999 * N / Li).astype(dtype)
         dgam = dev(gam)
         hg = ctx.hat_gamma(dgam)
         rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
         ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
-        close(table, rt, dtype, scale=8, what="finito_init table")
+        close(table, rt, dtype, scale=20, what="finito_init table")
         close(av, rav, dtype, scale=50, what="finito_init av")
         close(z, rz, dtype, scale=50, what="finito_init z")
     finally:
@@ -1162,22 +1278,22 @@ def test_random_shapes(ctx, ciao, case):
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
     table = torch.empty((N, d), dtype=tdt, device="cuda")
     ctx.full_gradient(dp, dev(x0), av)
-    close(av, O.full_pass(op, x0), dtype, scale=8, what=f"sweep ({ctx.last_kernel()})")
+    close(av, O.full_pass(op, x0), dtype, scale=200, what=f"sweep ({ctx.last_kernel()})")
     gamma = 0.5 / max(lam_f, 1.0)
     ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
     rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
-    close(table, rt, dtype, scale=8, what=f"saga_init table ({ctx.last_kernel()})")
+    close(table, rt, dtype, scale=200, what=f"saga_init table ({ctx.last_kernel()})")
     idx = ciao.IndexStream(N + d).rand_indices(N, 25)
     ctx.saga_steps(dp, dg, gamma, False, idx, table, av, z)
     O.saga_steps(op, og, dtype(gamma), False, idx, rt, rav, rz)
-    close(z, rz, dtype, scale=200, what=f"saga z ({ctx.last_kernel()})")
+    close(z, rz, dtype, scale=100, what=f"saga z ({ctx.last_kernel()})")
     Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1) + 1e-12
     gam = (0.999 * N / Li).astype(dtype)
     dgam = dev(gam)
     hg = ctx.hat_gamma(dgam)
     rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
     ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
-    close(table, rt, dtype, scale=8, what=f"finito_init table ({ctx.last_kernel()})")
+    close(table, rt, dtype, scale=20, what=f"finito_init table ({ctx.last_kernel()})")
     r = min(N, 9)
     batch = ciao.IndexStream(d).sample_without_replacement(N, r)
     ctx.set_option("chain_max_batch", 0)
@@ -1186,6 +1302,6 @@ def test_random_shapes(ctx, ciao, case):
     finally:
         ctx.set_option("chain_max_batch", -1)
     O.finito_steps(op, og, gam, rhg, [batch], rt, rav, rz)
-    close(table, rt, dtype, scale=50, what=f"finito batch table ({ctx.last_kernel()})")
-    close(z, rz, dtype, scale=300, what="finito batch z")
+    close(table, rt, dtype, scale=100, what=f"finito batch table ({ctx.last_kernel()})")
+    close(z, rz, dtype, scale=100, what="finito batch z")
     ctx.synchronize()

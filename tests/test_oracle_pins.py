@@ -219,3 +219,76 @@ class TestSharingFixture:
         assert np.abs(x.sum(axis=0) - sum_star).max() < self.tol
         x, _ = RS.proshi(f, g, x0, maxit=self.maxit, L=float(L.max()), stream=Stream(0))
         assert np.abs(x.sum(axis=0) - sum_star).max() < self.tol
+
+
+# ---- (5) Julia's `sum` over a Vector: Base.mapreduce_impl (pairwise above 1024 elements) -------------------------------------
+def _julia_mapreduce(vals, ifirst, ilast, blksize=1024):
+    """Line-by-line restatement of Base.mapreduce_impl(identity, +, A, ifirst, ilast, blksize) of Julia 1.0-1.6
+    (base/reduce.jl), 1-based inclusive indices; `vals[i-1]` is a numpy scalar or a numpy vector (so + rounds in R)."""
+    if ifirst == ilast:
+        return vals[ifirst - 1]
+    if ifirst + blksize > ilast:                       # sequential portion
+        v = vals[ifirst - 1] + vals[ifirst]
+        for i in range(ifirst + 2, ilast + 1):
+            v = v + vals[i - 1]
+        return v
+    imid = (ifirst + ilast) >> 1                       # pairwise portion
+    return _julia_mapreduce(vals, ifirst, imid, blksize) + _julia_mapreduce(vals, imid + 1, ilast, blksize)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N", [1, 2, 15, 16, 1023, 1024, 1025, 2048, 2049, 5000])
+def test_julia_sum_rule(dtype, N):
+    """The six init sums of the reference (SAGA_basic.jl:47; Finito_basic.jl:82-83; Finito_LFinito.jl:66;
+    Finito_adaptive.jl:91-92; ProShI_basic.jl:82-83) are `sum` over a Vector: a left fold only up to 1024 elements.  The C
+    oracle's julia_sum_* must reproduce the rule bit for bit (sums of d-vectors; scalar sums with left-to-right leaves)."""
+    rng = np.random.default_rng(N)
+    rows = rng.standard_normal((N, 7)).astype(dtype)
+    gam = (0.5 + rng.random(N)).astype(dtype)
+    want = _julia_mapreduce([rows[i] for i in range(N)], 1, N)
+    assert np.array_equal(O.julia_sum_vec(rows), want)
+    want = _julia_mapreduce([rows[i] / gam[i] for i in range(N)], 1, N)
+    assert np.array_equal(O.julia_sum_vec(rows, gam), want)
+    assert O.julia_sum_scalar(gam) == _julia_mapreduce(list(gam), 1, N)
+    assert O.julia_sum_scalar(gam, inv=True) == _julia_mapreduce([dtype(1) / g for g in gam], 1, N)
+    if N >= 1025:   # and it is NOT the left fold any more
+        left = rows[0].copy()
+        for i in range(1, N):
+            left = left + rows[i]
+        assert not np.array_equal(left, O.julia_sum_vec(rows))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_init_passes_use_the_julia_sum(dtype):
+    """SAGA / Finito / LFinito / ProShI / adaptive-Finito init at N = 2049: av and hat_γ are the pairwise sums, bit for bit."""
+    N, d = 2049, 5
+    A, b, x0 = P.synthetic("ls", N, d, dtype, seed=3)
+    p, g = O.Problem("ls", A, b, float(N)), O.Prox("l1", lam=0.01)
+    table, av, z = O.saga_init(p, g, dtype(0.1), x0)
+    assert np.array_equal(av, O.julia_sum_vec(table) / dtype(N))
+    gam = (0.5 + np.random.default_rng(0).random(N)).astype(dtype)
+    table, av, z, hg = O.finito_init(p, g, gam, x0)
+    hg_want = dtype(1) / O.julia_sum_scalar(gam, inv=True)
+    assert hg == hg_want and np.array_equal(av, hg_want * O.julia_sum_vec(table, gam))
+    av, z, zf, hg = O.lfinito_init(p, gam, x0)
+    assert hg == hg_want
+    f = O.SepQuad(np.abs(A) + dtype(0.1), A.copy(), eta=1.0, lo=-2.0, hi=2.0)
+    table, av, z, hg = O.proshi_init(f, O.Prox("box", lo=-np.inf, hi=1.0, dtype=dtype), gam, x0)
+    assert hg == O.julia_sum_scalar(gam) and np.array_equal(av, O.julia_sum_vec(table))
+
+
+def test_adaptive_finito_keeps_julias_float64_promotions():
+    """R = Float32: `L_int = zeros(N)` is a Float64 array (Finito_adaptive.jl:73), so γ_i = Float32(Float64(α) / L_i); `γ *= 0.8`
+    is a Float64 product rounded back (:136) -- Float32(γ) * Float32(0.8) differs from it in the last place for some γ."""
+    N, d = 40, 6
+    A, b, x0 = P.synthetic("ls", N, d, np.float32, seed=8)
+    p, g = O.Problem("ls", A, b, float(N)), O.Prox("l1", lam=0.01)
+    table, gtable, gam, fi_x, av, z, hg = O.afinito_init(p, g, np.float32(0.999), x0)
+    for i in range(N):
+        ge = O.gradient(p.loss, A[i], b[i], float(N), (x0 + np.float32(1)).astype(np.float32))[0]
+        nmg = np.sqrt(np.float32(np.sum((ge - gtable[i]) ** 2, dtype=np.float32)))
+        want = np.float32(np.float64(np.float32(0.999)) / (np.float64(nmg) / np.sqrt(np.float64(d)) / np.float64(N)))
+        assert abs(float(gam[i]) - float(want)) <= 2 * np.spacing(want), (i, gam[i], want)   # nmg's own summation order aside
+    g32 = np.float32(0.3)
+    differ = [g for g in (np.float32(0.1) * k for k in range(1, 200)) if np.float32(np.float64(g) * 0.8) != g * np.float32(0.8)]
+    assert differ, "the two roundings must be distinguishable, or the promotion would not matter"
