@@ -35,6 +35,13 @@ struct CiaoProxDesc
     lam::Float64; lo::Float64; hi::Float64
     lo_vec::Ptr{Cvoid}; hi_vec::Ptr{Cvoid}
 end
+const CIAO_MAX_SHARDS = 8
+struct CiaoShardTable                       # ciao_shard_table: fixed-size C arrays are NTuples
+    nshards::Int32; owner::Int32
+    row0::NTuple{9,Int64}
+    A::NTuple{8,Ptr{Cvoid}}; b::NTuple{8,Ptr{Cvoid}}; table::NTuple{8,Ptr{Cvoid}}
+end
+const CIAO_ABI_VERSION = Int32(2)
 const CIAO_F32, CIAO_F64 = Int32(0), Int32(1)
 const LOSS_LS, LOSS_LOGISTIC, LOSS_ZERO = Int32(0), Int32(1), Int32(2)
 const PROX_ZERO, PROX_L1, PROX_BOX = Int32(0), Int32(1), Int32(2)
@@ -54,6 +61,8 @@ end
 mutable struct Context
     h::Ptr{Cvoid}
     function Context(device::Integer = AMDGPU.device_id(AMDGPU.device()) - 1)
+        v = ccall((:ciao_abi_version, libciao), Int32, ())
+        v == CIAO_ABI_VERSION || error("libciao_hip.so has ABI version $v, this wrapper binds version $CIAO_ABI_VERSION")
         out = Ref{Ptr{Cvoid}}(C_NULL)
         stream = Base.unsafe_convert(Ptr{Cvoid}, AMDGPU.stream().stream)
         check(ccall((:ciao_ctx_create, libciao), Int32, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, stream, out))
@@ -153,6 +162,22 @@ end
 # multi-GPU: hand an RCCL communicator (ncclComm_t) to the context; tuning knobs
 set_rccl!(comm::Ptr{Cvoid}, lib::AbstractString = "librccl.so") =
     check(ccall((:ciao_ctx_set_rccl, libciao), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Cstring), context().h, comm, lib))
+# Row-sharded problem for the sequential chains (include/ciao_hip.h: ciao_ctx_set_shards): the chain owner reads the other
+# ranks' rows through peer-mapped pointers (ipc_open of the handles the other processes made with ipc_export).
+set_shards!(t::CiaoShardTable) =
+    check(ccall((:ciao_ctx_set_shards, libciao), Int32, (Ptr{Cvoid}, Ref{CiaoShardTable}), context().h, Ref(t)))
+clear_shards!() = check(ccall((:ciao_ctx_set_shards, libciao), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), context().h, C_NULL))
+function ipc_export(a::ROCArray)
+    handle = zeros(UInt8, 64); off = Ref{Int64}(0)
+    check(ccall((:ciao_ipc_export, libciao), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Ref{Int64}), dptr(a), handle, off))
+    return handle, off[]
+end
+function ipc_open(handle::Vector{UInt8}, offset::Integer)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ciao_ipc_open, libciao), Int32, (Ptr{UInt8}, Int64, Ref{Ptr{Cvoid}}), handle, offset, out))
+    return out[]
+end
+ipc_close(p::Ptr{Cvoid}, offset::Integer) = check(ccall((:ciao_ipc_close, libciao), Int32, (Ptr{Cvoid}, Int64), p, offset))
 set_option!(key::AbstractString, value::Integer) =
     check(ccall((:ciao_ctx_set_option, libciao), Int32, (Ptr{Cvoid}, Cstring, Int64), context().h, key, value))
 last_kernel() = unsafe_string(ccall((:ciao_ctx_last_kernel, libciao), Cstring, (Ptr{Cvoid},), context().h))
@@ -458,12 +483,12 @@ function Base.iterate(iter::FINITO_iterable{R}, state::FINITO_state{R}) where {R
     p, g = Ref(cproblem(iter.F)), Ref(iter.g)
     if iter.lfinito                                                # Finito_LFinito.jl:78-103
         iter.sweeping == 3 && (state.inds = randperm(state.d))
-        batches = [state.ind[j] for j in state.inds]
-        bptr = Int64[0; cumsum(length.(batches))]
-        bidx = to_dev_idx(vcat(batches...))
-        check(ccall((:ciao_lfinito_iterate, libciao), Int32,
-                    (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-                    context().h, p, g, dptr(state.γ), Float64(state.hat_γ), length(batches), bptr, dptr(bidx),
+        # the batches are always the static contiguous blocks (:44-49), visited in the order state.inds (:90): no index array
+        bfirst = Int64[state.ind[j][1] - 1 for j in state.inds]
+        blen = Int64[length(state.ind[j]) for j in state.inds]
+        check(ccall((:ciao_lfinito_iterate_blocks, libciao), Int32,
+                    (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    context().h, p, g, dptr(state.γ), Float64(state.hat_γ), length(bfirst), bfirst, blen,
                     dptr(state.av), dptr(state.z), dptr(state.z_full)))
     else                                                           # Finito_basic.jl:91-121
         finito_steps!(iter, state, 1)
@@ -475,6 +500,18 @@ end
 # in the reference's order (next_batch! n times), then shipped together.  Base.iterate uses n = 1; the functor uses
 # large n, because one iteration is 0.5-50 us of device work and a launch per iteration would be launch-bound.
 function finito_steps!(iter::FINITO_iterable{R}, state::FINITO_state{R}, n::Int) where {R}
+    if iter.sweeping != 1      # static batches are contiguous row blocks (Finito_basic.jl:52-58): no index array at all
+        bfirst = Vector{Int64}(undef, n); blen = Vector{Int64}(undef, n)
+        for t in 1:n
+            b = next_batch!(iter, state)
+            bfirst[t] = b[1] - 1; blen[t] = length(b)
+        end
+        check(ccall((:ciao_finito_steps_blocks, libciao), Int32,
+                    (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    context().h, Ref(cproblem(iter.F)), Ref(iter.g), dptr(state.γ), Float64(state.hat_γ), n, bfirst, blen,
+                    dptr(state.s), dptr(state.av), dptr(state.z)))
+        return n
+    end
     batches = [copy(next_batch!(iter, state)) for _ in 1:n]
     bptr = Int64[0; cumsum(length.(batches))]
     bidx = to_dev_idx(reduce(vcat, batches))
@@ -674,6 +711,18 @@ function Base.iterate(iter::Proshi_basic_iterable{R}) where {R}          # ProSh
 end
 
 function proshi_steps!(iter::Proshi_basic_iterable{R}, state::Proshi_basic_state{R}, n::Int) where {R}   # :91-124, n times
+    if iter.sweeping != 1      # static batches are contiguous blocks of agents (:50-57): no index array
+        bfirst = Vector{Int64}(undef, n); blen = Vector{Int64}(undef, n)
+        for t in 1:n
+            b = next_batch!(iter, state)
+            bfirst[t] = b[1] - 1; blen[t] = length(b)
+        end
+        check(ccall((:ciao_proshi_steps_blocks, libciao), Int32,
+                    (Ptr{Cvoid}, Ref{CiaoSepQuad}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    context().h, Ref(csepquad(iter.F)), Ref(iter.g), dptr(state.γ), Float64(state.hat_γ), n, bfirst, blen,
+                    dptr(state.s), dptr(state.av), dptr(state.z)))
+        return n
+    end
     batches = [copy(next_batch!(iter, state)) for _ in 1:n]             # :95-107 is Finito's batch logic verbatim
     bptr = Int64[0; cumsum(length.(batches))]
     bidx = to_dev_idx(reduce(vcat, batches))
