@@ -97,7 +97,8 @@ SIGNATURES = {
     "ciao_lfinito_init": (_i32, [_vp, _PP, _f64, _vp, _vp, _vp, _vp]),
     "ciao_lfinito_iterate": (_i32, [_vp, _PP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ciao_lfinito_iterate_blocks": (_i32, [_vp, _PP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "ciao_afinito_init": (_i32, [_vp, _PP, _GP, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ciao_afinito_init": (_i32, [_vp, _PP, _GP, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ciao_afinito_probe": (_i32, [_vp, _PP, _i64, _vp, _vp, _f64, C.POINTER(_f64)]),
     "ciao_afinito_steps": (_i32, [_vp, _PP, _GP, _f64, _f64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "ciao_proshi_init": (_i32, [_vp, _SP, _GP, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ciao_proshi_steps": (_i32, [_vp, _SP, _GP, _vp, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),

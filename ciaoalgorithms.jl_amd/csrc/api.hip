@@ -425,7 +425,7 @@ template <typename T>
 static bool batch_as_chain(const ciao_ctx *ctx, const ciao_problem *p, int64_t r)
 {
     if (ctx->hook) return false;                       // sharded batches need the all-reduce between kernels
-    if (p->d > 32 * CHAIN_NT) return false;            // the chain keeps d/256 elements per thread in registers
+    if (p->d > 32 * CHAIN_NT) return r <= 2;           // beyond 8192 elements the any-d chain runs at launch-pair speed: tiny batches only
     int64_t lim = ctx->chain_max_batch;
     if (lim < 0) {
         // whole-4-KiB rows: rows_split_kernel batches cost ~6.5 us up to r = 64, LDS-DMA chain steps 0.47 / 0.55 / 0.8 / 1.5 us at
@@ -628,12 +628,13 @@ static int32_t lfinito_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const cia
 
 template <typename T>
 static int32_t afinito_init_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha, const void *x0,
-                              void *table, void *meta, void *av, void *z, void *hat_gamma_dev)
+                              void *table, void *meta, void *av, void *z, void *hat_gamma_dev, const void *gam_override)
 {
     RowsArgs<T> a = rows_args<T>(p);
     a.x1 = (const T *)x0;
     a.table = (T *)table;
     a.meta = (T *)meta;
+    a.gam = (const T *)gam_override;   // stepsizes the host resolved by re-probing (entries > 0 are used as they are)
     a.alpha = (T)alpha;
     a.Nd = (double)p->N_total;
     Epilogue<T> e = epi_zero<T>();
@@ -857,8 +858,9 @@ int32_t ciao_ctx_synchronize(ciao_ctx *ctx)
     if (flag) {
         CIAO_HIP(hipMemsetAsync(ctx->errflag, 0, sizeof(int), ctx->stream));
         if (flag == 2) {
-            set_error("adaptive Finito init: grad f_i(x0 .+ 1) == grad f_i(x0) for some i; the reference then probes random "
-                      "points (Finito_adaptive.jl:78-85), which this path does not do");
+            set_error("adaptive Finito init: grad f_i(x0 .+ 1) == grad f_i(x0) for the samples with gamma_i = -1 in meta; the reference "
+                      "now probes random points (Finito_adaptive.jl:78-85): resolve them with ciao_afinito_probe and the host's "
+                      "draws, then repeat ciao_afinito_init with gam_override");
             return CIAO_ERR_UNSUPPORTED;
         }
         set_error("a sample index was outside [0, N): results since the last synchronize are invalid");
@@ -966,6 +968,8 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "svrg_cache_rowdots")) {
         ctx->svrg_cache_rowdots = value != 0;
         ctx->rowdot_A = nullptr;
+    } else if (!strcmp(key, "chain_big")) {
+        ctx->chain_big = value != 0;
     } else if (!strcmp(key, "chain_no_dma")) {
         ctx->chain_no_dma = value != 0;
     } else if (!strcmp(key, "graph_batches")) {
@@ -1336,8 +1340,28 @@ int32_t ciao_lfinito_iterate_blocks(ciao_ctx *ctx, const ciao_problem *p, const 
     return DISPATCH(p->dtype, lfinito_iterate_t, ctx, p, g, gam, hat_gamma, nb, src, av, z, z_full);
 }
 
+int32_t ciao_afinito_probe(ciao_ctx *ctx, const ciao_problem *p, int64_t i, const void *x0, const void *signs, double t,
+                           double *nmg_host)
+{
+    CIAO_ENTER(ctx);
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_REQUIRE(x0 && signs && nmg_host && t > 0, "NULL argument or t <= 0");
+    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO && i >= 0 && i < p->N, "sample index %lld outside [0, %lld) or no data terms", (long long)i,
+                 (long long)p->N);
+    if (p->dtype == CIAO_F64)
+        hipLaunchKernelGGL((afinito_probe_kernel<double>), dim3(1), dim3(WAVE), 0, ctx->stream, (const double *)p->A, (const double *)p->b,
+                           p->ld, p->d, p->loss, (double)p->lam, i, (const double *)x0, (const double *)signs, t, ctx->scal);
+    else
+        hipLaunchKernelGGL((afinito_probe_kernel<float>), dim3(1), dim3(WAVE), 0, ctx->stream, (const float *)p->A, (const float *)p->b,
+                           p->ld, p->d, p->loss, (float)p->lam, i, (const float *)x0, (const float *)signs, (float)t, ctx->scal);
+    CIAO_HIP(hipGetLastError());
+    CIAO_HIP(hipMemcpyAsync(nmg_host, ctx->scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CIAO_HIP(hipStreamSynchronize(ctx->stream));
+    return CIAO_OK;
+}
+
 int32_t ciao_afinito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha, const void *x0,
-                          void *table, void *meta, void *av, void *z, void *hat_gamma_dev)
+                          void *table, void *meta, void *av, void *z, void *hat_gamma_dev, const void *gam_override)
 {
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
@@ -1347,7 +1371,7 @@ int32_t ciao_afinito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
     CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO, "adaptive Finito needs data terms (the Lipschitz probe of Zero() is degenerate)");
     CIAO_REQUIRE(p->N >= 1, "adaptive Finito needs at least one term");
     CIAO_REQUIRE(!ctx->hook, "adaptive Finito is a sequential chain: replicas only, not valid on a row-sharded problem");
-    return DISPATCH(p->dtype, afinito_init_t, ctx, p, g, alpha, x0, table, meta, av, z, hat_gamma_dev);
+    return DISPATCH(p->dtype, afinito_init_t, ctx, p, g, alpha, x0, table, meta, av, z, hat_gamma_dev, gam_override);
 }
 
 int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha, double tol_b,

@@ -381,6 +381,128 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_kernel(ChainArgs<T> a)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Chains on rows of ANY length (d beyond 8192, where the per-thread register state of the kernels above no longer fits):
+// one 1024-thread workgroup, the iterate state stays in the caller's d-vectors (L2-resident: a few hundred KiB), every step
+// is two passes over the row -- dot product(s), then the element-wise update -- with one block-wide reduction in between.
+// The arithmetic is the reference's own operation order (as chain_kernel).  Bandwidth of one CU bounds it: a step moves
+// about 8 d-vectors through one L1 (measured: d = 16384 fp64, 128 KiB rows: a few microseconds per step) -- the point of
+// this kernel is that the sequential solvers exist for every d, not speed.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int CHAIN_BIG_NT = 1024;
+
+template <typename T, int ALG, int LOSS>
+__global__ void __launch_bounds__(CHAIN_BIG_NT) chain_big_kernel(ChainArgs<T> a)
+{
+    constexpr int NW = CHAIN_BIG_NT / WAVE;
+    constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
+    constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
+    __shared__ T red[2][NW][2];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t d = a.d;
+    T *p = (ALG == CA_SVRG) ? a.w : a.z;      // the point the moving gradient is taken at
+    const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
+    auto box = [&](int64_t k, T &lo, T &hi) {
+        lo = -INFINITY;
+        hi = INFINITY;
+        if (a.g.kind == CIAO_PROX_BOX) {
+            lo = a.g.lo_vec ? a.g.lo_vec[k] : a.g.lo;
+            hi = a.g.hi_vec ? a.g.hi_vec[k] : a.g.hi;
+        }
+    };
+    int par = 0;
+    int64_t inb = 0;
+    for (int64_t s = 0; s < a.nsteps; ++s) {
+        int64_t row = a.idx[s];
+        if ((uint64_t)row >= (uint64_t)a.N) {   // memory-safe: flag it, use row 0 (results are void once flagged)
+            if (tid == 0) *a.errflag = 1;
+            row = 0;
+        }
+        const T *ap = a.A + row * a.ld;          // Zero() terms alias a finite d-vector with ld = 0 and lam = 0 (see launch)
+        const T bi = a.b ? a.b[row] : T(0);
+        T *sp = HAS_TABLE ? a.table + row * d : nullptr;
+        if (ALG == CA_LFINITO && inb == 0) {     // Finito_LFinito.jl:92  z = prox(av)
+            for (int64_t k = tid; k < d; k += CHAIN_BIG_NT) {
+                T lo, hi;
+                box(k, lo, hi);
+                p[k] = prox_bf(a.av[k], a.hat_gamma * plam, lo, hi);
+            }
+            __syncthreads();
+        }
+        T d1 = T(0), d2 = T(0);
+        for (int64_t k = tid; k < d; k += CHAIN_BIG_NT) {
+            const T ak = ap[k];
+            d1 += ak * p[k];
+            if (TWO) d2 += ak * a.zf[k];
+        }
+        d1 = wave_allsum(d1);
+        if (TWO) d2 = wave_allsum(d2);
+        if (lane == 0) {
+            red[par][wib][0] = d1;
+            if (TWO) red[par][wib][1] = d2;
+        }
+        __syncthreads();
+        d1 = T(0);
+        d2 = T(0);
+#pragma unroll
+        for (int w = 0; w < NW; w += 4) {        // fixed association order: groups of four
+            d1 += (red[par][w][0] + red[par][w + 1][0]) + (red[par][w + 2][0] + red[par][w + 3][0]);
+            if (TWO) d2 += (red[par][w][1] + red[par][w + 1][1]) + (red[par][w + 2][1] + red[par][w + 3][1]);
+        }
+        par ^= 1;
+        const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
+        const GradCoef<T> gz = grad_coef_t<T, LOSS>(d2, bi, a.lam);
+        const T gi = (ALG == CA_FINITO || ALG == CA_LFINITO) ? (a.gam ? a.gam[row] : a.gam_uniform) : T(1);
+        const bool last_of_batch = (inb + 1 == a.batch) || (s + 1 == a.nsteps);
+        for (int64_t k = tid; k < d; k += CHAIN_BIG_NT) {
+            const T ak = ap[k];
+            T lo, hi;
+            box(k, lo, hi);
+            if (ALG == CA_SVRG) {                                            // SVRG_basic.jl:74-81
+                T t = gz.elem(ak) - gp.elem(ak);
+                t -= a.av[k];
+                t *= a.gamma;
+                t += p[k];
+                const T wn = prox_bf(t, a.gamma * plam, lo, hi);
+                p[k] = wn;
+                a.z[k] += wn;
+            } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
+                const T gn = gp.elem(ak);
+                const T sk = sp[k];
+                const T del = (gn - sk) * a.invN;
+                T avk = a.av[k], wv;
+                if (a.sag) {
+                    avk += del;
+                    wv = p[k] - a.gamma * avk;
+                } else {
+                    wv = p[k] - a.gamma * (gn - sk + avk);
+                    avk += del;
+                }
+                a.av[k] = avk;
+                p[k] = prox_bf(wv, a.gamma * plam, lo, hi);
+                sp[k] = gn;
+            } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
+                const T t = p[k] - (gi * a.invN) * gp.elem(ak);
+                const T avk = a.av[k] + (t - sp[k]) * (a.hat_gamma / gi);
+                a.av[k] = avk;
+                sp[k] = t;
+                if (last_of_batch) p[k] = prox_bf(avk, a.hat_gamma * plam, lo, hi);
+            } else {                                                         // Finito_LFinito.jl:93-98
+                const T c = a.hat_gamma * a.invN;
+                T avk = a.av[k];
+                avk += c * gz.elem(ak);
+                avk -= c * gp.elem(ak);
+                avk += (a.hat_gamma / gi) * (p[k] - a.zf[k]);
+                a.av[k] = avk;
+            }
+        }
+        if (++inb == a.batch) inb = 0;
+        __syncthreads();   // the next step's dot products read what this step wrote (same workgroup: one CU, one L1)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Fast chain: LDS-DMA row ring.
 //
 // The register-ring kernel above leaves the waits to hipcc, which drains the whole vector-memory queue once per ring
@@ -1412,6 +1534,31 @@ __global__ void __launch_bounds__(WAVE)
 }
 
 // elementwise prox!(y, g, x, gamma)  and the two small vector helpers the epoch tails need
+// One retry of adaptive Finito's Lipschitz probe for sample i (Finito_adaptive.jl:80-82): the probe point is x0 + t*signs
+// (signs = the host's +-1 draws), both gradients are multiples of a_i, so
+//   nmg = || grad f_i(x0 + t signs) - grad f_i(x0) || = | c(a_i'x0 + t a_i'signs) - c(a_i'x0) | * ||a_i||       (in R; one wave)
+template <typename T>
+__global__ void __launch_bounds__(WAVE)
+    afinito_probe_kernel(const T *A, const T *b, int64_t ld, int64_t d, int loss, T lam, int64_t i, const T *x0, const T *signs, T t, double *out)
+{
+    const int lane = threadIdx.x;
+    const T *ap = A + i * ld;
+    T d0 = T(0), ds = T(0), n2 = T(0);
+    for (int64_t k = lane; k < d; k += WAVE) {
+        const T ak = ap[k];
+        d0 += ak * x0[k];
+        ds += ak * signs[k];
+        n2 += ak * ak;
+    }
+    d0 = wave_allsum(d0);
+    ds = wave_allsum(ds);
+    n2 = wave_allsum(n2);
+    const T bi = b[i];
+    const T c0 = grad_coef(loss, d0, bi, lam).coef();
+    const T c1 = grad_coef(loss, d0 + t * ds, bi, lam).coef();
+    if (lane == 0) *out = (double)(fabs2(c1 - c0) * fsqrt(n2));
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) prox_kernel(int64_t d, ProxD<T> g, const T *x, T gamma, T scale, T *y)
 {

@@ -235,13 +235,20 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
             const T c0 = g1.coef();
             const T c1 = grad_coef(a.loss, d1 + sa, bi, a.lam).coef();
             T nmg = fabs2(c1 - c0) * fsqrt(n2);
-            if (nmg < Eps<T>::value) {   // the reference retries at random probe points here (:78-85): not on this path
+            // a.gam, when given, holds stepsizes resolved by the host (> 0: use it) -- the second pass after a re-probe
+            const T gov = a.gam ? a.gam[row] : T(0);
+            bool degenerate = false;
+            if (!(gov > T(0)) && nmg < Eps<T>::value) {
+                // grad f_i(x0 .+ 1) == grad f_i(x0) (a row whose entries sum to zero): the reference now probes at random points
+                // x0 .+ rand(t*[-1,1]) from its RNG (:78-85).  Random draws are a host input on this path: flag the row (gamma_i =
+                // -1 in meta, status 2), carry on with a finite placeholder, and let the host resolve it (ciao_afinito_probe)
                 if (lane == 0) *a.errflag = 2;
                 nmg = Eps<T>::value;
+                degenerate = true;
             }
             // L_int = zeros(N) is a Float64 array whatever R (:73): L = nmg / (t sqrt(d)) / N and alpha / L are Float64,
             // gamma_i is that quotient rounded to R (:86-88)
-            const T gi = (T)((double)a.alpha / (((double)nmg / sqrt((double)a.d)) / a.Nd));
+            const T gi = gov > T(0) ? gov : (T)((double)a.alpha / (((double)nmg / sqrt((double)a.d)) / a.Nd));
             const T rinv = T(1) / gi;
             const T cn = c0 * a.invN;
             V *sp = reinterpret_cast<V *>(tp);
@@ -257,7 +264,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
                 T *mp = a.meta + (row * 4 + lane) * 4;
                 mp[0] = c0;
                 mp[1] = loss_value(a.loss, d1, bi, a.lam);
-                mp[2] = gi;
+                mp[2] = degenerate ? T(-1) : gi;
                 mp[3] = d1;
             }
         } else {  // FINITO_INIT / FINITO_BATCH
@@ -847,28 +854,41 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_multi_kernel(RowsArgs<T> a)
 // hit).  Correctness path for small / odd shapes (e.g. the reference's own N=6,d=3 and N=8,d=5 tests).
 // Dynamic LDS layout: x1[d] | x2[d] (if TWO) | acc[NW][d]
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int NW, int MODE>
+// GLOBAL_ACC (rows too long for LDS: beyond ~72 KiB with one iterate, e.g. d = 16384 fp64): the iterate(s) are read from
+// global memory (cache-resident) and every WAVE accumulates into a partial d-vector of its own in the workspace -- one
+// partial per wave instead of one per block, nothing staged in LDS.  Each element of a wave's partial is only ever touched by
+// the lane that owns it (k = lane mod 64), so plain program order is all the ordering it needs.
+template <typename T, int NW, int MODE, bool GLOBAL_ACC = false>
 __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
 {
     constexpr bool TWO = (MODE == RM_GRAD2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
     const int64_t d = a.d;
-    T *x1s = smem;
-    T *x2s = smem + d;
-    T *accs = smem + (TWO ? 2 : 1) * d;
-
     const int lane = threadIdx.x & (WAVE - 1);
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t nwaves = (int64_t)gridDim.x * NW;
-    T *acc = accs + (int64_t)wib * d;
-
-    for (int64_t e = threadIdx.x; e < d; e += NW * WAVE) {
-        x1s[e] = a.x1[e];
-        if (TWO) x2s[e] = a.x2[e];
+    const T *x1s, *x2s;
+    T *acc;
+    if constexpr (GLOBAL_ACC) {
+        x1s = a.x1;
+        x2s = a.x2;
+        acc = a.partial + ((int64_t)blockIdx.x * NW + wib) * a.pstride;
+        for (int64_t e = lane; e < d; e += WAVE) acc[e] = T(0);
+    } else {
+        T *x1w = smem;
+        T *x2w = smem + d;
+        T *accs = smem + (TWO ? 2 : 1) * d;
+        acc = accs + (int64_t)wib * d;
+        for (int64_t e = threadIdx.x; e < d; e += NW * WAVE) {
+            x1w[e] = a.x1[e];
+            if (TWO) x2w[e] = a.x2[e];
+        }
+        for (int64_t e = threadIdx.x; e < (int64_t)NW * d; e += NW * WAVE) accs[e] = T(0);
+        __syncthreads();
+        x1s = x1w;
+        x2s = x2w;
     }
-    for (int64_t e = threadIdx.x; e < (int64_t)NW * d; e += NW * WAVE) accs[e] = T(0);
-    __syncthreads();
 
     T extra = T(0);
     for (int64_t q = (int64_t)blockIdx.x * NW + wib; q < a.nrows; q += nwaves) {
@@ -918,11 +938,14 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
             const T c0 = g1.coef();
             const T c1 = grad_coef(a.loss, d1 + sa, bi, a.lam).coef();
             T nmg = fabs2(c1 - c0) * fsqrt(n2);
-            if (nmg < Eps<T>::value) {
+            const T gov = a.gam ? a.gam[row] : T(0);   // host-resolved stepsize (second pass after a re-probe), see the fast kernel
+            bool degenerate = false;
+            if (!(gov > T(0)) && nmg < Eps<T>::value) {
                 if (lane == 0) *a.errflag = 2;
                 nmg = Eps<T>::value;
+                degenerate = true;
             }
-            const T gi = (T)((double)a.alpha / (((double)nmg / sqrt((double)d)) / a.Nd));   // Float64 as in the reference (:73, :86-88)
+            const T gi = gov > T(0) ? gov : (T)((double)a.alpha / (((double)nmg / sqrt((double)d)) / a.Nd));   // Float64 as in the reference (:73, :86-88)
             const T rinv = T(1) / gi;
             const T cn = c0 * a.invN;
             for (int64_t e = lane; e < d; e += WAVE) {
@@ -935,7 +958,7 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
                 T *mp = a.meta + (row * 4 + lane) * 4;
                 mp[0] = c0;
                 mp[1] = loss_value(a.loss, d1, bi, a.lam);
-                mp[2] = gi;
+                mp[2] = degenerate ? T(-1) : gi;
                 mp[3] = d1;
             }
         } else {
@@ -953,19 +976,24 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
         }
     }
 
-    __shared__ T red_extra[NW];
-    if (lane == 0) red_extra[wib] = extra;   // extra is wave-uniform
-    __syncthreads();
-    T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
-    for (int64_t e = threadIdx.x; e < d; e += NW * WAVE) {
-        T s = accs[e];
-        for (int w = 1; w < NW; ++w) s += accs[(int64_t)w * d + e];
-        pout[e] = s;
-    }
-    if (threadIdx.x == 0) {
-        T ex = T(0);
-        for (int w = 0; w < NW; ++w) ex += red_extra[w];
-        a.pextra[blockIdx.x] = ex;
+    if constexpr (GLOBAL_ACC) {
+        if (lane == 0) a.pextra[(int64_t)blockIdx.x * NW + wib] = extra;   // one partial (and one extra) per wave
+    } else {
+        __shared__ T red_extra[NW];
+        T *accs = smem + (TWO ? 2 : 1) * d;
+        if (lane == 0) red_extra[wib] = extra;   // extra is wave-uniform
+        __syncthreads();
+        T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
+        for (int64_t e = threadIdx.x; e < d; e += NW * WAVE) {
+            T s = accs[e];
+            for (int w = 1; w < NW; ++w) s += accs[(int64_t)w * d + e];
+            pout[e] = s;
+        }
+        if (threadIdx.x == 0) {
+            T ex = T(0);
+            for (int w = 0; w < NW; ++w) ex += red_extra[w];
+            a.pextra[blockIdx.x] = ex;
+        }
     }
 }
 

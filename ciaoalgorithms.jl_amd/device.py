@@ -393,10 +393,18 @@ class Context:
         return bidx
 
     # -- adaptive Finito -------------------------------------------------------------------------------------------------
-    def afinito_init(self, p, g, alpha, x0, table, meta, av, z, hat_gamma_dev):
+    def afinito_init(self, p, g, alpha, x0, table, meta, av, z, hat_gamma_dev, gam_override=None):
         L.check(self.lib.ciao_afinito_init(self._h, p.ref, g.ref, float(alpha), self._vec(x0, p, "x0"),
                                            self._vec(table, p, "table", p.N * p.d), self._vec(meta, p, "meta", p.N * 16),
-                                           self._vec(av, p, "av"), self._vec(z, p, "z"), self._vec(hat_gamma_dev, p, "hat_gamma", 1)))
+                                           self._vec(av, p, "av"), self._vec(z, p, "z"), self._vec(hat_gamma_dev, p, "hat_gamma", 1),
+                                           None if gam_override is None else self._vec(gam_override, p, "gam_override", p.N)))
+
+    def afinito_probe(self, p, i: int, x0, signs, t: float) -> float:
+        """One retry of the Lipschitz probe for sample i at x0 + t*signs (Finito_adaptive.jl:80-82); synchronises."""
+        out = C.c_double(0.0)
+        L.check(self.lib.ciao_afinito_probe(self._h, p.ref, int(i), self._vec(x0, p, "x0"), self._vec(signs, p, "signs"), float(t),
+                                            C.byref(out)))
+        return out.value
 
     def afinito_steps(self, p, g, alpha, tol_b, idx, table, meta, av, z, hat_gamma_dev) -> tuple[int, int]:
         """-> (steps completed, backtracking trials); synchronises."""

@@ -583,10 +583,33 @@ function Base.iterate(iter::FINITO_adaptive_iterable{R}) where {R}      # Finito
     meta = ROCArray{R}(undef, 4, 4, N)
     hg = ROCArray{R}(undef, 1)
     av, z = similar(x0d), similar(x0d)
-    check(ccall((:ciao_afinito_init, libciao), Int32,
-                (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-                context().h, Ref(cproblem(iter.F)), Ref(iter.g), Float64(iter.α), dptr(x0d), dptr(s), dptr(meta), dptr(av), dptr(z), dptr(hg)))
-    synchronize(context())           # a degenerate Lipschitz probe (reference :78-85 re-draws) surfaces here as an error
+    afinit(over) = check(ccall((:ciao_afinito_init, libciao), Int32,
+                (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                context().h, Ref(cproblem(iter.F)), Ref(iter.g), Float64(iter.α), dptr(x0d), dptr(s), dptr(meta), dptr(av), dptr(z), dptr(hg), dptr(over)))
+    afinit(nothing)
+    try
+        synchronize(context())
+    catch e
+        (e isa CiaoError && e.status == -3) || rethrow()
+        # Finito_adaptive.jl:78-85: samples whose probe at x0 .+ 1 saw no gradient change (gamma_i = -1 in meta) are re-probed at
+        # random points with the reference's own RNG calls, in increasing i; then the init pass is repeated with every gamma known
+        γh = Array(meta)[3, 1, :]
+        for i in findall(<(0), γh)
+            t = 1; nmg = Ref{Float64}(0.0)
+            while true
+                println("initial upper bound for L too small")
+                signs = ROCArray(R.(rand(t * [-1, 1], length(x0d)) ./ t))
+                check(ccall((:ciao_afinito_probe, libciao), Int32, (Ptr{Cvoid}, Ref{CiaoProblem}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ref{Float64}),
+                            context().h, Ref(cproblem(iter.F)), i - 1, dptr(x0d), dptr(signs), Float64(t), nmg))
+                t *= 2
+                R(nmg[]) < eps(R) || break
+            end
+            L_int = R(nmg[]) / (t * sqrt(length(x0d))); L_int /= N
+            γh[i] = iter.α / L_int
+        end
+        afinit(ROCArray(R.(γh)))
+        synchronize(context())
+    end
     state = FINITO_adaptive_state{R}(s, meta, hg, av, z, collect(1:N), 0, 0)
     return state, state
 end

@@ -46,6 +46,10 @@ class IndexStream:
         u = self._take(m) >> np.uint64(32)
         return ((u * np.uint64(N)) >> np.uint64(32)).astype(np.int64)
 
+    def rand_signs(self, n: int) -> np.ndarray:
+        """n i.i.d. uniform draws from {-1, +1} as int8 (the reference's rand([-1, 1], size(x0)), Finito_adaptive.jl:80)."""
+        return ((self._take(n) >> np.uint64(63)).astype(np.int8) * 2 - 1).astype(np.int8)
+
     def randperm(self, n: int) -> np.ndarray:
         """Uniform random permutation of 0..n-1 (argsort of n stream outputs; ties have probability ~n^2/2^64)."""
         return np.argsort(self._take(n), kind="stable").astype(np.int64)
@@ -113,6 +117,9 @@ class FixedStream:
         self._ipos += m
         assert out.size == 0 or (out.min() >= 0 and out.max() < N)
         return out.copy()
+
+    def rand_signs(self, n):
+        raise IndexError("FixedStream holds no sign draws")
 
     def randperm(self, n):
         p = self._perms.pop(0)

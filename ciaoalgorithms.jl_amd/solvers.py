@@ -36,6 +36,7 @@ import warnings
 import numpy as np
 import torch
 
+from ._lib import ERR_UNSUPPORTED, CiaoError
 from .device import Context, PackedF, default_context, torch_dtype
 from .operators import pack_F, pack_g, pack_sharing_F
 from .sampling import IndexStream
@@ -476,7 +477,32 @@ class FINITO_adaptive_iterable(_Iterable):
         hg = torch.empty(1, dtype=self.R, device=dev)
         av, z = self._new(), self._new()
         self.ctx.afinito_init(self.F, self.g, self.α, self._x0_dev, s, meta, av, z, hg)
-        self.ctx.synchronize()   # surfaces the degenerate-probe case (reference :78-85) as an error
+        try:
+            self.ctx.synchronize()
+        except CiaoError as e:
+            if e.status != ERR_UNSUPPORTED:
+                raise
+            # Finito_adaptive.jl:78-85: for samples whose probe gradient at x0 .+ 1 equals the one at x0 the reference draws
+            # random probe points x0 .+ rand(t*[-1,1]), t = 1, 2, 4, ...  The draws come from the injected stream, sample by
+            # sample in increasing i (the order in which the reference's loop meets them); then the init pass is repeated
+            # with every stepsize known.
+            np_R = np.float64 if self.R == torch.float64 else np.float32
+            gam = meta[:, 0, 2].clone()
+            eps = float(np.finfo(np_R).eps)
+            for i in torch.nonzero(gam < 0).flatten().tolist():
+                t = 1
+                while True:
+                    print("initial upper bound for L too small")                                   # :79
+                    signs = torch.from_numpy(self.stream.rand_signs(self.d).astype(np_R)).to(dev)   # :80
+                    nmg = self.ctx.afinito_probe(self.F, i, self._x0_dev, signs, float(t))          # :81-82
+                    t *= 2                                                                          # :83
+                    if not nmg < eps:
+                        break
+                L_int = np.float64(np_R(nmg)) / (np.float64(t) * np.sqrt(np.float64(self.d)))      # :86 (Float64 whatever R, :73)
+                L_int /= np.float64(self.N)                                                         # :87
+                gam[i] = float(np_R(np.float64(np_R(self.α)) / L_int))                              # :88
+            self.ctx.afinito_init(self.F, self.g, self.α, self._x0_dev, s, meta, av, z, hg, gam_override=gam.contiguous())
+            self.ctx.synchronize()
         st = FINITO_adaptive_state(s, meta, hg, av, z, self.N)
         st._it = self
         return st

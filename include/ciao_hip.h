@@ -280,13 +280,24 @@ CIAO_API int32_t ciao_lfinito_iterate_blocks(ciao_ctx *ctx, const ciao_problem *
  * x_i; `hat_gamma_dev` is a DEVICE scalar of R (it changes during backtracking).
  * Base.iterate(iter), :59-98: x_i = x0; gamma_i = alpha / L_i with L_i = ||grad f_i(x0 .+ 1) - grad f_i(x0)|| / (sqrt(d) N);
  * hat_gamma = 1/sum 1/gamma_i; av = hat_gamma (sum x_i/gamma_i - sum grad f_i / N); z = prox_{hat_gamma g}(av).
- * (The reference's random re-probe when the two gradients coincide, :78-85, is reported as CIAO_ERR_UNSUPPORTED by the
- * next ciao_ctx_synchronize.) */
+ * The reference's random re-probe (:78-85: when grad f_i(x0 .+ 1) == grad f_i(x0), i.e. for a row whose entries sum to zero,
+ * it probes at x0 .+ rand(t*[-1,1]) with t = 1, 2, 4, ...) needs RNG draws, which are a HOST input on this path: such
+ * samples get gamma_i = -1 in meta and the next ciao_ctx_synchronize returns CIAO_ERR_UNSUPPORTED.  The host then resolves
+ * them in increasing i with ciao_afinito_probe and its own +-1 draws (gamma_i = alpha / (nmg / (t sqrt(d)) / N) with the t
+ * AFTER its doubling, as the reference has it, :82-88) and repeats this call with `gam_override`: a device N-vector of R
+ * whose entries > 0 are taken as gamma_i (the others are computed as before); NULL = none. */
 CIAO_API int32_t ciao_afinito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha,
-                                   const void *x0, void *table, void *meta, void *av, void *z, void *hat_gamma_dev);
-/* nsteps consecutive Base.iterate(iter,state), :118-150, for the samples idx[0..nsteps) (the selection :104-116 is host
+                                   const void *x0, void *table, void *meta, void *av, void *z, void *hat_gamma_dev,
+                                   const void *gam_override);
+/* One retry of that probe for sample i: *nmg_host = || grad f_i(x0 + t*signs) - grad f_i(x0) || (signs: device d-vector of
+ * +-1 in R).  Synchronises. */
+CIAO_API int32_t ciao_afinito_probe(ciao_ctx *ctx, const ciao_problem *p, int64_t i, const void *x0, const void *signs, double t,
+                                    double *nmg_host);
+/* nsteps consecutive Base.iterate(iter,state), :120-152, for the samples idx[0..nsteps) (the selection :105-118 is host
  * logic).  Synchronises; *done_host = steps completed (< nsteps iff a stepsize fell below tol_b/N: the reference then
- * warns and ends the iteration, :121-124), *trials_host = backtracking trials taken. */
+ * warns and ends the iteration, :123-126), *trials_host = backtracking trials taken.  Julia's promotions are kept for
+ * R = Float32: the model value `0.5 * iter.N * iter.α / γ ...` and the comparison are Float64, `γ *= 0.8` is a Float64
+ * product rounded back (:128-136). */
 CIAO_API int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha,
                                     double tol_b, int64_t nsteps, const int64_t *idx, void *table, void *meta, void *av,
                                     void *z, void *hat_gamma_dev, int64_t *done_host, int64_t *trials_host);

@@ -873,6 +873,110 @@ def test_row_blocks_are_validated_on_the_host(ctx, ciao):
             ctx.finito_steps_blocks(dp, dg, gam, 0.01, first, length, table, av, z)
 
 
+@pytest.mark.parametrize("dtype,d", [(np.float64, 16384), (np.float64, 10001), (np.float32, 40000), (np.float32, 20001)])
+def test_rows_longer_than_lds(ctx, ciao, dtype, d):
+    """Rows beyond what one iterate plus one accumulator fit in LDS (72 KiB: d > 9216 fp64, > 18432 fp32) used to be outside
+    every rows kernel.  rows_generic_kernel<..., global_acc> keeps the iterate in global memory and one partial per WAVE in
+    the workspace: sweep, SAGA / Finito init, a Finito batch and an LFinito iteration against the oracle."""
+    import torch
+    from oracle import oracle as O
+    N = 24
+    A, b, x0 = P.synthetic("ls", N, d, dtype, seed=d)
+    op, dp = make("ls", A, b, float(N), dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.01)
+    tdt = dev(x0).dtype
+    av, z, zf = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(3))
+    ctx.full_gradient(dp, dev(x0), av)
+    assert "global_acc" in ctx.last_kernel() or "rows_split" in ctx.last_kernel()
+    close(av, O.full_pass(op, x0), dtype, scale=200, what=f"sweep d={d} ({ctx.last_kernel()})")
+    table = torch.empty((N, d), dtype=tdt, device="cuda")
+    ctx.saga_init(dp, dg, 0.1, dev(x0), table, av, z)
+    rt, rav, rz = O.saga_init(op, og, dtype(0.1), x0)
+    close(table, rt, dtype, scale=200, what="saga_init table (long rows)")
+    close(av, rav, dtype, scale=200, what="saga_init av (long rows)")
+    gam = torch.full((N,), 0.4, dtype=tdt, device="cuda")
+    hg = ctx.hat_gamma(gam)
+    ctx.finito_init(dp, dg, gam, hg, dev(x0), table, av, z)
+    rt, rav, rz, rhg = O.finito_init(op, og, gam.cpu().numpy(), x0)
+    close(av, rav, dtype, scale=200, what="finito_init av (long rows)")
+    batch = np.arange(3, 20, dtype=np.int64)
+    ctx.set_option("chain_max_batch", 0)
+    try:
+        ctx.finito_steps(dp, dg, gam, hg, np.array([0, batch.size], np.int64), batch, table, av, z)
+        O.finito_steps(op, og, gam.cpu().numpy(), rhg, [batch], rt, rav, rz)
+        close(z, rz, dtype, scale=500, what=f"finito batch z (long rows, {ctx.last_kernel()})")
+        close(table, rt, dtype, scale=500, what="finito batch table (long rows)")
+        ctx.lfinito_init(dp, hg, dev(x0), av, z, zf)
+        ctx.lfinito_iterate(dp, dg, gam, hg, np.array([0, 12, N], np.int64), np.arange(N, dtype=np.int64), av, z, zf)
+        rav, rz, rzf, rhg = O.lfinito_init(op, gam.cpu().numpy(), x0)
+        O.lfinito_iterate(op, og, gam.cpu().numpy(), rhg, [np.arange(12), np.arange(12, N)], rav, rz, rzf)
+        close(av, rav, dtype, scale=1000, what="lfinito av (long rows)")
+        close(z, rz, dtype, scale=1000, what="lfinito z (long rows)")
+    finally:
+        ctx.set_option("chain_max_batch", -1)
+    ctx.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d,forced", [(300, True), (1024, True), (9000, False), (16384, False), (8193, False)])
+def test_chains_on_rows_of_any_length(ctx, ciao, dtype, d, forced):
+    """Beyond 8192 elements the per-thread register state of the chain kernels no longer fits: chain_big_kernel keeps the
+    iterate state in the caller's vectors (VERDICT r1 "missing" item 5: these shapes used to return CIAO_ERR_UNSUPPORTED).
+    SVRG inner cycle, SAGA / SAG steps, Finito batches of 2 and the LFinito sweep against the oracle; at small d the kernel is
+    forced (option chain_big) and must agree with the register kernels' answers to the same tolerance."""
+    import torch
+    from oracle import oracle as O
+    N = 40
+    A, b, x0 = P.synthetic("logistic" if d % 2 else "ls", N, d, dtype, seed=d)
+    loss = "logistic" if d % 2 else "ls"
+    op, dp = make(loss, A, b, 1.0 if loss == "logistic" else float(N), dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.01)
+    tdt = dev(x0).dtype
+    gamma = 0.3 if loss == "logistic" else 1.0 / (7 * N * float(np.max(np.sum(A.astype(np.float64) ** 2, axis=1))))
+    idx = ciao.IndexStream(d).rand_indices(N, 150)
+    idx[4:7] = idx[4]
+    ctx.set_option("chain_big", 1 if forced else 0)
+    try:
+        av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+        ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+        ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
+        assert "chain_big_kernel" in ctx.last_kernel()
+        rav, rz, rzf, rw = O.svrg_init(op, x0)
+        O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
+        close(w, rw, dtype, scale=2000, what="svrg_inner w (any-d chain)")
+        close(z, rz, dtype, scale=2000, what="svrg_inner z (any-d chain)")
+        for sag in (False, True):
+            table = torch.empty((N, d), dtype=tdt, device="cuda")
+            sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+            ctx.saga_init(dp, dg, gamma, dev(x0), table, sav, sz)
+            ctx.saga_steps(dp, dg, gamma, sag, idx, table, sav, sz)
+            assert "chain_big_kernel" in ctx.last_kernel()
+            rt, rsav, rsz = O.saga_init(op, og, dtype(gamma), x0)
+            O.saga_steps(op, og, dtype(gamma), sag, idx, rt, rsav, rsz)
+            close(sz, rsz, dtype, scale=2000, what=f"saga z sag={sag} (any-d chain)")
+            close(table, rt, dtype, scale=2000, what="saga table (any-d chain)")
+        gam = torch.full((N,), 0.4, dtype=tdt, device="cuda")
+        hg = ctx.hat_gamma(gam)
+        table = torch.empty((N, d), dtype=tdt, device="cuda")
+        ctx.finito_init(dp, dg, gam, hg, dev(x0), table, av, z)
+        batches = [np.array([2 * k, 2 * k + 1], dtype=np.int64) for k in range(N // 2)]
+        ctx.finito_steps(dp, dg, gam, hg, np.arange(0, N + 1, 2, dtype=np.int64), np.concatenate(batches), table, av, z)
+        assert "chain_big_kernel" in ctx.last_kernel()
+        rt, rav, rz, rhg = O.finito_init(op, og, gam.cpu().numpy(), x0)
+        O.finito_steps(op, og, gam.cpu().numpy(), rhg, batches, rt, rav, rz)
+        close(z, rz, dtype, scale=5000, what="finito z (any-d chain)")
+        close(table, rt, dtype, scale=5000, what="finito table (any-d chain)")
+        ctx.lfinito_init(dp, hg, dev(x0), av, z, zf)
+        ctx.lfinito_iterate(dp, dg, gam, hg, np.arange(0, N + 1, 2, dtype=np.int64), np.concatenate(batches), av, z, zf)
+        rav, rz, rzf, rhg = O.lfinito_init(op, gam.cpu().numpy(), x0)
+        O.lfinito_iterate(op, og, gam.cpu().numpy(), rhg, batches, rav, rz, rzf)
+        close(z, rz, dtype, scale=5000, what="lfinito z (any-d chain)")
+        close(av, rav, dtype, scale=5000, what="lfinito av (any-d chain)")
+        ctx.synchronize()
+    finally:
+        ctx.set_option("chain_big", 0)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # adaptive Finito (SURVEY.md section 8f rank 2)
 # ----------------------------------------------------------------------------------------------------------------------
@@ -1127,19 +1231,13 @@ def test_row_length_boundaries(ctx, ciao, dtype, d):
     import torch
     from oracle import oracle as O
     from ciaoalgorithms_jl_amd._lib import CiaoError
-    rowb = d * np.dtype(dtype).itemsize
-    covered = (rowb % 16 == 0 and rowb <= 65536) or (256 <= d <= 4096) or 2 * rowb <= 144 * 1024
     N = 23
     A, b, x0 = P.synthetic("ls", N, d, dtype, seed=d)
     op, dp = make("ls", A, b, float(N), dtype)
     og, dg = make_g("l1", dtype, d, lam=0.02)
     tdt = dev(x0).dtype
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
-    if not covered:   # rows beyond every kernel's coverage are refused with a message, not mis-computed
-        with pytest.raises(CiaoError, match="outside the kernels' coverage"):
-            ctx.full_gradient(dp, dev(x0), av)
-        return
-    ctx.full_gradient(dp, dev(x0), av)
+    ctx.full_gradient(dp, dev(x0), av)   # every row length has a kernel (beyond LDS: the generic kernel with global accumulators)
     k_sweep = ctx.last_kernel()
     close(av, O.full_pass(op, x0), dtype, scale=100, what=f"sweep d={d} ({k_sweep})")
     table = torch.empty((N, d), dtype=tdt, device="cuda")
@@ -1171,7 +1269,7 @@ def test_row_length_boundaries(ctx, ciao, dtype, d):
 @pytest.mark.parametrize("d", [255, 257, 511, 513, 1023, 1025, 2047, 2049, 3071, 4095, 4096, 4097, 6000, 8192, 8193])
 def test_chain_row_length_boundaries(ctx, ciao, dtype, d):
     """SVRG inner cycle and SAGA steps on row lengths around the chain kernels' thresholds (LDS-DMA exact / masked, register
-    ring E = 1 / 4 / 8 / 16 / 32, and the refusal beyond 8192 elements)."""
+    ring E = 1 / 4 / 8 / 16 / 32, and beyond 8192 elements the any-length kernel chain_big_kernel)."""
     import torch
     from oracle import oracle as O
     from ciaoalgorithms_jl_amd._lib import CiaoError
@@ -1185,11 +1283,8 @@ def test_chain_row_length_boundaries(ctx, ciao, dtype, d):
     rav, rz, rzf, rw = O.svrg_init(op, x0)
     idx = ciao.IndexStream(d).rand_indices(N, 60)
     gamma = 0.05 / N
-    if d > 8192:
-        with pytest.raises(CiaoError, match="sequential chain kernels cover"):
-            ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
-        return
     ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
+    assert ("chain_big_kernel" in ctx.last_kernel()) == (d > 8192)
     O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
     close(w, rw, dtype, scale=500, what=f"svrg_inner w d={d} ({ctx.last_kernel()})")
     table = torch.empty((N, d), dtype=tdt, device="cuda")
@@ -1305,3 +1400,53 @@ def test_random_shapes(ctx, ciao, case):
     close(table, rt, dtype, scale=100, what=f"finito batch table ({ctx.last_kernel()})")
     close(z, rz, dtype, scale=100, what="finito batch z")
     ctx.synchronize()
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d", [1024, 50])
+def test_adaptive_finito_random_reprobe(ctx, ciao, dtype, d):
+    """Finito_adaptive.jl:78-85: when grad f_i(x0 .+ 1) == grad f_i(x0) (here: rows whose entries sum to exactly zero, probed at
+    x0 = 0) the reference probes random points x0 .+ rand(t*[-1,1]), t = 1, 2, 4, ...  The draws are an input on this path
+    (IndexStream.rand_signs): the device init flags those samples, the host mirror re-probes them in increasing i
+    (ciao_afinito_probe) and repeats the init pass with the resolved stepsizes.  Oracle: the same branch with the same draws
+    (roughly every second draw leaves a'signs = 0 again, so t doubles: the quirk of using t AFTER its doubling is covered)."""
+    import torch
+    from oracle import oracle as O
+    from ciaoalgorithms_jl_amd import solvers as S
+    N = 30
+    A, b, _ = P.synthetic("ls", N, d, dtype, seed=77)
+    for i in (3, 7, 8, 29):                    # rows with entries +v, -v and zeros: the sum is exactly 0 in any order
+        A[i] = 0
+        A[i, 5], A[i, 6] = dtype(0.7), dtype(-0.7)
+    x0 = np.zeros(d, dtype)
+    op, dp = make("ls", A, b, float(N), dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.02)
+    seed = 123
+    draws = ciao.IndexStream(seed)
+    signs = np.stack([draws.rand_signs(d).astype(dtype) for _ in range(64)])
+    with pytest.raises(RuntimeError):          # the oracle without draws refuses, as the device does without a host
+        O.afinito_init(op, og, dtype(0.999), x0)
+    rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(0.999), x0, retry_signs=signs)
+    it = S.iterator(S.Finito(dtype, adaptive=True), dev(x0), F=dp, g=dg, N=N, ctx=ctx, stream=ciao.IndexStream(seed))
+    st = next(iter(it))
+    close(st.γ, rgam, dtype, scale=200, what="gamma_i after the random re-probe")
+    close(st.av, rav, dtype, scale=200, what="av after the random re-probe")
+    close(st.z, rz, dtype, scale=200, what="z after the random re-probe")
+    assert abs(st.hat_γ - float(rhg)) <= 200 * float(np.finfo(dtype).eps) * float(rhg)
+    assert float(st.γ.min()) > 0
+    # the low-level contract: without a host the flagged samples carry gamma_i = -1 and the status is CIAO_ERR_UNSUPPORTED
+    table = torch.empty((N, d), dtype=dev(x0).dtype, device="cuda")
+    meta4 = torch.empty((N, 4, 4), dtype=dev(x0).dtype, device="cuda")
+    hg = torch.empty(1, dtype=dev(x0).dtype, device="cuda")
+    av, z = torch.empty(d, dtype=dev(x0).dtype, device="cuda"), torch.empty(d, dtype=dev(x0).dtype, device="cuda")
+    ctx.afinito_init(dp, dg, 0.999, dev(x0), table, meta4, av, z, hg)
+    with pytest.raises(ciao._lib.CiaoError) as e:
+        ctx.synchronize()
+    assert e.value.status == ciao._lib.ERR_UNSUPPORTED
+    assert sorted(torch.nonzero(meta4[:, 0, 2] < 0).flatten().tolist()) == [3, 7, 8, 29]
+    # and the steps run on from the resolved state exactly as the oracle's
+    idx = ciao.IndexStream(5).rand_indices(N, 60)
+    done, trials = ctx.afinito_steps(dp, dg, 0.999, 1e-9, idx, st.s, st.meta, st.av, st.z, st.hat_γ_dev)
+    rdone, rhg2, rtrials = O.afinito_steps(op, og, dtype(0.999), dtype(1e-9), idx, rt, rg, rgam, rfi, rhg, rav, rz)
+    assert done == rdone == 60
+    if trials == rtrials:
+        close(st.z, rz, dtype, scale=5000, what="z after 60 steps from the re-probed init")
