@@ -154,8 +154,55 @@ def pack_F(F, N: int, d: int, R, device=None) -> PackedF:
         y = np.concatenate([f.f.y for f in F], axis=0)
         return PackedF.logistic(_dev(A, dtype, device), _dev(y, dtype, device))
     kinds = sorted({type(f).__name__ for f in F})
-    raise TypeError(f"F of kinds {kinds} is not a family the device path can pack (LeastSquares rows, "
-                    f"Precompose(LogisticLoss) rows, Zero); there is no host fallback")
+    raise TypeError(f"F of kinds {kinds} is not a family the device path can pack (LeastSquares rows, Precompose(LogisticLoss) "
+                    f"rows, Zero).  An opaque operator object cannot be called per sample from a GPU kernel, and this path has no "
+                    f"host fallback on purpose (a silent CPU route would make every parity and performance statement about it void): "
+                    f"give F as one of those families, or as a device matrix via PackedF / pack_rows_from_host")
+
+
+def pack_rows_from_host(chunks, N: int, d: int, R, loss: str = "ls", lam: float = 1.0, device=None, N_total=None, row0: int = 0) -> PackedF:
+    """The step BEFORE the path at scale: at N = 10^7 nobody builds N one-row operator objects
+    (test_lasso.jl:50-58) -- the rows arrive as blocks of a host matrix (numpy arrays, np.memmap slices of a file on disk, a
+    generator that reads them).  `chunks` yields (A_k, b_k) in row order, A_k of shape (n_k, d); they are staged through two
+    pinned host buffers and copied on a stream of their own, so chunk k+1 is being read / converted on the host while chunk
+    k is on the wire, and never more than two chunks of host memory are held.  loss: "ls" (targets b, LeastSquares λ = lam)
+    or "logistic" (labels b in {-1, +1}).  Returns the PackedF the solvers take as F."""
+    dtype = torch_dtype(R)
+    np_R = np.float64 if dtype == torch.float64 else np.float32
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    A = torch.empty((N, d), dtype=dtype, device=device)
+    b = torch.empty((N,), dtype=dtype, device=device)
+    copy = torch.cuda.Stream(device=device)
+    stage, done = [None, None], [None, None]
+    at = 0
+    for k, (Ak, bk) in enumerate(chunks):
+        Ak = np.asarray(Ak)
+        bk = np.asarray(bk).reshape(-1)
+        n = Ak.shape[0]
+        if Ak.ndim != 2 or Ak.shape[1] != d or bk.shape[0] != n or at + n > N:
+            raise ValueError(f"chunk {k}: expected (n, {d}) rows with n targets and at most {N - at} rows left, got {Ak.shape} / {bk.shape}")
+        if np.iscomplexobj(Ak) or np.iscomplexobj(bk):
+            raise TypeError("complex data is outside the device path")
+        s = k & 1
+        if done[s] is not None:
+            done[s].synchronize()                        # the copy that last used this staging pair has left the host
+        if stage[s] is None or stage[s][0].shape[0] < n:
+            stage[s] = (torch.empty((n, d), dtype=dtype).pin_memory(), torch.empty((n,), dtype=dtype).pin_memory())
+        sa, sb = stage[s]
+        np.copyto(sa[:n].numpy(), Ak, casting="same_kind" if Ak.dtype.kind == "f" else "unsafe")   # converts to R on the way
+        np.copyto(sb[:n].numpy(), bk.astype(np_R, copy=False))
+        with torch.cuda.stream(copy):
+            A[at:at + n].copy_(sa[:n], non_blocking=True)
+            b[at:at + n].copy_(sb[:n], non_blocking=True)
+            done[s] = torch.cuda.Event()
+            done[s].record(copy)
+        at += n
+    if at != N:
+        raise ValueError(f"the chunks held {at} rows, expected {N}")
+    copy.synchronize()
+    torch.cuda.current_stream(device).wait_stream(copy)
+    kind = {"ls": L.LOSS_LS, "logistic": L.LOSS_LOGISTIC}[loss]
+    return PackedF(kind, A, b, float(lam) if loss == "ls" else 1.0, N_total=N_total, row0=row0)
 
 
 def pack_g(g, d: int, R, device=None) -> ProxG:

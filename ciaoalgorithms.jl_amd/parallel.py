@@ -256,5 +256,8 @@ def init_process_group_from_env(backend: str | None = None):
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl" and torch.cuda.is_available():   # bind the communicator to this rank's GPU (no guessing by global rank)
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local

@@ -433,3 +433,32 @@ def test_stop_callback_and_state_objective(api, ctx, capsys):
     out = capsys.readouterr().out.strip().splitlines()
     assert len(out) == 2 and all("| F = " in ln for ln in out)
     assert float(out[1].split("F =")[1]) <= float(out[0].split("F =")[1])
+
+
+def test_packing_rows_from_a_host_matrix_stream(api, ctx, tmp_path):
+    """rows arriving as blocks of a host matrix (here slices of an np.memmap on disk, float64 file ->
+    float32 problem) are staged through pinned buffers on a copy stream; the packed problem is the one a direct upload gives
+    and the solver runs on it."""
+    import torch
+    S, ops = api
+    rng = np.random.default_rng(0)
+    N, d = 5000, 256
+    path = tmp_path / "A.f64"
+    mm = np.memmap(path, dtype=np.float64, mode="w+", shape=(N, d))
+    mm[:] = rng.standard_normal((N, d)) / np.sqrt(d)
+    mm.flush()
+    b = (np.asarray(mm) @ (rng.standard_normal(d) * (rng.random(d) < 0.1)) + 0.01 * rng.standard_normal(N))
+    ro = np.memmap(path, dtype=np.float64, mode="r", shape=(N, d))
+    cuts = [0, 700, 701, 2500, 4999, N]
+    for R in (np.float32, np.float64):
+        F = ops.pack_rows_from_host(((ro[a:e], b[a:e]) for a, e in zip(cuts, cuts[1:])), N, d, R, loss="ls", lam=float(N))
+        want = torch.from_numpy(np.asarray(ro).astype(R)).cuda()
+        assert torch.equal(F.A, want) and torch.equal(F.b, torch.from_numpy(b.astype(R)).cuda())
+        assert F.N == F.N_total == N and F.d == d and F.lam == float(N)
+        Lc = N * np.sum(np.asarray(ro) ** 2, axis=1)
+        x, it = S.SVRG(R, γ=R(1 / (7 * Lc.max())), maxit=4)(np.zeros(d, R), F=F, g=ops.NormL1(0.01), N=N, ctx=ctx)
+        assert x.dtype == R and it == 4 and np.isfinite(x).all()
+    with pytest.raises(ValueError):
+        ops.pack_rows_from_host(iter([(ro[:10], b[:10])]), N, d, np.float64)
+    with pytest.raises(TypeError, match="no\s+host fallback|no host fallback"):
+        S.SVRG(np.float64, γ=0.1, maxit=2)(np.zeros(d), F=[object()] * 3, N=3, ctx=ctx)
