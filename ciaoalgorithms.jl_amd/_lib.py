@@ -17,8 +17,8 @@ ABI_VERSION = 2
 
 OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_ALLOC, ERR_HOOK = 0, -1, -2, -3, -4, -5
 F32, F64 = 0, 1
-LOSS_LS, LOSS_LOGISTIC, LOSS_ZERO = 0, 1, 2
-PROX_ZERO, PROX_L1, PROX_BOX = 0, 1, 2
+LOSS_LS, LOSS_LOGISTIC, LOSS_ZERO, LOSS_LS_COMPLEX = 0, 1, 2, 3
+PROX_ZERO, PROX_L1, PROX_BOX, PROX_L1_COMPLEX = 0, 1, 2, 3
 
 
 class CiaoError(RuntimeError):

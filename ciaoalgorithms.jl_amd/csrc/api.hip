@@ -106,7 +106,10 @@ static int32_t check_problem(ciao_ctx *ctx, const ciao_problem *p)
     ctx->rowdot_A = nullptr;
     CIAO_REQUIRE(p, "problem is NULL");
     CIAO_REQUIRE(p->dtype == CIAO_F32 || p->dtype == CIAO_F64, "problem.dtype must be CIAO_F32 or CIAO_F64 (got %d)", p->dtype);
-    CIAO_REQUIRE(p->loss >= CIAO_LOSS_LS && p->loss <= CIAO_LOSS_ZERO, "unknown loss kind %d", p->loss);
+    CIAO_REQUIRE(p->loss >= CIAO_LOSS_LS && p->loss <= CIAO_LOSS_LS_COMPLEX, "unknown loss kind %d", p->loss);
+    CIAO_REQUIRE(p->loss != CIAO_LOSS_LS_COMPLEX || (p->d % 2 == 0 && p->ld % 2 == 0),
+                 "complex problems store (re, im) pairs: d and ld count reals and must be even (got d=%lld ld=%lld)", (long long)p->d,
+                 (long long)p->ld);
     CIAO_REQUIRE(p->N >= 0 && p->d >= 1, "need N >= 0 and d >= 1 (got N=%lld d=%lld)", (long long)p->N, (long long)p->d);
     CIAO_REQUIRE(p->ld >= p->d, "row stride ld=%lld < d=%lld", (long long)p->ld, (long long)p->d);
     CIAO_REQUIRE(p->N_total >= p->N && p->N_total >= 1, "N_total=%lld must be >= max(N,1)", (long long)p->N_total);
@@ -120,8 +123,20 @@ static int32_t check_problem(ciao_ctx *ctx, const ciao_problem *p)
 static int32_t check_prox(const ciao_prox_desc *g)
 {
     if (!g) return CIAO_OK;
-    CIAO_REQUIRE(g->kind >= CIAO_PROX_ZERO && g->kind <= CIAO_PROX_BOX, "unknown prox kind %d", g->kind);
-    if (g->kind == CIAO_PROX_L1) CIAO_REQUIRE(g->lam >= 0.0, "NormL1 lambda must be >= 0");
+    CIAO_REQUIRE(g->kind >= CIAO_PROX_ZERO && g->kind <= CIAO_PROX_L1_COMPLEX, "unknown prox kind %d", g->kind);
+    if (g->kind == CIAO_PROX_L1 || g->kind == CIAO_PROX_L1_COMPLEX) CIAO_REQUIRE(g->lam >= 0.0, "NormL1 lambda must be >= 0");
+    return CIAO_OK;
+}
+
+// a complex problem takes g = Zero or the complex NormL1; a real problem never the complex NormL1
+static int32_t check_pair(const ciao_problem *p, const ciao_prox_desc *g)
+{
+    const int kind = g ? g->kind : CIAO_PROX_ZERO;
+    if (p->loss == CIAO_LOSS_LS_COMPLEX)
+        CIAO_REQUIRE(kind == CIAO_PROX_ZERO || kind == CIAO_PROX_L1_COMPLEX,
+                     "a complex problem takes g = Zero or CIAO_PROX_L1_COMPLEX (got prox kind %d)", kind);
+    else
+        CIAO_REQUIRE(kind != CIAO_PROX_L1_COMPLEX, "CIAO_PROX_L1_COMPLEX needs a complex problem (CIAO_LOSS_LS_COMPLEX)");
     return CIAO_OK;
 }
 
@@ -1101,6 +1116,7 @@ int32_t ciao_prox(ciao_ctx *ctx, int32_t dtype, int64_t d, const ciao_prox_desc 
     CIAO_REQUIRE(dtype == CIAO_F32 || dtype == CIAO_F64, "bad dtype %d", dtype);
     CIAO_REQUIRE(d >= 0 && (d == 0 || (x && y)), "bad d or NULL vector");
     CIAO_TRY(check_prox(g));
+    CIAO_REQUIRE(!(g && g->kind == CIAO_PROX_L1_COMPLEX) || d % 2 == 0, "CIAO_PROX_L1_COMPLEX works on (re, im) pairs: d must be even");
     if (d == 0) return CIAO_OK;
     if (dtype == CIAO_F64) return prox_launch<double>(ctx, d, g, (const double *)x, gamma, 1.0, (double *)y);
     return prox_launch<float>(ctx, d, g, (const float *)x, (float)gamma, 1.0f, (float *)y);
@@ -1120,6 +1136,7 @@ int32_t ciao_proxgrad_step(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_REQUIRE(x && av && y, "x, av or y is NULL");
     CIAO_REQUIRE(gamma > 0, "gamma must be > 0");
     return DISPATCH(p->dtype, proxgrad_t, ctx, p, g, gamma, x, av, y);
@@ -1130,6 +1147,7 @@ int32_t ciao_objective(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_des
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_REQUIRE(x && obj_host, "x or obj_host is NULL");
     return DISPATCH(p->dtype, objective_t, ctx, p, g, x, obj_host);
 }
@@ -1192,6 +1210,7 @@ int32_t ciao_saga_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_des
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_REQUIRE(x0 && av && z && (table || p->N == 0), "NULL state vector / table");
     CIAO_REQUIRE(gamma > 0, "gamma must be > 0");
     return DISPATCH(p->dtype, saga_init_t, ctx, p, g, gamma, x0, table, av, z);
@@ -1203,6 +1222,7 @@ int32_t ciao_saga_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_de
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_REQUIRE(nsteps >= 0 && (nsteps == 0 || idx), "nsteps < 0 or idx is NULL");
     CIAO_REQUIRE(nsteps == 0 || p->N > 0 || ctx->shards.nshards > 0, "cannot sample from an empty problem");
     CIAO_REQUIRE((table || ctx->shards.nshards > 0) && av && z, "NULL state vector / table");
@@ -1251,6 +1271,7 @@ int32_t ciao_finito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_d
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_REQUIRE(x0 && av && z && ((table && gam) || p->N == 0), "NULL state vector / table / gam");
     CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
     return DISPATCH(p->dtype, finito_init_t, ctx, p, g, gam, hat_gamma, x0, table, av, z);
@@ -1274,6 +1295,7 @@ int32_t ciao_finito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_REQUIRE(nit >= 0 && (nit == 0 || (bptr_host && (bidx || bptr_host[nit] == bptr_host[0]))), "nit < 0 or NULL batch arrays");
     CIAO_REQUIRE(nit == 0 || p->N > 0, "cannot sample from an empty problem");
     CIAO_REQUIRE(table && av && z && gam, "NULL state vector / table / gam");
@@ -1290,6 +1312,7 @@ int32_t ciao_finito_steps_blocks(ciao_ctx *ctx, const ciao_problem *p, const cia
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_TRY(check_blocks(ctx, p->N, nit, first_host, len_host, "ciao_finito_steps_blocks"));
     CIAO_REQUIRE(nit == 0 || p->N > 0 || ctx->hook, "cannot take batches from an empty problem");
     CIAO_REQUIRE(table && av && z && gam, "NULL state vector / table / gam");
@@ -1316,6 +1339,7 @@ int32_t ciao_lfinito_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_pr
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_REQUIRE(nb >= 0 && (nb == 0 || (bptr_host && (bidx || bptr_host[nb] == bptr_host[0]))), "nb < 0 or NULL batch arrays");
     CIAO_REQUIRE(av && z && z_full && gam, "NULL state vector / gam");
     CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
@@ -1331,6 +1355,7 @@ int32_t ciao_lfinito_iterate_blocks(ciao_ctx *ctx, const ciao_problem *p, const 
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_TRY(check_blocks(ctx, p->N, nb, first_host, len_host, "ciao_lfinito_iterate_blocks"));
     CIAO_REQUIRE(av && z && z_full && gam, "NULL state vector / gam");
     CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
@@ -1346,7 +1371,7 @@ int32_t ciao_afinito_probe(ciao_ctx *ctx, const ciao_problem *p, int64_t i, cons
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_REQUIRE(x0 && signs && nmg_host && t > 0, "NULL argument or t <= 0");
-    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO && i >= 0 && i < p->N, "sample index %lld outside [0, %lld) or no data terms", (long long)i,
+    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO && p->loss != CIAO_LOSS_LS_COMPLEX && i >= 0 && i < p->N, "sample index %lld outside [0, %lld) or no real data terms", (long long)i,
                  (long long)p->N);
     if (p->dtype == CIAO_F64)
         hipLaunchKernelGGL((afinito_probe_kernel<double>), dim3(1), dim3(WAVE), 0, ctx->stream, (const double *)p->A, (const double *)p->b,
@@ -1366,9 +1391,11 @@ int32_t ciao_afinito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_REQUIRE(x0 && av && z && hat_gamma_dev && ((table && meta) || p->N == 0), "NULL state vector / table / meta");
     CIAO_REQUIRE(alpha > 0 && alpha < 1, "alpha must be in (0, 1)");
     CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO, "adaptive Finito needs data terms (the Lipschitz probe of Zero() is degenerate)");
+    CIAO_REQUIRE(p->loss != CIAO_LOSS_LS_COMPLEX, "adaptive Finito has no complex path");
     CIAO_REQUIRE(p->N >= 1, "adaptive Finito needs at least one term");
     CIAO_REQUIRE(!ctx->hook, "adaptive Finito is a sequential chain: replicas only, not valid on a row-sharded problem");
     return DISPATCH(p->dtype, afinito_init_t, ctx, p, g, alpha, x0, table, meta, av, z, hat_gamma_dev, gam_override);
@@ -1381,10 +1408,11 @@ int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_REQUIRE(nsteps >= 0 && (nsteps == 0 || idx), "nsteps < 0 or idx is NULL");
     CIAO_REQUIRE(table && meta && av && z && hat_gamma_dev, "NULL state vector / table / meta");
     CIAO_REQUIRE(alpha > 0 && alpha < 1 && tol_b > 0, "need 0 < alpha < 1 and tol_b > 0");
-    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO && p->N >= 1, "adaptive Finito needs data terms");
+    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO && p->loss != CIAO_LOSS_LS_COMPLEX && p->N >= 1, "adaptive Finito needs real data terms");
     CIAO_REQUIRE(!ctx->hook, "adaptive Finito is a sequential chain: replicas only, not valid on a row-sharded problem");
     if (nsteps == 0) {
         if (done_host) *done_host = 0;

@@ -503,6 +503,150 @@ __global__ void __launch_bounds__(CHAIN_BIG_NT) chain_big_kernel(ChainArgs<T> a)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The chains for complex T (CIAO_LOSS_LS_COMPLEX; vectors are (re, im) pairs): chain_big_kernel's structure -- one
+// 1024-thread workgroup, state in the caller's vectors, two passes over the row per step -- with the complex residual
+// res = a_i . p - b_i, grad = (conj(a_k) res) lam, and the prox of g = Zero or complex NormL1 pair by pair.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int ALG>
+__global__ void __launch_bounds__(CHAIN_BIG_NT) chain_cplx_kernel(ChainArgs<T> a)
+{
+    constexpr int NW = CHAIN_BIG_NT / WAVE;
+    constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
+    constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
+    __shared__ T red[2][NW][4];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t d = a.d, dc = a.d / 2;
+    T *p = (ALG == CA_SVRG) ? a.w : a.z;
+    const bool l1 = (a.g.kind == CIAO_PROX_L1_COMPLEX);
+    auto proxc = [&](T tau, T vr, T vi, T &yr, T &yi) {
+        if (l1) {
+            prox_cpair(tau * a.g.lam, vr, vi, yr, yi);
+        } else {
+            yr = vr;
+            yi = vi;
+        }
+    };
+    int par = 0;
+    int64_t inb = 0;
+    for (int64_t s = 0; s < a.nsteps; ++s) {
+        int64_t row = a.idx[s];
+        if ((uint64_t)row >= (uint64_t)a.N) {
+            if (tid == 0) *a.errflag = 1;
+            row = 0;
+        }
+        const T *ap = a.A + row * a.ld;
+        const T br = a.b[2 * row], bi = a.b[2 * row + 1];
+        T *sp = HAS_TABLE ? a.table + row * d : nullptr;
+        if (ALG == CA_LFINITO && inb == 0) {     // Finito_LFinito.jl:92  z = prox(av)
+            for (int64_t e = tid; e < dc; e += CHAIN_BIG_NT) proxc(a.hat_gamma, a.av[2 * e], a.av[2 * e + 1], p[2 * e], p[2 * e + 1]);
+            __syncthreads();
+        }
+        T s1r = T(0), s1i = T(0), s2r = T(0), s2i = T(0);
+        for (int64_t e = tid; e < dc; e += CHAIN_BIG_NT) {
+            const T ar = ap[2 * e], ai = ap[2 * e + 1];
+            const T xr = p[2 * e], xi = p[2 * e + 1];
+            s1r += ar * xr - ai * xi;
+            s1i += ar * xi + ai * xr;
+            if (TWO) {
+                const T yr = a.zf[2 * e], yi = a.zf[2 * e + 1];
+                s2r += ar * yr - ai * yi;
+                s2i += ar * yi + ai * yr;
+            }
+        }
+        s1r = wave_allsum(s1r);
+        s1i = wave_allsum(s1i);
+        if (TWO) {
+            s2r = wave_allsum(s2r);
+            s2i = wave_allsum(s2i);
+        }
+        if (lane == 0) {
+            red[par][wib][0] = s1r;
+            red[par][wib][1] = s1i;
+            red[par][wib][2] = s2r;
+            red[par][wib][3] = s2i;
+        }
+        __syncthreads();
+        T t4[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int w = 0; w < NW; w += 4)
+                t4[c] += (red[par][w][c] + red[par][w + 1][c]) + (red[par][w + 2][c] + red[par][w + 3][c]);
+        par ^= 1;
+        const T rpr = t4[0] - br, rpi = t4[1] - bi;      // residual at p
+        const T rzr = t4[2] - br, rzi = t4[3] - bi;      // residual at z_full (TWO)
+        const T gi = (ALG == CA_FINITO || ALG == CA_LFINITO) ? (a.gam ? a.gam[row] : a.gam_uniform) : T(1);
+        const bool last_of_batch = (inb + 1 == a.batch) || (s + 1 == a.nsteps);
+        for (int64_t e = tid; e < dc; e += CHAIN_BIG_NT) {
+            const int64_t k = 2 * e;
+            const T ar = ap[k], ai = ap[k + 1];
+            T gpr, gpi, gzr, gzi;
+            cgrad_elem(ar, ai, rpr, rpi, a.lam, gpr, gpi);
+            cgrad_elem(ar, ai, rzr, rzi, a.lam, gzr, gzi);
+            if (ALG == CA_SVRG) {                                            // SVRG_basic.jl:74-81
+                T tr = gzr - gpr, ti = gzi - gpi;
+                tr -= a.av[k];
+                ti -= a.av[k + 1];
+                tr *= a.gamma;
+                ti *= a.gamma;
+                tr += p[k];
+                ti += p[k + 1];
+                T wr, wi;
+                proxc(a.gamma, tr, ti, wr, wi);
+                p[k] = wr;
+                p[k + 1] = wi;
+                a.z[k] += wr;
+                a.z[k + 1] += wi;
+            } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
+                const T sr = sp[k], si = sp[k + 1];
+                const T delr = (gpr - sr) * a.invN, deli = (gpi - si) * a.invN;
+                T avr = a.av[k], avi = a.av[k + 1], wr, wi;
+                if (a.sag) {
+                    avr += delr;
+                    avi += deli;
+                    wr = p[k] - a.gamma * avr;
+                    wi = p[k + 1] - a.gamma * avi;
+                } else {
+                    wr = p[k] - a.gamma * (gpr - sr + avr);
+                    wi = p[k + 1] - a.gamma * (gpi - si + avi);
+                    avr += delr;
+                    avi += deli;
+                }
+                a.av[k] = avr;
+                a.av[k + 1] = avi;
+                proxc(a.gamma, wr, wi, p[k], p[k + 1]);
+                sp[k] = gpr;
+                sp[k + 1] = gpi;
+            } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
+                const T tr = p[k] - (gi * a.invN) * gpr, ti = p[k + 1] - (gi * a.invN) * gpi;
+                const T avr = a.av[k] + (tr - sp[k]) * (a.hat_gamma / gi);
+                const T avi = a.av[k + 1] + (ti - sp[k + 1]) * (a.hat_gamma / gi);
+                a.av[k] = avr;
+                a.av[k + 1] = avi;
+                sp[k] = tr;
+                sp[k + 1] = ti;
+                if (last_of_batch) proxc(a.hat_gamma, avr, avi, p[k], p[k + 1]);
+            } else {                                                         // Finito_LFinito.jl:93-98
+                const T c = a.hat_gamma * a.invN;
+                T avr = a.av[k], avi = a.av[k + 1];
+                avr += c * gzr;
+                avi += c * gzi;
+                avr -= c * gpr;
+                avi -= c * gpi;
+                avr += (a.hat_gamma / gi) * (p[k] - a.zf[k]);
+                avi += (a.hat_gamma / gi) * (p[k + 1] - a.zf[k + 1]);
+                a.av[k] = avr;
+                a.av[k + 1] = avi;
+            }
+        }
+        if (++inb == a.batch) inb = 0;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Fast chain: LDS-DMA row ring.
 //
 // The register-ring kernel above leaves the waits to hipcc, which drains the whole vector-memory queue once per ring
@@ -1524,6 +1668,18 @@ __global__ void __launch_bounds__(WAVE)
 {
     const int lane = threadIdx.x;
     const T *ap = A ? A + i * ld : nullptr;
+    if (loss == CIAO_LOSS_LS_COMPLEX) {   // (re, im) pairs: res = a.x - b, y_k = (conj(a_k) res) lam, f = lam/2 |res|^2
+        T sr = T(0), si = T(0);
+        for (int64_t e = lane; e < d / 2; e += WAVE) {
+            sr += ap[2 * e] * x[2 * e] - ap[2 * e + 1] * x[2 * e + 1];
+            si += ap[2 * e] * x[2 * e + 1] + ap[2 * e + 1] * x[2 * e];
+        }
+        sr = wave_allsum(sr) - b[2 * i];
+        si = wave_allsum(si) - b[2 * i + 1];
+        for (int64_t e = lane; e < d / 2; e += WAVE) cgrad_elem(ap[2 * e], ap[2 * e + 1], sr, si, lam, y[2 * e], y[2 * e + 1]);
+        if (fval && lane == 0) *fval = (lam / T(2)) * (sr * sr + si * si);
+        return;
+    }
     T dot = T(0);
     for (int64_t e = lane; e < d; e += WAVE) dot += (ap ? ap[e] : T(0)) * x[e];
     dot = wave_allsum(dot);
@@ -1563,6 +1719,10 @@ template <typename T>
 __global__ void __launch_bounds__(256) prox_kernel(int64_t d, ProxD<T> g, const T *x, T gamma, T scale, T *y)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g.kind == CIAO_PROX_L1_COMPLEX) {   // (re, im) pairs: thread k takes coordinates 2k and 2k+1 (d is even)
+        if (2 * k + 1 < d) prox_cpair(gamma * g.lam, scale * x[2 * k], scale * x[2 * k + 1], y[2 * k], y[2 * k + 1]);
+        return;
+    }
     if (k < d) y[k] = prox_elem(g, scale * x[k], gamma, k);
 }
 
@@ -1585,7 +1745,11 @@ __global__ void __launch_bounds__(256) gvalue_kernel(int64_t d, ProxD<T> g, cons
 {
     __shared__ double s[256];
     double acc = 0.0;
-    for (int64_t k = threadIdx.x; k < d; k += 256) acc += (double)prox_value_elem(g, x[k]);
+    if (g.kind == CIAO_PROX_L1_COMPLEX) {   // lam * sum of complex moduli
+        for (int64_t k = threadIdx.x; 2 * k + 1 < d; k += 256) acc += (double)(g.lam * fhypot(x[2 * k], x[2 * k + 1]));
+    } else {
+        for (int64_t k = threadIdx.x; k < d; k += 256) acc += (double)prox_value_elem(g, x[k]);
+    }
     s[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {

@@ -120,6 +120,33 @@ __device__ __forceinline__ GradCoef<T> grad_coef(int loss, T dot, T bi, T lam)
     return g;
 }
 
+__device__ __forceinline__ float fhypot(float a, float b) { return hypotf(a, b); }
+__device__ __forceinline__ double fhypot(double a, double b) { return hypot(a, b); }
+
+// ---- complex T as interleaved (re, im) pairs (CIAO_LOSS_LS_COMPLEX / CIAO_PROX_L1_COMPLEX) --------------------------------
+// prox_{gl |.|}(v) for one complex coordinate: sign(v) * max(|v| - gl, 0) with the complex modulus and sign = v / |v|
+// (ProximalOperators.jl NormL1 on a complex array), in that operation order.
+template <typename T>
+__device__ __forceinline__ void prox_cpair(T gl, T vr, T vi, T &yr, T &yi)
+{
+    const T ax = fhypot(vr, vi);
+    if (ax > gl) {
+        const T m = ax - gl;
+        yr = (vr / ax) * m;
+        yi = (vi / ax) * m;
+    } else {
+        yr = T(0);
+        yi = T(0);
+    }
+}
+// grad f_i(x)_k = (conj(a_k) * res) * lam for the complex residual res = a_i.x - b_i   (mul!(y, A', res); y .*= lam)
+template <typename T>
+__device__ __forceinline__ void cgrad_elem(T ar, T ai, T rr, T ri, T lam, T &gr, T &gi)
+{
+    gr = (ar * rr + ai * ri) * lam;
+    gi = (ar * ri - ai * rr) * lam;
+}
+
 // f_i(x) given the same scalars (the value gradient! returns).
 template <typename T>
 __device__ __forceinline__ T loss_value(int loss, T dot, T bi, T lam)
@@ -182,6 +209,18 @@ __device__ __forceinline__ T prox_value_elem(const ProxD<T> &g, T v)
     return g.kind == CIAO_PROX_L1 ? g.lam * (v < T(0) ? -v : v) : T(0);
 }
 
+// prox of the two consecutive coordinates (k, k+1), k even: a complex pair for CIAO_PROX_L1_COMPLEX, two scalars otherwise
+template <typename T>
+__device__ __forceinline__ void prox_pair(const ProxD<T> &g, T v0, T v1, T gamma, int64_t k, T &y0, T &y1)
+{
+    if (g.kind == CIAO_PROX_L1_COMPLEX) {
+        prox_cpair(gamma * g.lam, v0, v1, y0, y1);
+    } else {
+        y0 = prox_elem(g, v0, gamma, k);
+        y1 = prox_elem(g, v1, gamma, k + 1);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Epilogue applied to a reduced d-vector `sum` (+ one extra reduced scalar), per coordinate k:
 //     a = c_acc*acc_in[k] + c_sum*sum[k] + cu*u[k] + cv*v[k]           (cu,cv = c_u,c_v, or +/- extra if uv_extra)
@@ -208,9 +247,11 @@ struct Epilogue {
     double obj_scale;
 };
 
-// operands already in registers (the caller requested them before its reduction): acc_in[k], u[k], v[k], pw[k]
+// The epilogue in two halves, so that callers owning two consecutive coordinates can apply a PAIR prox (complex NormL1):
+// epilogue_pre  -> a (written to av_out) and the prox argument t = p0*a + p1*pw[k]; operands already in registers
+// epilogue_post -> z_out[k] from the prox value
 template <typename T>
-__device__ __forceinline__ void epilogue_apply_pre(const Epilogue<T> &e, int64_t k, T sum, T extra, T acc_k, T u_k, T v_k, T pw_k)
+__device__ __forceinline__ T epilogue_pre(const Epilogue<T> &e, int64_t k, T sum, T extra, T acc_k, T u_k, T v_k, T pw_k)
 {
     const T hgx = e.inv_extra == 1 ? T(1) / extra : (e.inv_extra == 2 ? extra : T(1));
     if (e.inv_extra && e.hg_out && k == 0) *e.hg_out = hgx;
@@ -222,12 +263,29 @@ __device__ __forceinline__ void epilogue_apply_pre(const Epilogue<T> &e, int64_t
     if (e.u) a += cu * u_k;
     if (e.v) a += cv * v_k;
     if (e.av_out) e.av_out[k] = a;
+    T t = e.p0 * a;
+    if (e.pw) t += e.p1 * pw_k;
+    return t;
+}
+template <typename T>
+__device__ __forceinline__ T epilogue_tau(const Epilogue<T> &e, T extra)
+{
+    return e.inv_extra == 1 ? T(1) / extra : (e.inv_extra == 2 ? extra : e.tau);
+}
+template <typename T>
+__device__ __forceinline__ void epilogue_post(const Epilogue<T> &e, int64_t k, T t, T tau, T pz)
+{
+    e.z_out[k] = e.zmode == 1 ? (pz - t) / tau : pz;
+}
+
+// one coordinate, operands already in registers (the caller requested them before its reduction)
+template <typename T>
+__device__ __forceinline__ void epilogue_apply_pre(const Epilogue<T> &e, int64_t k, T sum, T extra, T acc_k, T u_k, T v_k, T pw_k)
+{
+    const T t = epilogue_pre(e, k, sum, extra, acc_k, u_k, v_k, pw_k);
     if (e.z_out) {
-        T t = e.p0 * a;
-        if (e.pw) t += e.p1 * pw_k;
-        const T tau = e.inv_extra ? hgx : e.tau;
-        const T pz = prox_elem(e.g, t, tau, k);
-        e.z_out[k] = e.zmode == 1 ? (pz - t) / tau : pz;
+        const T tau = epilogue_tau(e, extra);
+        epilogue_post(e, k, t, tau, prox_elem(e.g, t, tau, k));
     }
 }
 
@@ -236,6 +294,23 @@ __device__ __forceinline__ void epilogue_apply(const Epilogue<T> &e, int64_t k, 
 {
     epilogue_apply_pre(e, k, sum, extra, e.acc_in ? e.acc_in[k] : T(0), e.u ? e.u[k] : T(0), e.v ? e.v[k] : T(0),
                        e.pw ? e.pw[k] : T(0));
+}
+
+// two consecutive coordinates (k even): pair prox when g is the complex NormL1
+template <typename T>
+__device__ __forceinline__ void epilogue_apply2(const Epilogue<T> &e, int64_t k, T sum0, T sum1, T extra)
+{
+    const T t0 = epilogue_pre(e, k, sum0, extra, e.acc_in ? e.acc_in[k] : T(0), e.u ? e.u[k] : T(0), e.v ? e.v[k] : T(0),
+                              e.pw ? e.pw[k] : T(0));
+    const T t1 = epilogue_pre(e, k + 1, sum1, extra, e.acc_in ? e.acc_in[k + 1] : T(0), e.u ? e.u[k + 1] : T(0),
+                              e.v ? e.v[k + 1] : T(0), e.pw ? e.pw[k + 1] : T(0));
+    if (e.z_out) {
+        const T tau = epilogue_tau(e, extra);
+        T y0, y1;
+        prox_pair(e.g, t0, t1, tau, k, y0, y1);
+        epilogue_post(e, k, t0, tau, y0);
+        epilogue_post(e, k + 1, t1, tau, y1);
+    }
 }
 
 }  // namespace ciao

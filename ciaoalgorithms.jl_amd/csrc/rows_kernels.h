@@ -998,6 +998,92 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Complex T (CIAO_LOSS_LS_COMPLEX): every complex vector is (re, im) pairs of T.  Correctness path, one wave per row, per-wave
+// accumulators in the workspace (as rows_generic_kernel<..., GLOBAL_ACC>), the iterate(s) read from global memory.
+//   res = a_i . x - b_i  (complex, no conjugation: A*x);   grad f_i(x)_k = (conj(a_k) res) lam;   f_i = lam/2 |res|^2
+// Modes GRAD, GRAD2, SAGA_INIT, FINITO_INIT, FINITO_BATCH with exactly the formulas of the real kernels, pair by pair.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_cplx_kernel(RowsArgs<T> a)
+{
+    constexpr bool TWO = (MODE == RM_GRAD2);
+    static_assert(MODE != RM_AFINITO_INIT, "adaptive Finito has no complex path");
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t dc = a.d / 2;
+    const int64_t nwaves = (int64_t)gridDim.x * ROWS_WAVES;
+    T *acc = a.partial + ((int64_t)blockIdx.x * ROWS_WAVES + wib) * a.pstride;
+    for (int64_t e = lane; e < a.d; e += WAVE) acc[e] = T(0);
+    T extra = T(0);
+    for (int64_t q = (int64_t)blockIdx.x * ROWS_WAVES + wib; q < a.nrows; q += nwaves) {
+        int64_t row = a.idx ? a.idx[q] : a.row0 + q;
+        if ((uint64_t)row >= (uint64_t)a.N) {
+            if (lane == 0) *a.errflag = 1;
+            row = 0;
+        }
+        const T *ap = a.A + row * a.ld;
+        const T br = a.b[2 * row], bi = a.b[2 * row + 1];
+        T s1r = T(0), s1i = T(0), s2r = T(0), s2i = T(0);
+        for (int64_t e = lane; e < dc; e += WAVE) {
+            const T ar = ap[2 * e], ai = ap[2 * e + 1];
+            const T xr = a.x1[2 * e], xi = a.x1[2 * e + 1];
+            s1r += ar * xr - ai * xi;
+            s1i += ar * xi + ai * xr;
+            if (TWO) {
+                const T yr = a.x2[2 * e], yi = a.x2[2 * e + 1];
+                s2r += ar * yr - ai * yi;
+                s2i += ar * yi + ai * yr;
+            }
+        }
+        s1r = wave_allsum(s1r);
+        s1i = wave_allsum(s1i);
+        if (TWO) {
+            s2r = wave_allsum(s2r);
+            s2i = wave_allsum(s2i);
+        }
+        const T r1r = s1r - br, r1i = s1i - bi;          // res = A x - b
+        const T r2r = s2r - br, r2i = s2i - bi;
+        T *tp = a.table ? a.table + row * a.d : nullptr;
+        const T gi = (MODE == RM_GRAD || MODE == RM_SAGA_INIT) ? T(1) : (a.gam ? a.gam[row] : a.gam_uniform);
+        if (MODE == RM_GRAD && a.want_fval) extra += (a.lam / T(2)) * (r1r * r1r + r1i * r1i);
+        if (MODE == RM_GRAD2) extra += a.hat_gamma / gi;
+        const T cg = gi * a.invN;
+        const T rr = (MODE == RM_FINITO_INIT) ? T(1) / gi : a.hat_gamma / gi;
+        for (int64_t e = lane; e < dc; e += WAVE) {
+            const T ar = ap[2 * e], ai = ap[2 * e + 1];
+            T gr, gim;
+            cgrad_elem(ar, ai, r1r, r1i, a.lam, gr, gim);
+            if (MODE == RM_GRAD) {
+                acc[2 * e] += gr;
+                acc[2 * e + 1] += gim;
+            } else if (MODE == RM_GRAD2) {
+                T hr, hi;
+                cgrad_elem(ar, ai, r2r, r2i, a.lam, hr, hi);
+                acc[2 * e] += gr - hr;
+                acc[2 * e + 1] += gim - hi;
+            } else if (MODE == RM_SAGA_INIT) {
+                tp[2 * e] = gr;
+                tp[2 * e + 1] = gim;
+                acc[2 * e] += gr;
+                acc[2 * e + 1] += gim;
+            } else {
+                const T tr = a.x1[2 * e] - cg * gr, ti = a.x1[2 * e + 1] - cg * gim;
+                if (MODE == RM_FINITO_INIT) {
+                    acc[2 * e] += tr * rr;
+                    acc[2 * e + 1] += ti * rr;
+                } else {
+                    acc[2 * e] += (tr - tp[2 * e]) * rr;
+                    acc[2 * e + 1] += (ti - tp[2 * e + 1]) * rr;
+                }
+                tp[2 * e] = tr;
+                tp[2 * e + 1] = ti;
+            }
+        }
+    }
+    if (lane == 0) a.pextra[(int64_t)blockIdx.x * ROWS_WAVES + wib] = extra;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // finalize: sum the per-block partials in a fixed order and apply the epilogue.
 // A batch step is rows kernel -> finalize -> next rows kernel, so for batches of a few hundred rows this kernel is half of
 // the step (rocprofv3, r = 256, d = 4096 fp32: rows 6.4 us, finalize 5.0 us with the first version of this kernel, which
@@ -1077,14 +1163,29 @@ __global__ void __launch_bounds__(FIN_THREADS)
     if (ty == 0) {
         const V tot = (lds2[0][tx] + lds2[1][tx]) + (lds2[2][tx] + lds2[3][tx]);
         const T extra = lds_extra;
+        const bool cpairs = !raw_out && ep.z_out && ep.g.kind == CIAO_PROX_L1_COMPLEX;   // (re, im) pairs: d even, col even
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            if (col + v >= d) continue;
-            if (raw_out) {
-                raw_out[col + v] = tot[v];
-                if (col + v == 0) raw_out[d] = extra;
-            } else {
-                epilogue_apply_pre(ep, col + v, tot[v], extra, pa[v], pu[v], pv[v], pp[v]);
+        for (int v = 0; v < VEC; v += 2) {
+            if (cpairs) {
+                if (col + v + 1 >= d) continue;
+                const T t0 = epilogue_pre(ep, col + v, tot[v], extra, pa[v], pu[v], pv[v], pp[v]);
+                const T t1 = epilogue_pre(ep, col + v + 1, tot[v + 1], extra, pa[v + 1], pu[v + 1], pv[v + 1], pp[v + 1]);
+                const T tau = epilogue_tau(ep, extra);
+                T y0, y1;
+                prox_cpair(tau * ep.g.lam, t0, t1, y0, y1);
+                epilogue_post(ep, col + v, t0, tau, y0);
+                epilogue_post(ep, col + v + 1, t1, tau, y1);
+                continue;
+            }
+#pragma unroll
+            for (int w = v; w < v + 2; ++w) {
+                if (col + w >= d) continue;
+                if (raw_out) {
+                    raw_out[col + w] = tot[w];
+                    if (col + w == 0) raw_out[d] = extra;
+                } else {
+                    epilogue_apply_pre(ep, col + w, tot[w], extra, pa[w], pu[w], pv[w], pp[w]);
+                }
             }
         }
     }
@@ -1095,6 +1196,10 @@ template <typename T>
 __global__ void __launch_bounds__(256) epilogue_kernel(const T *__restrict__ raw, int64_t d, Epilogue<T> ep)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ep.z_out && ep.g.kind == CIAO_PROX_L1_COMPLEX) {   // (re, im) pairs: thread k takes coordinates 2k and 2k+1
+        if (2 * k + 1 < d) epilogue_apply2(ep, 2 * k, raw[2 * k], raw[2 * k + 1], raw[d]);
+        return;
+    }
     if (k < d) epilogue_apply(ep, k, raw[k], raw[d]);
 }
 

@@ -56,8 +56,11 @@ class PackedF:
             assert loss == L.LOSS_ZERO and d is not None and dtype is not None and N is not None
             self.N, self.d, self.ld, self.dtype = int(N), int(d), int(d), dtype
             self.device = torch.device("cuda", torch.cuda.current_device())
+        self.complex = (self.loss == L.LOSS_LS_COMPLEX)   # vectors are (re, im) pairs of the real dtype: d counts reals
+        if self.complex:
+            assert self.d % 2 == 0 and self.ld % 2 == 0, "complex rows are (re, im) pairs: an even number of reals"
         if b is not None:
-            assert b.is_cuda and b.dtype == self.dtype and b.is_contiguous() and b.shape == (self.N,)
+            assert b.is_cuda and b.dtype == self.dtype and b.is_contiguous() and b.shape == ((2 if self.complex else 1) * self.N,)
         elif loss != L.LOSS_ZERO:
             raise ValueError("b (targets / labels) is required for LeastSquares and logistic F")
         self.A, self.b, self.lam = A, b, float(lam)
@@ -115,6 +118,12 @@ class PackedF:
     def least_squares(A, b, lam=1.0, **kw):
         """f_i = LeastSquares(A[i:i,:], b[i:i], lam)  (test/test_lasso.jl:52-54)"""
         return PackedF(L.LOSS_LS, A, b, lam, **kw)
+
+    @staticmethod
+    def least_squares_complex(A_pairs, b_pairs, lam=1.0, **kw):
+        """Complex T (CIAOAlgorithms.jl:3; test_lasso.jl:3): f_i = LeastSquares(A[i:i,:], b[i:i], lam) with complex A, b given as
+        interleaved (re, im) pairs of the real dtype: A_pairs is N x 2n, b_pairs has 2N entries (torch.view_as_real)."""
+        return PackedF(L.LOSS_LS_COMPLEX, A_pairs, b_pairs, lam, **kw)
 
     @staticmethod
     def logistic(A, y, **kw):

@@ -116,15 +116,18 @@ def _dev(a: np.ndarray, dtype: torch.dtype, device) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a)).to(dtype=dtype, device=device).contiguous()
 
 
-def pack_F(F, N: int, d: int, R, device=None) -> PackedF:
-    """Recognise and pack the finite-sum term.  F is None (Zero()), a PackedF, or a sequence of N one-row operators."""
+def pack_F(F, N: int, d: int, R, device=None, complex_pairs: bool = False) -> PackedF:
+    """Recognise and pack the finite-sum term.  F is None (Zero()), a PackedF, or a sequence of N one-row operators.
+    d counts the REAL coordinates of x0; with complex_pairs (complex x0) they are (re, im) pairs and the operators' rows
+    have d/2 complex entries."""
     dtype = torch_dtype(R)
     device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    n = d // 2 if complex_pairs else d          # entries of one operator row
     if isinstance(F, PackedF):
         if F.dtype != dtype:
             raise TypeError(f"F is packed as {F.dtype} but the solver's real type is {dtype} (no silent promotion)")
         if F.d != d:
-            raise ValueError(f"F has d={F.d} but x0 has length {d}")
+            raise ValueError(f"F has d={F.d} but x0 has {d} (real) coordinates")
         return F
     if F is None:
         return PackedF.zero(N, d, dtype)
@@ -139,13 +142,21 @@ def pack_F(F, N: int, d: int, R, device=None) -> PackedF:
         lam = F[0].lam
         if any(f.lam != lam for f in F):
             raise TypeError("LeastSquares terms with different λ cannot be packed")
-        if any(f.A.shape != (1, d) for f in F):
+        if any(f.A.shape != (1, n) for f in F):
             raise TypeError("only one-row LeastSquares terms (A_i of size 1 x d) are packable")
-        if any(np.iscomplexobj(f.A) or np.iscomplexobj(f.b) for f in F):
-            raise TypeError("complex data is outside the device path")
         A = np.concatenate([f.A for f in F], axis=0)
         b = np.concatenate([f.b for f in F], axis=0)
+        if complex_pairs or np.iscomplexobj(A) or np.iscomplexobj(b):
+            # complex T: (re, im) pairs of R -- reinterpret(R, ...) in Julia terms (a complex problem needs a complex x0)
+            if not complex_pairs:
+                raise TypeError("complex LeastSquares terms need a complex x0 (one type T for the problem, CIAOAlgorithms.jl:3)")
+            ct = np.complex128 if dtype == torch.float64 else np.complex64
+            Ap = np.ascontiguousarray(A.astype(ct)).view(ct(0).real.dtype)
+            bp = np.ascontiguousarray(b.astype(ct)).view(ct(0).real.dtype)
+            return PackedF.least_squares_complex(_dev(Ap, dtype, device), _dev(bp, dtype, device), lam)
         return PackedF.least_squares(_dev(A, dtype, device), _dev(b, dtype, device), lam)
+    if complex_pairs:
+        raise TypeError("with a complex x0 the device path packs LeastSquares rows and Zero only")
     if all(isinstance(f, Precompose) and isinstance(f.f, LogisticLoss) for f in F):
         for f in F:
             if f.L.shape != (1, d) or f.f.y.shape != (1,) or f.f.mu != 1.0 or np.any(np.asarray(f.b) != 0):
@@ -205,7 +216,9 @@ def pack_rows_from_host(chunks, N: int, d: int, R, loss: str = "ls", lam: float 
     return PackedF(kind, A, b, float(lam) if loss == "ls" else 1.0, N_total=N_total, row0=row0)
 
 
-def pack_g(g, d: int, R, device=None) -> ProxG:
+def pack_g(g, d: int, R, device=None, complex_pairs: bool = False) -> ProxG:
+    """complex_pairs: the coordinates are (re, im) pairs of a complex vector (complex T): NormL1 is then the complex norm
+    (modulus soft-threshold); IndBox has no complex meaning."""
     dtype = torch_dtype(R)
     device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     if isinstance(g, ProxG):
@@ -213,7 +226,9 @@ def pack_g(g, d: int, R, device=None) -> ProxG:
     if g is None or isinstance(g, Zero):
         return ProxG(L.PROX_ZERO)
     if isinstance(g, NormL1):
-        return ProxG(L.PROX_L1, lam=g.lam)
+        return ProxG(L.PROX_L1_COMPLEX if complex_pairs else L.PROX_L1, lam=g.lam)
+    if complex_pairs:
+        raise TypeError(f"g of type {type(g).__name__} has no complex form on the device path (Zero, NormL1)")
     if isinstance(g, IndBox):
         lo_vec = hi_vec = None
         lo, hi = -float("inf"), float("inf")

@@ -50,21 +50,31 @@ def _pick(greek, ascii_, name):
     return greek if greek is not None else ascii_
 
 
+_CPLX = {torch.float32: torch.complex64, torch.float64: torch.complex128}
+
+
 def _x0_to_device(x0, dtype):
-    """Return (device vector, was_numpy).  A device tensor of the right dtype is used as is (no copy)."""
+    """Return (device vector of the real type, was_numpy, is_complex).  A real device tensor of the right dtype is used as is
+    (no copy).  Complex x0 (the reference's C <: RealOrComplex{R}, CIAOAlgorithms.jl:3) becomes its (re, im) pairs -- a view,
+    reinterpret(R, x0) in Julia terms -- and the solution is handed back as complex."""
     if isinstance(x0, torch.Tensor):
+        if x0.is_complex():
+            if x0.dtype != _CPLX[dtype]:
+                raise TypeError(f"x0 has dtype {x0.dtype} but the solver's real type is {dtype} (no silent promotion)")
+            t = x0 if x0.is_cuda else x0.cuda()
+            return torch.view_as_real(t.contiguous().view(-1)).reshape(-1), False, True
         if x0.dtype != dtype:
             raise TypeError(f"x0 has dtype {x0.dtype} but the solver's real type is {dtype} (no silent promotion)")
-        if x0.is_complex():
-            raise TypeError("complex iterates are outside the device path")
         t = x0 if x0.is_cuda else x0.cuda()
-        return t.contiguous().view(-1), False
+        return t.contiguous().view(-1), False, False
     a = np.asarray(x0)
     if np.iscomplexobj(a):
-        raise TypeError("complex iterates are outside the device path")
+        if torch_dtype(a.real.dtype) != dtype:
+            raise TypeError(f"x0 has dtype {a.dtype} but the solver's real type is {dtype} (no silent promotion)")
+        return torch.from_numpy(np.ascontiguousarray(a).reshape(-1).view(a.real.dtype)).cuda(), True, True
     if torch_dtype(a.dtype if a.dtype.kind == "f" else np.float64) != dtype:
         raise TypeError(f"x0 has dtype {a.dtype} but the solver's real type is {dtype} (no silent promotion)")
-    return torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).cuda(), True
+    return torch.from_numpy(np.ascontiguousarray(a).reshape(-1)).cuda(), True, False
 
 
 def _maxL(Lc):
@@ -80,13 +90,15 @@ class _Iterable:
         self.R = torch_dtype(R)
         self.x0 = x0  # NOT copied: `iter.x0 === x0` (test/test_lasso.jl:182)
         self.N = int(N)
-        self._x0_dev, self._numpy = _x0_to_device(x0, self.R)
-        self.d = self._x0_dev.numel()
+        self._x0_dev, self._numpy, self._complex = _x0_to_device(x0, self.R)
+        self.d = self._x0_dev.numel()                   # reals: twice the length of a complex x0
         self.ctx = ctx if ctx is not None else default_context()
-        self.F = pack_F(F, self.N, self.d, self.R, self._x0_dev.device)
+        self.F = pack_F(F, self.N, self.d, self.R, self._x0_dev.device, complex_pairs=self._complex)
         if self.F.N_total != self.N:
             raise ValueError(f"F holds N_total={self.F.N_total} terms but N={self.N}")
-        self.g = pack_g(g, self.d, self.R, self._x0_dev.device)
+        if self._complex != bool(getattr(self.F, "complex", False)) and self.F.loss != 2:
+            raise TypeError("x0 and F must both be complex or both be real (CIAOAlgorithms.jl:3: one type T for the problem)")
+        self.g = pack_g(g, self.d, self.R, self._x0_dev.device, complex_pairs=self._complex)
         self.stream = stream if stream is not None else IndexStream(0)
         self._state = None
         self._started = False
@@ -466,6 +478,8 @@ class FINITO_adaptive_iterable(_Iterable):
 
     def __init__(self, R, F, g, x0, N, L, tol, tol_b, sweeping, α, ctx=None, stream=None):
         super().__init__(R, F, g, x0, N, ctx, stream)
+        if self._complex:
+            raise TypeError("adaptive Finito has no complex form on the device path")
         self.L, self.tol, self.tol_b, self.sweeping, self.α = L, tol, tol_b, int(sweeping), α
         if self.F.row0 != 0 or self.F.N != self.N:
             raise ValueError("adaptive Finito is a sequential chain: it needs the whole problem on one device")
@@ -553,7 +567,9 @@ class Proshi_basic_iterable(_Iterable):
             raise TypeError("N (number of agents) is required")
         self.R = torch_dtype(R)
         self.x0, self.N = x0, int(N)
-        self._x0_dev, self._numpy = _x0_to_device(x0, self.R)
+        self._x0_dev, self._numpy, self._complex = _x0_to_device(x0, self.R)
+        if self._complex:
+            raise TypeError("complex agents are outside the ProShI device path")
         self.d = self._x0_dev.numel()
         self.ctx = ctx if ctx is not None else default_context()
         self.F = pack_sharing_F(F, self.N, self.d, self.R, self._x0_dev.device)
@@ -651,6 +667,11 @@ class _Solver:
         it.ctx.synchronize()
         if isinstance(state, Proshi_basic_state):   # Array{Array{R,1}}: one x_i per agent (test_sharing.jl:45)
             return ([row for row in sol.cpu().numpy()] if it._numpy else sol), num_iters
+        if it._complex:   # hand the (re, im) pairs back as the complex type x0 came in
+            if it._numpy:
+                h = sol.cpu().numpy()
+                return h.view(np.complex128 if h.dtype == np.float64 else np.complex64).reshape(np.shape(it.x0)), num_iters
+            return torch.view_as_complex(sol.view(-1, 2)).reshape(it.x0.shape), num_iters
         return (sol.cpu().numpy().reshape(np.shape(it.x0)) if it._numpy else sol), num_iters
 
 

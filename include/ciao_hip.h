@@ -58,14 +58,22 @@ enum { CIAO_F32 = 0, CIAO_F64 = 1 };
 enum {
     CIAO_LOSS_LS = 0,       /* LeastSquares(a_i' (1 x d), [b_i], lam): f_i(x) = lam/2 (a_i'x - b_i)^2   test/test_lasso.jl:54 */
     CIAO_LOSS_LOGISTIC = 1, /* Precompose(LogisticLoss([y_i],1), a_i', 1): log(1+exp(-y_i a_i'x))        test/test_logistic_l1.jl:36 */
-    CIAO_LOSS_ZERO = 2      /* Zero(): the default F = fill(Zero(), N)                                   SVRG/SVRG.jl:58 */
+    CIAO_LOSS_ZERO = 2,     /* Zero(): the default F = fill(Zero(), N)                                   SVRG/SVRG.jl:58 */
+    /* Complex T (src/CIAOAlgorithms.jl:3 RealOrComplex; test/test_lasso.jl:3 runs ComplexF32/64): LeastSquares with a complex
+     * row and target, f_i(x) = lam/2 |a_i.x - b_i|^2, grad = lam conj(a_i) (a_i.x - b_i).  Every complex vector is stored as
+     * interleaved (re, im) pairs of the REAL dtype -- what reinterpret(R, ::Vector{Complex{R}}) gives: d and ld count reals
+     * (d = 2 x the complex length, even), A is N x ld, b holds N pairs, tables N x d.  Correctness path: one wave per row, no
+     * tuning. */
+    CIAO_LOSS_LS_COMPLEX = 3
 };
 
 /* g families (rows O3, O4) */
 enum {
     CIAO_PROX_ZERO = 0, /* Zero(): prox = identity                       SVRG/SVRG.jl:49             */
     CIAO_PROX_L1 = 1,   /* NormL1(lam): soft threshold at gamma*lam      test/test_lasso.jl:59       */
-    CIAO_PROX_BOX = 2   /* IndBox(lo, hi): clamp, scalar or per-coordinate  test/test_sharing.jl:16   */
+    CIAO_PROX_BOX = 2,  /* IndBox(lo, hi): clamp, scalar or per-coordinate  test/test_sharing.jl:16   */
+    CIAO_PROX_L1_COMPLEX = 3   /* NormL1(lam) on complex coordinates stored as (re, im) pairs: y = sign(x) max(|x| - gamma lam, 0)
+                                  with the complex modulus and sign; d must be even */
 };
 
 /* Packed F = [f_1 .. f_N] (replaces the reference's Vector of N one-row operator objects, test/test_lasso.jl:50-58).

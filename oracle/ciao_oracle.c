@@ -23,6 +23,7 @@
 #define R_LOG log
 #define R_SQRT sqrt
 #define R_FABS fabs
+#define R_HYPOT hypot
 #define R_EPS DBL_EPSILON
 #include "ciao_oracle_impl.inc"
 #undef R
@@ -31,6 +32,7 @@
 #undef R_LOG
 #undef R_SQRT
 #undef R_FABS
+#undef R_HYPOT
 #undef R_EPS
 
 /* ---- fp32 instance (the reference keeps Float32 problems in Float32: test_lasso.jl:74) ---- */
@@ -40,6 +42,7 @@
 #define R_LOG logf
 #define R_SQRT sqrtf
 #define R_FABS fabsf
+#define R_HYPOT hypotf
 #define R_EPS FLT_EPSILON
 #include "ciao_oracle_impl.inc"
 #undef R
@@ -48,6 +51,7 @@
 #undef R_LOG
 #undef R_SQRT
 #undef R_FABS
+#undef R_HYPOT
 #undef R_EPS
 
 /*

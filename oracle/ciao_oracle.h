@@ -24,8 +24,10 @@
 extern "C" {
 #endif
 
-enum { ORC_LOSS_LS = 0, ORC_LOSS_LOGISTIC = 1, ORC_LOSS_ZERO = 2 };
-enum { ORC_PROX_ZERO = 0, ORC_PROX_L1 = 1, ORC_PROX_BOX = 2 };
+/* ORC_LOSS_LS_COMPLEX / ORC_PROX_L1_COMPLEX: complex T (CIAOAlgorithms.jl:3) with every complex vector stored as interleaved
+ * (re, im) pairs of R, i.e. reinterpret(R, ::Vector{Complex{R}}): d counts reals (even), b holds N pairs. */
+enum { ORC_LOSS_LS = 0, ORC_LOSS_LOGISTIC = 1, ORC_LOSS_ZERO = 2, ORC_LOSS_LS_COMPLEX = 3 };
+enum { ORC_PROX_ZERO = 0, ORC_PROX_L1 = 1, ORC_PROX_BOX = 2, ORC_PROX_L1_COMPLEX = 3 };
 
 /* F = [f_1..f_N] packed: row-major A (N x d), b (N) = targets (LS) or labels (logistic), lam = LeastSquares λ. */
 typedef struct {
@@ -48,7 +50,7 @@ typedef struct {
 } orc_prox_desc;
 
 #define ORC_DECL(R, S)                                                                                          \
-    R orc_gradient_##S(int loss, int64_t d, const R *a, R bi, R lam, const R *x, R *y);                        \
+    R orc_gradient_##S(int loss, int64_t d, const R *a, const R *bp, R lam, const R *x, R *y);                 \
     void orc_prox_##S(const orc_prox_desc *g, int64_t d, const R *x, R gamma, R *y);                           \
     void orc_full_pass_##S(const orc_problem *p, const R *x, R *av, R *tmp);                                   \
     void orc_svrg_init_##S(const orc_problem *p, const R *x0, R *av, R *z, R *z_full, R *w);                   \

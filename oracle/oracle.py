@@ -17,8 +17,20 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CIAO_ORACLE_LIB selects another build of the same sources (the AddressSanitizer/UBSan one from `make -C oracle asan`)
 _LIB_PATH = os.environ.get("CIAO_ORACLE_LIB") or os.path.join(_HERE, "libciao_oracle.so")
 
-LOSS_LS, LOSS_LOGISTIC, LOSS_ZERO = 0, 1, 2
-PROX_ZERO, PROX_L1, PROX_BOX = 0, 1, 2
+LOSS_LS, LOSS_LOGISTIC, LOSS_ZERO, LOSS_LS_COMPLEX = 0, 1, 2, 3
+PROX_ZERO, PROX_L1, PROX_BOX, PROX_L1_COMPLEX = 0, 1, 2, 3
+
+
+def as_pairs(a):
+    """A complex array as interleaved (re, im) pairs of its real type -- Julia's reinterpret(R, a); real arrays unchanged."""
+    a = np.ascontiguousarray(a)
+    return a.view(a.real.dtype) if np.iscomplexobj(a) else a
+
+
+def as_complex(a):
+    """The inverse view: (re, im) pairs -> complex."""
+    a = np.ascontiguousarray(a)
+    return a.view(np.complex128 if a.dtype == np.float64 else np.complex64)
 
 
 class _Problem(C.Structure):
@@ -52,7 +64,7 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         for sfx, ct in (("f64", C.c_double), ("f32", C.c_float)):
             getattr(_lib, f"orc_gradient_{sfx}").restype = ct
-            getattr(_lib, f"orc_gradient_{sfx}").argtypes = [C.c_int, C.c_int64, C.c_void_p, ct, ct, C.c_void_p, C.c_void_p]
+            getattr(_lib, f"orc_gradient_{sfx}").argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, ct, C.c_void_p, C.c_void_p]
             getattr(_lib, f"orc_objective_{sfx}").restype = C.c_double
             getattr(_lib, f"orc_julia_sum_scalar_{sfx}").restype = ct
             getattr(_lib, f"orc_julia_sum_scalar_{sfx}").argtypes = [C.c_int64, C.c_void_p, C.c_int]
@@ -95,13 +107,20 @@ class Problem:
     """Packed F = [f_1 .. f_N]: loss kind, row-major A (N x d), b (targets / labels), LeastSquares λ."""
 
     def __init__(self, loss, A, b=None, lam=1.0):
-        self.loss = {"ls": LOSS_LS, "logistic": LOSS_LOGISTIC, "zero": LOSS_ZERO}.get(loss, loss)
+        self.loss = {"ls": LOSS_LS, "logistic": LOSS_LOGISTIC, "zero": LOSS_ZERO, "ls_complex": LOSS_LS_COMPLEX}.get(loss, loss)
+        if np.iscomplexobj(A):   # complex T: LeastSquares on (re, im) pairs; d counts reals, b holds N pairs
+            assert self.loss in (LOSS_LS, LOSS_LS_COMPLEX)
+            self.loss = LOSS_LS_COMPLEX
+            A = as_pairs(A)
+            b = as_pairs(np.asarray(b, dtype=np.result_type(A.dtype, np.complex64)))
         self.A = np.ascontiguousarray(A)
         self.dtype = self.A.dtype
         _sfx(self.dtype)
         self.N, self.d = self.A.shape
         self.b = None if b is None else np.ascontiguousarray(b, dtype=self.dtype)
-        if self.loss != LOSS_ZERO:
+        if self.loss == LOSS_LS_COMPLEX:
+            assert self.d % 2 == 0 and self.b.shape == (2 * self.N,)
+        elif self.loss != LOSS_ZERO:
             assert self.b is not None and self.b.shape == (self.N,)
         self.lam = float(lam)
         self._c = _Problem(self.loss, 0, self.N, self.d, self.A.ctypes.data,
@@ -116,7 +135,7 @@ class Prox:
     """g: ('zero',) | ('l1', lam) | ('box', lo, hi) with scalar or per-coordinate bounds."""
 
     def __init__(self, kind="zero", lam=0.0, lo=-np.inf, hi=np.inf, dtype=np.float64):
-        self.kind = {"zero": PROX_ZERO, "l1": PROX_L1, "box": PROX_BOX}.get(kind, kind)
+        self.kind = {"zero": PROX_ZERO, "l1": PROX_L1, "box": PROX_BOX, "l1_complex": PROX_L1_COMPLEX}.get(kind, kind)
         self.lam = float(lam)
         self._lo_vec = self._hi_vec = None
         lo_s, hi_s = -np.inf, np.inf
@@ -143,10 +162,11 @@ class Prox:
 # ---------------------------------------------------------------------------------------------------------
 
 def gradient(loss, a, bi, lam, x):
-    """gradient(f_i, x) -> (grad, f_i(x))"""
+    """gradient(f_i, x) -> (grad, f_i(x)); for LOSS_LS_COMPLEX a, x are (re, im) pairs and bi the target's pair"""
     dt = a.dtype
     y = np.empty_like(x)
-    f = getattr(lib(), f"orc_gradient_{_sfx(dt)}")(int(loss), a.shape[0], _p(a), _ct(dt)(bi), _ct(dt)(lam), _p(x), _p(y))
+    bp = np.ascontiguousarray(np.atleast_1d(bi), dtype=dt)
+    f = getattr(lib(), f"orc_gradient_{_sfx(dt)}")(int(loss), a.shape[0], _p(a), _p(bp), _ct(dt)(lam), _p(x), _p(y))
     return y, f
 
 

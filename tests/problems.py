@@ -48,13 +48,27 @@ def lasso_known_answer(N=6, n=3, p=2, seed=0, dtype=np.float64, rho=10.0, lam=1.
     b = A @ x_star + y_star
     f_star = 0.5 * np.linalg.norm(A @ x_star - b) ** 2 + lam * np.abs(x_star).sum()
     L = N * np.sum(A ** 2, axis=1)
+    if np.dtype(dtype).kind == "c":   # T = ComplexF32 / ComplexF64 (test_lasso.jl:3): the same REAL data in complex containers,
+        R = np.zeros(1, dtype).real.dtype     # exactly as the reference builds it (rand(R, ...), zeros(T, n)); L stays real
+        return (A.astype(dtype), b.astype(dtype), L.astype(R), lam, np.zeros(n, dtype), x_star.astype(dtype), f_star)
     return (A.astype(dtype), b.astype(dtype), L.astype(dtype), lam, np.zeros(n, dtype), x_star, f_star)
 
 
 def lasso_cost(A, b, lam, x):
-    """cost_lasso of test/test_lasso.jl:45 (evaluated in float64)."""
-    A, b, x = (np.asarray(v, np.float64) for v in (A, b, x))
-    return 0.5 * np.linalg.norm(A @ x - b) ** 2 + lam * np.abs(x).sum()
+    """cost_lasso of test/test_lasso.jl:45 (evaluated in float64 / complex128)."""
+    wide = np.complex128 if any(np.iscomplexobj(v) for v in (A, b, x)) else np.float64
+    A, b, x = (np.asarray(v, wide) for v in (A, b, x))
+    return float(0.5 * np.linalg.norm(A @ x - b) ** 2 + lam * np.abs(x).sum())
+
+
+def synthetic_complex(N, n, dtype=np.complex128, seed=1):
+    """A genuinely complex least-squares problem: A (N x n), b (N), x (n) with independent real and imaginary parts."""
+    rng = np.random.default_rng(seed)
+    A = ((rng.standard_normal((N, n)) + 1j * rng.standard_normal((N, n))) / np.sqrt(2 * n)).astype(dtype)
+    x_true = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * (rng.random(n) < 0.2)
+    b = (A.astype(np.complex128) @ x_true + 0.01 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(dtype)
+    x = (0.3 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(dtype)
+    return A, b, x
 
 
 def synthetic(loss, N, d, dtype=np.float64, seed=1):

@@ -1,0 +1,247 @@
+"""GPU parity for complex T (CIAOAlgorithms.jl:3 `RealOrComplex`; test_lasso.jl:3 runs ComplexF32 / ComplexF64): every entry
+point that accepts CIAO_LOSS_LS_COMPLEX / CIAO_PROX_L1_COMPLEX against the CPU oracle on GENUINELY complex data
+(independent real and imaginary parts), vectors as interleaved (re, im) pairs of the real type.
+
+The reference's own complex tests hold real data in complex containers; those run in test_gpu_solvers.py::TestLassoComplex.
+Tolerances as in test_gpu_parity.py: scale * eps(R) * |oracle|_inf, scale written at each comparison.
+"""
+import numpy as np
+import pytest
+
+import problems as P
+from test_gpu_parity import close, dev, _batches
+
+pytestmark = pytest.mark.gpu
+
+RTYPE = {np.complex128: np.float64, np.complex64: np.float32}
+# complex entries per row n (d = 2n reals): below / at / across the wave-per-row and LDS-resident shapes
+CSHAPES = [(6, 3), (8, 5), (50, 50), (40, 128), (30, 300), (12, 512), (33, 1000), (9, 2048), (7, 4097)]
+
+
+def cmake(A, b, lam_f):
+    """(oracle Problem, device PackedF) over the same complex data."""
+    import torch
+    from oracle import oracle as O
+    from ciaoalgorithms_jl_amd.device import PackedF
+    op = O.Problem("ls", A, b, lam_f)
+    N = A.shape[0]
+    tA = torch.from_numpy(O.as_pairs(A).reshape(N, -1)).cuda()
+    tb = torch.from_numpy(O.as_pairs(b)).cuda()
+    return op, PackedF.least_squares_complex(tA, tb, lam_f)
+
+
+def cg(lam):
+    from oracle import oracle as O
+    from ciaoalgorithms_jl_amd.device import ProxG
+    import ciaoalgorithms_jl_amd._lib as L
+    return O.Prox("l1_complex", lam=lam), ProxG(L.PROX_L1_COMPLEX, lam=lam)
+
+
+@pytest.mark.parametrize("ctype", [np.complex128, np.complex64])
+def test_complex_gradient_prox_objective(ctx, ctype):
+    import torch
+    from oracle import oracle as O
+    R = RTYPE[ctype]
+    for N, n in ((9, 35), (5, 700)):
+        A, b, x = P.synthetic_complex(N, n, ctype, seed=n)
+        op, dp = cmake(A, b, 9.0)
+        xp = O.as_pairs(x)
+        y = torch.empty(2 * n, dtype=dev(xp).dtype, device="cuda")
+        fv = torch.empty(1, dtype=y.dtype, device="cuda")
+        for i in (0, N // 2, N - 1):
+            ctx.gradient(dp, i, dev(xp), y, fv)
+            gy, f = O.gradient(op.loss, O.as_pairs(A[i]), O.as_pairs(b[i:i + 1]), 9.0, xp)
+            close(y, gy, R, scale=1000, what=f"complex gradient i={i}")
+            close(fv, [f], R, scale=2000, what="complex f_i value")
+        og, dg = cg(0.3)
+        ctx.prox(dg, dev(xp), 0.5, y)
+        # the modulus goes through hypot: libm's and the device's may differ in the last place
+        close(y, O.prox(og, xp, R(0.5)), R, scale=8, what="complex prox")
+        yh = y.cpu().numpy()
+        ref = O.prox(og, xp, R(0.5))
+        assert np.array_equal(yh == 0, ref == 0) or np.abs(np.hypot(xp[0::2], xp[1::2]) - 0.15).min() < 1e-6
+        obj = ctx.objective(dp, dg, dev(xp))
+        robj = O.objective(op, og, xp)
+        assert abs(obj - robj) <= (1e-9 if R == np.float64 else 2e-4) * max(1.0, abs(robj))
+
+
+@pytest.mark.parametrize("ctype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("shape", CSHAPES)
+def test_complex_full_pass_and_proxgrad(ctx, ctype, shape):
+    import torch
+    from oracle import oracle as O
+    R = RTYPE[ctype]
+    N, n = shape
+    A, b, x = P.synthetic_complex(N, n, ctype, seed=N + n)
+    op, dp = cmake(A, b, float(N))
+    og, dg = cg(0.01)
+    xp = O.as_pairs(x)
+    av = torch.empty(2 * n, dtype=dev(xp).dtype, device="cuda")
+    ctx.full_gradient(dp, dev(xp), av)
+    assert "cplx" in ctx.last_kernel(), ctx.last_kernel()
+    rav = O.full_pass(op, xp)
+    # independent statement of the sum in numpy complex arithmetic
+    A128, x128 = A.astype(np.complex128), x.astype(np.complex128)
+    want = (float(N) * (A128.conj().T @ (A128 @ x128 - b.astype(np.complex128)))) / N
+    close(av, O.as_pairs(want), R, scale=200, what="complex full pass vs numpy complex")
+    close(av, rav, R, scale=200, what=f"complex full pass ({ctx.last_kernel()})")
+    y = torch.empty_like(av)
+    ctx.proxgrad_step(dp, dg, 0.05, dev(xp), av, y)
+    ry = O.prox(og, (xp - R(0.05) * rav).astype(R), R(0.05))
+    close(y, ry, R, scale=20, what="complex proxgrad y")
+    # the monitor rides on the same pass
+    obj = torch.full((3,), float("nan"), dtype=torch.float64, device="cuda")
+    ctx.set_monitor(dg, obj)
+    try:
+        ctx.full_gradient(dp, dev(xp), av)
+        ctx.synchronize()
+        ref = O.objective(op, og, xp)
+        assert abs(obj[0].item() - ref) <= (1e-11 if R == np.float64 else 5e-5) * max(1.0, abs(ref))
+    finally:
+        ctx.set_monitor(None, None)
+
+
+@pytest.mark.parametrize("ctype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("shape", CSHAPES)
+def test_complex_svrg_epochs(ctx, ciao, ctype, shape):
+    import torch
+    from oracle import oracle as O
+    R = RTYPE[ctype]
+    N, n = shape
+    A, b, x0 = P.synthetic_complex(N, n, ctype, seed=7)
+    op, dp = cmake(A, b, float(N))
+    og, dg = cg(0.01)
+    gamma = 1.0 / (7 * float(N) * np.max(np.sum(np.abs(A.astype(np.complex128)) ** 2, axis=1)))
+    xp = O.as_pairs(x0)
+    tdt = dev(xp).dtype
+    av, z, zf, w = (torch.empty(2 * n, dtype=tdt, device="cuda") for _ in range(4))
+    ctx.svrg_init(dp, dev(xp), av, z, zf, w)
+    rav, rz, rzf, rw = O.svrg_init(op, xp)
+    close(av, rav, R, scale=200, what="complex svrg_init av")
+    st = ciao.IndexStream(5)
+    for ep in range(3):
+        idx = st.rand_indices(N, 2 * N)
+        ctx.svrg_iterate(dp, dg, gamma, idx, ep == 1, av, z, zf, w)
+        O.svrg_iterate(op, og, R(gamma), idx, ep == 1, rav, rz, rzf, rw)
+        close(zf, rzf, R, scale=2000, what=f"complex svrg epoch {ep} z_full ({ctx.last_kernel()})")
+        close(w, rw, R, scale=2000, what=f"complex svrg epoch {ep} w")
+        close(av, rav, R, scale=500, what=f"complex svrg epoch {ep} av")
+    ctx.synchronize()
+
+
+@pytest.mark.parametrize("ctype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("sag", [False, True])
+@pytest.mark.parametrize("shape", CSHAPES)
+def test_complex_saga_steps(ctx, ciao, ctype, sag, shape):
+    import torch
+    from oracle import oracle as O
+    R = RTYPE[ctype]
+    N, n = shape
+    A, b, x0 = P.synthetic_complex(N, n, ctype, seed=9)
+    op, dp = cmake(A, b, float(N))
+    og, dg = cg(0.02)
+    gamma = 1.0 / ((16 if sag else 3) * float(N) * np.max(np.sum(np.abs(A.astype(np.complex128)) ** 2, axis=1)))
+    xp = O.as_pairs(x0)
+    tdt = dev(xp).dtype
+    table = torch.empty((N, 2 * n), dtype=tdt, device="cuda")
+    av, z = torch.empty(2 * n, dtype=tdt, device="cuda"), torch.empty(2 * n, dtype=tdt, device="cuda")
+    ctx.saga_init(dp, dg, gamma, dev(xp), table, av, z)
+    rt, rav, rz = O.saga_init(op, og, R(gamma), xp)
+    close(table, rt, R, scale=100, what="complex saga_init table")
+    close(av, rav, R, scale=100, what="complex saga_init av")
+    close(z, rz, R, scale=20, what="complex saga_init z")
+    st = ciao.IndexStream(21)
+    for chunk in (1, 2, 4 * N, 7):
+        idx = st.rand_indices(N, chunk)
+        if chunk == 7:
+            idx[:] = idx[0]
+        ctx.saga_steps(dp, dg, gamma, sag, idx, table, av, z)
+        O.saga_steps(op, og, R(gamma), sag, idx, rt, rav, rz)
+        close(z, rz, R, scale=500, what=f"complex saga z after chunk {chunk} ({ctx.last_kernel()})")
+        close(av, rav, R, scale=500, what=f"complex saga av after chunk {chunk}")
+        close(table, rt, R, scale=1000, what=f"complex saga table after chunk {chunk}")
+    close(av, table.double().mean(dim=0).cpu().numpy(), R, scale=200, what="complex av invariant")
+    ctx.synchronize()
+
+
+@pytest.mark.parametrize("ctype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("shape,r", [((6, 3), 1), ((8, 5), 3), ((50, 50), 7), ((64, 512), 16), ((300, 32), 100), ((20, 750), 4),
+                                     ((700, 512), 300), ((12, 4097), 5)])
+@pytest.mark.parametrize("path", ["chain", "rows"])
+def test_complex_finito_and_lfinito(ctx, ciao, ctype, shape, r, path):
+    import torch
+    from oracle import oracle as O
+    R = RTYPE[ctype]
+    N, n = shape
+    A, b, x0 = P.synthetic_complex(N, n, ctype, seed=4)
+    op, dp = cmake(A, b, float(N))
+    og, dg = cg(0.02)
+    Li = float(N) * np.sum(np.abs(A.astype(np.complex128)) ** 2, axis=1)
+    gam = (0.999 * N / Li).astype(R)
+    xp = O.as_pairs(x0)
+    tdt = dev(xp).dtype
+    table = torch.empty((N, 2 * n), dtype=tdt, device="cuda")
+    av, z, zf = (torch.empty(2 * n, dtype=tdt, device="cuda") for _ in range(3))
+    dgam = dev(gam)
+    hg = ctx.hat_gamma(dgam)
+    rt, rav, rz, rhg = O.finito_init(op, og, gam, xp)
+    ctx.finito_init(dp, dg, dgam, hg, dev(xp), table, av, z)
+    close(table, rt, R, scale=50, what="complex finito_init table")
+    close(av, rav, R, scale=200, what="complex finito_init av")
+    close(z, rz, R, scale=200, what="complex finito_init z")
+    ctx.set_option("chain_max_batch", 64 if path == "chain" else 0)
+    try:
+        st = ciao.IndexStream(33)
+        for mode, nit in (("random", 5), ("cyclic", 2 * (-(-N // r)) + 1)):
+            batches = _batches(st, N, r, nit, mode)
+            bptr = np.zeros(nit + 1, np.int64)
+            np.cumsum([len(x) for x in batches], out=bptr[1:])
+            ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(batches), table, av, z)
+            O.finito_steps(op, og, gam, rhg, batches, rt, rav, rz)
+            close(z, rz, R, scale=20000, what=f"complex finito z {mode} ({ctx.last_kernel()})")
+            close(av, rav, R, scale=20000, what=f"complex finito av {mode}")
+            close(table, rt, R, scale=20000, what=f"complex finito table {mode}")
+        # LFinito over the same problem
+        rav, rz, rzf, rhg = O.lfinito_init(op, gam, xp)
+        ctx.lfinito_init(dp, hg, dev(xp), av, z, zf)
+        close(av, rav, R, scale=500, what="complex lfinito_init av")
+        nb = -(-N // r)
+        static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in range(nb)]
+        for it in range(2):
+            order = np.arange(nb) if it == 0 else st.randperm(nb)
+            batches = [static[j] for j in order]
+            bptr = np.zeros(nb + 1, np.int64)
+            np.cumsum([len(x) for x in batches], out=bptr[1:])
+            ctx.lfinito_iterate(dp, dg, dgam, hg, bptr, np.concatenate(batches), av, z, zf)
+            O.lfinito_iterate(op, og, gam, rhg, batches, rav, rz, rzf)
+            close(zf, rzf, R, scale=5000, what=f"complex lfinito z_full it {it}")
+            close(z, rz, R, scale=10000, what=f"complex lfinito z it {it} ({ctx.last_kernel()})")
+            close(av, rav, R, scale=10000, what=f"complex lfinito av it {it}")
+    finally:
+        ctx.set_option("chain_max_batch", -1)
+    ctx.synchronize()
+
+
+def test_complex_argument_validation(ctx, ciao):
+    """Complex rows pair only with Zero / the complex NormL1; odd d, IndBox, the real NormL1, adaptive Finito are refused."""
+    import torch
+    from ciaoalgorithms_jl_amd.device import PackedF, ProxG
+    import ciaoalgorithms_jl_amd._lib as L
+    from oracle import oracle as O
+    A, b, x = P.synthetic_complex(6, 8, np.complex128)
+    _, dp = cmake(A, b, 6.0)
+    xp = dev(O.as_pairs(x))
+    av = torch.empty_like(xp)
+    y = torch.empty_like(xp)
+    for bad in (ProxG(L.PROX_L1, lam=0.1), ProxG(L.PROX_BOX, lo=-1.0, hi=1.0)):
+        with pytest.raises(ciao._lib.CiaoError):
+            ctx.proxgrad_step(dp, bad, 0.1, xp, av, y)
+    # the complex prox on a real problem is refused too
+    Ar, br, xr = P.synthetic("ls", 6, 16, np.float64)
+    dpr = PackedF.least_squares(dev(Ar), dev(br), 6.0)
+    with pytest.raises(ciao._lib.CiaoError):
+        ctx.proxgrad_step(dpr, ProxG(L.PROX_L1_COMPLEX, lam=0.1), 0.1, dev(xr), torch.empty(16, dtype=torch.float64, device="cuda"),
+                          torch.empty(16, dtype=torch.float64, device="cuda"))
+    # an odd number of reals is not a vector of pairs
+    with pytest.raises(ciao._lib.CiaoError):
+        ctx.prox(ProxG(L.PROX_L1_COMPLEX, lam=0.1), xp[:7], 0.5, y[:7])

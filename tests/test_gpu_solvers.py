@@ -150,7 +150,7 @@ class TestLogisticL1:
 
 
 # ======================================================================================================================
-# test/test_lasso.jl  (real types only: complex T is outside the device path)
+# test/test_lasso.jl  (real T here; T = ComplexF32 / ComplexF64 in TestLassoComplex below)
 # ======================================================================================================================
 @pytest.mark.parametrize("T", [np.float32, np.float64])
 class TestLasso:
@@ -249,6 +249,93 @@ class TestLasso:
         first = next(iter(S.iterator(mk(γ=γ), x0, F=F, g=g, N=N)))
         x1, n1 = mk(γ=γ, maxit=1)(x0, F=F, g=g, L=L, N=N)
         assert np.array_equal(S.solution(first).cpu().numpy(), x1)
+
+
+# ======================================================================================================================
+# test/test_lasso.jl for T in (ComplexF32, ComplexF64)  (test_lasso.jl:3): x0 = zeros(T, n), A and b real data in complex
+# containers, R = real(T) the solver parameter (:5); the solution comes back with eltype T
+# ======================================================================================================================
+@pytest.mark.parametrize("T", [np.complex64, np.complex128])
+class TestLassoComplex:
+    maxit, tol = 1000, 1e-4
+
+    @staticmethod
+    def R(T):
+        return np.zeros(1, T).real.dtype.type
+
+    def check(self, x, T, cost, f_star):
+        assert x.dtype == T and cost(x) - f_star < self.tol
+        assert not np.any(x.imag), "real data in complex containers: the imaginary parts stay exactly zero"
+
+    @pytest.mark.parametrize("sweeping", [1, 2, 3])
+    def test_basic_finito(self, api, T, sweeping):                          # :70-75
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        x, it = S.Finito(self.R(T), maxit=self.maxit, sweeping=sweeping)(x0, F=F, g=g, L=L, N=N)
+        self.check(x, T, cost, f_star)
+
+    @pytest.mark.parametrize("sweeping", [2, 3])
+    def test_lfinito(self, api, T, sweeping):                               # :78-85
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        x, it = S.Finito(self.R(T), maxit=self.maxit, sweeping=sweeping, LFinito=True)(x0, F=F, g=g, L=L, N=N)
+        self.check(x, T, cost, f_star)
+
+    @pytest.mark.parametrize("sweeping,batch,lf", [(1, 2, False), (2, 2, False), (3, 3, False), (2, 1, True), (3, 3, True)])
+    def test_minibatch(self, api, T, sweeping, batch, lf):                  # :101-125
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        x, it = S.Finito(self.R(T), maxit=self.maxit, sweeping=sweeping, LFinito=lf, minibatch=(True, batch))(
+            x0, F=F, g=g, L=L, N=N)
+        self.check(x, T, cost, f_star)
+
+    def test_svrg(self, api, T):                                            # :164-176
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        γ = float(1 / (7 * np.max(L)))
+        x, it = S.SVRG(self.R(T), maxit=self.maxit, γ=γ)(x0, F=F, g=g, N=N)
+        self.check(x, T, cost, f_star)
+        x, it = S.SVRG(self.R(T), maxit=16, γ=γ, m=1, plus=True)(x0, F=F, g=g, N=N)
+        self.check(x, T, cost, f_star)
+
+    @pytest.mark.parametrize("sag", [False, True])
+    def test_saga_sag(self, api, T, sag):                                   # :199-266
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        mk = (lambda **kw: S.SAG(self.R(T), **kw)) if sag else (lambda **kw: S.SAGA(self.R(T), **kw))
+        x, it = mk(maxit=10000 if sag else self.maxit)(x0, F=F, g=g, N=N, L=L)
+        self.check(x, T, cost, f_star)
+
+    def test_device_resident_complex_x0(self, api, T):
+        """torch complex x0 on the device in, the same complex dtype (and device) out."""
+        import torch
+        S, ops = api
+        A, b, L, lam, x0, x_star, f_star = P.lasso_known_answer(dtype=T)
+        N = A.shape[0]
+        F = [ops.LeastSquares(A[i:i + 1, :], b[i:i + 1], float(N)) for i in range(N)]
+        tx0 = torch.from_numpy(x0).cuda()
+        x, it = S.SAGA(self.R(T), maxit=self.maxit)(tx0, F=F, g=ops.NormL1(lam), N=N, L=L)
+        assert x.is_cuda and x.dtype == tx0.dtype and x.shape == tx0.shape
+        assert P.lasso_cost(A, b, lam, x.cpu().numpy()) - f_star < self.tol
+
+    def test_mixed_real_and_complex_is_a_type_error(self, api, T):
+        """One type T for the whole problem (CIAOAlgorithms.jl:3): complex rows with a real x0, complex x0
+        with IndBox, and the adaptive / ProShI variants (no complex form on the device path) are refused, not demoted."""
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        R = self.R(T)
+        Fr, gr, Lr, x0r, *_ = lasso_problem(ops, R)
+        with pytest.raises(TypeError):
+            S.SAGA(R, maxit=3)(x0r, F=F, g=g, N=N, L=L)
+        # real rows with a complex x0 are well defined (real A times complex x, as LeastSquares does in the reference): the rows
+        # are widened to T, and the run is the complex run
+        xa, _ = S.SAGA(R, maxit=50)(x0, F=Fr, g=g, N=N, L=L)
+        xb, _ = S.SAGA(R, maxit=50)(x0, F=F, g=g, N=N, L=L)
+        assert xa.dtype == T and np.array_equal(xa, xb)
+        with pytest.raises(TypeError):
+            S.SAGA(R, maxit=3)(x0, F=F, g=ops.IndBox(-1.0, 1.0), N=N, L=L)
+        with pytest.raises(TypeError):
+            S.Finito(R, maxit=3, adaptive=True)(x0, F=F, g=g, N=N, L=L)
 
 
 # ======================================================================================================================
@@ -460,5 +547,5 @@ def test_packing_rows_from_a_host_matrix_stream(api, ctx, tmp_path):
         assert x.dtype == R and it == 4 and np.isfinite(x).all()
     with pytest.raises(ValueError):
         ops.pack_rows_from_host(iter([(ro[:10], b[:10])]), N, d, np.float64)
-    with pytest.raises(TypeError, match="no\s+host fallback|no host fallback"):
+    with pytest.raises(TypeError, match=r"no\s+host fallback|no host fallback"):
         S.SVRG(np.float64, γ=0.1, maxit=2)(np.zeros(d), F=[object()] * 3, N=3, ctx=ctx)

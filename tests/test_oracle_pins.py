@@ -292,3 +292,54 @@ def test_adaptive_finito_keeps_julias_float64_promotions():
     g32 = np.float32(0.3)
     differ = [g for g in (np.float32(0.1) * k for k in range(1, 200)) if np.float32(np.float64(g) * 0.8) != g * np.float32(0.8)]
     assert differ, "the two roundings must be distinguishable, or the promotion would not matter"
+
+
+# ---- (6) complex T (CIAOAlgorithms.jl:3; test_lasso.jl:3 runs ComplexF32 / ComplexF64) --------------------------------------
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_complex_operators_against_numpy_complex_arithmetic(dtype):
+    """LeastSquares with a complex row (grad = lam * conj(a) * (a.x - b), value lam/2 |res|^2) and the complex NormL1 prox
+    (sign(x) max(|x| - gl, 0)) on (re, im) pairs, against numpy's complex arithmetic."""
+    A, b, x = P.synthetic_complex(7, 33, dtype, seed=4)
+    lam = 7.0
+    tol = 50 * np.finfo(A.real.dtype).eps
+    for i in (0, 3, 6):
+        y, f = O.gradient(O.LOSS_LS_COMPLEX, O.as_pairs(A[i]), O.as_pairs(b[i:i + 1]), lam, O.as_pairs(x))
+        res = A[i].astype(np.complex128) @ x.astype(np.complex128) - complex(b[i])
+        want = lam * np.conj(A[i].astype(np.complex128)) * res
+        assert np.abs(O.as_complex(y) - want).max() <= tol * np.abs(want).max()
+        assert abs(f - lam / 2 * abs(res) ** 2) <= tol * abs(f)
+    g = O.Prox("l1_complex", lam=0.3)
+    y = O.as_complex(O.prox(g, O.as_pairs(x), x.real.dtype.type(0.5)))
+    x128 = x.astype(np.complex128)
+    want = x128 / np.abs(x128) * np.maximum(np.abs(x128) - 0.15, 0)
+    assert np.abs(y - want).max() <= tol and np.count_nonzero(y == 0) > 0
+    p = O.Problem("ls", A, b, lam)
+    assert p.loss == O.LOSS_LS_COMPLEX and p.d == 66
+    obj = O.objective(p, g, O.as_pairs(x))
+    want = 0.5 * lam * np.mean(np.abs(A.astype(np.complex128) @ x128 - b) ** 2) + 0.3 * np.abs(x128).sum()
+    assert abs(obj - want) <= 1e3 * tol * abs(want)
+
+
+@pytest.mark.parametrize("ctype", [np.complex128, np.complex64])
+def test_reference_complex_lasso_is_the_real_lasso_in_complex_containers(ctype, Stream):
+    """test_lasso.jl for T = ComplexF32 / ComplexF64 builds REAL data in complex arrays (rand(R, ...), zeros(T, n)).  With zero
+    imaginary parts every complex operation of the restatement reduces to the real one exactly, so the complex run must
+    reproduce the real run BIT FOR BIT (real parts) with imaginary parts exactly zero -- for every algorithm -- and meet the
+    reference's own assertion (cost gap < 1e-4, eltype preserved)."""
+    rtype = np.zeros(1, ctype).real.dtype.type
+    A, b, L, lam, x0, x_star, f_star = P.lasso_known_answer(dtype=rtype)
+    N = A.shape[0]
+    Ac, bc, Lc, _, x0c, _, _ = P.lasso_known_answer(dtype=ctype)
+    pr, gr = O.Problem("ls", A, b, float(N)), O.Prox("l1", lam=lam)
+    pc, gc = O.Problem("ls", Ac, bc, float(N)), O.Prox("l1_complex", lam=lam)
+    runs = [("svrg", lambda p, g, x: RS.svrg(p, g, x, maxit=300, gamma=1 / (7 * L.max()), stream=Stream(0))),
+            ("saga", lambda p, g, x: RS.saga(p, g, x, maxit=1000, L=L, stream=Stream(0))),
+            ("finito", lambda p, g, x: RS.finito(p, g, x, maxit=1000, sweeping=2, L=L, stream=Stream(0))),
+            ("lfinito", lambda p, g, x: RS.finito(p, g, x, maxit=300, sweeping=3, lfinito=True, batch=2, L=L, stream=Stream(0)))]
+    for name, run in runs:
+        xr, _ = run(pr, gr, x0)
+        xc, _ = run(pc, gc, O.as_pairs(x0c))
+        xc = O.as_complex(xc)
+        assert xc.dtype == ctype
+        assert np.array_equal(xc.real, xr) and not np.any(xc.imag), name
+        assert P.lasso_cost(Ac, bc, lam, xc) - f_star < 1e-4, name
