@@ -41,7 +41,7 @@ class ProxDesc(C.Structure):
 
 class SepQuad(C.Structure):
     """ciao_sepquad"""
-    _fields_ = [("dtype", C.c_int32), ("_pad", C.c_int32), ("N", C.c_int64), ("d", C.c_int64), ("ld", C.c_int64),
+    _fields_ = [("dtype", C.c_int32), ("dense", C.c_int32), ("N", C.c_int64), ("d", C.c_int64), ("ld", C.c_int64),
                 ("N_total", C.c_int64), ("Q", C.c_void_p), ("q", C.c_void_p), ("eta", C.c_double), ("lo", C.c_double),
                 ("hi", C.c_double)]
 

@@ -712,6 +712,7 @@ static ProshiArgs<T> proshi_args(const ciao_sepquad *f, const void *gam, void *t
     a.gam = (const T *)gam;
     a.invN = T(1) / (T)f->N_total;
     a.table = (T *)table;
+    a.dense = f->dense;
     return a;
 }
 
@@ -767,6 +768,7 @@ static int32_t check_sepquad(ciao_ctx *ctx, const ciao_sepquad *f)
     ctx->rowdot_A = nullptr;
     CIAO_REQUIRE(f->dtype == CIAO_F32 || f->dtype == CIAO_F64, "bad dtype %d", f->dtype);
     CIAO_REQUIRE(f->N >= 0 && f->d >= 1 && f->ld >= f->d && f->N_total >= f->N && f->N_total >= 1, "bad shape");
+    CIAO_REQUIRE(f->dense == 0 || f->dense == 1, "ciao_sepquad.dense must be 0 or 1 (got %d)", f->dense);
     CIAO_REQUIRE(f->N == 0 || (f->Q && f->q), "Q or q is NULL");
     CIAO_REQUIRE(f->eta >= 0 && f->lo <= f->hi, "need eta >= 0 and lo <= hi");
     return CIAO_OK;

@@ -25,6 +25,7 @@ struct ProshiArgs {
     int64_t pstride;
     T *pextra;
     int *errflag;
+    int dense;             // Q holds N dense d x d blocks (row k of agent i at Q + (i*d + k)*ld) instead of N diagonals
 };
 
 // grad f_i(x)_k = Q_k x_k + q_k + eta (x_k - clamp(x_k, lo, hi))
@@ -171,6 +172,69 @@ __global__ void __launch_bounds__(256) proshi_vec_kernel(ProshiArgs<T> a)
     for (int j = 0; j < J; ++j)
         if (ok[j]) pout[tid + j * 256] = acc[j];
     if (tid == 0) a.pextra[blockIdx.x] = extra;
+}
+
+// Dense Quadratic(Q_i, q_i): grad f_i(x) = Q_i x + q_i + eta (x - clamp(x)) needs one d x d matrix-vector product per
+// visited agent, and the d*d*s bytes of Q_i are the traffic (the three d-vectors are noise next to them).  One workgroup per
+// agent: the point the gradient is taken at (x0, or s_i + gam_i z) is staged in LDS, every wave streams whole rows of Q_i
+// (consecutive rows of one agent are consecutive in memory, so the workgroup reads one contiguous d*ld block) and reduces
+// each dot product across its lanes in a fixed order; lane 0 finishes the element.  Row k is always handled by wave k mod 4,
+// so the workgroup's accumulator row in the workspace is updated without atomics.  Any d with d*sizeof(T) <= 64 KiB.
+template <typename T, bool INIT>
+__global__ void __launch_bounds__(256) proshi_dense_kernel(ProshiArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *sv = reinterpret_cast<T *>(smem_raw);
+    constexpr int NW = 4;
+    const int64_t d = a.d;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
+    for (int64_t e = threadIdx.x; e < d; e += 256) pout[e] = T(0);
+    T extra = T(0);
+    for (int64_t u = blockIdx.x; u < a.nrows; u += gridDim.x) {
+        int64_t row = a.idx ? a.idx[u] : a.row0 + u;
+        if ((uint64_t)row >= (uint64_t)a.N) {
+            if (threadIdx.x == 0) *a.errflag = 1;
+            row = 0;
+        }
+        const T gi = a.gam[row];
+        const T c = gi * a.invN;
+        T *sp = a.table + row * d;
+        const T *qp = a.q + row * a.ld;
+        const T *Qi = a.Q + row * d * a.ld;
+        __syncthreads();                                                    // the previous agent's dot products are done with sv
+        for (int64_t e = threadIdx.x; e < d; e += 256) sv[e] = INIT ? a.x[e] : sp[e] + gi * a.x[e];   // :77 / :112
+        __syncthreads();
+        for (int64_t k = wib; k < d; k += NW) {
+            const T *qr = Qi + k * a.ld;
+            T dot0 = T(0), dot1 = T(0), dot2 = T(0), dot3 = T(0);
+            int64_t e = lane;
+            for (; e + 3 * WAVE < d; e += 4 * WAVE) {
+                const T q0 = qr[e], q1 = qr[e + WAVE], q2 = qr[e + 2 * WAVE], q3 = qr[e + 3 * WAVE];
+                dot0 += q0 * sv[e];
+                dot1 += q1 * sv[e + WAVE];
+                dot2 += q2 * sv[e + 2 * WAVE];
+                dot3 += q3 * sv[e + 3 * WAVE];
+            }
+            for (; e < d; e += WAVE) dot0 += qr[e] * sv[e];
+            const T dot = wave_allsum((dot0 + dot1) + (dot2 + dot3));
+            if (lane == 0) {
+                const T x = sv[k];
+                const T pr = x < a.lo ? a.lo : (x > a.hi ? a.hi : x);
+                const T g = (dot + qp[k]) + a.eta * (x - pr);              // Quadratic: Q x + q ; SqrDistL2: eta (x - proj)
+                const T t = x - c * g;                                      // :79 / :114-115
+                if (INIT) {
+                    pout[k] += t;
+                } else {
+                    pout[k] += t - sp[k];                                   // :111, :116
+                }
+                sp[k] = t;                                                  // :117
+            }
+        }
+        if (INIT) extra += gi;                                              // :82  hat_γ = sum(γ)
+    }
+    if (threadIdx.x == 0) a.pextra[blockIdx.x] = extra;
 }
 
 // solution(state): s_i += γ_i z for every agent, in place (ProShI_basic.jl:127-132)

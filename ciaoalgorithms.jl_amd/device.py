@@ -137,18 +137,21 @@ class PackedF:
 
 class PackedSepQuad:
     """F = [f_1..f_N] with f_i = Sum(Quadratic(diagm(Q_i), q_i), SqrDistL2(IndBox(lo, hi), eta)) packed for the device
-    (the operator family of test/test_sharing.jl:16-25): Q, q row-major N x d device matrices."""
+    (the operator family of test/test_sharing.jl:16-25): q row-major N x d; Q the N x d diagonals, or N x d x d dense blocks."""
 
     def __init__(self, Q: torch.Tensor, q: torch.Tensor, eta: float = 0.0, lo: float = 0.0, hi: float = 0.0,
                  N_total: int | None = None, row0: int = 0):
-        assert Q.is_cuda and q.is_cuda and Q.shape == q.shape and Q.dim() == 2 and Q.dtype == q.dtype and Q.dtype in _DT
+        assert Q.is_cuda and q.is_cuda and q.dim() == 2 and Q.dtype == q.dtype and Q.dtype in _DT
         assert Q.is_contiguous() and q.is_contiguous()
+        # Q of shape N x d: the diagonals (the reference test's diagm); N x d x d: one dense matrix per agent
+        self.dense = Q.dim() == 3
+        assert (Q.shape == (q.shape[0], q.shape[1], q.shape[1])) if self.dense else (Q.shape == q.shape)
         self.Q, self.q, self.eta, self.lo, self.hi = Q, q, float(eta), float(lo), float(hi)
-        self.N, self.d = int(Q.shape[0]), int(Q.shape[1])
+        self.N, self.d = int(q.shape[0]), int(q.shape[1])
         self.dtype, self.device = Q.dtype, Q.device
         self.N_total = int(N_total) if N_total is not None else self.N
         self.row0, self.cyclic = int(row0), None
-        self._c = L.SepQuad(_DT[self.dtype], 0, self.N, self.d, self.d, self.N_total, Q.data_ptr() if self.N else None,
+        self._c = L.SepQuad(_DT[self.dtype], int(self.dense), self.N, self.d, self.d, self.N_total, Q.data_ptr() if self.N else None,
                             q.data_ptr() if self.N else None, self.eta, self.lo, self.hi)
 
     @property

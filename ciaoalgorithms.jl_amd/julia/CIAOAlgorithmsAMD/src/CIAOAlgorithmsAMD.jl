@@ -655,22 +655,24 @@ solution(state::FINITO_adaptive_state) = state.z                        # Finito
 # ProShI  (src/algorithms/ProShI/ProShI.jl, ProShI_basic.jl) -- sharing problems; the solution is the whole table
 # ======================================================================================================================
 struct CiaoSepQuad
-    dtype::Int32; _pad::Int32
+    dtype::Int32; dense::Int32
     N::Int64; d::Int64; ld::Int64; N_total::Int64
     Q::Ptr{Cvoid}; q::Ptr{Cvoid}
     eta::Float64; lo::Float64; hi::Float64
 end
 struct PackedSepQuad{R}
-    Q::ROCArray{R,2}; q::ROCArray{R,2}          # d x N column-major == N x d row-major
+    Q::ROCArray{R}                              # d x N (the diagonals) or d x d x N with Q[e, k, i] = Q_i[k, e] (dense)
+    q::ROCArray{R,2}                            # d x N column-major == N x d row-major
     eta::Float64; lo::Float64; hi::Float64; N::Int; d::Int
 end
 csepquad(f::PackedSepQuad{R}) where {R} =
-    CiaoSepQuad(dtype_code(R), 0, f.N, f.d, f.d, f.N, dptr(f.Q), dptr(f.q), f.eta, f.lo, f.hi)
+    CiaoSepQuad(dtype_code(R), Int32(ndims(f.Q) == 3), f.N, f.d, f.d, f.N, dptr(f.Q), dptr(f.q), f.eta, f.lo, f.hi)
 
-# F::Vector of Sum(Quadratic(diagonal Q, q), SqrDistL2(IndBox(lo, hi), η)) (test/test_sharing.jl:16-25) or lone Quadratic
+# F::Vector of Sum(Quadratic(Q, q), SqrDistL2(IndBox(lo, hi), η)) (test/test_sharing.jl:16-25) or lone Quadratic; all-diagonal
+# Q_i (the test's diagm) pack as d x N and run element-wise, anything else as N dense blocks
 function pack_sharing_F(::Type{R}, F, N::Int, d::Int) where {R}
     F isa PackedSepQuad{R} && return F
-    Q = Matrix{R}(undef, d, N); q = Matrix{R}(undef, d, N)
+    Qd = Array{R}(undef, d, d, N); q = Matrix{R}(undef, d, N)
     eta, lo, hi = nothing, 0.0, 0.0
     for i in 1:N
         parts = F[i] isa ProximalOperators.Sum ? collect(F[i].fs) : [F[i]]
@@ -679,8 +681,8 @@ function pack_sharing_F(::Type{R}, F, N::Int, d::Int) where {R}
         (length(quad) == 1 && length(dist) <= 1 && length(quad) + length(dist) == length(parts)) ||
             throw(ArgumentError("ProShI device path: each f_i must be Quadratic or Sum(Quadratic, SqrDistL2(IndBox, η))"))
         Qi = Matrix(quad[1].Q)
-        (size(Qi) == (d, d) && isdiag(Qi)) || throw(ArgumentError("ProShI device path: only diagonal Quadratic terms are packable"))
-        Q[:, i] .= diag(Qi); q[:, i] .= quad[1].q
+        size(Qi) == (d, d) || throw(ArgumentError("ProShI device path: Quadratic terms must be d x d"))
+        Qd[:, :, i] .= transpose(Qi); q[:, i] .= quad[1].q        # row k of Q_i contiguous
         e, l, h = 0.0, 0.0, 0.0
         if !isempty(dist)
             box = dist[1].ind
@@ -691,6 +693,7 @@ function pack_sharing_F(::Type{R}, F, N::Int, d::Int) where {R}
         eta === nothing && ((eta, lo, hi) = (e, l, h))
         (eta, lo, hi) == (e, l, h) || throw(ArgumentError("ProShI device path: all agents must share the same soft box"))
     end
+    Q = all(isdiag(view(Qd, :, :, i)) for i in 1:N) ? R[Qd[k, k, i] for k in 1:d, i in 1:N] : Qd
     return PackedSepQuad{R}(ROCArray(Q), ROCArray(q), eta === nothing ? 0.0 : eta, lo, hi, N, d)
 end
 

@@ -245,7 +245,7 @@ def pack_g(g, d: int, R, device=None, complex_pairs: bool = False) -> ProxG:
 
 
 def pack_sharing_F(F, N: int, d: int, R, device=None):
-    """Recognise F::Vector of Sum(Quadratic(diagonal Q, q), SqrDistL2(IndBox(lo, hi), η)) (test/test_sharing.jl:16-25), or a
+    """Recognise F::Vector of Sum(Quadratic(Q, q), SqrDistL2(IndBox(lo, hi), η)) (test/test_sharing.jl:16-25), or a
     lone Quadratic, and pack it as a PackedSepQuad.  Anything else raises TypeError."""
     from .device import PackedSepQuad
     dtype = torch_dtype(R)
@@ -264,10 +264,10 @@ def pack_sharing_F(F, N: int, d: int, R, device=None):
         dist = [t for t in parts if isinstance(t, SqrDistL2)]
         if len(quad) != 1 or len(dist) > 1 or len(quad) + len(dist) != len(parts):
             raise TypeError("ProShI device path: each f_i must be Quadratic or Sum(Quadratic, SqrDistL2(IndBox, η))")
-        Q = quad[0].Q
-        if Q.shape != (d, d) or np.any(Q - np.diag(np.diag(Q)) != 0):
-            raise TypeError("ProShI device path: only diagonal Quadratic terms of size d x d are packable")
-        Qs.append(np.diag(Q))
+        Q = np.asarray(quad[0].Q)
+        if Q.shape != (d, d):
+            raise TypeError(f"ProShI device path: Quadratic terms must be {d} x {d} (got {Q.shape})")
+        Qs.append(Q)
         qs.append(quad[0].q)
         e, l, h = (0.0, 0.0, 0.0)
         if dist:
@@ -279,4 +279,9 @@ def pack_sharing_F(F, N: int, d: int, R, device=None):
             eta, lo, hi = e, l, h
         elif (eta, lo, hi) != (e, l, h):
             raise TypeError("ProShI device path: all agents must share the same soft box (η, lo, hi)")
-    return PackedSepQuad(_dev(np.stack(Qs), dtype, device), _dev(np.stack(qs), dtype, device), eta, lo, hi)
+    # all-diagonal Q_i (the reference test's diagm) pack as N x d and run element-wise; otherwise N dense d x d blocks
+    if all(not np.any(Q - np.diag(np.diag(Q))) for Q in Qs):
+        Qp = np.stack([np.diag(Q) for Q in Qs])
+    else:
+        Qp = np.stack(Qs)
+    return PackedSepQuad(_dev(Qp, dtype, device), _dev(np.stack(qs), dtype, device), eta, lo, hi)

@@ -312,16 +312,19 @@ CIAO_API int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const 
 
 /* ---- ProShI  (ProShI/ProShI_basic.jl) ------------------------------------------------ */
 /* minimize (1/N) sum_i f_i(x_i) + g(sum_i x_i): the solution is the whole N x d table.  Operator family of the reference's
- * own test (test/test_sharing.jl:16-25): f_i = Sum(Quadratic(diagm(Q_i), q_i), SqrDistL2(IndBox(lo, hi), eta)), i.e.
- * grad f_i(x)_k = Q_ik x_k + q_ik + eta (x_k - clamp(x_k, lo, hi)) -- element-wise in each agent's own row. */
+ * own test (test/test_sharing.jl:16-25): f_i = Sum(Quadratic(Q_i, q_i), SqrDistL2(IndBox(lo, hi), eta)).
+ *   dense = 0: Q_i = diagm(Q[i,:]) as that test builds it; grad f_i(x)_k = Q_ik x_k + q_ik + eta (x_k - clamp(x_k, lo, hi)),
+ *              element-wise in each agent's own row.
+ *   dense = 1: a full d x d matrix per agent (ProShI_basic.jl:113 calls the operator's generic gradient!, which for Quadratic
+ *              is Q_i x + q_i): Q holds N row-major blocks, row k of agent i at Q + (i*d + k)*ld; needs d*sizeof(T) <= 64 KiB. */
 typedef struct {
     int32_t dtype;     /* CIAO_F32 / CIAO_F64                                  */
-    int32_t _pad;
+    int32_t dense;     /* 0: Q holds the N diagonals; 1: N dense d x d blocks  */
     int64_t N;         /* local agents (rows)                                  */
     int64_t d;
     int64_t ld;        /* row stride of Q and q in elements (>= d)             */
     int64_t N_total;   /* global number of agents (the 1/N factor)             */
-    const void *Q;     /* device N x ld: the diagonals of the Quadratic terms  */
+    const void *Q;     /* device N x ld diagonals, or (dense) N*d x ld rows    */
     const void *q;     /* device N x ld: their linear terms                    */
     double eta, lo, hi; /* SqrDistL2(IndBox(lo, hi), eta); eta = 0 drops it    */
 } ciao_sepquad;

@@ -77,10 +77,10 @@ typedef struct {
     int64_t orc_afinito_steps_##S(const orc_problem *p, const orc_prox_desc *g, R alpha, R tol_b,              \
                                   int64_t nsteps, const int64_t *idx, R *table, R *gtable, R *gam, R *fi_x,   \
                                   R *hat_gamma, R *av, R *z, int64_t *ntrials);                                \
-    void orc_proshi_init_##S(int64_t N, int64_t d, const R *Q, const R *q, R eta, R lo, R hi,                   \
+    void orc_proshi_init_##S(int64_t N, int64_t d, int32_t dense, const R *Q, const R *q, R eta, R lo, R hi,                   \
                              const orc_prox_desc *g, const R *gam, const R *x0, R *table, R *av, R *z,          \
                              R *hat_gamma);                                                                    \
-    void orc_proshi_steps_##S(int64_t N, int64_t d, const R *Q, const R *q, R eta, R lo, R hi,                  \
+    void orc_proshi_steps_##S(int64_t N, int64_t d, int32_t dense, const R *Q, const R *q, R eta, R lo, R hi,                  \
                               const orc_prox_desc *g, const R *gam, R hat_gamma, int64_t nit,                   \
                               const int64_t *bptr, const int64_t *bidx, R *table, R *av, R *z);                 \
     void orc_proshi_solution_##S(int64_t N, int64_t d, const R *gam, const R *z, R *table);                     \

@@ -290,19 +290,22 @@ def afinito_steps(p: Problem, g: Prox, alpha, tol_b, idx, table, gtable, gam, fi
 
 
 class SepQuad:
-    """F = [f_1..f_N], f_i = Sum(Quadratic(diagm(Q_i), q_i), SqrDistL2(IndBox(lo, hi), eta))  (test/test_sharing.jl:16-25)."""
+    """F = [f_1..f_N], f_i = Sum(Quadratic(Q_i, q_i), SqrDistL2(IndBox(lo, hi), eta))  (test/test_sharing.jl:16-25).
+    Q of shape N x d holds the diagonals (the test's diagm); N x d x d holds one dense matrix per agent."""
 
     def __init__(self, Q, q, eta, lo, hi):
         self.Q = np.ascontiguousarray(Q)
         self.dtype = self.Q.dtype
         self.q = np.ascontiguousarray(q, dtype=self.dtype)
-        assert self.Q.shape == self.q.shape and self.Q.ndim == 2
-        self.N, self.d = self.Q.shape
+        self.dense = self.Q.ndim == 3
+        self.N, self.d = self.q.shape
+        assert self.Q.shape == ((self.N, self.d, self.d) if self.dense else (self.N, self.d))
         self.eta, self.lo, self.hi = float(eta), float(lo), float(hi)
 
     def args(self):
         ct = _ct(self.dtype)
-        return (C.c_int64(self.N), C.c_int64(self.d), _p(self.Q), _p(self.q), ct(self.eta), ct(self.lo), ct(self.hi))
+        return (C.c_int64(self.N), C.c_int64(self.d), C.c_int32(int(self.dense)), _p(self.Q), _p(self.q), ct(self.eta), ct(self.lo),
+                ct(self.hi))
 
 
 def proshi_init(f: SepQuad, g: Prox, gam, x0):

@@ -1180,6 +1180,81 @@ def test_proshi_steps(ctx, ciao, dtype, shape, r, generic):
     ctx.synchronize()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape,r", [((3, 2), 1), ((5, 7), 2), ((40, 65), 5), ((12, 256), 12), ((600, 33), 300), ((6, 1000), 3),
+                                     ((3, 2048), 2)])
+def test_proshi_dense_quadratic(ctx, ciao, dtype, shape, r):
+    """f_i = Sum(Quadratic(Q_i, q_i), SqrDistL2(box, eta)) with a full d x d matrix per agent (ciao_sepquad.dense = 1;
+    ProShI_basic.jl:113 calls the operator's own gradient!, i.e. Q_i x + q_i): proshi_dense_kernel against the oracle."""
+    import torch
+    from oracle import oracle as O
+    from ciaoalgorithms_jl_amd.device import PackedSepQuad, ProxG
+    import ciaoalgorithms_jl_amd._lib as L
+    N, d = shape
+    rng = np.random.default_rng(N + d)
+    B = rng.standard_normal((N, d, d)) / np.sqrt(d)
+    Q = (np.einsum("nij,nik->njk", B, B) + 0.1 * np.eye(d)).astype(dtype)        # SPD, genuinely dense
+    q = rng.standard_normal((N, d)).astype(dtype)
+    eta, lo, hi = 3.0 * N, -2.0, 2.0
+    x0 = (0.5 * rng.standard_normal(d)).astype(dtype)
+    Lc = np.array([np.linalg.norm(Q[i].astype(np.float64), 2) for i in range(N)]) + eta
+    gam = (0.999 * N / Lc).astype(dtype)
+    g_hi = np.linspace(0.5, 1.5, d).astype(dtype)
+    of, og = O.SepQuad(Q, q, eta, lo, hi), O.Prox("box", lo=-np.inf, hi=g_hi, dtype=dtype)
+    df = PackedSepQuad(dev(Q), dev(q), eta, lo, hi)
+    assert df.dense and of.dense
+    dg = ProxG(L.PROX_BOX, lo=-float("inf"), hi_vec=dev(g_hi))
+    tdt = dev(x0).dtype
+    table = torch.empty((N, d), dtype=tdt, device="cuda")
+    av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+    hg = torch.empty(1, dtype=tdt, device="cuda")
+    ctx.proshi_init(df, dg, dev(gam), dev(x0), table, av, z, hg)
+    assert "proshi_dense_kernel" in ctx.last_kernel(), ctx.last_kernel()
+    rt, rav, rz, rhg = O.proshi_init(of, og, gam, x0)
+    # independent statement of the init table in numpy: s_i = x0 - gam_i/N (Q_i x0 + q_i + eta (x0 - clamp(x0)))
+    want = x0.astype(np.float64) - (gam.astype(np.float64) / N)[:, None] * (
+        np.einsum("nij,j->ni", Q.astype(np.float64), x0.astype(np.float64)) + q + eta * (x0 - np.clip(x0, lo, hi)).astype(np.float64))
+    close(table, want, dtype, scale=200, what="dense proshi init table vs numpy")
+    close(table, rt, dtype, scale=200, what="dense proshi init table")
+    close(av, rav, dtype, scale=500, what="dense proshi init av")
+    close(z, rz, dtype, scale=5000, what="dense proshi init z")
+    st = ciao.IndexStream(2)
+    batches = [st.sample_without_replacement(N, r) if 2 * r <= N else np.sort(st.randperm(N)[:r]) for _ in range(10)]
+    bptr = np.arange(len(batches) + 1, dtype=np.int64) * r
+    ctx.proshi_steps(df, dg, dev(gam), float(hg.item()), bptr, np.concatenate(batches), table, av, z)
+    O.proshi_steps(of, og, gam, rhg, batches, rt, rav, rz)
+    close(table, rt, dtype, scale=5000, what=f"dense proshi table ({ctx.last_kernel()})")
+    close(av, rav, dtype, scale=2000, what="dense proshi av")
+    close(z, rz, dtype, scale=50000, what="dense proshi z")
+    close(av, table.double().sum(dim=0).cpu().numpy(), dtype, scale=100, what="dense invariant av == sum_i s_i")
+    # contiguous blocks of agents (sweeping 2 / 3) are the same batches
+    t2, av2, z2 = table.clone(), av.clone(), z.clone()
+    first = np.array([0, N // 2], np.int64)
+    ln = np.array([N // 2, N - N // 2], np.int64)
+    ctx.proshi_steps_blocks(df, dg, dev(gam), float(hg.item()), first, ln, t2, av2, z2)
+    ctx.proshi_steps(df, dg, dev(gam), float(hg.item()), np.array([0, N // 2, N], np.int64), np.arange(N, dtype=np.int64), table, av, z)
+    assert torch.equal(t2, table) and torch.equal(av2, av) and torch.equal(z2, z)
+    ctx.synchronize()
+
+
+def test_proshi_dense_is_validated(ctx, ciao):
+    import torch
+    from ciaoalgorithms_jl_amd.device import PackedSepQuad, ProxG
+    import ciaoalgorithms_jl_amd._lib as L
+    d = 64 * 1024 // 4 + 4                                  # one element past 64 KiB of fp32
+    Q = torch.zeros((1, d, d), dtype=torch.float32, device="cuda")
+    q = torch.zeros((1, d), dtype=torch.float32, device="cuda")
+    df = PackedSepQuad(Q, q, 0.0, 0.0, 0.0)
+    v = lambda: torch.zeros(d, dtype=torch.float32, device="cuda")
+    with pytest.raises(ciao._lib.CiaoError, match="64 KiB"):
+        ctx.proshi_init(df, ProxG(L.PROX_ZERO), torch.ones(1, dtype=torch.float32, device="cuda"), v(), torch.zeros((1, d), dtype=torch.float32, device="cuda"),
+                        v(), v(), torch.zeros(1, dtype=torch.float32, device="cuda"))
+    df._c.dense = 7
+    with pytest.raises(ciao._lib.CiaoError, match="dense must be 0 or 1"):
+        ctx.proshi_init(df, ProxG(L.PROX_ZERO), torch.ones(1, dtype=torch.float32, device="cuda"), v(), torch.zeros((1, d), dtype=torch.float32, device="cuda"),
+                        v(), v(), torch.zeros(1, dtype=torch.float32, device="cuda"))
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # error behaviour at the boundary
 # ----------------------------------------------------------------------------------------------------------------------

@@ -14,6 +14,11 @@ import problems as P
 pytestmark = pytest.mark.gpu
 
 
+def ciao_stream(seed):
+    from ciaoalgorithms_jl_amd.sampling import IndexStream
+    return IndexStream(seed)
+
+
 @pytest.fixture(scope="module")
 def api(ciao, ctx):
     import ciaoalgorithms_jl_amd.operators as ops
@@ -440,7 +445,39 @@ class TestSharing:
         S, ops = api
         F, g, L, x0, sum_star, N = self._problem(ops)
         with pytest.raises(TypeError):
-            S.Proshi(self.T, maxit=3)(x0, F=[ops.Quadratic(np.ones((2, 2)), np.ones(2))] * N, g=g, L=L, N=N)   # dense Q
+            S.Proshi(self.T, maxit=3)(x0, F=[ops.Quadratic(np.ones((3, 3)), np.ones(3))] * N, g=g, L=L, N=N)   # Q is not d x d
+        with pytest.raises(TypeError):
+            S.Proshi(self.T, maxit=3)(x0, F=[ops.LeastSquares(np.ones((1, 2)), np.ones(1), 1.0)] * N, g=g, L=L, N=N)
+
+    @pytest.mark.parametrize("sweeping,batch", [(1, 1), (2, 2), (3, 3)])
+    def test_dense_quadratic_terms(self, api, sweeping, batch):
+        """ProShI_basic.jl:113 calls the operator's generic gradient!, so Quadratic(Q, q) with a full matrix is as valid as the
+        test's diagm.  (1) the reference fixture -- Q_i handed over as d x d matrices whose off-diagonal entries are zero --
+        is recognised as diagonal, takes the element-wise path and reproduces sum_star; (2) genuinely dense SPD Q_i follow
+        the oracle's iterable step for step on the same index stream."""
+        from oracle import oracle as O
+        from oracle import ref_solvers as RS
+        S, ops = api
+        F, g, L, x0, sum_star, N = self._problem(ops)
+        x, it = S.Proshi(self.T, maxit=self.maxit, sweeping=sweeping, minibatch=(True, batch))(x0, F=F, g=g, L=L, N=N)
+        assert np.abs(np.sum(x, axis=0) - sum_star).max() < self.tol
+        # genuinely dense: Q_i = B_i' B_i + I, d = 6, N = 5
+        rng = np.random.default_rng(3)
+        N, d = 5, 6
+        B = rng.standard_normal((N, d, d))
+        Q = np.einsum("nij,nik->njk", B, B) + np.eye(d)
+        q = rng.standard_normal((N, d))
+        eta, lo, hi = 10.0 * N, -2.0, 2.0
+        Lc = np.array([np.linalg.norm(Q[i], 2) + eta for i in range(N)])
+        box = ops.IndBox(lo, hi)
+        F = [ops.Sum(ops.Quadratic(Q[i], q[i]), ops.SqrDistL2(box, eta)) for i in range(N)]
+        x0 = np.zeros(d)
+        x, it = S.Proshi(self.T, maxit=300, sweeping=sweeping, minibatch=(True, batch))(x0, F=F, g=ops.IndBox(-np.inf, 1.0), L=Lc, N=N,
+                                                                                       stream=ciao_stream(0))
+        xr, _ = RS.proshi(O.SepQuad(Q, q, eta, lo, hi), O.Prox("box", lo=-np.inf, hi=1.0), x0, maxit=300, sweeping=sweeping,
+                          batch=batch, L=Lc, stream=ciao_stream(0))
+        assert np.abs(np.asarray(x) - xr).max() <= 1e-10 * max(1.0, np.abs(xr).max())
+        assert np.all(np.sum(x, axis=0) <= 1.0 + 1e-9)              # the coupling constraint holds at the solution
 
 
 # ======================================================================================================================
