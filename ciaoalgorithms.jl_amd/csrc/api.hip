@@ -1373,7 +1373,7 @@ int32_t ciao_afinito_probe(ciao_ctx *ctx, const ciao_problem *p, int64_t i, cons
     CIAO_ENTER(ctx);
     CIAO_TRY(check_problem(ctx, p));
     CIAO_REQUIRE(x0 && signs && nmg_host && t > 0, "NULL argument or t <= 0");
-    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO && p->loss != CIAO_LOSS_LS_COMPLEX && i >= 0 && i < p->N, "sample index %lld outside [0, %lld) or no real data terms", (long long)i,
+    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO && i >= 0 && i < p->N, "sample index %lld outside [0, %lld) or no data terms", (long long)i,
                  (long long)p->N);
     if (p->dtype == CIAO_F64)
         hipLaunchKernelGGL((afinito_probe_kernel<double>), dim3(1), dim3(WAVE), 0, ctx->stream, (const double *)p->A, (const double *)p->b,
@@ -1397,7 +1397,6 @@ int32_t ciao_afinito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
     CIAO_REQUIRE(x0 && av && z && hat_gamma_dev && ((table && meta) || p->N == 0), "NULL state vector / table / meta");
     CIAO_REQUIRE(alpha > 0 && alpha < 1, "alpha must be in (0, 1)");
     CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO, "adaptive Finito needs data terms (the Lipschitz probe of Zero() is degenerate)");
-    CIAO_REQUIRE(p->loss != CIAO_LOSS_LS_COMPLEX, "adaptive Finito has no complex path");
     CIAO_REQUIRE(p->N >= 1, "adaptive Finito needs at least one term");
     CIAO_REQUIRE(!ctx->hook, "adaptive Finito is a sequential chain: replicas only, not valid on a row-sharded problem");
     return DISPATCH(p->dtype, afinito_init_t, ctx, p, g, alpha, x0, table, meta, av, z, hat_gamma_dev, gam_override);
@@ -1414,7 +1413,7 @@ int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox
     CIAO_REQUIRE(nsteps >= 0 && (nsteps == 0 || idx), "nsteps < 0 or idx is NULL");
     CIAO_REQUIRE(table && meta && av && z && hat_gamma_dev, "NULL state vector / table / meta");
     CIAO_REQUIRE(alpha > 0 && alpha < 1 && tol_b > 0, "need 0 < alpha < 1 and tol_b > 0");
-    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO && p->loss != CIAO_LOSS_LS_COMPLEX && p->N >= 1, "adaptive Finito needs real data terms");
+    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO && p->N >= 1, "adaptive Finito needs data terms");
     CIAO_REQUIRE(!ctx->hook, "adaptive Finito is a sequential chain: replicas only, not valid on a row-sharded problem");
     if (nsteps == 0) {
         if (done_host) *done_host = 0;

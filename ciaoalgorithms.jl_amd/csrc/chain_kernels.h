@@ -1344,6 +1344,180 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_chain_kernel(AFinitoArgs<T> 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Adaptive Finito on rows of ANY length, real or complex (CPLX: (re, im) pairs, CIAO_LOSS_LS_COMPLEX with g = Zero or the
+// complex NormL1).  Same step as afinito_chain_kernel, same structure as chain_big_kernel: one 1024-thread workgroup, the
+// state (av, z) and the table row stay in the caller's vectors (L2-resident), thread t owns coordinates t, t+1024, ... in
+// every loop, so the only cross-thread traffic is the reduction of each trial (a.z, ||z - s_i||^2) and the per-sample
+// scalars, which thread 0 stores and everybody reads after the barrier that opens the next step.
+// Complex scalars: c = lam res and a.x_i are complex, the model's linear term is Re(conj(c) (a.z - a.x_i)); the meta slots
+// are laid out as rows_cplx_kernel<AFINITO_INIT> leaves them (copies 0/2 real parts, 1/3 imaginary parts).
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, bool CPLX>
+__global__ void __launch_bounds__(CHAIN_BIG_NT) afinito_big_kernel(AFinitoArgs<T> a, int loss)
+{
+    constexpr int NW = CHAIN_BIG_NT / WAVE;
+    __shared__ T red[2][NW][4];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t d = a.d;
+    const int64_t units = CPLX ? d / 2 : d;        // coordinates a thread steps through: complex entries or reals
+    const bool l1c = (a.g.kind == CIAO_PROX_L1_COMPLEX);
+    // z = prox_{tau g}(av) for the thread's unit e
+    auto prox_unit = [&](int64_t e, T tau) {
+        if (CPLX) {
+            const T vr = a.av[2 * e], vi = a.av[2 * e + 1];
+            if (l1c) {
+                prox_cpair(tau * a.g.lam, vr, vi, a.z[2 * e], a.z[2 * e + 1]);
+            } else {
+                a.z[2 * e] = vr;
+                a.z[2 * e + 1] = vi;
+            }
+        } else {
+            a.z[e] = prox_elem(a.g, a.av[e], tau, e);
+        }
+    };
+    T hg = *a.hg;
+    int par = 0;
+    long long done = 0, trials = 0;
+    for (int64_t s = 0; s < a.nsteps; ++s) {
+        int64_t row = a.idx[s];
+        if ((uint64_t)row >= (uint64_t)a.N) {
+            if (tid == 0) *a.errflag = 1;
+            row = 0;
+        }
+        const T *ap = a.A + row * a.ld;
+        T *sp = a.table + row * d;
+        const T br = CPLX ? a.b[2 * row] : (a.b ? a.b[row] : T(0));
+        const T bi = CPLX ? a.b[2 * row + 1] : T(0);
+        __syncthreads();                                  // the scalars the previous step stored are visible
+        const T *mp = a.meta + row * 16;
+        const T c_or = mp[0], fi_x = mp[1], as_r = mp[3];
+        const T c_oi = CPLX ? mp[4] : T(0), as_i = CPLX ? mp[7] : T(0);
+        T gi = mp[2];
+        T dzr = T(0), dzi = T(0), fi_z = T(0);
+        bool stop = false;
+        while (true) {
+            if (gi < a.tol_b * a.invN) {                  // Finito_adaptive.jl:121-124: the stepsize collapsed
+                stop = true;
+                break;
+            }
+            ++trials;
+            T p1r = T(0), p1i = T(0), p2 = T(0);
+            for (int64_t e = tid; e < units; e += CHAIN_BIG_NT) {
+                if (CPLX) {
+                    const T ar = ap[2 * e], ai = ap[2 * e + 1];
+                    const T zr = a.z[2 * e], zi = a.z[2 * e + 1];
+                    p1r += ar * zr - ai * zi;
+                    p1i += ar * zi + ai * zr;
+                    const T rr = zr - sp[2 * e], ri = zi - sp[2 * e + 1];
+                    p2 += rr * rr + ri * ri;
+                } else {
+                    const T zv = a.z[e];
+                    p1r += ap[e] * zv;
+                    const T rv = zv - sp[e];
+                    p2 += rv * rv;
+                }
+            }
+            p1r = wave_allsum(p1r);
+            if (CPLX) p1i = wave_allsum(p1i);
+            p2 = wave_allsum(p2);
+            if (lane == 0) {
+                red[par][wib][0] = p1r;
+                red[par][wib][1] = p1i;
+                red[par][wib][2] = p2;
+            }
+            __syncthreads();
+            T t3[3] = {T(0), T(0), T(0)};
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int w = 0; w < NW; w += 4)
+                    t3[c] += (red[par][w][c] + red[par][w + 1][c]) + (red[par][w + 2][c] + red[par][w + 3][c]);
+            par ^= 1;
+            dzr = t3[0];
+            dzi = t3[1];
+            const T n2 = t3[2];
+            T lin;
+            if (CPLX) {
+                const T rr = dzr - br, ri = dzi - bi;
+                fi_z = (a.lam / T(2)) * (rr * rr + ri * ri);                             // :125
+                lin = c_or * (dzr - as_r) + c_oi * (dzi - as_i);                         // real_dot(grad f_i(x_i), z - x_i)
+            } else {
+                fi_z = loss_value(loss, dzr, br, a.lam);
+                lin = c_or * (dzr - as_r);
+            }
+            const double fi_model = (double)(fi_x + lin) + (0.5 * a.Nd * (double)a.alpha / (double)gi) * (double)n2;   // :126-129 (Float64)
+            const T tol = T(10) * Eps<T>::value * (T(1) + fabs2(fi_z));                  // :130
+            if ((double)fi_z <= fi_model + (double)tol) break;                           // :131
+            const T gb = gi;                                                             // :133
+            gi = (T)((double)gi * 0.8);                                                  // :134
+            const T hg_old = hg;
+            hg = T(1) / (T(1) / hg_old + T(1) / gi - T(1) / gb);                         // :139
+            for (int64_t e = tid; e < units; e += CHAIN_BIG_NT) {
+#pragma unroll
+                for (int c = 0; c < (CPLX ? 2 : 1); ++c) {
+                    const int64_t k = CPLX ? 2 * e + c : e;
+                    T t = a.av[k] / hg_old;                                              // :136
+                    t += sp[k] / gi;                                                     // :137
+                    t -= sp[k] / gb;                                                     // :138
+                    t *= hg;                                                             // :140
+                    a.av[k] = t;
+                }
+                prox_unit(e, hg);                                                        // :141
+            }
+        }
+        if (stop) break;
+        // the main step, :145-150
+        T c_nr, c_ni = T(0);
+        if (CPLX) {
+            c_nr = a.lam * (dzr - br);
+            c_ni = a.lam * (dzi - bi);
+        } else {
+            c_nr = grad_coef(loss, dzr, br, a.lam).coef();
+        }
+        const T r1 = hg / gi;
+        const T cc = hg * a.invN;
+        const T dcr = c_or - c_nr, dci = c_oi - c_ni;       // + (hg/N) grad_old - (hg/N) grad_new, both multiples of conj(a_i)
+        for (int64_t e = tid; e < units; e += CHAIN_BIG_NT) {
+            if (CPLX) {
+                const T ar = ap[2 * e], ai = ap[2 * e + 1];
+                const T zr = a.z[2 * e], zi = a.z[2 * e + 1];
+                T tr = a.av[2 * e] + r1 * (zr - sp[2 * e]);                              // :145
+                T ti = a.av[2 * e + 1] + r1 * (zi - sp[2 * e + 1]);
+                tr += cc * (ar * dcr + ai * dci);                                        // :147, :149   conj(a) (c_old - c_new)
+                ti += cc * (ar * dci - ai * dcr);
+                sp[2 * e] = zr;                                                          // :146  s_i = z
+                sp[2 * e + 1] = zi;
+                a.av[2 * e] = tr;
+                a.av[2 * e + 1] = ti;
+            } else {
+                const T zv = a.z[e];
+                T t = a.av[e] + r1 * (zv - sp[e]);
+                t += (cc * dcr) * ap[e];
+                sp[e] = zv;
+                a.av[e] = t;
+            }
+            prox_unit(e, hg);                                                            // :150
+        }
+        if (tid < 4) {
+            T *mw = a.meta + (row * 4 + tid) * 4;
+            const bool im = CPLX && (tid & 1);
+            mw[0] = im ? c_ni : c_nr;
+            mw[1] = fi_z;                                                                // :148 fi_x[i] = f_i(z)
+            mw[2] = gi;
+            mw[3] = im ? dzi : dzr;
+        }
+        ++done;
+    }
+    if (tid == 0) {
+        *a.hg = hg;
+        a.counters[0] = done;
+        a.counters[1] = trials;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Adaptive Finito, fast path: the same step as afinito_chain_kernel with the inputs of step s (row a_i, table row s_i,
 // this wave's copy of the sample's scalars) brought in by LDS-DMA DEPTH steps ahead and retired with hand-counted waits,
 // exactly as chain_dma_kernel does (the compiler-scheduled version above drains the whole memory queue twice per step:
@@ -1699,6 +1873,20 @@ __global__ void __launch_bounds__(WAVE)
 {
     const int lane = threadIdx.x;
     const T *ap = A + i * ld;
+    if (loss == CIAO_LOSS_LS_COMPLEX) {   // complex T: `signs` has d/2 REAL entries, added to the real parts (rand(t*[-1,1], size(x0)))
+        T sr = T(0), si = T(0), m2 = T(0);
+        for (int64_t e = lane; e < d / 2; e += WAVE) {
+            const T ar = ap[2 * e], ai = ap[2 * e + 1];
+            sr += ar * signs[e];
+            si += ai * signs[e];
+            m2 += ar * ar + ai * ai;
+        }
+        sr = wave_allsum(sr);
+        si = wave_allsum(si);
+        m2 = wave_allsum(m2);
+        if (lane == 0) *out = (double)(fhypot(lam * (t * sr), lam * (t * si)) * fsqrt(m2));   // |c1 - c0| ||a_i||, c1 - c0 = lam t a.signs
+        return;
+    }
     T d0 = T(0), ds = T(0), n2 = T(0);
     for (int64_t k = lane; k < d; k += WAVE) {
         const T ak = ap[k];

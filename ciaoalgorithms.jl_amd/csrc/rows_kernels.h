@@ -1001,13 +1001,17 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
 // Complex T (CIAO_LOSS_LS_COMPLEX): every complex vector is (re, im) pairs of T.  Correctness path, one wave per row, per-wave
 // accumulators in the workspace (as rows_generic_kernel<..., GLOBAL_ACC>), the iterate(s) read from global memory.
 //   res = a_i . x - b_i  (complex, no conjugation: A*x);   grad f_i(x)_k = (conj(a_k) res) lam;   f_i = lam/2 |res|^2
-// Modes GRAD, GRAD2, SAGA_INIT, FINITO_INIT, FINITO_BATCH with exactly the formulas of the real kernels, pair by pair.
+// Modes GRAD, GRAD2, SAGA_INIT, FINITO_INIT, FINITO_BATCH, AFINITO_INIT with the formulas of the real kernels, pair by pair.
+// AFINITO_INIT: the probe point is x0 .+ one(R) (Finito_adaptive.jl:74) -- a REAL one added to every complex entry, so
+// a.(xeps - x0) = sum_k a_k; sqrt(length(x0)) counts complex entries (:86).  The per-sample scalars are complex now: the 16
+// meta slots of a sample hold {Re c, f_i, gamma, Re a.x_i} in copies 0 and 2 and {Im c, f_i, gamma, Im a.x_i} in copies 1
+// and 3 (c = lam res, grad f_i = conj(a_i) c); gamma stays at slot 2 of every copy, where the host reads it.
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T, int MODE>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_cplx_kernel(RowsArgs<T> a)
 {
     constexpr bool TWO = (MODE == RM_GRAD2);
-    static_assert(MODE != RM_AFINITO_INIT, "adaptive Finito has no complex path");
+    constexpr bool AF = (MODE == RM_AFINITO_INIT);
     const int lane = threadIdx.x & (WAVE - 1);
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t dc = a.d / 2;
@@ -1023,7 +1027,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_cplx_kernel(RowsArgs<T> a)
         }
         const T *ap = a.A + row * a.ld;
         const T br = a.b[2 * row], bi = a.b[2 * row + 1];
-        T s1r = T(0), s1i = T(0), s2r = T(0), s2i = T(0);
+        T s1r = T(0), s1i = T(0), s2r = T(0), s2i = T(0), n2 = T(0);
         for (int64_t e = lane; e < dc; e += WAVE) {
             const T ar = ap[2 * e], ai = ap[2 * e + 1];
             const T xr = a.x1[2 * e], xi = a.x1[2 * e + 1];
@@ -1034,17 +1038,57 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_cplx_kernel(RowsArgs<T> a)
                 s2r += ar * yr - ai * yi;
                 s2i += ar * yi + ai * yr;
             }
+            if (AF) {            // s2 = sum_k a_k = a.(xeps - x0);  n2 = ||a||^2
+                s2r += ar;
+                s2i += ai;
+                n2 += ar * ar + ai * ai;
+            }
         }
         s1r = wave_allsum(s1r);
         s1i = wave_allsum(s1i);
-        if (TWO) {
+        if (TWO || AF) {
             s2r = wave_allsum(s2r);
             s2i = wave_allsum(s2i);
         }
+        if (AF) n2 = wave_allsum(n2);
         const T r1r = s1r - br, r1i = s1i - bi;          // res = A x - b
         const T r2r = s2r - br, r2i = s2i - bi;
         T *tp = a.table ? a.table + row * a.d : nullptr;
-        const T gi = (MODE == RM_GRAD || MODE == RM_SAGA_INIT) ? T(1) : (a.gam ? a.gam[row] : a.gam_uniform);
+        T gi = (MODE == RM_GRAD || MODE == RM_SAGA_INIT) ? T(1) : (a.gam ? a.gam[row] : a.gam_uniform);
+        if (AF) {                                                             // Finito_adaptive.jl:73-88
+            const T c0r = a.lam * r1r, c0i = a.lam * r1i;
+            const T c1r = a.lam * ((s1r + s2r) - br), c1i = a.lam * ((s1i + s2i) - bi);
+            T nmg = fhypot(c1r - c0r, c1i - c0i) * fsqrt(n2);                 // || conj(a) (c1 - c0) || = |c1 - c0| ||a||
+            const T gov = a.gam ? a.gam[row] : T(0);                          // host-resolved stepsize (after a re-probe)
+            bool degenerate = false;
+            if (!(gov > T(0)) && nmg < Eps<T>::value) {
+                if (lane == 0) *a.errflag = 2;
+                nmg = Eps<T>::value;
+                degenerate = true;
+            }
+            gi = gov > T(0) ? gov : (T)((double)a.alpha / (((double)nmg / sqrt((double)dc)) / a.Nd));
+            const T rinv = T(1) / gi;
+            const T fv = (a.lam / T(2)) * (r1r * r1r + r1i * r1i);
+            for (int64_t e = lane; e < dc; e += WAVE) {
+                const T ar = ap[2 * e], ai = ap[2 * e + 1];
+                T gr, gim;
+                cgrad_elem(ar, ai, r1r, r1i, a.lam, gr, gim);
+                const T xr = a.x1[2 * e], xi = a.x1[2 * e + 1];
+                tp[2 * e] = xr;                                                // :68  s_i = x0
+                tp[2 * e + 1] = xi;
+                acc[2 * e] += xr * rinv - gr * a.invN;                         // :92  sum(s ./ gamma) - sum(grad f) / N
+                acc[2 * e + 1] += xi * rinv - gim * a.invN;
+            }
+            extra += rinv;
+            if (lane < 4) {
+                T *mp = a.meta + (row * 4 + lane) * 4;
+                mp[0] = (lane & 1) ? c0i : c0r;
+                mp[1] = fv;
+                mp[2] = degenerate ? T(-1) : gi;
+                mp[3] = (lane & 1) ? s1i : s1r;
+            }
+            continue;
+        }
         if (MODE == RM_GRAD && a.want_fval) extra += (a.lam / T(2)) * (r1r * r1r + r1i * r1i);
         if (MODE == RM_GRAD2) extra += a.hat_gamma / gi;
         const T cg = gi * a.invN;

@@ -414,8 +414,9 @@ class Context:
     def afinito_probe(self, p, i: int, x0, signs, t: float) -> float:
         """One retry of the Lipschitz probe for sample i at x0 + t*signs (Finito_adaptive.jl:80-82); synchronises."""
         out = C.c_double(0.0)
-        L.check(self.lib.ciao_afinito_probe(self._h, p.ref, int(i), self._vec(x0, p, "x0"), self._vec(signs, p, "signs"), float(t),
-                                            C.byref(out)))
+        n_signs = p.d // 2 if getattr(p, "complex", False) else p.d     # complex T: one real draw per complex entry
+        L.check(self.lib.ciao_afinito_probe(self._h, p.ref, int(i), self._vec(x0, p, "x0"), self._vec(signs, p, "signs", n_signs),
+                                            float(t), C.byref(out)))
         return out.value
 
     def afinito_steps(self, p, g, alpha, tol_b, idx, table, meta, av, z, hat_gamma_dev) -> tuple[int, int]:

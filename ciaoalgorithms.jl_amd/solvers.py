@@ -478,8 +478,6 @@ class FINITO_adaptive_iterable(_Iterable):
 
     def __init__(self, R, F, g, x0, N, L, tol, tol_b, sweeping, α, ctx=None, stream=None):
         super().__init__(R, F, g, x0, N, ctx, stream)
-        if self._complex:
-            raise TypeError("adaptive Finito has no complex form on the device path")
         self.L, self.tol, self.tol_b, self.sweeping, self.α = L, tol, tol_b, int(sweeping), α
         if self.F.row0 != 0 or self.F.N != self.N:
             raise ValueError("adaptive Finito is a sequential chain: it needs the whole problem on one device")
@@ -503,16 +501,17 @@ class FINITO_adaptive_iterable(_Iterable):
             np_R = np.float64 if self.R == torch.float64 else np.float32
             gam = meta[:, 0, 2].clone()
             eps = float(np.finfo(np_R).eps)
+            n_x0 = self.d // 2 if self._complex else self.d     # length(x0): complex entries; the draws are real and go to the real parts
             for i in torch.nonzero(gam < 0).flatten().tolist():
                 t = 1
                 while True:
                     print("initial upper bound for L too small")                                   # :79
-                    signs = torch.from_numpy(self.stream.rand_signs(self.d).astype(np_R)).to(dev)   # :80
+                    signs = torch.from_numpy(self.stream.rand_signs(n_x0).astype(np_R)).to(dev)     # :80
                     nmg = self.ctx.afinito_probe(self.F, i, self._x0_dev, signs, float(t))          # :81-82
                     t *= 2                                                                          # :83
                     if not nmg < eps:
                         break
-                L_int = np.float64(np_R(nmg)) / (np.float64(t) * np.sqrt(np.float64(self.d)))      # :86 (Float64 whatever R, :73)
+                L_int = np.float64(np_R(nmg)) / (np.float64(t) * np.sqrt(np.float64(n_x0)))        # :86 (Float64 whatever R, :73)
                 L_int /= np.float64(self.N)                                                         # :87
                 gam[i] = float(np_R(np.float64(np_R(self.α)) / L_int))                              # :88
             self.ctx.afinito_init(self.F, self.g, self.α, self._x0_dev, s, meta, av, z, hg, gam_override=gam.contiguous())

@@ -298,14 +298,16 @@ CIAO_API int32_t ciao_afinito_init(ciao_ctx *ctx, const ciao_problem *p, const c
                                    const void *x0, void *table, void *meta, void *av, void *z, void *hat_gamma_dev,
                                    const void *gam_override);
 /* One retry of that probe for sample i: *nmg_host = || grad f_i(x0 + t*signs) - grad f_i(x0) || (signs: device d-vector of
- * +-1 in R).  Synchronises. */
+ * +-1 in R; for CIAO_LOSS_LS_COMPLEX d/2 real +-1 entries, added to the real parts as rand(t*[-1,1], size(x0)) does, and
+ * sqrt(length(x0)) in the host's formula counts the d/2 complex entries).  Synchronises. */
 CIAO_API int32_t ciao_afinito_probe(ciao_ctx *ctx, const ciao_problem *p, int64_t i, const void *x0, const void *signs, double t,
                                     double *nmg_host);
 /* nsteps consecutive Base.iterate(iter,state), :120-152, for the samples idx[0..nsteps) (the selection :105-118 is host
  * logic).  Synchronises; *done_host = steps completed (< nsteps iff a stepsize fell below tol_b/N: the reference then
  * warns and ends the iteration, :123-126), *trials_host = backtracking trials taken.  Julia's promotions are kept for
  * R = Float32: the model value `0.5 * iter.N * iter.α / γ ...` and the comparison are Float64, `γ *= 0.8` is a Float64
- * product rounded back (:128-136). */
+ * product rounded back (:128-136).  Rows of any length and complex T run afinito_big_kernel (state in the caller's vectors);
+ * meta for complex T: copies 0/2 hold {Re c, f_i, gamma_i, Re a_i.x_i}, copies 1/3 the imaginary parts (c = lam res). */
 CIAO_API int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double alpha,
                                     double tol_b, int64_t nsteps, const int64_t *idx, void *table, void *meta, void *av,
                                     void *z, void *hat_gamma_dev, int64_t *done_host, int64_t *trials_host);

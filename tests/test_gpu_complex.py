@@ -222,8 +222,72 @@ def test_complex_finito_and_lfinito(ctx, ciao, ctype, shape, r, path):
     ctx.synchronize()
 
 
+@pytest.mark.parametrize("ctype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("shape", [(6, 3), (8, 5), (50, 50), (30, 300), (24, 512), (10, 2500)])
+def test_complex_adaptive_finito(ctx, ciao, ctype, shape):
+    """Finito_adaptive.jl for complex T: init (probe at x0 .+ one(R): real parts only; sqrt(length(x0)) = complex entries) and
+    the backtracking steps (afinito_big_kernel<cplx>) against the oracle; invariants of the state as in the real test."""
+    import torch
+    from oracle import oracle as O
+    R = RTYPE[ctype]
+    N, n = shape
+    A, b, x0 = P.synthetic_complex(N, n, ctype, seed=12)
+    op, dp = cmake(A, b, float(N))
+    og, dg = cg(0.02)
+    xp = O.as_pairs(x0)
+    tdt = dev(xp).dtype
+    alpha, tol_b = 0.999, 1e-9
+    table = torch.empty((N, 2 * n), dtype=tdt, device="cuda")
+    meta = torch.empty((N, 4, 4), dtype=tdt, device="cuda")
+    hg = torch.empty(1, dtype=tdt, device="cuda")
+    av, z = torch.empty(2 * n, dtype=tdt, device="cuda"), torch.empty(2 * n, dtype=tdt, device="cuda")
+    ctx.afinito_init(dp, dg, alpha, dev(xp), table, meta, av, z, hg)
+    assert "rows_cplx_kernel" in ctx.last_kernel()
+    rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, R(alpha), xp)
+    close(meta[:, 0, 2], rgam, R, scale=200, what="complex adaptive init gamma_i")
+    close(meta[:, 0, 1], rfi, R, scale=200, what="complex adaptive init f_i(x0)")
+    close(hg, [rhg], R, scale=200, what="complex adaptive init hat_gamma")
+    close(av, rav, R, scale=500, what="complex adaptive init av")
+    close(z, rz, R, scale=500, what="complex adaptive init z")
+    assert torch.equal(table, dev(xp).expand(N, -1))
+    # independent statement of gamma_i: L_i = || conj(a_i) lam sum_k a_ik || / sqrt(n) / N
+    A128 = A.astype(np.complex128)
+    Lint = float(N) * np.abs(A128.sum(axis=1)) * np.linalg.norm(A128, axis=1) / np.sqrt(n) / N
+    close(meta[:, 0, 2], alpha / Lint, R, scale=200, what="complex adaptive gamma_i vs numpy")
+    st = ciao.IndexStream(3)
+    idx = np.concatenate([st.rand_indices(N, 3 * N), np.arange(N, dtype=np.int64), np.full(4, 1, np.int64)])
+    done, trials = ctx.afinito_steps(dp, dg, alpha, tol_b, idx, table, meta, av, z, hg)
+    assert "afinito_big_kernel" in ctx.last_kernel() and "cplx" in ctx.last_kernel()
+    rdone, rhg, rtrials = O.afinito_steps(op, og, R(alpha), R(tol_b), idx, rt, rg, rgam, rfi, rhg, rav, rz)
+    assert done == rdone == len(idx)
+    assert abs(trials - rtrials) <= max(2, 0.02 * rtrials), (trials, rtrials)
+    if trials == rtrials:
+        close(z, rz, R, scale=5000, what=f"complex adaptive z ({ctx.last_kernel()})")
+        close(av, rav, R, scale=5000, what="complex adaptive av")
+        close(hg, [rhg], R, scale=200, what="complex adaptive hat_gamma")
+        close(meta[:, 0, 2], rgam, R, scale=5000, what="complex adaptive gamma_i")
+        close(table, rt, R, scale=5000, what="complex adaptive table")
+        cdev = (meta[:, 0, 0].double() + 1j * meta[:, 1, 0].double()).cpu().numpy()          # c_i = lam res_i
+        close(O.as_pairs((np.conj(A128) * cdev[:, None])).reshape(N, -1), rg, R, scale=2000, what="complex gradient table conj(a_i) c_i")
+    # invariants: av == hat_gamma (sum_i x_i/gamma_i - (1/N) sum_i grad f_i); stored scalars consistent with stored points
+    md = meta.double().cpu().numpy()
+    gam = md[:, 0, 2]
+    hgd = float(hg.item())
+    assert abs(hgd - 1.0 / (1.0 / gam).sum()) <= (1e-10 if R == np.float64 else 2e-4) * hgd
+    tab = O.as_complex(table.double().cpu().numpy().reshape(-1)).reshape(N, n)
+    c = md[:, 0, 0] + 1j * md[:, 1, 0]
+    inv = hgd * ((tab / gam[:, None]).sum(axis=0) - (np.conj(A128) * c[:, None]).sum(axis=0) / N)
+    close(av, O.as_pairs(inv), R, scale=2000, what="complex adaptive invariant av")
+    dots = (A128 * tab).sum(axis=1)
+    close(md[:, 0, 3] + 0 * md[:, 1, 3], dots.real, R, scale=50, what="Re a_i.x_i")
+    close(md[:, 1, 3], dots.imag, R, scale=50, what="Im a_i.x_i")
+    close(np.stack([c.real, c.imag]), np.stack([(float(N) * (dots - b)).real, (float(N) * (dots - b)).imag]), R, scale=50, what="c_i = lam res_i")
+    assert np.array_equal(md[:, 0], md[:, 2]) and np.array_equal(md[:, 1], md[:, 3])
+    ctx.synchronize()
+
+
 def test_complex_argument_validation(ctx, ciao):
-    """Complex rows pair only with Zero / the complex NormL1; odd d, IndBox, the real NormL1, adaptive Finito are refused."""
+    """Complex rows pair only with Zero / the complex NormL1; odd d, IndBox and the real NormL1 are refused."""
     import torch
     from ciaoalgorithms_jl_amd.device import PackedF, ProxG
     import ciaoalgorithms_jl_amd._lib as L

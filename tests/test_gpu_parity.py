@@ -1097,6 +1097,48 @@ def test_adaptive_finito_variants(ctx, ciao, kind, gkind, no_dma):
     ctx.synchronize()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kind,N,d,forced", [("ls", 20, 5000, False), ("logistic", 12, 9000, False), ("ls", 6, 20001, False),
+                                             ("logistic", 30, 300, True), ("ls", 16, 1024, True)])
+def test_adaptive_finito_on_rows_of_any_length(ctx, ciao, dtype, kind, N, d, forced):
+    """Rows beyond the register-resident shapes (d > 4096; these used to return CIAO_ERR_UNSUPPORTED) run afinito_big_kernel
+    with the state in the caller's vectors; option chain_big forces it at any d, where it must agree with the fast kernels."""
+    import torch
+    from oracle import oracle as O
+    A, b, x0 = P.synthetic(kind, N, d, dtype, seed=d)
+    lam_f = 1.0 if kind == "logistic" else float(N)
+    op, dp = make(kind, A, b, lam_f, dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.01)
+    alpha, tol_b = 0.999, 1e-9
+    tdt = dev(x0).dtype
+    table = torch.empty((N, d), dtype=tdt, device="cuda")
+    meta4 = torch.empty((N, 4, 4), dtype=tdt, device="cuda")
+    hg = torch.empty(1, dtype=tdt, device="cuda")
+    av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+    ctx.afinito_init(dp, dg, alpha, dev(x0), table, meta4, av, z, hg)
+    rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(alpha), x0)
+    close(meta4[:, 0, 2], rgam, dtype, scale=5000, what="adaptive init gamma_i, long rows")   # c(x0 .+ 1) - c(x0) cancels
+    close(av, rav, dtype, scale=1000, what="adaptive init av, long rows")
+    idx = np.concatenate([ciao.IndexStream(4).rand_indices(N, 3 * N), np.full(3, 2, np.int64)])
+    ctx.set_option("chain_big", int(forced))
+    try:
+        done, trials = ctx.afinito_steps(dp, dg, alpha, tol_b, idx, table, meta4, av, z, hg)
+        assert "afinito_big_kernel" in ctx.last_kernel(), ctx.last_kernel()
+    finally:
+        ctx.set_option("chain_big", 0)
+    rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(alpha), dtype(tol_b), idx, rt, rg, rgam, rfi, rhg, rav, rz)
+    assert done == rdone == len(idx)
+    assert abs(trials - rtrials) <= max(2, 0.02 * rtrials), (trials, rtrials)
+    if trials == rtrials:
+        close(z, rz, dtype, scale=5000, what=f"adaptive z ({ctx.last_kernel()})")
+        close(av, rav, dtype, scale=5000, what="adaptive av, long rows")
+        close(hg, [rhg], dtype, scale=200, what="adaptive hat_gamma, long rows")
+        close(table, rt, dtype, scale=5000, what="adaptive table, long rows")
+        close(meta4[:, 0, 2], rgam, dtype, scale=5000, what="adaptive gamma_i, long rows")
+    assert torch.equal(meta4[:, 0], meta4[:, 1]) and torch.equal(meta4[:, 0], meta4[:, 2]) and torch.equal(meta4[:, 0], meta4[:, 3])
+    ctx.synchronize()
+
+
 @pytest.mark.parametrize("d", [64, 1024])
 def test_adaptive_finito_stops_when_the_stepsize_collapses(ctx, ciao, d):
     """tol_b so large that the very first step finds gamma_i < tol_b/N: the chain ends (reference :121-124)."""
@@ -1193,11 +1235,11 @@ def test_proshi_dense_quadratic(ctx, ciao, dtype, shape, r):
     N, d = shape
     rng = np.random.default_rng(N + d)
     B = rng.standard_normal((N, d, d)) / np.sqrt(d)
-    Q = (np.einsum("nij,nik->njk", B, B) + 0.1 * np.eye(d)).astype(dtype)        # SPD, genuinely dense
+    Q = (B.transpose(0, 2, 1) @ B + 0.1 * np.eye(d)).astype(dtype)                # SPD, genuinely dense
     q = rng.standard_normal((N, d)).astype(dtype)
     eta, lo, hi = 3.0 * N, -2.0, 2.0
     x0 = (0.5 * rng.standard_normal(d)).astype(dtype)
-    Lc = np.array([np.linalg.norm(Q[i].astype(np.float64), 2) for i in range(N)]) + eta
+    Lc = np.array([np.linalg.norm(Q[i].astype(np.float64)) for i in range(N)]) + eta   # Frobenius >= spectral norm
     gam = (0.999 * N / Lc).astype(dtype)
     g_hi = np.linspace(0.5, 1.5, d).astype(dtype)
     of, og = O.SepQuad(Q, q, eta, lo, hi), O.Prox("box", lo=-np.inf, hi=g_hi, dtype=dtype)
@@ -1213,7 +1255,7 @@ def test_proshi_dense_quadratic(ctx, ciao, dtype, shape, r):
     rt, rav, rz, rhg = O.proshi_init(of, og, gam, x0)
     # independent statement of the init table in numpy: s_i = x0 - gam_i/N (Q_i x0 + q_i + eta (x0 - clamp(x0)))
     want = x0.astype(np.float64) - (gam.astype(np.float64) / N)[:, None] * (
-        np.einsum("nij,j->ni", Q.astype(np.float64), x0.astype(np.float64)) + q + eta * (x0 - np.clip(x0, lo, hi)).astype(np.float64))
+        Q.astype(np.float64) @ x0.astype(np.float64) + q + eta * (x0 - np.clip(x0, lo, hi)).astype(np.float64))
     close(table, want, dtype, scale=200, what="dense proshi init table vs numpy")
     close(table, rt, dtype, scale=200, what="dense proshi init table")
     close(av, rav, dtype, scale=500, what="dense proshi init av")

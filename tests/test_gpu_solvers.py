@@ -286,6 +286,15 @@ class TestLassoComplex:
         x, it = S.Finito(self.R(T), maxit=self.maxit, sweeping=sweeping, LFinito=True)(x0, F=F, g=g, L=L, N=N)
         self.check(x, T, cost, f_star)
 
+    @pytest.mark.parametrize("sweeping", [1, 2, 3])
+    def test_adaptive_finito(self, api, T, sweeping):                       # :88-98
+        S, ops = api
+        F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
+        R = self.R(T)
+        x, it = S.Finito(R, maxit=self.maxit, tol=R(1e-5), sweeping=sweeping, adaptive=True)(x0, F=F, g=g, L=L, N=N)
+        self.check(x, T, cost, f_star)
+        assert it == self.maxit
+
     @pytest.mark.parametrize("sweeping,batch,lf", [(1, 2, False), (2, 2, False), (3, 3, False), (2, 1, True), (3, 3, True)])
     def test_minibatch(self, api, T, sweeping, batch, lf):                  # :101-125
         S, ops = api
@@ -325,7 +334,7 @@ class TestLassoComplex:
 
     def test_mixed_real_and_complex_is_a_type_error(self, api, T):
         """One type T for the whole problem (CIAOAlgorithms.jl:3): complex rows with a real x0, complex x0
-        with IndBox, and the adaptive / ProShI variants (no complex form on the device path) are refused, not demoted."""
+        with IndBox are refused, not demoted."""
         S, ops = api
         F, g, L, x0, N, cost, f_star = lasso_problem(ops, T)
         R = self.R(T)
@@ -339,8 +348,6 @@ class TestLassoComplex:
         assert xa.dtype == T and np.array_equal(xa, xb)
         with pytest.raises(TypeError):
             S.SAGA(R, maxit=3)(x0, F=F, g=ops.IndBox(-1.0, 1.0), N=N, L=L)
-        with pytest.raises(TypeError):
-            S.Finito(R, maxit=3, adaptive=True)(x0, F=F, g=g, N=N, L=L)
 
 
 # ======================================================================================================================

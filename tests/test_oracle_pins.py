@@ -335,7 +335,9 @@ def test_reference_complex_lasso_is_the_real_lasso_in_complex_containers(ctype, 
     runs = [("svrg", lambda p, g, x: RS.svrg(p, g, x, maxit=300, gamma=1 / (7 * L.max()), stream=Stream(0))),
             ("saga", lambda p, g, x: RS.saga(p, g, x, maxit=1000, L=L, stream=Stream(0))),
             ("finito", lambda p, g, x: RS.finito(p, g, x, maxit=1000, sweeping=2, L=L, stream=Stream(0))),
-            ("lfinito", lambda p, g, x: RS.finito(p, g, x, maxit=300, sweeping=3, lfinito=True, batch=2, L=L, stream=Stream(0)))]
+            ("lfinito", lambda p, g, x: RS.finito(p, g, x, maxit=300, sweeping=3, lfinito=True, batch=2, L=L, stream=Stream(0))),
+            # adaptive: x0 .+ one(R) touches the real parts only and sqrt(length(x0)) counts complex entries (Finito_adaptive.jl:74,86)
+            ("adaptive", lambda p, g, x: RS.finito(p, g, x, maxit=1000, sweeping=2, adaptive=True, tol=1e-5, L=L, stream=Stream(0)))]
     for name, run in runs:
         xr, _ = run(pr, gr, x0)
         xc, _ = run(pc, gc, O.as_pairs(x0c))
