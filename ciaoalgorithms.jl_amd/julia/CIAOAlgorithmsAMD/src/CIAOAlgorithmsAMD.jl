@@ -43,8 +43,8 @@ struct CiaoShardTable                       # ciao_shard_table: fixed-size C arr
 end
 const CIAO_ABI_VERSION = Int32(2)
 const CIAO_F32, CIAO_F64 = Int32(0), Int32(1)
-const LOSS_LS, LOSS_LOGISTIC, LOSS_ZERO = Int32(0), Int32(1), Int32(2)
-const PROX_ZERO, PROX_L1, PROX_BOX = Int32(0), Int32(1), Int32(2)
+const LOSS_LS, LOSS_LOGISTIC, LOSS_ZERO, LOSS_LS_COMPLEX = Int32(0), Int32(1), Int32(2), Int32(3)
+const PROX_ZERO, PROX_L1, PROX_BOX, PROX_L1_COMPLEX = Int32(0), Int32(1), Int32(2), Int32(3)
 dtype_code(::Type{Float32}) = CIAO_F32
 dtype_code(::Type{Float64}) = CIAO_F64
 
@@ -78,6 +78,14 @@ context() = (default_ctx[] === nothing && (default_ctx[] = Context()); default_c
 dptr(a::ROCArray) = Base.unsafe_convert(Ptr{Cvoid}, pointer(a))
 dptr(::Nothing) = C_NULL
 
+# complex T (CIAOAlgorithms.jl:3; test/test_lasso.jl:3 runs ComplexF32 / ComplexF64): every complex vector travels as its
+# interleaved (re, im) pairs -- reinterpret(R, x) -- and d counts reals.  LeastSquares rows pair with Zero / NormL1 only.
+reals(::Type{R}, x::AbstractArray{<:Real}) where {R} = R.(vec(x))
+reals(::Type{R}, x::AbstractArray{<:Complex}) where {R} = collect(reinterpret(R, Complex{R}.(vec(x))))
+nreals(x0::AbstractArray) = eltype(x0) <: Complex ? 2 * length(x0) : length(x0)
+host_solution(sol::ROCArray{R}, x0::AbstractArray) where {R} =
+    eltype(x0) <: Complex ? reshape(collect(reinterpret(Complex{R}, Array(sol))), size(x0)) : reshape(Array(sol), size(x0))
+
 # ---- packing: recognise the operator families of the reference's tests (SURVEY.md section 8b) -------------------------
 # F::Vector of one-row LeastSquares / Precompose(LogisticLoss) / Zero  ->  (A as a d x N Julia matrix = row-major N x d)
 struct PackedF{R}
@@ -88,10 +96,23 @@ struct PackedF{R}
     N::Int
     d::Int
 end
-function pack_F(::Type{R}, F, N::Int, d::Int) where {R}
+function pack_F(::Type{R}, F, N::Int, d::Int; cplx::Bool = false) where {R}
     F isa PackedF{R} && return F
     if F === nothing || all(f -> f isa ProximalOperators.Zero, F)
         return PackedF{R}(LOSS_ZERO, nothing, nothing, 0.0, N, d)
+    elseif cplx && all(f -> f isa ProximalOperators.LeastSquares, F)
+        # complex x0: rows of d/2 complex entries (real rows are widened: real A times complex x is what LeastSquares computes)
+        lam = F[1].lambda
+        n = d ÷ 2
+        all(f -> f.lambda == lam && size(f.A) == (1, n), F) || throw(ArgumentError("unpackable LeastSquares terms"))
+        A = Matrix{Complex{R}}(undef, n, N); b = Vector{Complex{R}}(undef, N)
+        for i in 1:N
+            A[:, i] .= vec(F[i].A); b[i] = F[i].b[1]
+        end
+        return PackedF{R}(LOSS_LS_COMPLEX, ROCArray(reshape(collect(reinterpret(reshape, R, A)), d, N)),      # 2 x n x N -> (re, im) interleaved rows
+                          ROCArray(collect(reinterpret(R, b))), Float64(lam), N, d)
+    elseif cplx
+        throw(ArgumentError("with a complex x0 the device path packs LeastSquares rows and Zero only"))
     elseif all(f -> f isa ProximalOperators.LeastSquares, F)
         lam = F[1].lambda
         all(f -> f.lambda == lam && size(f.A) == (1, d), F) || throw(ArgumentError("unpackable LeastSquares terms"))
@@ -113,10 +134,11 @@ end
 cproblem(p::PackedF{R}) where {R} =
     CiaoProblem(p.loss, dtype_code(R), p.N, p.d, p.d, p.N, dptr(p.A), dptr(p.b), p.lam)
 
-function pack_g(::Type{R}, g, d::Int) where {R}
+function pack_g(::Type{R}, g, d::Int; cplx::Bool = false) where {R}
     g isa ProximalOperators.Zero && return (CiaoProxDesc(PROX_ZERO, 0, 0.0, -Inf, Inf, C_NULL, C_NULL), nothing)
     g isa ProximalOperators.NormL1 && g.lambda isa Real &&
-        return (CiaoProxDesc(PROX_L1, 0, Float64(g.lambda), -Inf, Inf, C_NULL, C_NULL), nothing)
+        return (CiaoProxDesc(cplx ? PROX_L1_COMPLEX : PROX_L1, 0, Float64(g.lambda), -Inf, Inf, C_NULL, C_NULL), nothing)
+    cplx && throw(ArgumentError("with a complex x0 g must be Zero or NormL1 (IndBox has no complex form)"))
     if g isa ProximalOperators.IndBox
         lo = g.lb isa Real ? nothing : ROCArray(R.(vec(g.lb)))
         hi = g.ub isa Real ? nothing : ROCArray(R.(vec(g.ub)))
@@ -236,7 +258,7 @@ function Base.iterate(iter::SVRG_basic_iterable{R}) where {R}          # SVRG_ba
     else
         γ = iter.γ
     end
-    x0d = ROCArray(R.(vec(iter.x0)))
+    x0d = ROCArray(reals(R, iter.x0))
     av, z, z_full, w = (similar(x0d) for _ in 1:4)
     p = Ref(cproblem(iter.F))
     check(ccall((:ciao_svrg_init, libciao), Int32,
@@ -264,11 +286,10 @@ solution(state::SVRG_basic_state) = state.z_full                                
 
 function iterator(solver::SVRG{R}, x0::AbstractArray{C}; F = nothing, g = ProximalOperators.Zero(), L = nothing,
                   μ = nothing, N) where {R,C<:RealOrComplex{R}}
-    C <: Complex && throw(ArgumentError("complex iterates are outside the device path"))
-    d = length(x0)
+    d = nreals(x0)                      # reals: twice the length of a complex x0
     m = solver.m === nothing ? N : solver.m
-    gd, keep = pack_g(R, g, d)
-    return SVRG_basic_iterable{R,typeof(x0)}(pack_F(R, F, N, d), gd, keep, x0, N, L, μ, solver.γ, m, solver.plus)
+    gd, keep = pack_g(R, g, d; cplx = C <: Complex)
+    return SVRG_basic_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex), gd, keep, x0, N, L, μ, solver.γ, m, solver.plus)
 end
 
 function (solver::SVRG{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrComplex{R}}   # SVRG.jl:46-84
@@ -286,7 +307,7 @@ function (solver::SVRG{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrCo
     end
     solver.verbose && mod(num_iters, solver.freq) !== 0 && disp(num_iters, state_final)
     synchronize(context())
-    return reshape(Array(solution(state_final)), size(x0)), num_iters
+    return host_solution(solution(state_final), x0), num_iters
 end
 
 # ======================================================================================================================
@@ -328,7 +349,7 @@ function Base.iterate(iter::SAGA_basic_iterable{R}) where {R}          # SAGA_ba
     else
         γ = iter.γ
     end
-    x0d = ROCArray(R.(vec(iter.x0)))
+    x0d = ROCArray(reals(R, iter.x0))
     s = ROCArray{R}(undef, length(x0d), iter.N)
     av, z = similar(x0d), similar(x0d)
     p, g = Ref(cproblem(iter.F)), Ref(iter.g)
@@ -358,10 +379,9 @@ solution(state::SAGA_basic_state) = state.z                                     
 
 function iterator(solver::SAGA{R}, x0::AbstractArray{C}; F = nothing, g = ProximalOperators.Zero(), L = nothing,
                   N) where {R,C<:RealOrComplex{R}}
-    C <: Complex && throw(ArgumentError("complex iterates are outside the device path"))
-    d = length(x0)
-    gd, keep = pack_g(R, g, d)
-    return SAGA_basic_iterable{R,typeof(x0)}(pack_F(R, F, N, d), gd, keep, x0, N, L, solver.γ, solver.SAG_flag)
+    d = nreals(x0)                      # reals: twice the length of a complex x0
+    gd, keep = pack_g(R, g, d; cplx = C <: Complex)
+    return SAGA_basic_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex), gd, keep, x0, N, L, solver.γ, solver.SAG_flag)
 end
 
 function (solver::SAGA{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrComplex{R}}   # SAGA.jl:44-73
@@ -380,7 +400,7 @@ function (solver::SAGA{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrCo
     end
     solver.verbose && mod(num_iters, solver.freq) !== 0 && disp(num_iters, state)
     synchronize(context())
-    return reshape(Array(solution(state)), size(x0)), num_iters
+    return host_solution(solution(state), x0), num_iters
 end
 
 # ======================================================================================================================
@@ -444,7 +464,7 @@ function Base.iterate(iter::FINITO_iterable{R}) where {R}    # Finito_basic.jl:4
     hg = Ref{Float64}(0.0)
     check(ccall((:ciao_hat_gamma, libciao), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ref{Float64}),
                 context().h, dtype_code(R), N, dptr(γ), hg))
-    x0d = ROCArray(R.(vec(iter.x0)))
+    x0d = ROCArray(reals(R, iter.x0))
     av, z = similar(x0d), similar(x0d)
     p, g = Ref(cproblem(iter.F)), Ref(iter.g)
     if iter.lfinito
@@ -525,14 +545,13 @@ solution(state::FINITO_state) = state.z                            # Finito_basi
 
 function iterator(solver::Finito{R}, x0::AbstractArray{C}; F = nothing, g = ProximalOperators.Zero(), L = nothing,
                   N) where {R,C<:RealOrComplex{R}}
-    C <: Complex && throw(ArgumentError("complex iterates are outside the device path"))
-    d = length(x0)
-    gd, keep = pack_g(R, g, d)
+    d = nreals(x0)                      # reals: twice the length of a complex x0
+    gd, keep = pack_g(R, g, d; cplx = C <: Complex)
     if solver.adaptive && !solver.LFinito                          # Finito.jl:95-108: no minibatch in the adaptive mode
         solver.minibatch[1] && @warn "minibatch is not supported for adaptive Finito"
-        return FINITO_adaptive_iterable{R,typeof(x0)}(pack_F(R, F, N, d), gd, keep, x0, N, solver.tol_b, solver.sweeping, solver.α)
+        return FINITO_adaptive_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex), gd, keep, x0, N, solver.tol_b, solver.sweeping, solver.α)
     end
-    return FINITO_iterable{R,typeof(x0)}(pack_F(R, F, N, d), gd, keep, x0, N, L, solver.γ, solver.sweeping,
+    return FINITO_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex), gd, keep, x0, N, L, solver.γ, solver.sweeping,
                                          solver.minibatch[2], solver.α, solver.LFinito)
 end
 
@@ -559,7 +578,7 @@ function (solver::Finito{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOr
     end
     solver.verbose && mod(num_iters, solver.freq) !== 0 && disp(num_iters, state)
     synchronize(context())
-    return reshape(Array(solution(state)), size(x0)), num_iters
+    return host_solution(solution(state), x0), num_iters
 end
 
 # ======================================================================================================================
@@ -578,7 +597,7 @@ end
 
 function Base.iterate(iter::FINITO_adaptive_iterable{R}) where {R}      # Finito_adaptive.jl:59-98
     N = iter.N
-    x0d = ROCArray(R.(vec(iter.x0)))
+    x0d = ROCArray(reals(R, iter.x0))
     s = ROCArray{R}(undef, length(x0d), N)
     meta = ROCArray{R}(undef, 4, 4, N)
     hg = ROCArray{R}(undef, 1)
@@ -598,13 +617,13 @@ function Base.iterate(iter::FINITO_adaptive_iterable{R}) where {R}      # Finito
             t = 1; nmg = Ref{Float64}(0.0)
             while true
                 println("initial upper bound for L too small")
-                signs = ROCArray(R.(rand(t * [-1, 1], length(x0d)) ./ t))
+                signs = ROCArray(R.(rand(t * [-1, 1], length(iter.x0)) ./ t))   # real draws, one per entry of x0 (complex: real parts)
                 check(ccall((:ciao_afinito_probe, libciao), Int32, (Ptr{Cvoid}, Ref{CiaoProblem}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ref{Float64}),
                             context().h, Ref(cproblem(iter.F)), i - 1, dptr(x0d), dptr(signs), Float64(t), nmg))
                 t *= 2
                 R(nmg[]) < eps(R) || break
             end
-            L_int = R(nmg[]) / (t * sqrt(length(x0d))); L_int /= N
+            L_int = R(nmg[]) / (t * sqrt(length(iter.x0))); L_int /= N
             γh[i] = iter.α / L_int
         end
         afinit(ROCArray(R.(γh)))
@@ -726,7 +745,7 @@ function Base.iterate(iter::Proshi_basic_iterable{R}) where {R}          # ProSh
     γh = finito_gammas(iter, R)                                          # :61-74, the same rule as Finito
     γh === nothing && return nothing
     γ = ROCArray(γh)
-    x0d = ROCArray(R.(vec(iter.x0)))
+    x0d = ROCArray(reals(R, iter.x0))
     s = ROCArray{R}(undef, length(x0d), N)
     av, z, hg = similar(x0d), similar(x0d), ROCArray{R}(undef, 1)
     check(ccall((:ciao_proshi_init, libciao), Int32,
@@ -770,7 +789,7 @@ function solution(state::Proshi_basic_state)                             # :127-
 end
 
 function iterator(solver::Proshi{R}, x0::AbstractArray{C}; F, g = ProximalOperators.Zero(), L = nothing, N) where {R,C<:RealOrComplex{R}}
-    C <: Complex && throw(ArgumentError("complex iterates are outside the device path"))
+    C <: Complex && throw(ArgumentError("complex agents are outside the ProShI device path"))
     d = length(x0)
     gd, keep = pack_g(R, g, d)
     return Proshi_basic_iterable{R,typeof(x0)}(pack_sharing_F(R, F, N, d), gd, keep, x0, N, L, solver.γ, solver.sweeping,
