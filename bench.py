@@ -236,12 +236,23 @@ def run_rank(args):
         if want == "rccl" and backend == "nccl":
             try:
                 comm = RcclComm(rank, world, dev.index)
+            except Exception as e:   # a box whose RCCL cannot be loaded natively still gets a (truthfully labelled) number
+                print(f"[bench] rank {rank}: native RCCL path unavailable ({e!r})", file=sys.stderr)
+                comm = None
+            # every rank must take the same path: one that failed while the others succeeded would leave them waiting in
+            # ncclAllReduce for a rank that is in torch's collective instead
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                if rank == 0:
+                    print("[bench] falling back to torch.distributed for the collective on every rank", file=sys.stderr)
+            else:
                 ctx.set_rccl(comm)
                 rccl_ranks = comm.count()
                 collective = "rccl ncclAllReduce(d+1) per step, issued by the library on its stream"
-            except Exception as e:   # a box whose RCCL cannot be loaded natively still gets a (truthfully labelled) number
-                print(f"[bench] native RCCL path unavailable ({e!r}); falling back to torch.distributed", file=sys.stderr)
-                comm = None
         if comm is None:
             hook = AllReduceHook(dev)
             ctx.set_allreduce(hook)

@@ -206,12 +206,19 @@ class RcclComm:
         self._lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         self._lib.ncclGetErrorString.restype = C.c_char_p
         uid = _NcclUniqueId()
+        err = None
         if rank == 0:
-            self._check(self._lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+            r = self._lib.ncclGetUniqueId(C.byref(uid))
+            if r != 0:
+                err = f"ncclGetUniqueId failed: {self._lib.ncclGetErrorString(r).decode()}"
         if world > 1:
-            box = [C.string_at(C.addressof(uid), 128) if rank == 0 else None]
+            # rank 0 always broadcasts -- the id, or its failure -- so that no rank is left waiting for the other
+            box = [(err, C.string_at(C.addressof(uid), 128)) if rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
-            C.memmove(C.addressof(uid), box[0], 128)
+            err = box[0][0]
+            C.memmove(C.addressof(uid), box[0][1], 128)
+        if err:
+            raise RuntimeError(err)
         torch.cuda.set_device(device)
         comm = C.c_void_p()
         self._check(self._lib.ncclCommInitRank(C.byref(comm), world, uid, rank), "ncclCommInitRank")
