@@ -176,4 +176,80 @@ def run(ctx, dev, quick=False):
                                                "kernel": ctx.last_kernel()}
     del Q, q, table, f
     torch.cuda.empty_cache()
+
+    # ---- ProShI with dense Quadratic(Q_i) blocks (ciao_sepquad.dense): N agents x (d x d), d = 256 fp64 -------------------
+    N, d = 8192 // scale, 256
+    Q = torch.empty((N * d, d), dtype=torch.float64, device=dev)
+    q = torch.empty((N, d), dtype=torch.float64, device=dev)
+    ctx.synth_normal(Q, 0, seed=9, scale=1.0 / np.sqrt(d))
+    ctx.synth_normal(q, 0, seed=10, scale=1.0)
+    f = PackedSepQuad(Q.view(N, d, d), q, eta=30.0, lo=-2.0, hi=2.0)
+    gam = torch.full((N,), 0.999 * N / 40.0, dtype=torch.float64, device=dev)
+    x0 = torch.zeros(d, dtype=torch.float64, device=dev)
+    table = torch.empty((N, d), dtype=torch.float64, device=dev)
+    av, z = torch.empty_like(x0), torch.empty_like(x0)
+    ctx.proshi_init(f, gbox, gam, x0, table, av, z, hgd)
+    t = _timed(ctx, lambda: ctx.proshi_init(f, gbox, gam, x0, table, av, z, hgd), reps=3)
+    out["proshi_dense_init_f64_d256"] = {"seconds": t, "alg_GBps": N * d * d * 8 / t / 1e9, "N": N, "kernel": ctx.last_kernel()}
+    hg = float(hgd.item())
+    r, nit = 1024 // scale, 16
+    batches = [st.sample_without_replacement(N, r) for _ in range(nit)]
+    bptr = np.arange(nit + 1, dtype=np.int64) * r
+    bidx = ctx._idx(np.concatenate(batches))
+    ctx.proshi_steps(f, gbox, gam, hg, bptr[:2], bidx[:r], table, av, z)
+    t = _timed(ctx, lambda: ctx.proshi_steps(f, gbox, gam, hg, bptr, bidx, table, av, z))
+    out[f"proshi_dense_batch_r{r}_f64_d256"] = {"agents_per_s": nit * r / t, "alg_GBps": nit * r * d * d * 8 / t / 1e9,
+                                                 "kernel": ctx.last_kernel()}
+    del Q, q, table, f
+    torch.cuda.empty_cache()
+
+    # ---- complex T (LOSS_LS_COMPLEX): the sweep and the SVRG chain on 512 complex entries per row (= 1024 fp64 reals) -----------
+    from ciaoalgorithms_jl_amd.device import PackedF
+    N, n = 1_000_000 // scale, 512
+    A = torch.empty((N, 2 * n), dtype=torch.float64, device=dev)
+    b = torch.empty((2 * N,), dtype=torch.float64, device=dev)
+    ctx.synth_normal(A, 0, seed=11, scale=1.0 / np.sqrt(2 * n))
+    ctx.synth_normal(b.view(N, 2), 0, seed=12, scale=1.0)
+    Fc = PackedF.least_squares_complex(A, b, float(N))
+    gc = ProxG(L.PROX_L1_COMPLEX, lam=1e-3)
+    x0 = torch.zeros(2 * n, dtype=torch.float64, device=dev)
+    av, z, zf, w = (torch.empty_like(x0) for _ in range(4))
+    ctx.full_gradient(Fc, x0, av)
+    ctx.timing_enable(True)
+    ctx.timing_read()
+    for _ in range(3):
+        ctx.full_gradient(Fc, x0, av)
+    ms, k = ctx.timing_read()
+    ctx.timing_enable(False)
+    out["sweep_complex_f64_n512"] = {"kernel_ms": ms / max(k, 1), "alg_GBps": N * (2 * n * 8 + 16) / (ms / max(k, 1) * 1e-3) / 1e9, "N": N,
+                                     "kernel": ctx.last_kernel()}
+    ctx.svrg_init(Fc, x0, av, z, zf, w)
+    m = 20_000 // scale
+    idx = ctx._idx(st.rand_indices(N, m))
+    ctx.svrg_inner(Fc, gc, 1.0 / (7 * 1.3 * N), idx[:100], av, z, zf, w)
+    t = _timed(ctx, lambda: ctx.svrg_inner(Fc, gc, 1.0 / (7 * 1.3 * N), idx, av, z, zf, w))
+    out["svrg_inner_complex_f64_n512"] = {"updates_per_s": m / t, "us_per_update": t / m * 1e6, "m": m, "kernel": ctx.last_kernel()}
+    del Fc, A, b
+    torch.cuda.empty_cache()
+
+    # ---- adaptive Finito on rows beyond the register-resident shapes (afinito_big_kernel), d = 8192 fp64 --------------------
+    N, d = 20_000 // scale, 8192
+    F = _problem(ctx, dev, N, d, torch.float64, False)
+    g = ProxG(L.PROX_L1, lam=1e-3)
+    x0 = torch.zeros(d, dtype=torch.float64, device=dev)
+    table = torch.empty((N, d), dtype=torch.float64, device=dev)
+    meta4 = torch.empty((N, 4, 4), dtype=torch.float64, device=dev)
+    hgd = torch.empty(1, dtype=torch.float64, device=dev)
+    av, z = torch.empty_like(x0), torch.empty_like(x0)
+    ctx.afinito_init(F, g, 0.999, x0, table, meta4, av, z, hgd)
+    k = 5_000 // scale
+    idx = ctx._idx(st.rand_indices(N, k))
+    ctx.afinito_steps(F, g, 0.999, 1e-9, idx[:100], table, meta4, av, z, hgd)
+    t0 = time.perf_counter()
+    done, trials = ctx.afinito_steps(F, g, 0.999, 1e-9, idx, table, meta4, av, z, hgd)
+    t = time.perf_counter() - t0
+    out["adaptive_finito_steps_f64_d8192"] = {"updates_per_s": done / t, "us_per_update": t / max(done, 1) * 1e6, "steps": done,
+                                              "trials_per_step": trials / max(done, 1), "kernel": ctx.last_kernel()}
+    del F, table
+    torch.cuda.empty_cache()
     return out

@@ -1128,6 +1128,143 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_cplx_kernel(RowsArgs<T> a)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Complex T, the streaming kernel: rows_split_kernel's layout (one workgroup per row, thread t owns the 16-byte chunks
+// t + 256 j of every vector, accumulators and the iterate in registers, one raw barrier per row) with complex arithmetic
+// on the chunk's (re, im) pairs -- one complex per chunk for fp64, two for fp32.  Rows of whole 16-byte chunks up to 64 KiB;
+// dead chunks of the last group are masked.  Everything else complex (odd complex counts in fp32, longer rows, the adaptive
+// init) stays on rows_cplx_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int J, int MODE>
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_csplit_kernel(RowsArgs<T> a)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int NC = VEC / 2;                       // complex numbers per chunk
+    using V = typename ChunkOf<T, VEC>::type;
+    constexpr bool TWO = (MODE == RM_GRAD2);
+    constexpr bool TABLE = (MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH);
+    constexpr bool TREAD = (MODE == RM_FINITO_BATCH);
+    static_assert(MODE != RM_AFINITO_INIT, "the adaptive init keeps to rows_cplx_kernel");
+
+    __shared__ T red[2][ROWS_WAVES][4];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t nchunks = a.d / VEC;
+
+    bool ok[J];
+    V x1[J], x2[J], acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        ok[j] = tid + j * ROWS_BLOCK < nchunks;
+        x1[j] = ok[j] ? reinterpret_cast<const V *>(a.x1)[tid + j * ROWS_BLOCK] : V(T(0));
+        x2[j] = (TWO && ok[j]) ? reinterpret_cast<const V *>(a.x2)[tid + j * ROWS_BLOCK] : V(T(0));
+        acc[j] = V(T(0));
+    }
+    T extra = T(0);
+    int par = 0;
+    for (int64_t q = blockIdx.x; q < a.nrows; q += gridDim.x) {
+        int64_t row = a.idx ? a.idx[q] : a.row0 + q;
+        if (a.idx && (uint64_t)row >= (uint64_t)a.N) {
+            if (tid == 0) *a.errflag = 1;
+            row = 0;
+        }
+        V *sp = TABLE ? reinterpret_cast<V *>(a.table + row * a.d) : nullptr;
+        const V *ap = reinterpret_cast<const V *>(a.A + row * a.ld);
+        V ar[J], sr[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) ar[j] = ok[j] ? __builtin_nontemporal_load(&ap[tid + j * ROWS_BLOCK]) : V(T(0));
+        if (TREAD) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) sr[j] = ok[j] ? __builtin_nontemporal_load(&sp[tid + j * ROWS_BLOCK]) : V(T(0));
+        }
+        const T br = a.b[2 * row], bi = a.b[2 * row + 1];
+        const T gi = (MODE == RM_GRAD || MODE == RM_SAGA_INIT) ? T(1) : (a.gam ? a.gam[row] : a.gam_uniform);
+        T s1r = T(0), s1i = T(0), s2r = T(0), s2i = T(0);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const T pr = ar[j][2 * c], pi = ar[j][2 * c + 1];
+                s1r += pr * x1[j][2 * c] - pi * x1[j][2 * c + 1];
+                s1i += pr * x1[j][2 * c + 1] + pi * x1[j][2 * c];
+                if (TWO) {
+                    s2r += pr * x2[j][2 * c] - pi * x2[j][2 * c + 1];
+                    s2i += pr * x2[j][2 * c + 1] + pi * x2[j][2 * c];
+                }
+            }
+        s1r = wave_allsum(s1r);
+        s1i = wave_allsum(s1i);
+        if (TWO) {
+            s2r = wave_allsum(s2r);
+            s2i = wave_allsum(s2i);
+        }
+        if (lane == 0) {
+            red[par][wib][0] = s1r;
+            red[par][wib][1] = s1i;
+            if (TWO) {
+                red[par][wib][2] = s2r;
+                red[par][wib][3] = s2i;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        s1r = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+        s1i = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+        if (TWO) {
+            s2r = (red[par][0][2] + red[par][1][2]) + (red[par][2][2] + red[par][3][2]);
+            s2i = (red[par][0][3] + red[par][1][3]) + (red[par][2][3] + red[par][3][3]);
+        }
+        par ^= 1;
+        const T r1r = s1r - br, r1i = s1i - bi;          // res = a.x - b
+        const T r2r = s2r - br, r2i = s2i - bi;
+        if (MODE == RM_GRAD && a.want_fval) extra += (a.lam / T(2)) * (r1r * r1r + r1i * r1i);
+        if (MODE == RM_GRAD2) extra += a.hat_gamma / gi;
+        const T cg = gi * a.invN;
+        const T rr = (MODE == RM_FINITO_INIT) ? T(1) / gi : a.hat_gamma / gi;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            V tv;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                T gr, gim;
+                cgrad_elem(ar[j][2 * c], ar[j][2 * c + 1], r1r, r1i, a.lam, gr, gim);
+                if (MODE == RM_GRAD) {
+                    acc[j][2 * c] += gr;
+                    acc[j][2 * c + 1] += gim;
+                } else if (MODE == RM_GRAD2) {
+                    T hr, hi;
+                    cgrad_elem(ar[j][2 * c], ar[j][2 * c + 1], r2r, r2i, a.lam, hr, hi);
+                    acc[j][2 * c] += gr - hr;
+                    acc[j][2 * c + 1] += gim - hi;
+                } else if (MODE == RM_SAGA_INIT) {
+                    tv[2 * c] = gr;
+                    tv[2 * c + 1] = gim;
+                    acc[j][2 * c] += gr;
+                    acc[j][2 * c + 1] += gim;
+                } else {
+                    const T tr = x1[j][2 * c] - cg * gr, ti = x1[j][2 * c + 1] - cg * gim;
+                    if (MODE == RM_FINITO_INIT) {
+                        acc[j][2 * c] += tr * rr;
+                        acc[j][2 * c + 1] += ti * rr;
+                    } else {
+                        acc[j][2 * c] += (tr - sr[j][2 * c]) * rr;
+                        acc[j][2 * c + 1] += (ti - sr[j][2 * c + 1]) * rr;
+                    }
+                    tv[2 * c] = tr;
+                    tv[2 * c + 1] = ti;
+                }
+            }
+            if (TABLE && ok[j]) TSTORE(tv, &sp[tid + j * ROWS_BLOCK]);
+        }
+    }
+    V *pout = reinterpret_cast<V *>(a.partial + (int64_t)blockIdx.x * a.pstride);
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+        if (ok[j]) PSTORE(acc[j], &pout[tid + j * ROWS_BLOCK]);
+    if (tid == 0) a.pextra[blockIdx.x] = extra;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // finalize: sum the per-block partials in a fixed order and apply the epilogue.
 // A batch step is rows kernel -> finalize -> next rows kernel, so for batches of a few hundred rows this kernel is half of
 // the step (rocprofv3, r = 256, d = 4096 fp32: rows 6.4 us, finalize 5.0 us with the first version of this kernel, which

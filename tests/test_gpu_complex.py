@@ -102,6 +102,60 @@ def test_complex_full_pass_and_proxgrad(ctx, ctype, shape):
 
 
 @pytest.mark.parametrize("ctype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("n", [64, 300, 512, 1000, 4096])
+def test_complex_streaming_kernel_equals_the_plain_one(ctx, ciao, ctype, n):
+    """Rows of whole 16-byte chunks take rows_csplit_kernel (one workgroup per row, registers); force_generic routes the same
+    calls through rows_cplx_kernel.  Every mode (sweep, two-point batch, SAGA init, Finito init and batch) on both."""
+    import torch
+    from oracle import oracle as O
+    R = RTYPE[ctype]
+    N = 70
+    A, b, x = P.synthetic_complex(N, n, ctype, seed=n)
+    _, dp = cmake(A, b, float(N))
+    _, dg = cg(0.02)
+    xp = dev(O.as_pairs(x))
+    gam = dev(np.linspace(0.5, 1.5, N).astype(R))
+    hg = ctx.hat_gamma(gam)
+    idx = np.sort(ciao.IndexStream(1).sample_without_replacement(N, 20))
+    bptr = np.array([0, 20], np.int64)
+    res = {}
+    for generic in (0, 1):
+        ctx.set_option("force_generic", generic)
+        ctx.set_option("chain_max_batch", 0)
+        try:
+            names = []
+            av = torch.empty_like(xp)
+            ctx.full_gradient(dp, xp, av)
+            names.append(ctx.last_kernel())
+            table = torch.empty((N, 2 * n), dtype=xp.dtype, device="cuda")
+            sav, sz = torch.empty_like(xp), torch.empty_like(xp)
+            ctx.saga_init(dp, dg, 0.01, xp, table, sav, sz)
+            names.append(ctx.last_kernel())
+            ftab = torch.empty_like(table)
+            fav, fz = torch.empty_like(xp), torch.empty_like(xp)
+            ctx.finito_init(dp, dg, gam, hg, xp, ftab, fav, fz)
+            names.append(ctx.last_kernel())
+            ctx.finito_steps(dp, dg, gam, hg, bptr, idx, ftab, fav, fz)
+            names.append(ctx.last_kernel())
+            lav, lz, lzf = (torch.empty_like(xp) for _ in range(3))
+            ctx.lfinito_init(dp, hg, xp, lav, lz, lzf)
+            ctx.lfinito_iterate(dp, dg, gam, hg, bptr, idx, lav, lz, lzf)
+            names.append(ctx.last_kernel())
+        finally:
+            ctx.set_option("force_generic", 0)
+            ctx.set_option("chain_max_batch", -1)
+        rowb = 2 * n * np.dtype(R).itemsize
+        streaming = not generic and rowb % 16 == 0 and 64 <= rowb // 16 <= 4096       # the planner's rule (rows_launch.inc)
+        want = "rows_csplit_kernel" if streaming else "rows_cplx_kernel"
+        assert all(want in k for k in names), names
+        res[generic] = [t.cpu().numpy() for t in (av, table, sav, sz, ftab, fav, fz, lav, lz, lzf)]
+    for u, v, what in zip(res[0], res[1], ("av", "saga table", "saga av", "saga z", "finito table", "finito av", "finito z", "lfinito av",
+                                           "lfinito z", "lfinito z_full")):
+        close(u, v, R, scale=500, what=f"streaming vs plain complex kernel: {what}")
+    ctx.synchronize()
+
+
+@pytest.mark.parametrize("ctype", [np.complex128, np.complex64])
 @pytest.mark.parametrize("shape", CSHAPES)
 def test_complex_svrg_epochs(ctx, ciao, ctype, shape):
     import torch
