@@ -647,6 +647,220 @@ __global__ void __launch_bounds__(CHAIN_BIG_NT) chain_cplx_kernel(ChainArgs<T> a
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Complex chains, register-resident: up to 2048 complex entries per row (EP pairs per thread, 256 threads).  The iterate
+// state (p, av, z_full / the SVRG accumulator) lives in registers for the whole launch, thread t owning the pairs
+// t + 256 j; the next step's row (and table row) is requested one step ahead and is in flight while this step computes; one
+// raw barrier per step for the 4-wave exchange of the complex dot product(s).  Formulas as in chain_cplx_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int ALG, int EP>
+__global__ void __launch_bounds__(CHAIN_NT) chain_cplx_reg_kernel(ChainArgs<T> a)
+{
+    constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
+    constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
+    __shared__ T red[2][CHAIN_NW][4];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t d = a.d, dc = a.d / 2;
+    T *pmem = (ALG == CA_SVRG) ? a.w : a.z;
+    const bool l1 = (a.g.kind == CIAO_PROX_L1_COMPLEX);
+    auto proxc = [&](T tau, T vr, T vi, T &yr, T &yi) {
+        if (l1) {
+            prox_cpair(tau * a.g.lam, vr, vi, yr, yi);
+        } else {
+            yr = vr;
+            yi = vi;
+        }
+    };
+    bool ok[EP];
+    int64_t ke[EP];                                   // offset of the pair's real part; dead pairs point at pair 0 and are masked
+    T pr[EP], pi[EP], avr[EP], avi[EP], qr[EP], qi[EP];   // q: z_full (SVRG, LFinito) ; the SVRG accumulator z rides in zr/zi
+    T zr[EP], zi[EP];
+#pragma unroll
+    for (int j = 0; j < EP; ++j) {
+        const int64_t e = tid + (int64_t)j * CHAIN_NT;
+        ok[j] = e < dc;
+        ke[j] = ok[j] ? 2 * e : 0;
+        pr[j] = ok[j] ? pmem[ke[j]] : T(0);
+        pi[j] = ok[j] ? pmem[ke[j] + 1] : T(0);
+        avr[j] = ok[j] ? a.av[ke[j]] : T(0);
+        avi[j] = ok[j] ? a.av[ke[j] + 1] : T(0);
+        qr[j] = (TWO && ok[j]) ? a.zf[ke[j]] : T(0);
+        qi[j] = (TWO && ok[j]) ? a.zf[ke[j] + 1] : T(0);
+        zr[j] = (ALG == CA_SVRG && ok[j]) ? a.z[ke[j]] : T(0);
+        zi[j] = (ALG == CA_SVRG && ok[j]) ? a.z[ke[j] + 1] : T(0);
+    }
+    auto row_of = [&](int64_t s) -> int64_t {
+        int64_t r = a.idx[s];
+        if ((uint64_t)r >= (uint64_t)a.N) {
+            if (tid == 0) *a.errflag = 1;
+            r = 0;
+        }
+        return r;
+    };
+    auto load = [&](int64_t r, T(&xr)[EP], T(&xi)[EP], T(&tr)[EP], T(&ti)[EP], T &br, T &bi, T &gi) {
+        const T *ap = a.A + r * a.ld;
+        const T *sp = HAS_TABLE ? a.table + r * d : nullptr;
+#pragma unroll
+        for (int j = 0; j < EP; ++j) {
+            xr[j] = ap[ke[j]];
+            xi[j] = ap[ke[j] + 1];
+            if (HAS_TABLE) {
+                tr[j] = sp[ke[j]];
+                ti[j] = sp[ke[j] + 1];
+            }
+        }
+        br = a.b[2 * r];
+        bi = a.b[2 * r + 1];
+        gi = (ALG == CA_FINITO || ALG == CA_LFINITO) ? (a.gam ? a.gam[r] : a.gam_uniform) : T(1);
+    };
+    T ar[EP], ai[EP], sr[EP], si[EP], br = T(0), bi = T(0), gi = T(1);
+    T arn[EP], ain[EP], srn[EP], sin_[EP], brn = T(0), bin = T(0), gin = T(1);
+    int64_t row = 0, rown = 0;
+    if (a.nsteps > 0) {
+        row = row_of(0);
+        load(row, ar, ai, sr, si, br, bi, gi);
+    }
+    int par = 0;
+    int64_t inb = 0;
+    for (int64_t s = 0; s < a.nsteps; ++s) {
+        const bool more = s + 1 < a.nsteps;
+        bool same = false;
+        if (more) {
+            rown = row_of(s + 1);
+            same = (rown == row);
+            if (!same) load(rown, arn, ain, srn, sin_, brn, bin, gin);   // in flight while this step computes
+        }
+        if (ALG == CA_LFINITO && inb == 0) {     // Finito_LFinito.jl:92  z = prox(av)
+#pragma unroll
+            for (int j = 0; j < EP; ++j) proxc(a.hat_gamma, avr[j], avi[j], pr[j], pi[j]);
+        }
+        T s1r = T(0), s1i = T(0), s2r = T(0), s2i = T(0);
+#pragma unroll
+        for (int j = 0; j < EP; ++j) {
+            const T xr = ok[j] ? ar[j] : T(0), xi = ok[j] ? ai[j] : T(0);
+            s1r += xr * pr[j] - xi * pi[j];
+            s1i += xr * pi[j] + xi * pr[j];
+            if (TWO) {
+                s2r += xr * qr[j] - xi * qi[j];
+                s2i += xr * qi[j] + xi * qr[j];
+            }
+        }
+        s1r = wave_allsum(s1r);
+        s1i = wave_allsum(s1i);
+        if (TWO) {
+            s2r = wave_allsum(s2r);
+            s2i = wave_allsum(s2i);
+        }
+        if (lane == 0) {
+            red[par][wib][0] = s1r;
+            red[par][wib][1] = s1i;
+            if (TWO) {
+                red[par][wib][2] = s2r;
+                red[par][wib][3] = s2i;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // raw barrier: the next row's loads stay in flight across it
+        const T t0 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+        const T t1 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+        T t2 = T(0), t3 = T(0);
+        if (TWO) {
+            t2 = (red[par][0][2] + red[par][1][2]) + (red[par][2][2] + red[par][3][2]);
+            t3 = (red[par][0][3] + red[par][1][3]) + (red[par][2][3] + red[par][3][3]);
+        }
+        par ^= 1;
+        const T rpr = t0 - br, rpi = t1 - bi;      // residual at p
+        const T rzr = t2 - br, rzi = t3 - bi;      // residual at z_full (TWO)
+        const bool last_of_batch = (inb + 1 == a.batch) || (s + 1 == a.nsteps);
+        T *sp = HAS_TABLE ? a.table + row * d : nullptr;
+#pragma unroll
+        for (int j = 0; j < EP; ++j) {
+            if (!ok[j]) continue;
+            T gpr, gpi, gzr, gzi;
+            cgrad_elem(ar[j], ai[j], rpr, rpi, a.lam, gpr, gpi);
+            cgrad_elem(ar[j], ai[j], rzr, rzi, a.lam, gzr, gzi);
+            if (ALG == CA_SVRG) {                                            // SVRG_basic.jl:74-81
+                T tr = gzr - gpr, ti = gzi - gpi;
+                tr -= avr[j];
+                ti -= avi[j];
+                tr *= a.gamma;
+                ti *= a.gamma;
+                tr += pr[j];
+                ti += pi[j];
+                proxc(a.gamma, tr, ti, pr[j], pi[j]);
+                zr[j] += pr[j];
+                zi[j] += pi[j];
+            } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
+                const T delr = (gpr - sr[j]) * a.invN, deli = (gpi - si[j]) * a.invN;
+                T wr, wi;
+                if (a.sag) {
+                    avr[j] += delr;
+                    avi[j] += deli;
+                    wr = pr[j] - a.gamma * avr[j];
+                    wi = pi[j] - a.gamma * avi[j];
+                } else {
+                    wr = pr[j] - a.gamma * (gpr - sr[j] + avr[j]);
+                    wi = pi[j] - a.gamma * (gpi - si[j] + avi[j]);
+                    avr[j] += delr;
+                    avi[j] += deli;
+                }
+                proxc(a.gamma, wr, wi, pr[j], pi[j]);
+                sr[j] = gpr;                                                 // the row's new table entry (kept for `same`)
+                si[j] = gpi;
+                sp[ke[j]] = gpr;
+                sp[ke[j] + 1] = gpi;
+            } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
+                const T tr = pr[j] - (gi * a.invN) * gpr, ti = pi[j] - (gi * a.invN) * gpi;
+                avr[j] += (tr - sr[j]) * (a.hat_gamma / gi);
+                avi[j] += (ti - si[j]) * (a.hat_gamma / gi);
+                sr[j] = tr;
+                si[j] = ti;
+                sp[ke[j]] = tr;
+                sp[ke[j] + 1] = ti;
+                if (last_of_batch) proxc(a.hat_gamma, avr[j], avi[j], pr[j], pi[j]);
+            } else {                                                         // Finito_LFinito.jl:93-98
+                const T c = a.hat_gamma * a.invN;
+                avr[j] += c * gzr;
+                avi[j] += c * gzi;
+                avr[j] -= c * gpr;
+                avi[j] -= c * gpi;
+                avr[j] += (a.hat_gamma / gi) * (pr[j] - qr[j]);
+                avi[j] += (a.hat_gamma / gi) * (pi[j] - qi[j]);
+            }
+        }
+        if (++inb == a.batch) inb = 0;
+        if (more && !same) {
+#pragma unroll
+            for (int j = 0; j < EP; ++j) {
+                ar[j] = arn[j];
+                ai[j] = ain[j];
+                if (HAS_TABLE) {
+                    sr[j] = srn[j];
+                    si[j] = sin_[j];
+                }
+            }
+            br = brn;
+            bi = bin;
+            gi = gin;
+            row = rown;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < EP; ++j) {
+        if (!ok[j]) continue;
+        pmem[ke[j]] = pr[j];
+        pmem[ke[j] + 1] = pi[j];
+        a.av[ke[j]] = avr[j];
+        a.av[ke[j] + 1] = avi[j];
+        if (ALG == CA_SVRG) {
+            a.z[ke[j]] = zr[j];
+            a.z[ke[j] + 1] = zi[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Fast chain: LDS-DMA row ring.
 //
 // The register-ring kernel above leaves the waits to hipcc, which drains the whole vector-memory queue once per ring
