@@ -320,10 +320,13 @@ def run_rank(args):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             tj = json.load(fh)
-        traffic = tj.get(f"{args.loss}_{args.dtype}_N{n_local}_d{d}")
-        if traffic is not None and tj.get("kernel") and tj["kernel"].split(" grid")[0] != kernel_name.split(" grid")[0]:
+        tkey = f"{args.loss}_{args.dtype}_N{n_local}_d{d}"
+        traffic = tj.get(tkey)
+        counted = tj.get("kernels", {}).get(tkey, {}).get("rocprof_name")
+        if traffic is not None and counted and counted.split("<")[0] != kernel_name.split("<")[0]:
             traffic = None   # the dominant kernel has changed since the counter pass: do not present a stale figure
-        traffic_src = {"file": "profiles/pmc_traffic.json", "measured_at": tj.get("measured_at"), "static": True} if traffic else None
+        traffic_src = {"file": "profiles/pmc_traffic.json", "measured_at": tj.get("measured_at"), "kernel_counted": counted,
+                       "static": True} if traffic else None
     except Exception:
         traffic = None
 

@@ -37,7 +37,7 @@ def close(dev, ref, dtype, scale=8, what=""):
     # every comparison is logged as (error in eps units, scale allowed); conftest.py writes gpurun_out/parity_observed.json
     import inspect
     fr = inspect.stack()[1]
-    P.PARITY_LOG.append({"test": fr.function, "line": fr.lineno, "what": what, "dtype": np.dtype(dtype).name,
+    P.PARITY_LOG.append({"file": os.path.basename(fr.filename), "test": fr.function, "line": fr.lineno, "what": what, "dtype": np.dtype(dtype).name,
                          "ratio": float(err / unit), "scale": float(scale)})
     if not CALIBRATE:
         assert err <= bound, f"{what}: max abs err {err:.3e} = {err / unit:.1f} eps > {scale} eps ({bound:.3e})"
@@ -596,7 +596,7 @@ def test_chain_over_a_shard_table_is_bitwise_the_unsharded_chain(ctx, ciao, dtyp
     rav, rz, rzf, rw = O_svrg_state(op, x0)
     from oracle import oracle as O
     O.svrg_inner(op, og, dtype(0.4), idx, rav, rz, rzf, rw)
-    close(outs[1][0], rw, dtype, scale=20000, what="sharded svrg_inner w vs oracle")
+    close(outs[1][0], rw, dtype, scale=10, what="sharded svrg_inner w vs oracle")
 
 
 def O_svrg_state(op, x0):
@@ -898,20 +898,20 @@ def test_rows_longer_than_lds(ctx, ciao, dtype, d):
     hg = ctx.hat_gamma(gam)
     ctx.finito_init(dp, dg, gam, hg, dev(x0), table, av, z)
     rt, rav, rz, rhg = O.finito_init(op, og, gam.cpu().numpy(), x0)
-    close(av, rav, dtype, scale=200, what="finito_init av (long rows)")
+    close(av, rav, dtype, scale=20, what="finito_init av (long rows)")
     batch = np.arange(3, 20, dtype=np.int64)
     ctx.set_option("chain_max_batch", 0)
     try:
         ctx.finito_steps(dp, dg, gam, hg, np.array([0, batch.size], np.int64), batch, table, av, z)
         O.finito_steps(op, og, gam.cpu().numpy(), rhg, [batch], rt, rav, rz)
-        close(z, rz, dtype, scale=500, what=f"finito batch z (long rows, {ctx.last_kernel()})")
-        close(table, rt, dtype, scale=500, what="finito batch table (long rows)")
+        close(z, rz, dtype, scale=50, what=f"finito batch z (long rows, {ctx.last_kernel()})")
+        close(table, rt, dtype, scale=20, what="finito batch table (long rows)")
         ctx.lfinito_init(dp, hg, dev(x0), av, z, zf)
         ctx.lfinito_iterate(dp, dg, gam, hg, np.array([0, 12, N], np.int64), np.arange(N, dtype=np.int64), av, z, zf)
         rav, rz, rzf, rhg = O.lfinito_init(op, gam.cpu().numpy(), x0)
         O.lfinito_iterate(op, og, gam.cpu().numpy(), rhg, [np.arange(12), np.arange(12, N)], rav, rz, rzf)
-        close(av, rav, dtype, scale=1000, what="lfinito av (long rows)")
-        close(z, rz, dtype, scale=1000, what="lfinito z (long rows)")
+        close(av, rav, dtype, scale=100, what="lfinito av (long rows)")
+        close(z, rz, dtype, scale=100, what="lfinito z (long rows)")
     finally:
         ctx.set_option("chain_max_batch", -1)
     ctx.synchronize()
@@ -943,8 +943,8 @@ def test_chains_on_rows_of_any_length(ctx, ciao, dtype, d, forced):
         assert "chain_big_kernel" in ctx.last_kernel()
         rav, rz, rzf, rw = O.svrg_init(op, x0)
         O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
-        close(w, rw, dtype, scale=2000, what="svrg_inner w (any-d chain)")
-        close(z, rz, dtype, scale=2000, what="svrg_inner z (any-d chain)")
+        close(w, rw, dtype, scale=50, what="svrg_inner w (any-d chain)")
+        close(z, rz, dtype, scale=50, what="svrg_inner z (any-d chain)")
         for sag in (False, True):
             table = torch.empty((N, d), dtype=tdt, device="cuda")
             sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
@@ -953,8 +953,8 @@ def test_chains_on_rows_of_any_length(ctx, ciao, dtype, d, forced):
             assert "chain_big_kernel" in ctx.last_kernel()
             rt, rsav, rsz = O.saga_init(op, og, dtype(gamma), x0)
             O.saga_steps(op, og, dtype(gamma), sag, idx, rt, rsav, rsz)
-            close(sz, rsz, dtype, scale=2000, what=f"saga z sag={sag} (any-d chain)")
-            close(table, rt, dtype, scale=2000, what="saga table (any-d chain)")
+            close(sz, rsz, dtype, scale=50, what=f"saga z sag={sag} (any-d chain)")
+            close(table, rt, dtype, scale=200, what="saga table (any-d chain)")
         gam = torch.full((N,), 0.4, dtype=tdt, device="cuda")
         hg = ctx.hat_gamma(gam)
         table = torch.empty((N, d), dtype=tdt, device="cuda")
@@ -964,14 +964,14 @@ def test_chains_on_rows_of_any_length(ctx, ciao, dtype, d, forced):
         assert "chain_big_kernel" in ctx.last_kernel()
         rt, rav, rz, rhg = O.finito_init(op, og, gam.cpu().numpy(), x0)
         O.finito_steps(op, og, gam.cpu().numpy(), rhg, batches, rt, rav, rz)
-        close(z, rz, dtype, scale=5000, what="finito z (any-d chain)")
-        close(table, rt, dtype, scale=5000, what="finito table (any-d chain)")
+        close(z, rz, dtype, scale=200, what="finito z (any-d chain)")
+        close(table, rt, dtype, scale=200, what="finito table (any-d chain)")
         ctx.lfinito_init(dp, hg, dev(x0), av, z, zf)
         ctx.lfinito_iterate(dp, dg, gam, hg, np.arange(0, N + 1, 2, dtype=np.int64), np.concatenate(batches), av, z, zf)
         rav, rz, rzf, rhg = O.lfinito_init(op, gam.cpu().numpy(), x0)
         O.lfinito_iterate(op, og, gam.cpu().numpy(), rhg, batches, rav, rz, rzf)
-        close(z, rz, dtype, scale=5000, what="lfinito z (any-d chain)")
-        close(av, rav, dtype, scale=5000, what="lfinito av (any-d chain)")
+        close(z, rz, dtype, scale=200, what="lfinito z (any-d chain)")
+        close(av, rav, dtype, scale=200, what="lfinito av (any-d chain)")
         ctx.synchronize()
     finally:
         ctx.set_option("chain_big", 0)
@@ -1117,8 +1117,8 @@ def test_adaptive_finito_on_rows_of_any_length(ctx, ciao, dtype, kind, N, d, for
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
     ctx.afinito_init(dp, dg, alpha, dev(x0), table, meta4, av, z, hg)
     rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(alpha), x0)
-    close(meta4[:, 0, 2], rgam, dtype, scale=5000, what="adaptive init gamma_i, long rows")   # c(x0 .+ 1) - c(x0) cancels
-    close(av, rav, dtype, scale=1000, what="adaptive init av, long rows")
+    close(meta4[:, 0, 2], rgam, dtype, scale=10000, what="adaptive init gamma_i, long rows")   # c(x0 .+ 1) - c(x0) cancels
+    close(av, rav, dtype, scale=500, what="adaptive init av, long rows")
     idx = np.concatenate([ciao.IndexStream(4).rand_indices(N, 3 * N), np.full(3, 2, np.int64)])
     ctx.set_option("chain_big", int(forced))
     try:
@@ -1130,11 +1130,11 @@ def test_adaptive_finito_on_rows_of_any_length(ctx, ciao, dtype, kind, N, d, for
     assert done == rdone == len(idx)
     assert abs(trials - rtrials) <= max(2, 0.02 * rtrials), (trials, rtrials)
     if trials == rtrials:
-        close(z, rz, dtype, scale=5000, what=f"adaptive z ({ctx.last_kernel()})")
-        close(av, rav, dtype, scale=5000, what="adaptive av, long rows")
-        close(hg, [rhg], dtype, scale=200, what="adaptive hat_gamma, long rows")
-        close(table, rt, dtype, scale=5000, what="adaptive table, long rows")
-        close(meta4[:, 0, 2], rgam, dtype, scale=5000, what="adaptive gamma_i, long rows")
+        close(z, rz, dtype, scale=500, what=f"adaptive z ({ctx.last_kernel()})")
+        close(av, rav, dtype, scale=500, what="adaptive av, long rows")
+        close(hg, [rhg], dtype, scale=1000, what="adaptive hat_gamma, long rows")
+        close(table, rt, dtype, scale=500, what="adaptive table, long rows")
+        close(meta4[:, 0, 2], rgam, dtype, scale=2000, what="adaptive gamma_i, long rows")
     assert torch.equal(meta4[:, 0], meta4[:, 1]) and torch.equal(meta4[:, 0], meta4[:, 2]) and torch.equal(meta4[:, 0], meta4[:, 3])
     ctx.synchronize()
 
@@ -1256,19 +1256,19 @@ def test_proshi_dense_quadratic(ctx, ciao, dtype, shape, r):
     # independent statement of the init table in numpy: s_i = x0 - gam_i/N (Q_i x0 + q_i + eta (x0 - clamp(x0)))
     want = x0.astype(np.float64) - (gam.astype(np.float64) / N)[:, None] * (
         Q.astype(np.float64) @ x0.astype(np.float64) + q + eta * (x0 - np.clip(x0, lo, hi)).astype(np.float64))
-    close(table, want, dtype, scale=200, what="dense proshi init table vs numpy")
-    close(table, rt, dtype, scale=200, what="dense proshi init table")
-    close(av, rav, dtype, scale=500, what="dense proshi init av")
-    close(z, rz, dtype, scale=5000, what="dense proshi init z")
+    close(table, want, dtype, scale=10, what="dense proshi init table vs numpy")
+    close(table, rt, dtype, scale=10, what="dense proshi init table")
+    close(av, rav, dtype, scale=50, what="dense proshi init av")
+    close(z, rz, dtype, scale=100, what="dense proshi init z")
     st = ciao.IndexStream(2)
     batches = [st.sample_without_replacement(N, r) if 2 * r <= N else np.sort(st.randperm(N)[:r]) for _ in range(10)]
     bptr = np.arange(len(batches) + 1, dtype=np.int64) * r
     ctx.proshi_steps(df, dg, dev(gam), float(hg.item()), bptr, np.concatenate(batches), table, av, z)
     O.proshi_steps(of, og, gam, rhg, batches, rt, rav, rz)
-    close(table, rt, dtype, scale=5000, what=f"dense proshi table ({ctx.last_kernel()})")
-    close(av, rav, dtype, scale=2000, what="dense proshi av")
-    close(z, rz, dtype, scale=50000, what="dense proshi z")
-    close(av, table.double().sum(dim=0).cpu().numpy(), dtype, scale=100, what="dense invariant av == sum_i s_i")
+    close(table, rt, dtype, scale=200, what=f"dense proshi table ({ctx.last_kernel()})")
+    close(av, rav, dtype, scale=500, what="dense proshi av")
+    close(z, rz, dtype, scale=500, what="dense proshi z")
+    close(av, table.double().sum(dim=0).cpu().numpy(), dtype, scale=50, what="dense invariant av == sum_i s_i")
     # contiguous blocks of agents (sweeping 2 / 3) are the same batches
     t2, av2, z2 = table.clone(), av.clone(), z.clone()
     first = np.array([0, N // 2], np.int64)
@@ -1356,13 +1356,13 @@ def test_row_length_boundaries(ctx, ciao, dtype, d):
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
     ctx.full_gradient(dp, dev(x0), av)   # every row length has a kernel (beyond LDS: the generic kernel with global accumulators)
     k_sweep = ctx.last_kernel()
-    close(av, O.full_pass(op, x0), dtype, scale=100, what=f"sweep d={d} ({k_sweep})")
+    close(av, O.full_pass(op, x0), dtype, scale=200, what=f"sweep d={d} ({k_sweep})")
     table = torch.empty((N, d), dtype=tdt, device="cuda")
     gamma = 0.5 / N
     ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
     rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
-    close(table, rt, dtype, scale=200, what=f"saga_init table d={d} ({ctx.last_kernel()})")
-    close(av, rav, dtype, scale=100, what="saga_init av")
+    close(table, rt, dtype, scale=500, what=f"saga_init table d={d} ({ctx.last_kernel()})")
+    close(av, rav, dtype, scale=200, what="saga_init av")
     Li = float(N) * np.sum(A.astype(np.float64) ** 2, axis=1)
     gam = (0.999 * N / Li).astype(dtype)
     dgam = dev(gam)
@@ -1545,9 +1545,9 @@ def test_adaptive_finito_random_reprobe(ctx, ciao, dtype, d):
     rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(0.999), x0, retry_signs=signs)
     it = S.iterator(S.Finito(dtype, adaptive=True), dev(x0), F=dp, g=dg, N=N, ctx=ctx, stream=ciao.IndexStream(seed))
     st = next(iter(it))
-    close(st.γ, rgam, dtype, scale=200, what="gamma_i after the random re-probe")
-    close(st.av, rav, dtype, scale=200, what="av after the random re-probe")
-    close(st.z, rz, dtype, scale=200, what="z after the random re-probe")
+    close(st.γ, rgam, dtype, scale=500, what="gamma_i after the random re-probe")
+    close(st.av, rav, dtype, scale=50, what="av after the random re-probe")
+    close(st.z, rz, dtype, scale=50, what="z after the random re-probe")
     assert abs(st.hat_γ - float(rhg)) <= 200 * float(np.finfo(dtype).eps) * float(rhg)
     assert float(st.γ.min()) > 0
     # the low-level contract: without a host the flagged samples carry gamma_i = -1 and the status is CIAO_ERR_UNSUPPORTED
@@ -1566,4 +1566,4 @@ def test_adaptive_finito_random_reprobe(ctx, ciao, dtype, d):
     rdone, rhg2, rtrials = O.afinito_steps(op, og, dtype(0.999), dtype(1e-9), idx, rt, rg, rgam, rfi, rhg, rav, rz)
     assert done == rdone == 60
     if trials == rtrials:
-        close(st.z, rz, dtype, scale=5000, what="z after 60 steps from the re-probed init")
+        close(st.z, rz, dtype, scale=500, what="z after 60 steps from the re-probed init")

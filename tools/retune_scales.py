@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""retune_scales.py PARITY_OBSERVED.json [--write] -- set every `scale=` of tests/test_gpu_parity.py from what a GPU run
+"""retune_scales.py PARITY_OBSERVED.json [--write] -- set every `scale=` of tests/test_gpu_parity.py and tests/test_gpu_complex.py from what a GPU run
 observed: scale = 10 x (largest error in eps units seen at that call site, over both dtypes and all parametrisations),
 rounded up to the next of 1-2-5 x 10^k, floor 8.  The log comes from a run of the same file (line numbers must match):
 CIAO_PARITY_CALIBRATE=1 python -m pytest tests/test_gpu_parity.py -m gpu   ->  gpurun_out/parity_observed.json."""
@@ -10,7 +10,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "tests", "test_gpu_parity.py")
+FILES = ("test_gpu_parity.py", "test_gpu_complex.py")
 
 
 def nice(x):
@@ -22,19 +22,19 @@ def nice(x):
     return int(10 ** (e + 1))
 
 
-def main():
-    log = json.load(open(sys.argv[1]))
+def retune(fname, log, write):
+    path = os.path.join(ROOT, "tests", fname)
     worst = {}
     for r in log:
-        if r["line"] <= 0:
+        if r["line"] <= 0 or r.get("file", "test_gpu_parity.py") != fname:
             continue
         worst[r["line"]] = max(worst.get(r["line"], 0.0), r["ratio"])
-    lines = open(PATH).read().split("\n")
+    lines = open(path).read().split("\n")
     changed = 0
     for ln, ratio in sorted(worst.items()):
         src = lines[ln - 1]
         if "close(" not in src:
-            print(f"line {ln}: no close( call there -- the log does not belong to this file", file=sys.stderr)
+            print(f"{fname} line {ln}: no close( call there -- the log does not belong to this file", file=sys.stderr)
             return 1
         new = nice(10.0 * ratio)
         if re.search(r"scale=[^,)]+", src):
@@ -46,11 +46,19 @@ def main():
         if out != src:
             changed += 1
             lines[ln - 1] = out
-        print(f"{ln:5d}  observed {ratio:10.2f} eps  ->  scale={new:<8}  {src.strip()[:90]}")
-    if "--write" in sys.argv:
-        open(PATH, "w").write("\n".join(lines))
-        print(f"{changed} call sites rewritten")
+        print(f"{fname}:{ln:5d}  observed {ratio:10.2f} eps  ->  scale={new:<8}  {src.strip()[:90]}")
+    if write:
+        open(path, "w").write("\n".join(lines))
+        print(f"{fname}: {changed} call sites rewritten")
     return 0
+
+
+def main():
+    log = json.load(open(sys.argv[1]))
+    rc = 0
+    for f in FILES:
+        rc |= retune(f, log, "--write" in sys.argv)
+    return rc
 
 
 if __name__ == "__main__":
