@@ -150,7 +150,9 @@ def dry_rank(args):
     if rank == 0:
         print(json.dumps({"metric": "sweep_sample_gradients_per_sec", "value": None, "unit": "sample-gradients/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "dry_run": True, "max_rank_seconds": float(el.item()),
-                          "config": {"workload": "launcher_dry_run", "collective": "gloo(dry run)" if world > 1 else "none"}}),
+                          "config": {"workload": "launcher_dry_run", "collective": "gloo(dry run)" if world > 1 else "none",
+                                     "launcher": "bench.py spawned the ranks" if os.environ.get("CIAO_BENCH_SPAWNED") else
+                                     ("external launcher (WORLD_SIZE set)" if world > 1 else "single process")}}),
               flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -70,3 +70,35 @@ def test_two_ranks_on_the_one_gpu_real_step():
     assert j["rccl_ranks"] is None and j["allreduce_us_per_step"] is not None
     assert j["value"] > 0 and j["roofline"]["kernel_launches"] == 3
     assert j["config"]["launcher"] == "bench.py spawned the ranks"
+
+
+def _torchrun(n, args, env_extra=None, timeout=600, port=29631):
+    """The driver's own command for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_the_drivers_torchrun_command_line_dry():
+    """Under torch.distributed.run every process is one rank (no respawn); rank 0 prints the one line."""
+    r = _torchrun(2, ["--dry-run", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["config"]["launcher"] == "external launcher (WORLD_SIZE set)"
+
+
+@pytest.mark.gpu
+def test_the_drivers_torchrun_command_line_real_step():
+    """The same command with the real sweep, two ranks sharing the one GPU of the test box (gloo rehearsal of the collective)."""
+    r = _torchrun(2, ["--steps", "3", "--warmup", "1", "--rows-per-gpu", "200000", "--no-cpu", "--no-extras", "--no-chains"],
+                  {"CIAO_BENCH_BACKEND": "gloo"}, port=29633)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["N_total"] == 400000 and j["value"] > 0
+    assert j["config"]["launcher"] == "external launcher (WORLD_SIZE set)"
