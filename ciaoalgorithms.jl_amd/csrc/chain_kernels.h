@@ -877,11 +877,21 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cplx_reg_kernel(ChainArgs<T> a
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
 {
+#ifdef CIAO_GLDS_SAVE_M0
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_dst)
                  : "memory");
+#else
+    // m0 (the LDS destination base of the DMA) is declared clobbered instead of saved and restored around every load: hipcc
+    // never holds a value in m0 across statements (it sets it next to the few instructions that read it), and two scalar
+    // moves per load are on the chain's issue path
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory", "m0");
+#pragma clang diagnostic pop
+#endif
 }
 
 template <int N>
@@ -934,7 +944,12 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
     constexpr int WAIT_N = (PIPE ? DEPTH - 2 : DEPTH - 1) * OPS_PER_STEP;
     constexpr int ROW_BYTES = J * NT * 16;
     static_assert(!SHARDED || ALG == CA_SVRG || ALG == CA_SAGA, "only the SVRG and SAGA chains run over a shard table");
-    constexpr bool STAGE_PTR = SHARDED;
+    // Chains without a table (SVRG, LFinito) need a step's row only as an ADDRESS: the staged entry is the row's address
+    // itself (resolved while staging, with full parallelism), which takes the 64-bit multiply -- nine scalar instructions -- out
+    // of every step.  Chains with a table also need the row index (table row, hazard flags): they keep it and compute
+    // the address in the step, or -- over a shard table -- stage the address in a second array.
+    constexpr bool PTR_IN_ROW = !HAS_TABLE;
+    constexpr bool STAGE_PTR = SHARDED && HAS_TABLE;
     static_assert(CH % DEPTH == 0 && DEPTH % 2 == 0, "ring slots must line up with chunk starts; ping-pong needs even DEPTH");
 
     // one dynamic LDS block, carved by hand (16-byte aligned pieces):
@@ -1081,7 +1096,6 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 *a.errflag = 1;
                 r = 0;
             }
-            s_row[DEPTH + e] = r;
             const T *arow, *bp;
             if (SHARDED) {   // global row -> (shard, local row): the shard's base may be another GPU's memory
                 int64_t local;
@@ -1092,6 +1106,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 arow = a.A + r * a.ld;
                 bp = a.b ? a.b + r : nullptr;
             }
+            s_row[DEPTH + e] = PTR_IN_ROW ? (int64_t)(uintptr_t)arow : r;
             if (STAGE_PTR) s_ptr[DEPTH + e] = reinterpret_cast<const unsigned char *>(arow);
             if (e < nch) {
                 s_b[e] = bp ? *bp : T(0);
@@ -1113,8 +1128,9 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
 #pragma unroll
             for (int u = 0; u < DEPTH; ++u) {
                 const int64_t r0 = uniform64(s_row[DEPTH + u]);
-                refill(u, r0, STAGE_PTR ? reinterpret_cast<const unsigned char *>(uniform64((int64_t)(uintptr_t)s_ptr[DEPTH + u]))
-                                        : reinterpret_cast<const unsigned char *>(a.A + r0 * a.ld));
+                refill(u, r0, PTR_IN_ROW ? reinterpret_cast<const unsigned char *>((uintptr_t)r0)
+                              : STAGE_PTR ? reinterpret_cast<const unsigned char *>(uniform64((int64_t)(uintptr_t)s_ptr[DEPTH + u]))
+                                          : reinterpret_cast<const unsigned char *>(a.A + r0 * a.ld));
             }
         }
         wait_vmcnt<0>();          // ring fully landed: the counted waits below assume the steady-state op sequence
@@ -1139,8 +1155,9 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 }
                 const int64_t row = uniform64(x.row);
                 const int64_t row_n = uniform64(x.row_n);
-                const unsigned char *ptr_n = STAGE_PTR ? reinterpret_cast<const unsigned char *>(uniform64((int64_t)(uintptr_t)x.ptr_n))
-                                                       : reinterpret_cast<const unsigned char *>(a.A + row_n * a.ld);
+                const unsigned char *ptr_n = PTR_IN_ROW ? reinterpret_cast<const unsigned char *>((uintptr_t)row_n)
+                                             : STAGE_PTR ? reinterpret_cast<const unsigned char *>(uniform64((int64_t)(uintptr_t)x.ptr_n))
+                                                         : reinterpret_cast<const unsigned char *>(a.A + row_n * a.ld);
                 const T bi = x.bi;
 
                 if (ALG == CA_LFINITO && inb == 0) {   // Finito_LFinito.jl:92  z = prox(av)
@@ -1167,13 +1184,23 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                         d1 = fmad(x.ar[j][v], p[j][v], d1);
                         if (TWO) d2 = fmad(x.ar[j][v], zf[j][v], d2);
                     }
+#ifdef CIAO_CHAIN_READLANE   // experiment: the all-lanes sum through v_readlane, lane 0 stores
                 d1 = wave_allsum(d1);
                 if (TWO) d2 = wave_allsum(d2);
-                CIAO_STAMP(2);   // T3: closes [T2, T3] = prefetch of the next step's inputs + dot + in-wave reduction
+                CIAO_STAMP(2);
                 if (lane == 0) {
                     red[par][wib][0] = d1;
                     if (TWO) red[par][wib][1] = d2;
                 }
+#else
+                d1 = wave_sum_lane63(d1);   // bitwise the same total, in lane 63 only: no v_readlane / scalar round trip
+                if (TWO) d2 = wave_sum_lane63(d2);
+                CIAO_STAMP(2);   // T3: closes [T2, T3] = prefetch of the next step's inputs + dot + in-wave reduction
+                if (lane == WAVE - 1) {
+                    red[par][wib][0] = d1;
+                    if (TWO) red[par][wib][1] = d2;
+                }
+#endif
                 // work that does not need the dot product goes between the LDS write and the barrier, where it overlaps the
                 // other waves' arrival:  temp = gamma*(a*dc - av) + w  =  (gamma*a)*dc + (w - gamma*av)
                 V q1[J], q2[J];
@@ -1323,7 +1350,7 @@ constexpr size_t chain_dma_lds_bytes()
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
     constexpr int DEPTH = DmaDepth<J * NT / 256, HAS_TABLE>::value;
     constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO || ALG == CA_SVRGC);
-    constexpr bool STAGE_PTR = SHARDED;
+    constexpr bool STAGE_PTR = SHARDED && HAS_TABLE;
     return (size_t)DEPTH * J * NT * 16 * (HAS_TABLE ? 2 : 1) + (STAGE_PTR ? 2 : 1) * (CHAIN_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
            CHAIN_CHUNK * sizeof(T) * (PER_SAMPLE_GAM ? 2 : 1) + (HAS_TABLE ? CHAIN_CHUNK * sizeof(int) : 0) + 16 +
            2 * NW * 2 * sizeof(T);

@@ -60,6 +60,37 @@ __device__ __forceinline__ T wave_allsum(T v)
     return (r0 + r1) + (r2 + r3);
 }
 
+// The same sum, delivered to LANE 63 ONLY (the other lanes hold partial sums): for the chains' cross-wave exchange, where one
+// lane stores the wave's partial.  After the four in-row stages every lane holds its row-of-16 sum r0..r3; row_bcast:15 adds
+// lane 15 of the previous row into rows 1 and 3, row_bcast:31 adds lane 31 into rows 2 and 3, so lane 63 ends with
+// (r3 + r2) + (r1 + r0) -- bitwise the value wave_allsum returns, (r0 + r1) + (r2 + r3), without the eight v_readlane and the
+// scalar round trip.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_rows(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xF, false));
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_rows(double v)
+{
+    long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xFFFFFFFFLL), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWS, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWS, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum_lane63(T v)
+{
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    v += dpp_rows<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_rows<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Operators (ProximalOperators.jl 0.14 formulas)
 // ------------------------------------------------------------------------------------------------------------------
