@@ -107,19 +107,29 @@ struct ChainDepth {
 
 // Branch-free prox for one coordinate: soft threshold (gl = tau*lambda, 0 unless NormL1) then clamp (lo/hi = -/+inf
 // unless IndBox).  One straight-line form for Zero / NormL1 / IndBox keeps the dependent chain free of branches.
+// clamp(v, -t, t) on the chains: fmin/fmax make hipcc canonicalise their operands first (v_max_f64 x, x: three extra
+// instructions per step); the two machine instructions themselves, with the negation as a source modifier, do not.
+__device__ __forceinline__ float clamp_chain(float v, float t) { return clamp_sym(v, t); }
+__device__ __forceinline__ double clamp_chain(double v, double t)
+{
+    double m, r;
+    asm("v_max_f64 %0, %1, -%2" : "=v"(m) : "v"(v), "v"(t));
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(m), "v"(t));
+    return r;
+}
 template <typename T>
 __device__ __forceinline__ T prox_bf(T v, T gl, T lo, T hi)
 {
     // soft threshold as v - clamp(v, -gl, gl): the same value as the reference's three-way form for every finite v
     // (v > gl: v - gl; v < -gl: v + gl; else v - v = 0) in three instructions instead of compares + 64-bit selects
-    const T s = v - clamp_sym(v, gl);
+    const T s = v - clamp_chain(v, gl);
     return fmin2(fmax2(s, lo), hi);
 }
 // the same without the box (g = Zero or NormL1: lo/hi are -/+inf and the clamp would be the identity)
 template <typename T>
 __device__ __forceinline__ T prox_l1(T v, T gl)
 {
-    return v - clamp_sym(v, gl);
+    return v - clamp_chain(v, gl);
 }
 
 // LOSS is a template parameter here (CIAO_LOSS_LS also serves Zero(): lam = 0 and no data), FULL = every thread's E
@@ -1138,14 +1148,20 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
         if (PIPE) fetch(in[0], 0, 0);
 
         // ---- the dependent chain ----------------------------------------------------------------------------------------
-        for (int s0 = 0; s0 < nch; s0 += DEPTH) {
+        // DEPTH steps (one ring revolution), in four versions selected ONCE per group instead of once per step: with / without
+        // the IndBox clamp (HB), and with / without the end-of-chunk checks (CHK: a group whose every step exists and has a
+        // successor in this chunk needs none -- all but the last group of a chunk).  The per-step tests and branches were
+        // a sixth of the step's instructions.
+        auto group = [&](auto hb_tag, auto chk_tag, const int s0) {
+            constexpr bool HB = decltype(hb_tag)::value;
+            constexpr bool CHK = decltype(chk_tag)::value;
 #pragma unroll
             for (int u = 0; u < DEPTH; ++u) {
                 const int s = s0 + u;
-                if (s >= nch) break;
+                if (CHK && s >= nch) return;
                 StepIn &x = in[PIPE ? (u & 1) : 0];
                 if (PIPE) {
-                    if (s + 1 < nch) {   // next step's inputs: retire its DMA (one step less lead), read, do not wait
+                    if (!CHK || s + 1 < nch) {   // next step's inputs: retire its DMA (one step less lead), read, do not wait
                         wait_vmcnt<WAIT_N>();
                         fetch(in[(u + 1) & 1], (u + 1) % DEPTH, s + 1);
                     }
@@ -1218,7 +1234,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 CIAO_STAMP(4);   // T0: closes [T4, T0] = waiting for the other waves
                 d1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
                 if (TWO) d2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
-                if (NW == 8) {   // fixed association order: two groups of four
+                if constexpr (NW == 8) {   // fixed association order: two groups of four
                     d1 += (red[par][4][0] + red[par][5][0]) + (red[par][6][0] + red[par][7][0]);
                     if (TWO) d2 += (red[par][4][1] + red[par][5][1]) + (red[par][6][1] + red[par][7][1]);
                 }
@@ -1232,8 +1248,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
 
                 // everything after the exchange, instantiated twice: with the IndBox clamp and without it (g = Zero / NormL1),
                 // selected by ONE workgroup-uniform branch per step instead of a select per coordinate
-                auto update = [&](auto hb_tag) {
-                    constexpr bool HB = decltype(hb_tag)::value;
+                {
                     const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
                     if (SVRG_ANY) {                                                  // SVRG_basic.jl:74-81
                         // a_i'z_full: recomputed (CA_SVRG) or the value the last full pass stored for this row (CA_SVRGC)
@@ -1304,11 +1319,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                                 av[j][v] = fmad(rr, p[j][v] - zf[j][v], av[j][v]);
                             }
                     }
-                };
-                if (hasbox)
-                    update(std::true_type{});
-                else
-                    update(std::false_type{});
+                }
 
                 if (++inb == a.batch) inb = 0;
                 if (!(CIAO_CHAIN_DBG & 1)) refill(u, row_n, ptr_n);   // after this step's table stores (program order); the look-ahead entry always exists
@@ -1317,6 +1328,19 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 for (int j = 0; j < J; ++j) asm volatile("" : "+v"(p[j]));   // the update is done HERE
 #endif
                 CIAO_STAMP(1);   // T2: closes [T1, T2] = link function + element-wise update + prox + DMA issue
+            }
+        };
+        for (int s0 = 0; s0 < nch; s0 += DEPTH) {
+            if (s0 + DEPTH < nch) {
+                if (hasbox)
+                    group(std::true_type{}, std::false_type{}, s0);
+                else
+                    group(std::false_type{}, std::false_type{}, s0);
+            } else {
+                if (hasbox)
+                    group(std::true_type{}, std::true_type{}, s0);
+                else
+                    group(std::false_type{}, std::true_type{}, s0);
             }
         }
     }

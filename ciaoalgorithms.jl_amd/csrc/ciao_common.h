@@ -65,18 +65,19 @@ __device__ __forceinline__ T wave_allsum(T v)
 // lane 15 of the previous row into rows 1 and 3, row_bcast:31 adds lane 31 into rows 2 and 3, so lane 63 ends with
 // (r3 + r2) + (r1 + r0) -- bitwise the value wave_allsum returns, (r0 + r1) + (r2 + r3), without the eight v_readlane and the
 // scalar round trip.
+// (the rows outside ROWS receive an UNDEFINED value -- no zero-fill moves: only lanes 31 and 63 of the result are ever used)
 template <int CTRL, int ROWS>
 __device__ __forceinline__ float dpp_rows(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, ROWS, 0xF, false));
 }
 template <int CTRL, int ROWS>
 __device__ __forceinline__ double dpp_rows(double v)
 {
     long long b = __double_as_longlong(v);
     int lo = (int)(b & 0xFFFFFFFFLL), hi = (int)(b >> 32);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWS, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWS, 0xF, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, ROWS, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, ROWS, 0xF, false);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 template <typename T>
