@@ -297,9 +297,9 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_kernel(ChainArgs<T> a)
                     d1 += aj * p[j];
                     if (TWO) d2 += aj * zf[j];
                 }
-                d1 = wave_allsum(d1);
-                if (TWO) d2 = wave_allsum(d2);
-                if (lane == 0) {
+                d1 = wave_sum_lane63(d1);
+                if (TWO) d2 = wave_sum_lane63(d2);
+                if (lane == WAVE - 1) {   // the lane that holds the wave's sum
                     red[par][wib][0] = d1;
                     if (TWO) red[par][wib][1] = d2;
                 }
@@ -446,9 +446,9 @@ __global__ void __launch_bounds__(CHAIN_BIG_NT) chain_big_kernel(ChainArgs<T> a)
             d1 += ak * p[k];
             if (TWO) d2 += ak * a.zf[k];
         }
-        d1 = wave_allsum(d1);
-        if (TWO) d2 = wave_allsum(d2);
-        if (lane == 0) {
+        d1 = wave_sum_lane63(d1);
+        if (TWO) d2 = wave_sum_lane63(d2);
+        if (lane == WAVE - 1) {   // the lane that holds the wave's sum
             red[par][wib][0] = d1;
             if (TWO) red[par][wib][1] = d2;
         }
@@ -565,13 +565,13 @@ __global__ void __launch_bounds__(CHAIN_BIG_NT) chain_cplx_kernel(ChainArgs<T> a
                 s2i += ar * yi + ai * yr;
             }
         }
-        s1r = wave_allsum(s1r);
-        s1i = wave_allsum(s1i);
+        s1r = wave_sum_lane63(s1r);
+        s1i = wave_sum_lane63(s1i);
         if (TWO) {
-            s2r = wave_allsum(s2r);
-            s2i = wave_allsum(s2i);
+            s2r = wave_sum_lane63(s2r);
+            s2i = wave_sum_lane63(s2i);
         }
-        if (lane == 0) {
+        if (lane == WAVE - 1) {   // the lane that holds the wave's sum
             red[par][wib][0] = s1r;
             red[par][wib][1] = s1i;
             red[par][wib][2] = s2r;
@@ -756,13 +756,13 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cplx_reg_kernel(ChainArgs<T> a
                 s2i += xr * qi[j] + xi * qr[j];
             }
         }
-        s1r = wave_allsum(s1r);
-        s1i = wave_allsum(s1i);
+        s1r = wave_sum_lane63(s1r);
+        s1i = wave_sum_lane63(s1i);
         if (TWO) {
-            s2r = wave_allsum(s2r);
-            s2i = wave_allsum(s2i);
+            s2r = wave_sum_lane63(s2r);
+            s2i = wave_sum_lane63(s2i);
         }
-        if (lane == 0) {
+        if (lane == WAVE - 1) {   // the lane that holds the wave's sum
             red[par][wib][0] = s1r;
             red[par][wib][1] = s1i;
             if (TWO) {
@@ -1524,9 +1524,9 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_chain_kernel(AFinitoArgs<T> 
                 p1 = fmad(valid[j] ? ar[j] : T(0), z[j], p1);
                 p2 = fmad(res[j], res[j], p2);
             }
-            p1 = wave_allsum(p1);
-            p2 = wave_allsum(p2);
-            if (lane == 0) {
+            p1 = wave_sum_lane63(p1);
+            p2 = wave_sum_lane63(p2);
+            if (lane == WAVE - 1) {   // the lane that holds the wave's sum
                 red[par][wib][0] = p1;
                 red[par][wib][1] = p2;
             }
@@ -1700,10 +1700,10 @@ __global__ void __launch_bounds__(CHAIN_BIG_NT) afinito_big_kernel(AFinitoArgs<T
                     p2 += rv * rv;
                 }
             }
-            p1r = wave_allsum(p1r);
-            if (CPLX) p1i = wave_allsum(p1i);
-            p2 = wave_allsum(p2);
-            if (lane == 0) {
+            p1r = wave_sum_lane63(p1r);
+            if (CPLX) p1i = wave_sum_lane63(p1i);
+            p2 = wave_sum_lane63(p2);
+            if (lane == WAVE - 1) {   // the lane that holds the wave's sum
                 red[par][wib][0] = p1r;
                 red[par][wib][1] = p1i;
                 red[par][wib][2] = p2;
@@ -2032,9 +2032,9 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
                             p1 = fmad(x.ar[j][v], p[j][v], p1);
                             p2 = fmad(res[j][v], res[j][v], p2);
                         }
-                    p1 = wave_allsum(p1);
-                    p2 = wave_allsum(p2);
-                    if (lane == 0) {
+                    p1 = wave_sum_lane63(p1);
+                    p2 = wave_sum_lane63(p2);
+                    if (lane == WAVE - 1) {   // the lane that holds the wave's sum
                         red[par][wib][0] = p1;
                         red[par][wib][1] = p2;
                     }

@@ -450,9 +450,9 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
                 d1 += x.ar[j][v] * x1[j][v];
                 if (TWO) d2 += x.ar[j][v] * x2[j][v];
             }
-        d1 = wave_allsum(d1);
-        if (TWO) d2 = wave_allsum(d2);
-        if (lane == 0) {
+        d1 = wave_sum_lane63(d1);
+        if (TWO) d2 = wave_sum_lane63(d2);
+        if (lane == WAVE - 1) {   // the lane that holds the wave's sum
             red[par][wib][0] = d1;
             if (TWO) red[par][wib][1] = d2;
         }
@@ -1192,13 +1192,13 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_csplit_kernel(RowsArgs<T> a)
                     s2i += pr * x2[j][2 * c + 1] + pi * x2[j][2 * c];
                 }
             }
-        s1r = wave_allsum(s1r);
-        s1i = wave_allsum(s1i);
+        s1r = wave_sum_lane63(s1r);
+        s1i = wave_sum_lane63(s1i);
         if (TWO) {
-            s2r = wave_allsum(s2r);
-            s2i = wave_allsum(s2i);
+            s2r = wave_sum_lane63(s2r);
+            s2i = wave_sum_lane63(s2i);
         }
-        if (lane == 0) {
+        if (lane == WAVE - 1) {   // the lane that holds the wave's sum
             red[par][wib][0] = s1r;
             red[par][wib][1] = s1i;
             if (TWO) {
