@@ -945,7 +945,7 @@ template <typename T, int J, int ALG, int LOSS, bool MASKED, int NT, bool SHARDE
 __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
 {
     constexpr int NW = NT / WAVE;
-    static_assert(NW == 4 || NW == 8, "four or eight waves");
+    static_assert(NW == 1 || NW == 4 || NW == 8, "one, four or eight waves");
     using V = typename VecOfC<T>::type;
     constexpr int VEC = 16 / sizeof(T);
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
@@ -956,7 +956,8 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
     constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO || ALG == CA_SVRGC);   // s_g staging
     // MASKED (rows shorter than J*4096 bytes): the table stores of chunk groups beyond the row are predicated off and may
     // not issue at all, so only the (always issued, address-clamped) LDS-DMA loads are counted -- stricter waits, still safe
-    constexpr int OPS_PER_STEP = HAS_TABLE ? (MASKED ? 2 * J : 3 * J) : J;
+    // (one wave issues four waves' worth of operations per step: counting its stores as well would pass the 6-bit counter)
+    constexpr int OPS_PER_STEP = HAS_TABLE ? ((MASKED || NW == 1) ? 2 * J : 3 * J) : J;
     // PIPE: the LDS reads of step s+1 (its ring slot and its staged scalars) are issued at the top of step s and land
     // while step s reduces its dot product, so only one LDS round trip (the 4-partial exchange) stays on the
     // dependent path.  It costs one step of DMA lead, hence only with DEPTH >= 4.
@@ -1216,6 +1217,12 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                         d1 = fmad(x.ar[j][v], p[j][v], d1);
                         if (TWO) d2 = fmad(x.ar[j][v], zf[j][v], d2);
                     }
+                if constexpr (NW == 1) {
+                    // ONE wave owns the whole row: the reduced dot is broadcast from lane 63 through an SGPR, and the LDS
+                    // exchange (write, lgkmcnt(0), barrier, read: the largest piece of a four-wave step) does not exist
+                    d1 = readlane(wave_sum_lane63(d1), WAVE - 1);
+                    if (TWO) d2 = readlane(wave_sum_lane63(d2), WAVE - 1);
+                } else {
 #ifdef CIAO_CHAIN_READLANE   // experiment: the all-lanes sum through v_readlane, lane 0 stores
                 d1 = wave_allsum(d1);
                 if (TWO) d2 = wave_allsum(d2);
@@ -1233,6 +1240,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                     if (TWO) red[par][wib][1] = d2;
                 }
 #endif
+                }
                 // work that does not need the dot product goes between the LDS write and the barrier, where it overlaps the
                 // other waves' arrival:  temp = gamma*(a*dc - av) + w  =  (gamma*a)*dc + (w - gamma*av)
                 V q1[J], q2[J];
@@ -1243,7 +1251,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                         q2[j] = p[j] - gav[j];
                     }
                 }
-                if (!(CIAO_CHAIN_DBG & 2)) {
+                if constexpr (NW > 1 && !(CIAO_CHAIN_DBG & 2)) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 CIAO_STAMP(3);   // T4: closes [T3, T4] = partial written, LDS idle
                 __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue

@@ -46,6 +46,10 @@ def ctx(ciao):
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     from ciaoalgorithms_jl_amd.device import Context
     c = Context(0)
+    for kv in os.environ.get("CIAO_TEST_OPTS", "").split(","):      # tuning experiments: run the suite with a library option set
+        if "=" in kv:
+            k, v = kv.split("=")
+            c.set_option(k, int(v))
     yield c
     c.synchronize()
     c.close()

@@ -11,6 +11,9 @@ from ciaoalgorithms_jl_amd.device import Context, PackedF, ProxG
 from ciaoalgorithms_jl_amd.sampling import IndexStream
 torch.cuda.set_device(0)
 ctx = Context(0)
+for kv in os.environ.get("CIAO_OPTS", "").split(","):
+    if "=" in kv:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 out = []
 for dt in (torch.float64, torch.float32):
     N, d, m = 200_000, int(os.environ.get("CIAO_D", "1024")), 100_000
