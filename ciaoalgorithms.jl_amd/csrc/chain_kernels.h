@@ -1169,9 +1169,10 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
         // the IndBox clamp (HB), and with / without the end-of-chunk checks (CHK: a group whose every step exists and has a
         // successor in this chunk needs none -- all but the last group of a chunk).  The per-step tests and branches were
         // a sixth of the step's instructions.
-        auto group = [&](auto hb_tag, auto chk_tag, const int s0) {
+        auto group = [&](auto hb_tag, auto chk_tag, auto sag_tag, const int s0) {
             constexpr bool HB = decltype(hb_tag)::value;
             constexpr bool CHK = decltype(chk_tag)::value;
+            constexpr bool SAG = decltype(sag_tag)::value;   // SAGA chains only: SAG steps with the new average (a select per element otherwise)
 #pragma unroll
             for (int u = 0; u < DEPTH; ++u) {
                 const int s = s0 + u;
@@ -1256,7 +1257,14 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 CIAO_STAMP(3);   // T4: closes [T3, T4] = partial written, LDS idle
                 __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue
                 CIAO_STAMP(4);   // T0: closes [T4, T0] = waiting for the other waves
-                d1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+                {
+                    T lo = red[par][0][0] + red[par][1][0], hi = red[par][2][0] + red[par][3][0];
+                    // fp64: pin the two pair sums right behind the LDS read -- hipcc otherwise slides the hoisted, independent
+                    // multiplies in front of them and the dependent chain starts late (two-dot SVRG step 0.351 -> 0.327 us; the
+                    // one-dot step does not change).  fp32 is better left to the compiler (0.262 vs 0.268 with the pin).
+                    if constexpr (sizeof(T) == 8) asm volatile("" : "+v"(lo), "+v"(hi));
+                    d1 = lo + hi;
+                }
                 if (TWO) d2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
                 if constexpr (NW == 8) {   // fixed association order: two groups of four
                     d1 += (red[par][4][0] + red[par][5][0]) + (red[par][6][0] + red[par][7][0]);
@@ -1301,7 +1309,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                                 const T del = gn - x.sr[j][v];
                                 // SAGA steps with (g_new - s_i + av_old), SAG with av_new (SAGA_basic.jl:58-62)
                                 const T avn = fmad(del, a.invN, av[j][v]);
-                                const T wv = fmad(ngam, a.sag ? avn : del + av[j][v], p[j][v]);
+                                const T wv = fmad(ngam, SAG ? avn : del + av[j][v], p[j][v]);
                                 av[j][v] = avn;
                                 p[j][v] = HB ? prox_bf(wv, gl, plo[j][v], phi[j][v]) : prox_l1(wv, gl);
                                 gnv[v] = gn;
@@ -1354,17 +1362,28 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 CIAO_STAMP(1);   // T2: closes [T1, T2] = link function + element-wise update + prox + DMA issue
             }
         };
+        // the run-time flags become compile-time tags of the group (SAG only exists for the SAGA chain)
+        auto pick_sag = [&](auto hb_tag, auto chk_tag, const int s0) {
+            if constexpr (ALG == CA_SAGA) {
+                if (a.sag)
+                    group(hb_tag, chk_tag, std::true_type{}, s0);
+                else
+                    group(hb_tag, chk_tag, std::false_type{}, s0);
+            } else {
+                group(hb_tag, chk_tag, std::false_type{}, s0);
+            }
+        };
         for (int s0 = 0; s0 < nch; s0 += DEPTH) {
             if (s0 + DEPTH < nch) {
                 if (hasbox)
-                    group(std::true_type{}, std::false_type{}, s0);
+                    pick_sag(std::true_type{}, std::false_type{}, s0);
                 else
-                    group(std::false_type{}, std::false_type{}, s0);
+                    pick_sag(std::false_type{}, std::false_type{}, s0);
             } else {
                 if (hasbox)
-                    group(std::true_type{}, std::true_type{}, s0);
+                    pick_sag(std::true_type{}, std::true_type{}, s0);
                 else
-                    group(std::false_type{}, std::true_type{}, s0);
+                    pick_sag(std::false_type{}, std::true_type{}, s0);
             }
         }
     }
