@@ -18,6 +18,11 @@ int32_t launch_rows_raw(ciao_ctx *ctx, int mode, RowsArgs<T> &a);
 template <typename T>
 int32_t launch_chain(ciao_ctx *ctx, int alg, ChainArgs<T> &a);
 
+// the LDS-DMA fast chain for one (algorithm, loss); J256 = row bytes / 4096 rounded up to a power of two.  Defined in
+// chain_dma_launch.inc, instantiated in chain_dma{0,1,2}_f32/f64.hip.
+template <typename T, int ALG, int LOSS>
+int32_t launch_dma(ciao_ctx *ctx, int J256, bool masked, ChainArgs<T> &a);
+
 // ProShI agent rows (init or one batch) + finalize + epilogue.  Specialised in rows_f32.hip / rows_f64.hip.
 template <typename T>
 int32_t launch_proshi(ciao_ctx *ctx, bool init, ProshiArgs<T> &a, const Epilogue<T> &ep);
