@@ -1137,7 +1137,13 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
             if (STAGE_PTR) s_ptr[DEPTH + e] = reinterpret_cast<const unsigned char *>(arow);
             if (e < nch) {
                 s_b[e] = bp ? *bp : T(0);
-                if (PER_SAMPLE_GAM) s_g[e] = a.gam ? a.gam[r] : a.gam_uniform;
+                if (PER_SAMPLE_GAM) {
+                    const T gv = a.gam ? a.gam[r] : a.gam_uniform;
+                    // SVRG with cached row dots: what the step needs of a_i'z_full is the link-function coefficient at it,
+                    // which does not depend on the chain -- evaluated HERE, 256 steps at a time, instead of once per step on
+                    // the chain's only wave per SIMD (for the logistic loss that is an exp and a division per step)
+                    s_g[e] = (ALG == CA_SVRGC) ? grad_coef_t<T, LOSS>(gv, bp ? *bp : T(0), a.lam).coef() : gv;
+                }
             }
         }
         __syncthreads();
@@ -1284,9 +1290,10 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                     const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
                     if (SVRG_ANY) {                                                  // SVRG_basic.jl:74-81
                         // a_i'z_full: recomputed (CA_SVRG) or the value the last full pass stored for this row (CA_SVRGC)
-                        const GradCoef<T> gz = grad_coef_t<T, LOSS>(ALG == CA_SVRGC ? x.gi : d2, bi, a.lam);
+                        // the coefficient at a_i'z_full: staged ready-made (CA_SVRGC), or from this step's second dot product
+                        const T cz = (ALG == CA_SVRGC) ? x.gi : grad_coef_t<T, LOSS>(d2, bi, a.lam).coef();
                         const T gl = a.gamma * plam;
-                        const T dc = gz.coef() - gp.coef();
+                        const T dc = cz - gp.coef();
     #pragma unroll
                         for (int j = 0; j < ((CIAO_CHAIN_DBG & 4) ? 0 : J); ++j)
     #pragma unroll
