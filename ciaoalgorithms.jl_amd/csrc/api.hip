@@ -985,6 +985,8 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "svrg_cache_rowdots")) {
         ctx->svrg_cache_rowdots = value != 0;
         ctx->rowdot_A = nullptr;
+    } else if (!strcmp(key, "chain_four_waves")) {
+        ctx->chain_four_waves = value;
     } else if (!strcmp(key, "chain_one_wave")) {
         ctx->chain_one_wave = value;
     } else if (!strcmp(key, "chain_big")) {
