@@ -1,3 +1,3 @@
 #define CIAO_T float
-#define CIAO_DMA_PART 1
+#define CIAO_DMA_PART 3
 #include "chain_dma_launch.inc"

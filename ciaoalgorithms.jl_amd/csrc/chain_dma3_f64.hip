@@ -1,0 +1,3 @@
+#define CIAO_T double
+#define CIAO_DMA_PART 3
+#include "chain_dma_launch.inc"

@@ -19,7 +19,7 @@ template <typename T>
 int32_t launch_chain(ciao_ctx *ctx, int alg, ChainArgs<T> &a);
 
 // the LDS-DMA fast chain for one (algorithm, loss); J256 = row bytes / 4096 rounded up to a power of two.  Defined in
-// chain_dma_launch.inc, instantiated in chain_dma{0,1,2}_f32/f64.hip.
+// chain_dma_launch.inc, instantiated in chain_dma{0..4}_f32/f64.hip.
 template <typename T, int ALG, int LOSS>
 int32_t launch_dma(ciao_ctx *ctx, int J256, bool masked, ChainArgs<T> &a);
 

@@ -643,6 +643,48 @@ def test_shard_table_is_validated(ctx, ciao):
         ctx.set_shards(None)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d", [52, 128, 200, 256, 512])
+def test_short_rows_run_the_chains_on_one_wave(ctx, ciao, dtype, d):
+    """Rows of up to 2 KiB (fp64 also 4 KiB) take the single-wave chain (block=64: no cross-wave exchange); option
+    chain_four_waves keeps them on the four-wave kernel.  Both against the oracle, SVRG and SAGA."""
+    import torch
+    from oracle import oracle as O
+    N = 40
+    rowb = d * np.dtype(dtype).itemsize
+    if rowb % 16:
+        pytest.skip("not whole 16-byte chunks: register-ring kernel")
+    one_wave = rowb <= (4096 if dtype == np.float64 else 2048)
+    A, b, x0 = P.synthetic("logistic", N, d, dtype, seed=d)
+    op, dp = make("logistic", A, b, 1.0, dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.01)
+    gamma = 1.0 / (7 * 0.25 * np.max(np.sum(A.astype(np.float64) ** 2, axis=1)))
+    tdt = dev(x0).dtype
+    idx = ciao.IndexStream(3).rand_indices(N, 3 * N)
+    rav, rz, rzf, rw = O.svrg_init(op, x0)
+    O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
+    rt, rsav, rsz = O.saga_init(op, og, dtype(gamma), x0)
+    O.saga_steps(op, og, dtype(gamma), False, idx, rt, rsav, rsz)
+    for four in (0, 1):
+        ctx.set_option("chain_four_waves", four)
+        try:
+            av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+            ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+            ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w)
+            name = ctx.last_kernel() if "chain" in ctx.last_kernel() else ""
+            table = torch.empty((N, d), dtype=tdt, device="cuda")
+            sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+            ctx.saga_init(dp, dg, gamma, dev(x0), table, sav, sz)
+            ctx.saga_steps(dp, dg, gamma, False, idx, table, sav, sz)
+            assert ("block=64" in ctx.last_kernel()) == (one_wave and not four), ctx.last_kernel()
+        finally:
+            ctx.set_option("chain_four_waves", 0)
+        close(zf, rzf, dtype, scale=2000, what=f"short rows svrg z_full (four_waves={four})")
+        close(sz, rsz, dtype, scale=2000, what=f"short rows saga z (four_waves={four}; {ctx.last_kernel()})")
+        close(table, rt, dtype, scale=2000, what=f"short rows saga table (four_waves={four})")
+    ctx.synchronize()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # SAGA / SAG
 # ----------------------------------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@ timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_solve
 rc=$?
 tail -3 gpurun_out/s25_tests.log
 [ $rc -eq 0 ] || exit $rc
-for d in 50 128 256 512; do
+for d in 128 512; do
   echo "d=$d one wave  : $(CIAO_D=$d python tools/chain_time.py 2>/dev/null)"
   echo "d=$d four waves: $(CIAO_D=$d CIAO_OPTS=chain_four_waves=1 python tools/chain_time.py 2>/dev/null)"
 done | tee gpurun_out/s25_ab.txt
