@@ -156,9 +156,13 @@ __device__ __forceinline__ int64_t uniform64(int64_t v)
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-template <typename T, int E, int ALG, int LOSS, bool FULL>
-__global__ void __launch_bounds__(CHAIN_NT) chain_kernel(ChainArgs<T> a)
+// NT = 256 (four waves, thread t owns elements t + 256 j) or 64: rows of up to 512 elements on ONE wave -- the reduced dot
+// product reaches every lane through an SGPR and the LDS exchange + barrier of every step disappears (as in chain_dma_kernel).
+template <typename T, int E, int ALG, int LOSS, bool FULL, int NT = CHAIN_NT>
+__global__ void __launch_bounds__(NT) chain_kernel(ChainArgs<T> a)
 {
+    constexpr int NW = NT / WAVE;
+    static_assert(NW == 1 || NW == CHAIN_NW, "one wave or four");
     constexpr int DEPTH = ChainDepth<E>::value;
     constexpr int CH = CHAIN_CHUNK;
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
@@ -166,7 +170,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_kernel(ChainArgs<T> a)
     constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO);
     static_assert(CH % DEPTH == 0, "ring slots must line up with chunk starts");
 
-    __shared__ T red[2][CHAIN_NW][2];
+    __shared__ T red[2][NW][2];
     // per-chunk staging of everything that is gathered by sample index: rows (with DEPTH entries of history in front
     // and DEPTH entries of look-ahead behind), b_i, gamma_i and the table-row hazard flags
     __shared__ int64_t s_row[CH + 2 * DEPTH];
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_kernel(ChainArgs<T> a)
     int64_t eidx[E], ecl[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        eidx[j] = tid + (int64_t)j * CHAIN_NT;
+        eidx[j] = tid + (int64_t)j * NT;
         valid[j] = FULL || eidx[j] < d;
         ecl[j] = valid[j] ? eidx[j] : d - 1;   // clamped: loads stay unconditional and in bounds
     }
@@ -237,7 +241,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_kernel(ChainArgs<T> a)
         if (tid < DEPTH && base > 0) hist = s_row[CH + tid];   // last DEPTH rows of the previous (full) chunk
         __syncthreads();
         if (tid < DEPTH) s_row[tid] = hist;
-        for (int e = tid; e < nch + DEPTH; e += CHAIN_NT) {
+        for (int e = tid; e < nch + DEPTH; e += NT) {
             int64_t st = base + e;
             if (st > a.nsteps - 1) st = a.nsteps - 1;   // look-ahead past the end repeats the last row (harmless loads)
             int64_t r = a.idx[st];
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_kernel(ChainArgs<T> a)
         }
         __syncthreads();
         if (HAS_TABLE) {
-            for (int e = tid; e < nch; e += CHAIN_NT) {
+            for (int e = tid; e < nch; e += NT) {
                 const int64_t r = s_row[DEPTH + e];
                 bool st = false;
 #pragma unroll
@@ -299,14 +303,19 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_kernel(ChainArgs<T> a)
                 }
                 d1 = wave_sum_lane63(d1);
                 if (TWO) d2 = wave_sum_lane63(d2);
-                if (lane == WAVE - 1) {   // the lane that holds the wave's sum
-                    red[par][wib][0] = d1;
-                    if (TWO) red[par][wib][1] = d2;
+                if constexpr (NW == 1) {
+                    d1 = readlane(d1, WAVE - 1);
+                    if (TWO) d2 = readlane(d2, WAVE - 1);
+                } else {
+                    if (lane == WAVE - 1) {   // the lane that holds the wave's sum
+                        red[par][wib][0] = d1;
+                        if (TWO) red[par][wib][1] = d2;
+                    }
+                    __syncthreads();
+                    d1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+                    if (TWO) d2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+                    par ^= 1;
                 }
-                __syncthreads();
-                d1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
-                if (TWO) d2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
-                par ^= 1;
 
                 const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
                 if (ALG == CA_SVRG) {                                            // SVRG_basic.jl:74-81

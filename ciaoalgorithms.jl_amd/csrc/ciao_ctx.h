@@ -64,6 +64,7 @@ struct ciao_ctx {
     int64_t chain_one_wave = 0;     // experiment: 4 KiB rows on a single-wave chain (no cross-wave exchange)
     int64_t chain_big = 0;          // testing: route chains through chain_big_kernel (the any-d kernel) whatever d
     int64_t chain_no_dma = 0;       // testing: route chains through the register-ring kernel instead of the LDS-DMA one
+    int chain_last_one_wave = 0;    // E of the single-wave register-ring chain the last launch took, 0 = four waves
     int chain_last_dma = 0;
     bool chain_last_masked = false;
     long long *chain_dbg = nullptr;   // timing builds only (CIAO_CHAIN_DBG & 8): device buffer for cycle stamps
