@@ -107,6 +107,7 @@ SIGNATURES = {
     "ciao_synth_normal": (_i32, [_vp, _i32, _vp, _i64, _i64, _i64, _i64, C.c_uint64, _f64]),
     "ciao_synth_targets": (_i32, [_vp, _PP, _vp, _f64, _i32, _i64, C.c_uint64, _vp]),
     "ciao_sample_batches": (_i32, [C.c_uint64, C.c_uint64, _i64, _i64, _i64, _vp, C.POINTER(C.c_uint64)]),
+    "ciao_sample_uniform": (_i32, [_vp, C.c_uint64, C.c_uint64, _i64, _i64, _vp]),
 }
 
 _lib = None

@@ -1538,6 +1538,31 @@ inline uint64_t splitmix_at(uint64_t seed, uint64_t k)   // output number k (0-b
 }
 }  // namespace
 
+namespace {
+__global__ void __launch_bounds__(256) sample_uniform_kernel(uint64_t seed, uint64_t pos, uint64_t N, int64_t m, int64_t *out)
+{
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < m; k += (int64_t)gridDim.x * 256) {
+        uint64_t z = seed + (pos + (uint64_t)k + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        out[k] = (int64_t)(((z >> 32) * N) >> 32);
+    }
+}
+}  // namespace
+
+int32_t ciao_sample_uniform(ciao_ctx *ctx, uint64_t seed, uint64_t pos, int64_t N, int64_t m, int64_t *out_dev)
+{
+    CIAO_ENTER(ctx);
+    CIAO_REQUIRE(ctx, "ctx is NULL");
+    CIAO_REQUIRE(N > 0 && N < (1ll << 32) && m >= 0 && (out_dev || m == 0), "need 0 < N < 2^32, m >= 0 and an output array");
+    if (m == 0) return CIAO_OK;
+    const int64_t grid = std::min<int64_t>((m + 255) / 256, (int64_t)ctx->num_cu * 8);
+    hipLaunchKernelGGL(sample_uniform_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, seed, pos, (uint64_t)N, m, out_dev);
+    CIAO_HIP(hipGetLastError());
+    return CIAO_OK;
+}
+
 int32_t ciao_sample_batches(uint64_t seed, uint64_t pos, int64_t N, int64_t r, int64_t n, int64_t *out_host,
                             uint64_t *pos_out_host)
 {

@@ -291,6 +291,16 @@ class Context:
             t.record_stream(self.stream)
         return t
 
+    def sample_uniform(self, seed: int, pos: int, N: int, m: int) -> torch.Tensor:
+        """m uniform draws from 0..N-1 of the injected index stream (outputs pos .. pos+m-1), generated on the device
+        (ciao_sample_uniform): the values sampling.IndexStream.rand_indices produces on the host."""
+        out = torch.empty(int(m), dtype=torch.int64, device=f"cuda:{self.device}")
+        L.check(self.lib.ciao_sample_uniform(self._h, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_uint64(int(pos)), int(N), int(m),
+                                             C.c_void_p(out.data_ptr())))
+        if self.stream is not None:
+            out.record_stream(self.stream)
+        return out
+
     # -- L1 plugin API ----------------------------------------------------------------------------------------------
     def gradient(self, p: PackedF, i: int, x, y, fval=None):
         L.check(self.lib.ciao_gradient(self._h, p.ref, int(i), self._vec(x, p, "x"), self._vec(y, p, "y"), _ptr(fval)))

@@ -46,6 +46,19 @@ class IndexStream:
         u = self._take(m) >> np.uint64(32)
         return ((u * np.uint64(N)) >> np.uint64(32)).astype(np.int64)
 
+    def rand_indices_device(self, ctx, N: int, m: int):
+        """The same m draws, generated on the device by `ctx` (device.Context.sample_uniform): returns (device int64 tensor,
+        last index as a host int or None when m == 0).  The stream position advances exactly as rand_indices does, so host
+        and device draws can be mixed freely."""
+        assert 0 < N < (1 << 32)
+        t = ctx.sample_uniform(self.seed, self.pos, N, m)
+        last = None
+        if m > 0:
+            u = _splitmix64(self.seed, self.pos + m - 1, 1) >> np.uint64(32)
+            last = int(((u * np.uint64(N)) >> np.uint64(32))[0])
+        self.pos += m
+        return t, last
+
     def rand_signs(self, n: int) -> np.ndarray:
         """n i.i.d. uniform draws from {-1, +1} as int8 (the reference's rand([-1, 1], size(x0)), Finito_adaptive.jl:80)."""
         return ((self._take(n) >> np.uint64(63)).astype(np.int8) * 2 - 1).astype(np.int8)

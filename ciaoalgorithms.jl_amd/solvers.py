@@ -129,6 +129,15 @@ class _Iterable:
 
     _rides_on_full_pass = False
 
+    def _draw(self, N, m):
+        """m uniform indices of the injected stream -> (indices, last index on the host).  Long runs are generated ON THE DEVICE
+        when the stream can (sampling.IndexStream: an epoch of 10^7 draws costs the host about a second and 80 MB of PCIe);
+        short ones and replayed streams (FixedStream) on the host."""
+        if m >= 4096 and hasattr(self.stream, "rand_indices_device") and 0 < N < (1 << 32):
+            return self.stream.rand_indices_device(self.ctx, N, m)
+        idx = self.stream.rand_indices(N, m)
+        return idx, (int(idx[-1]) if m > 0 else None)
+
     def _new(self):
         return torch.empty(self.d, dtype=self.R, device=self._x0_dev.device)
 
@@ -223,7 +232,7 @@ class SVRG_basic_iterable(_Iterable):
 
     def _step(self, st, n):                                                # SVRG_basic.jl:71-96
         for _ in range(n):
-            idx = self.stream.rand_indices(self.N, st.m)                   # :73
+            idx, _ = self._draw(self.N, st.m)                              # :73
             fresh = self.shards is None and st._tok is not None and st._tok == self._versions(st)
             self._monitor_on()
             self.ctx.svrg_iterate(self.F, self.g, st.γ, idx, self.plus, st.av, st.z, st.z_full, st.w, reuse_rowdots=fresh)
@@ -271,9 +280,9 @@ class SAGA_basic_iterable(_Iterable):
         return st
 
     def _step(self, st, n):                                                # SAGA_basic.jl:53-68, n consecutive calls
-        idx = self.stream.rand_indices(self.N, n)                          # :55 (one draw per iteration)
+        idx, last = self._draw(self.N, n)                                  # :55 (one draw per iteration)
         self.ctx.saga_steps(self.F, self.g, st.γ, self.SAG, idx, st.s, st.av, st.z)
-        st.ind = int(idx[-1]) + 1 if n > 0 else st.ind                     # 1-based like the reference's state.ind
+        st.ind = last + 1 if n > 0 else st.ind                             # 1-based like the reference's state.ind
 
 
 # ======================================================================================================================

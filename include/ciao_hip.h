@@ -371,6 +371,11 @@ CIAO_API int32_t ciao_synth_targets(ciao_ctx *ctx, const ciao_problem *p, const 
  * draw batches at that rate. */
 CIAO_API int32_t ciao_sample_batches(uint64_t seed, uint64_t pos, int64_t N, int64_t r, int64_t n, int64_t *out_host,
                             uint64_t *pos_out_host);
+/* m i.i.d. uniform draws from 0..N-1 of the same stream (outputs pos .. pos+m-1; the rule of `rand(state.ind, m)`,
+ * SVRG_basic.jl:73, and `rand(1:N)`, SAGA_basic.jl:55, on the injected stream: ((splitmix64 >> 32) * N) >> 32), written to the
+ * DEVICE array out_dev[m] on the ctx's stream: an epoch's 10^7 indices cost the host a second and 80 MB of PCIe, the device
+ * microseconds.  Needs 0 < N < 2^32. */
+CIAO_API int32_t ciao_sample_uniform(ciao_ctx *ctx, uint64_t seed, uint64_t pos, int64_t N, int64_t m, int64_t *out_dev);
 
 #endif /* CIAO_BENCH_API */
 

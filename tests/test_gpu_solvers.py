@@ -593,3 +593,34 @@ def test_packing_rows_from_a_host_matrix_stream(api, ctx, tmp_path):
         ops.pack_rows_from_host(iter([(ro[:10], b[:10])]), N, d, np.float64)
     with pytest.raises(TypeError, match=r"no\s+host fallback|no host fallback"):
         S.SVRG(np.float64, γ=0.1, maxit=2)(np.zeros(d), F=[object()] * 3, N=3, ctx=ctx)
+
+
+def test_long_index_draws_are_generated_on_the_device(api, ciao, ctx):
+    """Draws of 4096 indices or more come from ciao_sample_uniform (the injected stream evaluated on the device): the same values
+    as IndexStream.rand_indices on the host, at any stream position, and SVRG / SAGA through the functors follow the oracle's
+    iterables, which draw on the host."""
+    import torch
+    from oracle import oracle as O
+    from oracle import ref_solvers as RS
+    from ciaoalgorithms_jl_amd.device import PackedF, ProxG
+    import ciaoalgorithms_jl_amd._lib as L
+    S, ops = api
+    for seed, pos, N, m in ((0, 0, 7, 5), (3, 12345, 10_000_000, 100_000), (2 ** 63 + 5, 2 ** 40, 4_000_000_000, 70_001)):
+        a, b = ciao.IndexStream(seed), ciao.IndexStream(seed)
+        a.pos = b.pos = pos
+        host = a.rand_indices(N, m)
+        dev_t, last = b.rand_indices_device(ctx, N, m)
+        assert np.array_equal(dev_t.cpu().numpy(), host) and last == int(host[-1]) and a.pos == b.pos
+    N, d = 6000, 32
+    A, bb, _ = P.synthetic("ls", N, d, np.float64, seed=5)
+    x0 = np.zeros(d)
+    Li = float(N) * np.sum(A * A, axis=1)
+    F = PackedF.least_squares(torch.from_numpy(A).cuda(), torch.from_numpy(bb).cuda(), float(N))
+    g, og, op = ProxG(L.PROX_L1, lam=0.01), O.Prox("l1", lam=0.01), O.Problem("ls", A, bb, float(N))
+    gamma = 1.0 / (7 * Li.max())
+    x, it = S.SVRG(np.float64, γ=gamma, maxit=2)(x0, F=F, g=g, N=N, ctx=ctx, stream=ciao.IndexStream(1))
+    xr, _ = RS.svrg(op, og, x0, maxit=2, gamma=gamma, stream=ciao.IndexStream(1))
+    assert np.abs(x - xr).max() <= 1e-9 * max(np.abs(xr).max(), 1e-30) + 1e-13
+    x, it = S.SAGA(np.float64, γ=1.0 / (3 * Li.max()), maxit=9000)(x0, F=F, g=g, N=N, ctx=ctx, stream=ciao.IndexStream(2))
+    xr, _ = RS.saga(op, og, x0, maxit=9000, gamma=1.0 / (3 * Li.max()), stream=ciao.IndexStream(2))
+    assert np.abs(x - xr).max() <= 1e-9 * max(np.abs(xr).max(), 1e-30) + 1e-13
