@@ -60,6 +60,21 @@ def run(ctx, dev, quick=False):
     del F, idx
     torch.cuda.empty_cache()
 
+    # ---- S3 on short rows (single-wave chain, no cross-wave exchange): d = 128 fp64, and BASELINE config #1's shape d = 50 -------
+    for dd in (128, 50):
+        N = 1_000_000 // scale
+        F = _problem(ctx, dev, N, dd, torch.float64, False)
+        x0 = torch.zeros(dd, dtype=torch.float64, device=dev)
+        av, z, zf, w = (torch.empty_like(x0) for _ in range(4))
+        ctx.svrg_init(F, x0, av, z, zf, w)
+        m = 200_000 // scale
+        idx = ctx._idx(st.rand_indices(N, m))
+        ctx.svrg_inner(F, g, 1.0 / (7 * 1.3 * N), idx[:1000], av, z, zf, w)
+        t = _timed(ctx, lambda: ctx.svrg_inner(F, g, 1.0 / (7 * 1.3 * N), idx, av, z, zf, w))
+        out[f"svrg_inner_f64_d{dd}"] = {"updates_per_s": m / t, "us_per_update": t / m * 1e6, "m": m, "N": N, "kernel": ctx.last_kernel()}
+        del F, idx
+        torch.cuda.empty_cache()
+
     # ---- G2 / G3: SAGA init (table write sweep) and SAGA steps, l1-logistic d=1024 fp32 -----------------------------
     N, d = 2_000_000 // scale, 1024
     F = _problem(ctx, dev, N, d, torch.float32, True)
