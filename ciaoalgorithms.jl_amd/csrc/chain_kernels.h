@@ -1862,25 +1862,30 @@ __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst)
 
 constexpr int AF_CHUNK = 512;
 
-template <typename T, int J>
+template <typename T, int J, int NT = CHAIN_NT>
 constexpr size_t afinito_dma_lds_bytes()
 {
-    constexpr int DEPTH = DmaDepth<J, true>::value;
-    return (size_t)2 * DEPTH * J * CHAIN_NT * 16 + (size_t)DEPTH * CHAIN_NW * 256 + (AF_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
-           AF_CHUNK * sizeof(T) + AF_CHUNK * sizeof(int) + 16 + 2 * CHAIN_NW * 2 * sizeof(T);
+    constexpr int NW = NT / WAVE;
+    constexpr int DEPTH = DmaDepth<(J * NT + 255) / 256, true>::value;
+    return (size_t)2 * DEPTH * J * NT * 16 + (size_t)DEPTH * NW * 256 + (AF_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
+           AF_CHUNK * sizeof(T) + AF_CHUNK * sizeof(int) + 16 + 2 * NW * 2 * sizeof(T);
 }
 
-template <typename T, int J, int LOSS, bool MASKED>
-__global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
+// NT = 256, or 64: rows of up to 2 KiB on ONE wave (J = 1 / 2), where the exchange of every trial disappears (as in
+// chain_dma_kernel).  The per-sample scalars keep their N x 4 x 4 layout: the single wave reads copy 0 and writes all four.
+template <typename T, int J, int LOSS, bool MASKED, int NT = CHAIN_NT>
+__global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
 {
+    constexpr int NW = NT / WAVE;
+    static_assert(NW == 1 || NW == CHAIN_NW, "one wave or four");
     using V = typename VecOfC<T>::type;
     constexpr int VEC = 16 / sizeof(T);
-    constexpr int DEPTH = DmaDepth<J, true>::value;
+    constexpr int DEPTH = DmaDepth<(J * NT + 255) / 256, true>::value;
     constexpr int CH = AF_CHUNK;
     constexpr int OPS_PER_STEP = (MASKED ? 2 * J : 3 * J) + 1;   // MASKED: predicated table stores are not counted (chain_dma_kernel)
     constexpr bool PIPE = DEPTH >= 4;
     constexpr int WAIT_N = (PIPE ? DEPTH - 2 : DEPTH - 1) * OPS_PER_STEP;
-    constexpr int ROW_BYTES = J * CHAIN_NT * 16;
+    constexpr int ROW_BYTES = J * NT * 16;
     constexpr int MDW = 4 * sizeof(T) / 4;   // dwords in one copy of a sample's scalars
     static_assert(CH % DEPTH == 0 && DEPTH % 2 == 0, "ring slots must line up with chunk starts; ping-pong needs even DEPTH");
     static_assert(WAIT_N <= 63, "vmcnt is a 6-bit counter");
@@ -1890,7 +1895,7 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
     unsigned char *ringA = dsm;
     unsigned char *ringT = ringA + DEPTH * ROW_BYTES;
     unsigned char *ringM = ringT + DEPTH * ROW_BYTES;
-    unsigned char *cur = ringM + DEPTH * CHAIN_NW * 256;
+    unsigned char *cur = ringM + DEPTH * NW * 256;
     int64_t *s_row = reinterpret_cast<int64_t *>(cur);
     cur += (CH + 2 * DEPTH) * sizeof(int64_t);
     T *s_b = reinterpret_cast<T *>(cur);
@@ -1898,7 +1903,7 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
     int *s_stale = reinterpret_cast<int *>(cur);
     cur += CH * sizeof(int);
     cur += (16 - (reinterpret_cast<uintptr_t>(cur) & 15)) & 15;
-    T(*red)[CHAIN_NW][2] = reinterpret_cast<T(*)[CHAIN_NW][2]>(cur);
+    T(*red)[NW][2] = reinterpret_cast<T(*)[NW][2]>(cur);
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -1914,7 +1919,7 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
     int64_t cl[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const int64_t c = tid + (int64_t)j * CHAIN_NT;
+        const int64_t c = tid + (int64_t)j * NT;
         ok[j] = !MASKED || c < nchunks;
         cl[j] = ok[j] ? c : 0;
     }
@@ -1957,13 +1962,13 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
         const unsigned char *sp = reinterpret_cast<const unsigned char *>(a.table + r * d);
 #pragma unroll
         for (int j = 0; j < J; ++j)
-            glds16(ap + cl[j] * 16, ringA_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
+            glds16(ap + cl[j] * 16, ringA_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
 #pragma unroll
         for (int j = 0; j < J; ++j)
-            glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * CHAIN_NW + wib) * 1024));
+            glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
         // this wave's copy of the scalars: lanes l and l + MDW fetch the same dword, only the first MDW LDS dwords are read back
-        const unsigned char *mp = reinterpret_cast<const unsigned char *>(a.meta + (r * CHAIN_NW + wib) * 4);
-        glds4(mp + (lane & (MDW - 1)) * 4, ringM_off + (uint32_t)((u * CHAIN_NW + wib) * 256));
+        const unsigned char *mp = reinterpret_cast<const unsigned char *>(a.meta + (r * CHAIN_NW + wib) * 4);   // CHAIN_NW = the layout's four copies
+        glds4(mp + (lane & (MDW - 1)) * 4, ringM_off + (uint32_t)((u * NW + wib) * 256));
     };
 
     struct StepIn {
@@ -1977,11 +1982,11 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
     auto fetch = [&](StepIn &x, int u, int s) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            x.ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
-            x.sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * CHAIN_NW + wib) * 64 + lane) * 16);
+            x.ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * NW + wib) * 64 + lane) * 16);
+            x.sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * NW + wib) * 64 + lane) * 16);
             if (MASKED && !ok[j]) x.ar[j] = x.sr[j] = V(T(0));
         }
-        const T *mp = reinterpret_cast<const T *>(ringM + (u * CHAIN_NW + wib) * 256);
+        const T *mp = reinterpret_cast<const T *>(ringM + (u * NW + wib) * 256);
 #pragma unroll
         for (int q = 0; q < 4; ++q) x.m[q] = mp[q];
         x.row = s_row[DEPTH + s];
@@ -2001,7 +2006,7 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
         if (tid < DEPTH && base > 0) hist = s_row[CH + tid];
         __syncthreads();
         if (tid < DEPTH) s_row[tid] = hist;
-        for (int e = tid; e < nch + DEPTH; e += CHAIN_NT) {
+        for (int e = tid; e < nch + DEPTH; e += NT) {
             int64_t st = base + e;
             if (st > a.nsteps - 1) st = a.nsteps - 1;
             int64_t r = a.idx[st];
@@ -2013,7 +2018,7 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
             if (e < nch) s_b[e] = a.b ? a.b[r] : T(0);
         }
         __syncthreads();
-        for (int e = tid; e < nch; e += CHAIN_NT) {
+        for (int e = tid; e < nch; e += NT) {
             const int64_t r = s_row[DEPTH + e];
             bool st = false;
 #pragma unroll
@@ -2077,19 +2082,27 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
                         }
                     p1 = wave_sum_lane63(p1);
                     p2 = wave_sum_lane63(p2);
-                    if (lane == WAVE - 1) {   // the lane that holds the wave's sum
-                        red[par][wib][0] = p1;
-                        red[par][wib][1] = p2;
+                    if constexpr (NW > 1) {
+                        if (lane == WAVE - 1) {   // the lane that holds the wave's sum
+                            red[par][wib][0] = p1;
+                            red[par][wib][1] = p2;
+                        }
                     }
                     // the two divisions of the step depend only on gamma_i and hat_gamma: issued here, they run in the shadow of
                     // the exchange instead of behind it
                     const double qc = 0.5 * a.Nd * (double)a.alpha / (double)gi;                // :128 (Float64 in the reference whatever R)
                     const T r1 = hg / gi;                                                       // :145
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue
-                    dz = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
-                    const T n2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
-                    par ^= 1;
+                    T n2;
+                    if constexpr (NW == 1) {   // one wave: the sums reach every lane through SGPRs, no LDS exchange
+                        dz = readlane(p1, WAVE - 1);
+                        n2 = readlane(p2, WAVE - 1);
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue
+                        dz = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+                        n2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+                        par ^= 1;
+                    }
                     fi_z = loss_value(LOSS, dz, bi, a.lam);                                     // :125
                     const double fi_model = (double)(fi_x + c_old * (dz - as_i)) + qc * (double)n2;   // :126-129
                     const T tol = T(10) * Eps<T>::value * (T(1) + fabs2(fi_z));                 // :130
@@ -2132,8 +2145,8 @@ __global__ void __launch_bounds__(CHAIN_NT) afinito_dma_kernel(AFinitoArgs<T> a)
                     }
                 }
                 prox_all(hg * plam);                                                            // :150
-                if (lane == 0) {
-                    T *mp = a.meta + (row * CHAIN_NW + wib) * 4;
+                if (NW == 1 ? lane < CHAIN_NW : lane == 0) {   // one wave keeps all four copies of the layout identical
+                    T *mp = a.meta + (row * CHAIN_NW + (NW == 1 ? lane : wib)) * 4;
                     mp[0] = c_new;
                     mp[1] = fi_z;                                                               // :148 fi_x[i] = f_i(z)
                     mp[2] = gi;

@@ -11,8 +11,13 @@ from ciaoalgorithms_jl_amd.device import Context, PackedF, ProxG
 from ciaoalgorithms_jl_amd.sampling import IndexStream
 torch.cuda.set_device(0)
 ctx = Context(0)
+for kv in os.environ.get("CIAO_OPTS", "").split(","):
+    if "=" in kv:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 out = []
 cases = [(torch.float64, 200_000, 1024), (torch.float64, 2_000, 1024), (torch.float32, 200_000, 1024), (torch.float64, 100_000, 4096)]
+if os.environ.get("CIAO_D"):
+    cases = [(torch.float64, 200_000, int(os.environ["CIAO_D"])), (torch.float32, 200_000, int(os.environ["CIAO_D"]))]
 for dt, N, d in cases:
     k = 100_000
     A = torch.empty((N, d), dtype=dt, device="cuda"); b = torch.empty((N,), dtype=dt, device="cuda")
