@@ -1610,3 +1610,98 @@ def test_adaptive_finito_random_reprobe(ctx, ciao, dtype, d):
     assert done == rdone == 60
     if trials == rtrials:
         close(st.z, rz, dtype, scale=500, what="z after 60 steps from the re-probed init")
+
+
+def _random_chain_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        N = int(rng.choice([2, 3, 7, 33, 100]))
+        d = int(rng.choice([rng.integers(1, 70), rng.integers(70, 600), 2 * int(rng.integers(35, 300)), 4 * int(rng.integers(16, 700)),
+                            rng.integers(600, 3000)]))
+        dtype = [np.float64, np.float32][int(rng.integers(0, 2))]
+        loss = ["ls", "logistic"][int(rng.integers(0, 2))]
+        gk = ["zero", "l1", "box", "boxvec"][int(rng.integers(0, 4))]
+        alg = ["svrg", "svrg_cached", "saga", "sag", "finito", "lfinito"][int(rng.integers(0, 6))]
+        r = int(rng.choice([1, 1, 2, 5]))
+        out.append((alg, N, d, dtype, loss, gk, min(r, N)))
+    return out
+
+
+# CIAO_FUZZ_CASES / CIAO_FUZZ_SEED: a longer one-off hunt with other seeds (the default 160 cases with seed 77 are the suite's)
+@pytest.mark.parametrize("case", _random_chain_cases(int(os.environ.get("CIAO_FUZZ_CASES", "160")), int(os.environ.get("CIAO_FUZZ_SEED", "77"))),
+                         ids=lambda c: f"{c[0]}-N{c[1]}-d{c[2]}-{'f64' if c[3] == np.float64 else 'f32'}-{c[4]}-{c[5]}-r{c[6]}")
+def test_random_chain_configurations(ctx, ciao, case):
+    """Seeded random (algorithm, N, d, type, loss, g, batch) through the chain kernels -- every prox family (the IndBox clamp is its
+    own version of each step group), single-wave and four-wave shapes, masked and exact rows, chunks and single elements --
+    against the oracle on the same index stream."""
+    import torch
+    from oracle import oracle as O
+    alg, N, d, dtype, loss, gk, r = case
+    A, b, x0 = P.synthetic(loss, N, d, dtype, seed=N * 31 + d)
+    lam_f = float(N) if loss == "ls" else 1.0
+    op, dp = make(loss, A, b, lam_f, dtype)
+    og, dg = make_g(gk, dtype, d, lam=0.02)
+    Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1) + 1e-12
+    tdt = dev(x0).dtype
+    st = ciao.IndexStream(N * 1000 + d)
+    new = lambda: torch.empty(d, dtype=tdt, device="cuda")
+    S = 5000
+    if alg in ("svrg", "svrg_cached"):
+        gamma = 1.0 / (7 * Li.max())
+        av, z, zf, w = new(), new(), new(), new()
+        ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+        rav, rz, rzf, rw = O.svrg_init(op, x0)
+        for ep in range(2):
+            idx = st.rand_indices(N, 3 * N + 5)
+            ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w, reuse_rowdots=(alg == "svrg_cached"))
+            O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
+        close(zf, rzf, dtype, scale=S, what=f"random chain {alg} z_full ({ctx.last_kernel()})")
+        close(av, rav, dtype, scale=S, what=f"random chain {alg} av")
+    elif alg in ("saga", "sag"):
+        gamma = 1.0 / ((16 if alg == "sag" else 3) * Li.max())
+        table = torch.empty((N, d), dtype=tdt, device="cuda")
+        av, z = new(), new()
+        ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
+        rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
+        idx = st.rand_indices(N, 6 * N + 3)
+        ctx.saga_steps(dp, dg, gamma, alg == "sag", idx, table, av, z)
+        O.saga_steps(op, og, dtype(gamma), alg == "sag", idx, rt, rav, rz)
+        close(z, rz, dtype, scale=S, what=f"random chain {alg} z ({ctx.last_kernel()})")
+        close(table, rt, dtype, scale=S, what=f"random chain {alg} table")
+    else:
+        gam = (0.999 * N / Li).astype(dtype)
+        dgam = dev(gam)
+        hg = ctx.hat_gamma(dgam)
+        nb = -(-N // r)
+        static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in range(nb)]
+        ctx.set_option("chain_max_batch", 64)
+        try:
+            if alg == "finito":
+                table = torch.empty((N, d), dtype=tdt, device="cuda")
+                av, z = new(), new()
+                rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
+                ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
+                batches = [st.sample_without_replacement(N, r) for _ in range(2 * nb + 3)]
+                bptr = np.zeros(len(batches) + 1, np.int64)
+                np.cumsum([len(x) for x in batches], out=bptr[1:])
+                ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(batches), table, av, z)
+                O.finito_steps(op, og, gam, rhg, batches, rt, rav, rz)
+                close(z, rz, dtype, scale=20000, what=f"random chain finito z ({ctx.last_kernel()})")
+                close(table, rt, dtype, scale=20000, what="random chain finito table")
+            else:
+                av, z, zf = new(), new(), new()
+                rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
+                ctx.lfinito_init(dp, hg, dev(x0), av, z, zf)
+                for it in range(2):
+                    order = np.arange(nb) if it == 0 else st.randperm(nb)
+                    batches = [static[j] for j in order]
+                    bptr = np.zeros(nb + 1, np.int64)
+                    np.cumsum([len(x) for x in batches], out=bptr[1:])
+                    ctx.lfinito_iterate(dp, dg, dgam, hg, bptr, np.concatenate(batches), av, z, zf)
+                    O.lfinito_iterate(op, og, gam, rhg, batches, rav, rz, rzf)
+                close(zf, rzf, dtype, scale=20000, what=f"random chain lfinito z_full ({ctx.last_kernel()})")
+                close(av, rav, dtype, scale=20000, what="random chain lfinito av")
+        finally:
+            ctx.set_option("chain_max_batch", -1)
+    ctx.synchronize()
