@@ -186,7 +186,9 @@ def run_rank(args):
     backend = os.environ.get("CIAO_BENCH_BACKEND", "nccl")        # "nccl" IS RCCL on ROCm; gloo = one-GPU rehearsal only
     if world > 1 or force_dist:
         import torch.distributed as dist
-        if backend == "nccl" and world > torch.cuda.device_count():
+        # one process may see only ITS GPU (a launcher that masks devices per rank): then device_count is 1 and that is fine
+        masked = any(os.environ.get(k) for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+        if backend == "nccl" and world > torch.cuda.device_count() and not masked:
             print(f"[bench] {world} ranks need {world} GPUs (found {torch.cuda.device_count()}); RCCL takes one rank per device. "
                   f"CIAO_BENCH_BACKEND=gloo rehearses several ranks on one GPU.", file=sys.stderr)
             return 2
