@@ -443,13 +443,16 @@ static bool batch_as_chain(const ciao_ctx *ctx, const ciao_problem *p, int64_t r
     if (p->d > 32 * CHAIN_NT) return r <= 2;           // beyond 8192 elements the any-d chain runs at launch-pair speed: tiny batches only
     int64_t lim = ctx->chain_max_batch;
     if (lim < 0) {
-        // whole-4-KiB rows: rows_split_kernel batches cost ~6.5 us up to r = 64, LDS-DMA chain steps 0.47 / 0.55 / 0.8 / 1.5 us at
-        // 4 / 8 / 16 / 32 KiB rows; other shapes: ~14 us per wave-per-row batch against ~1 us per register-chain step
+        // measured after the chain work of round 2 (tools/gpu_s34.sh, profiles/r02_batch_chain_crossover.txt; Finito, fp32): a
+        // batch-parallel step costs 7.5-9.5 us up to r = 64 whatever r; a chain step 0.39 / 0.50 / 0.82 / 1.6 us per sample at
+        // 4 / 8 / 16 / 32 KiB rows, 0.29-0.34 us on the single-wave shapes (rows of up to 2 KiB)
         const int64_t rowb = p->d * (int64_t)sizeof(T);
         if (rowb % 4096 == 0 && rowb <= 32768 && rowb != 12288 && rowb != 20480 && rowb != 24576 && rowb != 28672)
-            lim = rowb == 4096 ? 14 : (rowb == 8192 ? 12 : (rowb == 16384 ? 8 : 4));
+            lim = rowb == 4096 ? 22 : (rowb == 8192 ? 15 : (rowb == 16384 ? 10 : 5));
         else if (rowb < 1024)
-            lim = 28;   // rows under 1 KiB: chain steps 0.3-0.5 us against ~14 us per batch on the scalar generic kernel
+            lim = 28;   // rows under 1 KiB: chain steps 0.2-0.5 us against ~14 us per batch on the scalar generic kernel
+        else if (rowb <= 2048 && rowb % 16 == 0)
+            lim = 22;
         else
             lim = 14;
     }

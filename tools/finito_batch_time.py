@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times Finito batch steps (d = 4096 f32, N = 250k) for the batch sizes given on the command line; prints us per batch."""
+"""Times Finito batch steps (d = 4096 f32 unless CIAO_D / CIAO_F64 say otherwise, N = 250k) for the batch sizes given on the command
+line; prints us per batch."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,9 @@ for kv in os.environ.get("CIAO_OPTS", "").split(","):
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
 rs = [int(a) for a in sys.argv[1:]] or [64, 256, 1024, 4096]
-N, d, dt = 250_000, 4096, torch.float32
+N = 250_000
+d = int(os.environ.get("CIAO_D", "4096"))
+dt = torch.float64 if os.environ.get("CIAO_F64") else torch.float32
 A = torch.empty((N, d), dtype=dt, device="cuda"); b = torch.empty((N,), dtype=dt, device="cuda")
 ctx.synth_normal(A, 0, 1, 1 / np.sqrt(d))
 F = PackedF(L.LOSS_LS, A, b, float(N))
@@ -39,7 +42,7 @@ for r in rs:
     ctx.finito_steps(F, g, gam, hg, bptr[:3], bidx[:2 * r], table, av, z); ctx.synchronize()
     t0 = time.perf_counter(); ctx.finito_steps(F, g, gam, hg, bptr, bidx, table, av, z); ctx.synchronize()
     t = time.perf_counter() - t0
-    out.append(f"r={r}: {t / nit * 1e6:.2f} us/batch, {nit * r * (3 * d * 4 + 16) / t / 1e9:.0f} GB/s [{ctx.last_kernel()}]")
+    out.append(f"r={r}: {t / nit * 1e6:.2f} us/batch, {nit * r * (3 * d * A.element_size() + 16) / t / 1e9:.0f} GB/s [{ctx.last_kernel()}]")
     print(out[-1], flush=True)
 if os.environ.get("CIAO_BLOCKS"):   # static contiguous batches: index lists vs the index-free *_blocks entry point
     for r in rs:
