@@ -180,6 +180,23 @@ def run(ctx, dev, quick=False):
     t = _timed(ctx, lambda: ctx.proshi_init(f, gbox, gam, x0, table, av, z, hgd))
     out["proshi_init_f64_d1024"] = {"seconds": t, "alg_GBps": N * 3 * d * 8 / t / 1e9, "N": N, "kernel": ctx.last_kernel()}
     hg = float(hgd.item())
+    # small batches (the reference's default is one agent per iteration): one coordinate-parallel chain launch for the whole run;
+    # the same through the batch-parallel launch pair for comparison
+    for r in (1, 16):
+        nit = 20000 // r // scale
+        bidx = ctx._idx(st.sample_batches(N, r, nit).reshape(-1).copy())
+        bptr = np.arange(nit + 1, dtype=np.int64) * r
+        for lim, tag in ((-1, ""), (0, "_launch_pair")):
+            if lim == 0 and r == 1:
+                nn = nit // 10
+            else:
+                nn = nit
+            ctx.set_option("proshi_chain_max_batch", lim)
+            ctx.proshi_steps(f, gbox, gam, hg, bptr[:3], bidx[:2 * r], table, av, z)
+            t = _timed(ctx, lambda: ctx.proshi_steps(f, gbox, gam, hg, bptr[:nn + 1], bidx[:nn * r], table, av, z))
+            ctx.set_option("proshi_chain_max_batch", -1)
+            out[f"proshi_batch_r{r}_f64_d1024{tag}"] = {"iterations_per_s": nn / t, "us_per_iteration": t / nn * 1e6, "agents_per_s": nn * r / t,
+                                                         "kernel": ctx.last_kernel()}
     for r in (4096, 65536 // scale):
         nit = 16
         batches = [st.sample_without_replacement(N, r) for _ in range(nit)]

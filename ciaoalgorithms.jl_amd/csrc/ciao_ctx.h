@@ -60,6 +60,7 @@ struct ciao_ctx {
     int64_t sweep_prefetch = -1;    // gradient sweeps: 1 = two-deep register pipeline, 0 = occupancy only, -1 = by row size
     int64_t chain_max_batch = -1;   // Finito/LFinito batches up to this size run as a sequential chain (-1 = automatic)
     int64_t svrg_cache_rowdots = 1; // reuse a_i'z_full from the full pass inside the SVRG inner cycle (ciao_svrg_iterate)
+    int64_t proshi_chain_max_batch = -1;   // ProShI batches up to this size run as one coordinate-parallel chain launch (-1 = automatic)
     int64_t chain_four_waves = 0;   // testing: short rows (<= 2 KiB) on the four-wave chain instead of the single-wave one
     int64_t chain_one_wave = 0;     // experiment: 4 KiB rows on a single-wave chain (no cross-wave exchange)
     int64_t chain_big = 0;          // testing: route chains through chain_big_kernel (the any-d kernel) whatever d

@@ -5,6 +5,8 @@
 // fixed-order finalize as the rows kernels.  HBM-bound: 3 rows read (Q_i, q_i, s_i) + 1 written per agent = 4*d*s bytes.
 #pragma once
 
+#include <type_traits>
+
 #include "ciao_common.h"
 
 namespace ciao {
@@ -235,6 +237,141 @@ __global__ void __launch_bounds__(256) proshi_dense_kernel(ProshiArgs<T> a)
         if (INIT) extra += gi;                                              // :82  hat_γ = sum(γ)
     }
     if (threadIdx.x == 0) a.pextra[blockIdx.x] = extra;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Small batches (the reference's default is ONE agent per iteration, ProShI.jl:27): with the separable operator family every
+// step of ProShI_basic.jl:109-121 is element-wise -- agent update, av update AND the z update touch coordinate k only --
+// so nothing couples the coordinates and a whole run of iterations is one launch in which thread k carries (av_k, z_k) in
+// registers through every visited agent, in the reference's own operation order (:111-117 per agent, :119-121 per batch):
+// no reduction, no barrier in the loop, no second kernel.  Against ~8 us per iteration for the launch pair of the
+// batch-parallel path.  The visited agents' (Q, q, s, gamma) are prefetched PDEPTH visits ahead through register rings
+// (indices and hazard flags staged in LDS per chunk of visits, exactly as the chain kernels do); an agent revisited inside
+// the look-ahead window has its table entry re-read at use (this thread stored it: program order).
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct ProshiChainArgs {
+    const T *Q, *q;
+    int64_t ld, d, N;
+    T eta, lo, hi;
+    const T *gam;
+    T invN, hat_gamma;
+    const int64_t *idx;        // visited agents, batch after batch
+    int64_t nvisits, batch;    // every batch has `batch` members
+    ProxD<T> g;
+    T *table, *av, *z;
+    int *errflag;
+};
+
+constexpr int PROSHI_CH = 1024;   // visits staged at a time
+constexpr int PROSHI_PD = 8;      // look-ahead in visits
+
+template <typename T>
+__global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a)
+{
+    constexpr int CH = PROSHI_CH, PD = PROSHI_PD;
+    static_assert(CH % PD == 0, "ring slots line up with chunk starts");
+    __shared__ int64_t s_row[CH + 2 * PD];
+    __shared__ int s_back[CH];   // 0, or how many visits ago (1..PD) this agent was last updated: its prefetched table entry is stale
+    const int tid = threadIdx.x;
+    const int64_t k0 = (int64_t)blockIdx.x * 256 + tid;
+    const bool live = k0 < a.d;
+    const int64_t k = live ? k0 : a.d - 1;     // dead threads of the last block shadow a live coordinate and never store
+    T av = a.av[k], z = a.z[k];
+    // g's parameters for coordinate k, fetched ONCE (prox_elem would re-load the IndBox vectors at every batch end: conditional
+    // loads in the loop, and the compiler drains the whole prefetch queue behind each of them)
+    const T gl = (a.g.kind == CIAO_PROX_L1) ? a.hat_gamma * a.g.lam : T(0);
+    T plo = -INFINITY, phi = INFINITY;
+    if (a.g.kind == CIAO_PROX_BOX) {
+        plo = a.g.lo_vec ? a.g.lo_vec[k] : a.g.lo;
+        phi = a.g.hi_vec ? a.g.hi_vec[k] : a.g.hi;
+    }
+    // register rings, statically indexed: every load of the loop is unconditional and in program order, so that hipcc retires
+    // them with counted waits (a conditional re-read of a stale table entry made it drain the queue on every visit: 0.86 us)
+    T Qr[PD], qr[PD], sr[PD], gr[PD], hist[PD];   // hist[u] = the table entry the visit of slot u wrote
+#pragma unroll
+    for (int u = 0; u < PD; ++u) hist[u] = T(0);
+    auto refill = [&](int u, int64_t r) {
+        Qr[u] = a.Q[r * a.ld + k];
+        qr[u] = a.q[r * a.ld + k];
+        sr[u] = a.table[r * a.d + k];
+        gr[u] = a.gam[r];
+    };
+    int64_t inb = 0;
+    for (int64_t base = 0; base < a.nvisits; base += CH) {
+        const int nch = (int)((a.nvisits - base) < CH ? (a.nvisits - base) : CH);
+        __syncthreads();
+        int64_t hrow = -1;
+        if (tid < PD && base > 0) hrow = s_row[CH + tid];
+        __syncthreads();
+        if (tid < PD) s_row[tid] = hrow;
+        for (int e = tid; e < nch + PD; e += 256) {
+            int64_t v = base + e;
+            if (v > a.nvisits - 1) v = a.nvisits - 1;          // look-ahead past the end repeats the last agent (harmless loads)
+            int64_t r = a.idx[v];
+            if ((uint64_t)r >= (uint64_t)a.N) {
+                *a.errflag = 1;
+                r = 0;
+            }
+            s_row[PD + e] = r;
+        }
+        __syncthreads();
+        for (int e = tid; e < nch; e += 256) {
+            const int64_t r = s_row[PD + e];
+            int back = 0;
+#pragma unroll
+            for (int j = PD; j >= 1; --j)
+                if (s_row[PD + e - j] == r) back = j;          // the most recent occurrence wins (smallest j)
+            s_back[e] = back;
+        }
+        __syncthreads();
+        if (base == 0) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) refill(u, s_row[PD + u]);
+        }
+        // one ring revolution; CHK = false when every visit of the group exists (all groups of a chunk but possibly the last)
+        auto group = [&](auto chk_tag, const int s0) {
+            constexpr bool CHK = decltype(chk_tag)::value;
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int s = s0 + u;
+                if (CHK && s >= nch) return;
+                const int64_t row = s_row[PD + s];
+                const int64_t row_n = s_row[PD + s + PD];
+                const int back = s_back[s];
+                T sv = sr[u];
+#pragma unroll
+                for (int j = 1; j <= PD; ++j) sv = (back == j) ? hist[(u - j + PD) % PD] : sv;   // written j visits ago by this thread
+                const T gi = gr[u];
+                av -= sv;                                                        // :111
+                const T s2 = sv + gi * z;                                        // :112
+                const T pr = s2 < a.lo ? a.lo : (s2 > a.hi ? a.hi : s2);
+                T gt = (Qr[u] * s2 + qr[u]) + a.eta * (s2 - pr);                 // :113  Quadratic: Q x + q ; SqrDistL2: eta (x - proj)
+                gt *= -(gi * a.invN);                                            // :114
+                gt += s2;                                                        // :115
+                av += gt;                                                        // :116
+                if (live) a.table[row * a.d + k] = gt;                           // :117
+                hist[u] = gt;
+                if (++inb == a.batch) {
+                    inb = 0;
+                    z = fmin2(fmax2(av - clamp_sym(av, gl), plo), phi);          // :119  prox_{hat_gamma g}(av), branch-free
+                    z -= av;                                                     // :120
+                    z /= a.hat_gamma;                                            // :121
+                }
+                refill(u, row_n);                                                // after this visit's store (program order)
+            }
+        };
+        for (int s0 = 0; s0 < nch; s0 += PD) {
+            if (s0 + PD <= nch)
+                group(std::false_type{}, s0);
+            else
+                group(std::true_type{}, s0);
+        }
+    }
+    if (live) {
+        a.av[k] = av;
+        a.z[k] = z;
+    }
 }
 
 // solution(state): s_i += γ_i z for every agent, in place (ProShI_basic.jl:127-132)

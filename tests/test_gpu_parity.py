@@ -1321,6 +1321,66 @@ def test_proshi_dense_quadratic(ctx, ciao, dtype, shape, r):
     ctx.synchronize()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape,r", [((3, 2), 1), ((3, 2), 3), ((5, 7), 2), ((40, 300), 1), ((64, 1024), 8), ((200, 1500), 12), ((9, 4099), 4)])
+def test_proshi_small_batches_run_as_one_coordinate_parallel_chain(ctx, ciao, dtype, shape, r):
+    """Batches of up to 12 separable agents: a run of iterations is ONE launch (proshi_chain_kernel: thread k carries av_k, z_k
+    through every visited agent, the reference's operation order, no reduction).  Against the oracle, against the batch-parallel
+    path (option proshi_chain_max_batch = 0), index lists and row blocks, with agents revisited inside the look-ahead window
+    (N = 3) and a per-coordinate IndBox as g."""
+    import torch
+    from oracle import oracle as O
+    from ciaoalgorithms_jl_amd.device import PackedSepQuad, ProxG
+    import ciaoalgorithms_jl_amd._lib as L
+    N, d = shape
+    rng = np.random.default_rng(N * 13 + d)
+    Q = rng.uniform(-1.0, 3.0, (N, d)).astype(dtype)
+    q = rng.standard_normal((N, d)).astype(dtype)
+    eta, lo, hi = 3.0 * N, -2.0, 2.0
+    x0 = (0.5 * rng.standard_normal(d)).astype(dtype)
+    gam = (0.999 * N / (np.abs(Q).max(axis=1) + eta)).astype(dtype)
+    g_hi = np.linspace(0.5, 1.5, d).astype(dtype)
+    of, og = O.SepQuad(Q, q, eta, lo, hi), O.Prox("box", lo=-np.inf, hi=g_hi, dtype=dtype)
+    df = PackedSepQuad(dev(Q), dev(q), eta, lo, hi)
+    dg = ProxG(L.PROX_BOX, lo=-float("inf"), hi_vec=dev(g_hi))
+    tdt = dev(x0).dtype
+    st = ciao.IndexStream(4)
+    nit = 40
+    batches = [st.sample_without_replacement(N, r) for _ in range(nit)]
+    bptr = np.arange(nit + 1, dtype=np.int64) * r
+    rt, rav, rz, rhg = O.proshi_init(of, og, gam, x0)
+    O.proshi_steps(of, og, gam, rhg, batches, rt, rav, rz)
+    res = {}
+    for lim in (-1, 0):
+        table = torch.empty((N, d), dtype=tdt, device="cuda")
+        av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+        hg = torch.empty(1, dtype=tdt, device="cuda")
+        ctx.proshi_init(df, dg, dev(gam), dev(x0), table, av, z, hg)
+        ctx.set_option("proshi_chain_max_batch", lim)
+        try:
+            ctx.proshi_steps(df, dg, dev(gam), float(hg.item()), bptr, np.concatenate(batches), table, av, z)
+            assert ("proshi_chain_kernel" in ctx.last_kernel()) == (lim == -1), ctx.last_kernel()
+        finally:
+            ctx.set_option("proshi_chain_max_batch", -1)
+        close(table, rt, dtype, scale=5000, what=f"proshi small batches table ({ctx.last_kernel()})")
+        close(av, rav, dtype, scale=2000, what="proshi small batches av")
+        close(z, rz, dtype, scale=50000, what="proshi small batches z")
+        res[lim] = (table, av, z)
+    # static contiguous blocks (sweeping 2 / 3) through the chain == the same batches as index lists
+    if r <= N:
+        nb = N // r
+        first = (np.arange(3 * nb) % nb * r).astype(np.int64)
+        ln = np.full(3 * nb, r, np.int64)
+        t1, a1, z1 = (x.clone() for x in res[-1])
+        t2, a2, z2 = (x.clone() for x in res[-1])
+        ctx.proshi_steps_blocks(df, dg, dev(gam), float(rhg), first, ln, t1, a1, z1)
+        assert "proshi_chain_kernel" in ctx.last_kernel()
+        idx = (first[:, None] + np.arange(r)[None, :]).reshape(-1)
+        ctx.proshi_steps(df, dg, dev(gam), float(rhg), np.arange(3 * nb + 1, dtype=np.int64) * r, idx, t2, a2, z2)
+        assert torch.equal(t1, t2) and torch.equal(a1, a2) and torch.equal(z1, z2)
+    ctx.synchronize()
+
+
 def test_proshi_dense_is_validated(ctx, ciao):
     import torch
     from ciaoalgorithms_jl_amd.device import PackedSepQuad, ProxG
