@@ -748,9 +748,9 @@ static int32_t proshi_steps_t(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_p
         CIAO_REQUIRE(r >= 1 || (ctx->hook && r == 0), "ProShI batch %lld is empty", (long long)t);
         // Small batches of separable agents: a whole run of equal-sized batches is ONE coordinate-parallel launch
         // (proshi_chain_kernel) instead of two launches per iteration.  Crossover (option proshi_chain_max_batch, -1 = automatic),
-        // measured at d = 1024 fp64: a visit costs the chain 0.44-0.49 us (0.49 us per iteration at r = 1, 7.1 at r = 16), a
+        // measured at d = 1024 (tools/proshi_chain_time.py): a visit costs the chain 0.31-0.35 us in fp64, 0.24-0.26 in fp32; a
         // batch-parallel iteration 6.1-6.7 us whatever r.
-        const int64_t lim = ctx->proshi_chain_max_batch >= 0 ? ctx->proshi_chain_max_batch : 12;
+        const int64_t lim = ctx->proshi_chain_max_batch >= 0 ? ctx->proshi_chain_max_batch : 18;
         if (!ctx->hook && !f->dense && r >= 1 && r <= lim) {
             int64_t t1 = t + 1;
             while (t1 < nit && src.size(t1) == r) ++t1;
@@ -776,7 +776,11 @@ static int32_t proshi_steps_t(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_p
             c.z = (T *)z;
             c.errflag = ctx->errflag;
             const int64_t grid = (f->d + 255) / 256;
-            hipLaunchKernelGGL((proshi_chain_kernel<T>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, c);
+            constexpr size_t lds = proshi_chain_lds_bytes<T>();
+            auto kern = &proshi_chain_kernel<T>;
+            if (lds > 60 * 1024)
+                CIAO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx->stream, c);
             CIAO_HIP(hipGetLastError());
             char nm[128];
             snprintf(nm, sizeof nm, "proshi_chain_kernel<%s> grid=%lld block=256 visits=%lld batch=%lld", sizeof(T) == 8 ? "f64" : "f32",

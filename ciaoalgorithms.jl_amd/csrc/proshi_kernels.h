@@ -7,6 +7,7 @@
 
 #include <type_traits>
 
+#include "chain_kernels.h"
 #include "ciao_common.h"
 
 namespace ciao {
@@ -263,39 +264,83 @@ struct ProshiChainArgs {
     int *errflag;
 };
 
-constexpr int PROSHI_CH = 1024;   // visits staged at a time
-constexpr int PROSHI_PD = 8;      // look-ahead in visits
+constexpr int PROSHI_CH = 1008;   // visits staged at a time (a multiple of both look-ahead depths)
+// look-ahead in visits: as deep as the 6-bit vmcnt allows -- (PD - 1) * (3 DW loads + 1 store) <= 63
+template <typename T>
+struct ProshiDepth {
+    static constexpr int value = sizeof(T) == 8 ? 9 : 16;
+};
 
+template <typename T>
+constexpr size_t proshi_chain_lds_bytes()
+{
+    constexpr int PD = ProshiDepth<T>::value;
+    return (size_t)PD * 3 * (sizeof(T) / 4) * 4 * 256 + (PROSHI_CH + 2 * PD) * sizeof(int64_t) + PROSHI_CH * sizeof(int) +
+           PROSHI_CH * sizeof(T) + (size_t)PD * 256 * sizeof(T) + 16;
+}
+
+// The prefetched (Q, q, s) of a visit travel by LDS-DMA (global_load_lds_dword: one dword per lane, two per fp64 value) into a
+// ring of PD visits and are retired with hand-counted waits, as in chain_dma_kernel: with register rings hipcc drains the whole
+// load queue at the loop's back-edge once per ring revolution (measured at d = 1024: 0.44-0.49 us per visit; here 0.31-0.35 fp64, 0.24-0.26 fp32).  gamma_i is staged
+// in LDS with the indices.  No compiler-visible load is left inside the loop.
 template <typename T>
 __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a)
 {
-    constexpr int CH = PROSHI_CH, PD = PROSHI_PD;
-    static_assert(CH % PD == 0, "ring slots line up with chunk starts");
-    __shared__ int64_t s_row[CH + 2 * PD];
-    __shared__ int s_back[CH];   // 0, or how many visits ago (1..PD) this agent was last updated: its prefetched table entry is stale
+    constexpr int CH = PROSHI_CH, PD = ProshiDepth<T>::value, NW = 4;
+    constexpr int DW = sizeof(T) / 4;                 // dwords per value
+    constexpr int OPS = 3 * DW + 1;                   // per visit and thread: 3 DW LDS-DMA loads + the table store (EVERY thread stores: see below)
+    constexpr int WAIT_N = (PD - 1) * OPS;
+    static_assert(CH % PD == 0 && WAIT_N <= 63, "ring slots line up with chunk starts; vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    uint32_t *ring = reinterpret_cast<uint32_t *>(psm);                     // [PD][3][DW][NW][64]
+    unsigned char *cur = psm + (size_t)PD * 3 * DW * NW * 256;
+    int64_t *s_row = reinterpret_cast<int64_t *>(cur);
+    cur += (CH + 2 * PD) * sizeof(int64_t);
+    T *s_gam = reinterpret_cast<T *>(cur);
+    cur += CH * sizeof(T);
+    int *s_back = reinterpret_cast<int *>(cur);   // 0, or how many visits ago (1..PD) this agent was last updated: its prefetched entry is stale
+    cur += CH * sizeof(int);
+    cur += (16 - (reinterpret_cast<uintptr_t>(cur) & 15)) & 15;
+    // hist[u][tid] = the table entry this thread's visit of slot u wrote: an agent revisited inside the window takes its value from
+    // here.  In LDS, not in registers: indexed by (u - back) the compiler turns a register ring into scratch memory, and the
+    // flat load + vmcnt(0) behind it drained the DMA queue on every visit (0.4-0.6 us per visit)
+    T *hist = reinterpret_cast<T *>(cur);
+    const uint32_t ring_off = (uint32_t)(uintptr_t)ring;
     const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t k0 = (int64_t)blockIdx.x * 256 + tid;
     const bool live = k0 < a.d;
     const int64_t k = live ? k0 : a.d - 1;     // dead threads of the last block shadow a live coordinate and never store
     T av = a.av[k], z = a.z[k];
-    // g's parameters for coordinate k, fetched ONCE (prox_elem would re-load the IndBox vectors at every batch end: conditional
-    // loads in the loop, and the compiler drains the whole prefetch queue behind each of them)
+    // g's parameters for coordinate k, fetched once
     const T gl = (a.g.kind == CIAO_PROX_L1) ? a.hat_gamma * a.g.lam : T(0);
     T plo = -INFINITY, phi = INFINITY;
     if (a.g.kind == CIAO_PROX_BOX) {
         plo = a.g.lo_vec ? a.g.lo_vec[k] : a.g.lo;
         phi = a.g.hi_vec ? a.g.hi_vec[k] : a.g.hi;
     }
-    // register rings, statically indexed: every load of the loop is unconditional and in program order, so that hipcc retires
-    // them with counted waits (a conditional re-read of a stale table entry made it drain the queue on every visit: 0.86 us)
-    T Qr[PD], qr[PD], sr[PD], gr[PD], hist[PD];   // hist[u] = the table entry the visit of slot u wrote
 #pragma unroll
-    for (int u = 0; u < PD; ++u) hist[u] = T(0);
+    for (int u = 0; u < PD; ++u) hist[u * 256 + tid] = T(0);
     auto refill = [&](int u, int64_t r) {
-        Qr[u] = a.Q[r * a.ld + k];
-        qr[u] = a.q[r * a.ld + k];
-        sr[u] = a.table[r * a.d + k];
-        gr[u] = a.gam[r];
+        const unsigned char *src[3] = {reinterpret_cast<const unsigned char *>(a.Q + r * a.ld + k),
+                                       reinterpret_cast<const unsigned char *>(a.q + r * a.ld + k),
+                                       reinterpret_cast<const unsigned char *>(a.table + r * a.d + k)};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int w = 0; w < DW; ++w) glds4(src[c] + 4 * w, ring_off + (uint32_t)((((u * 3 + c) * DW + w) * NW + wib) * 256));
+    };
+    auto slot = [&](int u, int c) -> T {   // plain LDS reads of what this lane's own DMA brought in
+        uint32_t wv[DW];
+#pragma unroll
+        for (int w = 0; w < DW; ++w) wv[w] = ring[(((u * 3 + c) * DW + w) * NW + wib) * 64 + lane];
+        T out;
+        if constexpr (DW == 2)
+            out = __longlong_as_double((long long)(((uint64_t)wv[1] << 32) | wv[0]));
+        else
+            out = __int_as_float((int)wv[0]);
+        return out;
     };
     int64_t inb = 0;
     for (int64_t base = 0; base < a.nvisits; base += CH) {
@@ -314,6 +359,7 @@ __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a)
                 r = 0;
             }
             s_row[PD + e] = r;
+            if (e < nch) s_gam[e] = a.gam[r];
         }
         __syncthreads();
         for (int e = tid; e < nch; e += 256) {
@@ -327,8 +373,10 @@ __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a)
         __syncthreads();
         if (base == 0) {
 #pragma unroll
-            for (int u = 0; u < PD; ++u) refill(u, s_row[PD + u]);
+            for (int u = 0; u < PD; ++u) refill(u, uniform64(s_row[PD + u]));
         }
+        wait_vmcnt<0>();          // ring fully landed: the counted waits below assume the steady-state op sequence
+        drain_vmcnt_visible();    // ... and hipcc knows that the staging loads are retired too
         // one ring revolution; CHK = false when every visit of the group exists (all groups of a chunk but possibly the last)
         auto group = [&](auto chk_tag, const int s0) {
             constexpr bool CHK = decltype(chk_tag)::value;
@@ -336,28 +384,37 @@ __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a)
             for (int u = 0; u < PD; ++u) {
                 const int s = s0 + u;
                 if (CHK && s >= nch) return;
-                const int64_t row = s_row[PD + s];
-                const int64_t row_n = s_row[PD + s + PD];
+                wait_vmcnt<WAIT_N>();                                            // slot u's DMA (issued PD visits ago) has landed
+                const int64_t row = uniform64(s_row[PD + s]);
+                const int64_t row_n = uniform64(s_row[PD + s + PD]);
                 const int back = s_back[s];
-                T sv = sr[u];
-#pragma unroll
-                for (int j = 1; j <= PD; ++j) sv = (back == j) ? hist[(u - j + PD) % PD] : sv;   // written j visits ago by this thread
-                const T gi = gr[u];
+                const T Qv = slot(u, 0), qv = slot(u, 1);
+                T sv = slot(u, 2);
+                {
+                    int hs = u - back;                                           // the slot of the visit `back` visits ago
+                    hs += hs < 0 ? PD : 0;
+                    const T hv = hist[hs * 256 + tid];                           // (back == 0: this slot's own old entry, ignored)
+                    sv = back ? hv : sv;
+                }
+                const T gi = s_gam[s];
                 av -= sv;                                                        // :111
                 const T s2 = sv + gi * z;                                        // :112
                 const T pr = s2 < a.lo ? a.lo : (s2 > a.hi ? a.hi : s2);
-                T gt = (Qr[u] * s2 + qr[u]) + a.eta * (s2 - pr);                 // :113  Quadratic: Q x + q ; SqrDistL2: eta (x - proj)
+                T gt = (Qv * s2 + qv) + a.eta * (s2 - pr);                       // :113  Quadratic: Q x + q ; SqrDistL2: eta (x - proj)
                 gt *= -(gi * a.invN);                                            // :114
                 gt += s2;                                                        // :115
                 av += gt;                                                        // :116
-                if (live) a.table[row * a.d + k] = gt;                           // :117
-                hist[u] = gt;
+                // :117 -- unconditional: a dead thread of the last block shadows coordinate d-1 with the identical state and inputs,
+                // so it stores the identical value; every wave then issues the same op sequence and the counted waits are exact
+                a.table[row * a.d + k] = gt;
+                hist[u * 256 + tid] = gt;
                 if (++inb == a.batch) {
                     inb = 0;
                     z = fmin2(fmax2(av - clamp_sym(av, gl), plo), phi);          // :119  prox_{hat_gamma g}(av), branch-free
                     z -= av;                                                     // :120
                     z /= a.hat_gamma;                                            // :121
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this lane's LDS reads of slot u are done before the DMA overwrites it
                 refill(u, row_n);                                                // after this visit's store (program order)
             }
         };
@@ -368,6 +425,7 @@ __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a)
                 group(std::true_type{}, s0);
         }
     }
+    wait_vmcnt<0>();   // nothing may still be writing LDS when the workgroup retires
     if (live) {
         a.av[k] = av;
         a.z[k] = z;

@@ -1322,9 +1322,9 @@ def test_proshi_dense_quadratic(ctx, ciao, dtype, shape, r):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("shape,r", [((3, 2), 1), ((3, 2), 3), ((5, 7), 2), ((40, 300), 1), ((64, 1024), 8), ((200, 1500), 12), ((9, 4099), 4)])
+@pytest.mark.parametrize("shape,r", [((3, 2), 1), ((3, 2), 3), ((5, 7), 2), ((40, 300), 1), ((64, 1024), 8), ((200, 1500), 18), ((9, 4099), 4)])
 def test_proshi_small_batches_run_as_one_coordinate_parallel_chain(ctx, ciao, dtype, shape, r):
-    """Batches of up to 12 separable agents: a run of iterations is ONE launch (proshi_chain_kernel: thread k carries av_k, z_k
+    """Batches of up to 18 separable agents: a run of iterations is ONE launch (proshi_chain_kernel: thread k carries av_k, z_k
     through every visited agent, the reference's operation order, no reduction).  Against the oracle, against the batch-parallel
     path (option proshi_chain_max_batch = 0), index lists and row blocks, with agents revisited inside the look-ahead window
     (N = 3) and a per-coordinate IndBox as g."""
