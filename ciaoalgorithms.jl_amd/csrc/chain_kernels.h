@@ -1853,11 +1853,11 @@ __global__ void __launch_bounds__(CHAIN_BIG_NT) afinito_big_kernel(AFinitoArgs<T
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst)
 {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
+    // m0 declared clobbered, not saved and restored (see glds16)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory", "m0");
+#pragma clang diagnostic pop
 }
 
 constexpr int AF_CHUNK = 512;
