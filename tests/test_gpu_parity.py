@@ -1578,7 +1578,7 @@ def _random_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _random_cases(48, 2024), ids=lambda c: f"N{c[0]}-d{c[1]}-pad{c[2]}-{'f64' if c[3] == np.float64 else 'f32'}-{c[4]}")
+@pytest.mark.parametrize("case", _random_cases(int(os.environ.get("CIAO_FUZZ_SHAPES", "48")), int(os.environ.get("CIAO_FUZZ_SEED", "2024"))), ids=lambda c: f"N{c[0]}-d{c[1]}-pad{c[2]}-{'f64' if c[3] == np.float64 else 'f32'}-{c[4]}")
 def test_random_shapes(ctx, ciao, case):
     """Sweep, both table inits, a Finito batch (batch-parallel) and a short SAGA chain on seeded random (N, d, row stride,
     type, loss): every combination lands on some kernel, and that kernel agrees with the oracle."""
