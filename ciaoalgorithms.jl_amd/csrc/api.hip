@@ -926,6 +926,11 @@ int32_t ciao_ctx_synchronize(ciao_ctx *ctx)
                       "draws, then repeat ciao_afinito_init with gam_override");
             return CIAO_ERR_UNSUPPORTED;
         }
+        if (flag == 3) {
+            set_error("internal: a wave of the wave-specialised chain kernel gave up waiting for another (chain_ws_kernel spin limit); "
+                      "results since the last synchronize are invalid -- option chain_no_ws=1 selects the previous chain kernel");
+            return CIAO_ERR_HIP;
+        }
         set_error("a sample index was outside [0, N): results since the last synchronize are invalid");
         return CIAO_ERR_ARG;
     }
@@ -1042,6 +1047,11 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
         ctx->chain_big = value != 0;
     } else if (!strcmp(key, "chain_no_dma")) {
         ctx->chain_no_dma = value != 0;
+    } else if (!strcmp(key, "chain_no_ws")) {
+        ctx->chain_no_ws = value != 0;
+    } else if (!strcmp(key, "chain_ws_issuers")) {
+        CIAO_REQUIRE(value >= 0 && value <= 2, "chain_ws_issuers must be 0 (automatic), 1 or 2");
+        ctx->chain_ws_issuers = value;
     } else if (!strcmp(key, "graph_batches")) {
         ctx->graph_batches = value != 0;
     } else if (!strcmp(key, "force_generic")) {

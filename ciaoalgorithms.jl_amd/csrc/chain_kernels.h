@@ -939,6 +939,45 @@ __device__ __forceinline__ void drain_vmcnt_visible()
     asm volatile("" ::: "memory");
 }
 
+// The reads of the cross-wave exchange in two halves (issue, wait), so that work can be placed between them: N 16-byte reads of
+// the partials from LDS byte address `addr`, then an lgkmcnt(0) that also (re)defines the registers -- no use of them can move
+// above the wait.
+template <typename V>
+__device__ __forceinline__ void xchg_issue(uint32_t addr, V (&rv)[1])
+{
+    asm volatile("ds_read_b128 %0, %1" : "=&v"(rv[0]) : "v"(addr) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void xchg_issue(uint32_t addr, V (&rv)[2])
+{
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(rv[0]), "=&v"(rv[1]) : "v"(addr) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void xchg_issue(uint32_t addr, V (&rv)[4])
+{
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+                 : "=&v"(rv[0]), "=&v"(rv[1]), "=&v"(rv[2]), "=&v"(rv[3]) : "v"(addr) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void xchg_issue(uint32_t addr, V (&rv)[8])
+{
+    xchg_issue(addr, reinterpret_cast<V (&)[4]>(rv[0]));
+    xchg_issue(addr + 64, reinterpret_cast<V (&)[4]>(rv[4]));
+}
+// fp64, one value per wave in 16-byte slots {value, unused}: the four values by two ds_read2_b64 (8-byte units 0,2 and 4,6)
+template <typename V>
+__device__ __forceinline__ void xchg_issue_single64(uint32_t addr, V (&rv)[2])
+{
+    asm volatile("ds_read2_b64 %0, %2 offset1:2\n\tds_read2_b64 %1, %2 offset0:4 offset1:6" : "=&v"(rv[0]), "=&v"(rv[1]) : "v"(addr) : "memory");
+}
+template <typename V, int N>
+__device__ __forceinline__ void xchg_wait(V (&rv)[N])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(rv[i]));
+}
+
 template <int J, bool TABLE>   // J = row bytes / 4096
 struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at 0.4-0.9 us per step, within 128 KiB of LDS for the rings:
                     // with a table ring beside the row ring 64 KiB each, without one the row ring takes it all
@@ -1267,16 +1306,48 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                         q2[j] = p[j] - gav[j];
                     }
                 }
-                if constexpr (NW > 1 && !(CIAO_CHAIN_DBG & 2)) {
+                if constexpr (NW == 4 && !(CIAO_CHAIN_DBG & 2)) {
+                    // The exchange with its reads in two halves, and in between -- while the partials travel from LDS, about
+                    // ninety cycles in which this wave has nothing else to do -- everything of the step that does not need
+                    // the dot product: the DMA of the row DEPTH steps ahead (its slot's row is in registers since the last
+                    // step) and SVRG's `z += w` (SVRG_basic.jl:81) for the iterate of the PREVIOUS step.  tools/micro/xchg_lab.hip:
+                    // two dozen independent instructions cost 140 cycles after the exchange, 46 in its shadows.
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue
+                    const uint32_t raddr = (uint32_t)(uintptr_t)&red[par][0][0];
+                    constexpr bool SINGLE64 = (sizeof(T) == 8 && !TWO);
+                    V rv[SINGLE64 ? 2 : (int)(NW * 2 * sizeof(T) / 16)];
+                    if constexpr (SINGLE64) xchg_issue_single64(raddr, rv); else xchg_issue(raddr, rv);
+                    if (!(CIAO_CHAIN_DBG & 1)) refill(u, row_n, ptr_n);
+                    if (SVRG_ANY) {
+                        if (u > 0 || s0 > 0 || base > 0) {   // compile-time true except in the first step of a ring revolution
+#pragma unroll
+                            for (int j = 0; j < J; ++j) {
+                                zs[j] += p[j];
+                                asm volatile("" : "+v"(zs[j]));
+                            }
+                        }
+                    }
+                    xchg_wait(rv);
+                    // element k of the parity's slots [wave][2]: SINGLE64 holds {w0, w1}, {w2, w3}; otherwise the slots as they lie
+                    auto val = [&](int w, int c) -> T {
+                        if constexpr (SINGLE64) return rv[w / 2][w % 2];
+                        const int k = w * 2 + c;
+                        return rv[k / VEC][k % VEC];
+                    };
+                    {
+                        T lo = val(0, 0) + val(1, 0), hi = val(2, 0) + val(3, 0);
+                        // fp64: pin the two pair sums right behind the LDS read (two-dot SVRG step 0.351 -> 0.327 us; fp32 is better
+                        // left to the compiler, 0.262 vs 0.268 with the pin)
+                        if constexpr (sizeof(T) == 8) asm volatile("" : "+v"(lo), "+v"(hi));
+                        d1 = lo + hi;
+                    }
+                    if (TWO) d2 = (val(0, 1) + val(1, 1)) + (val(2, 1) + val(3, 1));
+                } else if constexpr (NW > 1 && !(CIAO_CHAIN_DBG & 2)) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                CIAO_STAMP(3);   // T4: closes [T3, T4] = partial written, LDS idle
                 __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue
-                CIAO_STAMP(4);   // T0: closes [T4, T0] = waiting for the other waves
                 {
                     T lo = red[par][0][0] + red[par][1][0], hi = red[par][2][0] + red[par][3][0];
-                    // fp64: pin the two pair sums right behind the LDS read -- hipcc otherwise slides the hoisted, independent
-                    // multiplies in front of them and the dependent chain starts late (two-dot SVRG step 0.351 -> 0.327 us; the
-                    // one-dot step does not change).  fp32 is better left to the compiler (0.262 vs 0.268 with the pin).
                     if constexpr (sizeof(T) == 8) asm volatile("" : "+v"(lo), "+v"(hi));
                     d1 = lo + hi;
                 }
@@ -1285,11 +1356,6 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                     d1 += (red[par][4][0] + red[par][5][0]) + (red[par][6][0] + red[par][7][0]);
                     if (TWO) d2 += (red[par][4][1] + red[par][5][1]) + (red[par][6][1] + red[par][7][1]);
                 }
-#if (CIAO_CHAIN_DBG & 8)
-                asm volatile("" : "+v"(d1));   // the sum is formed HERE, before the stamp
-                ++stamp_steps;
-#endif
-                CIAO_STAMP(0);   // T1: closes [T0, T1] = read the four partials and add them
                 }
                 par ^= 1;
 
@@ -1309,7 +1375,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                             for (int v = 0; v < VEC; ++v) {
                                 const T t = fmad(q1[j][v], dc, q2[j][v]);
                                 p[j][v] = HB ? prox_bf(t, gl, plo[j][v], phi[j][v]) : prox_l1(t, gl);
-                                zs[j][v] += p[j][v];
+                                if (!(NW == 4 && !(CIAO_CHAIN_DBG & 2))) zs[j][v] += p[j][v];   // four waves: in the next step's exchange shadow
                             }
                     } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
                         V *sp = reinterpret_cast<V *>(table_row<SHARDED>(a, row));
@@ -1370,7 +1436,9 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 }
 
                 if (++inb == a.batch) inb = 0;
-                if (!(CIAO_CHAIN_DBG & 1)) refill(u, row_n, ptr_n);   // after this step's table stores (program order); the look-ahead entry always exists
+                // one or eight waves: the refill at the end of the step (four waves: in the exchange's shadow, above -- a table row
+                // it fetches that this step is about to rewrite is flagged stale either way: the flag compares DEPTH steps back)
+                if (!(NW == 4 && !(CIAO_CHAIN_DBG & 2)) && !(CIAO_CHAIN_DBG & 1)) refill(u, row_n, ptr_n);
 #if (CIAO_CHAIN_DBG & 8)
 #pragma unroll
                 for (int j = 0; j < J; ++j) asm volatile("" : "+v"(p[j]));   // the update is done HERE
@@ -1404,6 +1472,10 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
         }
     }
     wait_vmcnt<0>();   // nothing may still be writing LDS when the workgroup retires
+    if (SVRG_ANY && NW == 4 && !(CIAO_CHAIN_DBG & 2) && a.nsteps > 0) {   // the last step's `z += w`
+#pragma unroll
+        for (int j = 0; j < J; ++j) zs[j] += p[j];
+    }
 #if (CIAO_CHAIN_DBG & 8)
     if (a.dbg && lane == 0) {
         for (int k = 0; k < 5; ++k) a.dbg[wib * 6 + k] = (long long)stamp_sum[k];

@@ -65,6 +65,9 @@ struct ciao_ctx {
     int64_t chain_one_wave = 0;     // experiment: 4 KiB rows on a single-wave chain (no cross-wave exchange)
     int64_t chain_big = 0;          // testing: route chains through chain_big_kernel (the any-d kernel) whatever d
     int64_t chain_no_dma = 0;       // testing: route chains through the register-ring kernel instead of the LDS-DMA one
+    int64_t chain_no_ws = 0;        // testing: SVRG / SAGA chains on chain_dma_kernel instead of the wave-specialised chain_ws_kernel
+    int64_t chain_ws_issuers = 0;   // tuning: issuer waves of chain_ws_kernel, 1 or 2 (0 = automatic)
+    int chain_last_ws = 0;          // issuer waves of the wave-specialised chain the last launch took, 0 = another kernel
     int chain_last_one_wave = 0;    // E of the single-wave register-ring chain the last launch took, 0 = four waves
     int chain_last_dma = 0;
     bool chain_last_masked = false;

@@ -23,6 +23,11 @@ int32_t launch_chain(ciao_ctx *ctx, int alg, ChainArgs<T> &a);
 template <typename T, int ALG, int LOSS>
 int32_t launch_dma(ciao_ctx *ctx, int J256, bool masked, ChainArgs<T> &a);
 
+// the wave-specialised chain (chain_ws_kernels.h: consumer / stager / issuer waves, barrier-free exchange) for SVRG, SVRG with
+// cached row dots and SAGA / SAG on 4 / 8 / 16 KiB rows.  Defined in chain_ws_launch.inc, instantiated in chain_ws{0,1,3}_f32/f64.hip.
+template <typename T, int ALG, int LOSS>
+int32_t launch_ws(ciao_ctx *ctx, int J256, bool masked, ChainArgs<T> &a);
+
 // ProShI agent rows (init or one batch) + finalize + epilogue.  Specialised in rows_f32.hip / rows_f64.hip.
 template <typename T>
 int32_t launch_proshi(ciao_ctx *ctx, bool init, ProshiArgs<T> &a, const Epilogue<T> &ep);

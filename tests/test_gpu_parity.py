@@ -589,7 +589,7 @@ def test_chain_over_a_shard_table_is_bitwise_the_unsharded_chain(ctx, ciao, dtyp
             ctx.synchronize()
         finally:
             ctx.set_shards(None)
-        assert "chain_dma_kernel" in k1 and "chain_dma_kernel" in k2
+        assert "chain_dma_kernel" in k1 and ("chain_ws_kernel" in k2 or "chain_dma_kernel" in k2)
         outs.append([t.cpu().numpy() for t in (w, z, sz, sav, table)])
     for u, v in zip(*outs):
         assert np.array_equal(u, v)
@@ -688,6 +688,62 @@ def test_short_rows_run_the_chains_on_one_wave(ctx, ciao, dtype, d):
 # ----------------------------------------------------------------------------------------------------------------------
 # SAGA / SAG
 # ----------------------------------------------------------------------------------------------------------------------
+# rows of 2-8 KiB (fp64: 4-8 KiB) take chain_ws_kernel, the wave-specialised chain (consumer / stager / issuer waves, barrier-free
+# exchange); option chain_no_ws=1 keeps them on chain_dma_kernel.  Same arithmetic, operation for operation.
+WS_CASES = [(np.float64, 1024), (np.float64, 1000), (np.float64, 600), (np.float64, 520), (np.float32, 1024), (np.float32, 2048),
+            (np.float32, 1500), (np.float32, 1000), (np.float32, 516), (np.float32, 700)]
+
+
+@pytest.mark.parametrize("dtype,d", WS_CASES)
+@pytest.mark.parametrize("sag", [False, True])
+@pytest.mark.parametrize("loss,gk", [("logistic", "l1"), ("ls", "box"), ("ls", "zero"), ("logistic", "boxvec")])
+def test_wave_specialised_saga_is_bitwise_the_dma_chain(ctx, ciao, dtype, d, sag, loss, gk):
+    """chain_ws_kernel against chain_dma_kernel (BITWISE: state, aggregate and every table row) and against the oracle, on
+    (a) N = 9: nearly every step finds its table row among the last R+K+3 samples -- the stale re-read path, the deferred
+    store flushed early; (b) N = 700 with runs of repeated samples; (c) chains of 1 ... 40 steps (shorter than a ring
+    revolution, than the stager's block, ending mid-revolution) continued from one another; both issuer counts."""
+    import torch
+    from oracle import oracle as O
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    for N, m in ((9, 400), (700, 1300)):
+        A, b, x0 = P.synthetic(loss, N, d, dtype, seed=d + N)
+        op, dp = make(loss, A, b, 1.0 if loss == "logistic" else float(N), dtype)
+        og, dg = make_g(gk, dtype, d, lam=0.01)
+        L2 = np.max(np.sum(A.astype(np.float64) ** 2, axis=1)) * (0.25 if loss == "logistic" else N)
+        gamma = 1.0 / ((16 if sag else 3) * L2)
+        idx = ciao.IndexStream(d).rand_indices(N, m)
+        idx[20:24] = idx[20]
+        idx[100:103] = idx[99]
+        cuts = [0, 1, 2, 5, 6, 46, 47, 80, 81, 82, 83, 200, m]      # chains of 1, 1, 3, 1, 40, 1, 33, 1, 1, 1, 117, ... steps
+        rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
+        O.saga_steps(op, og, dtype(gamma), sag, idx, rt, rav, rz)
+        outs = {}
+        for name, opts in (("dma", {"chain_no_ws": 1}), ("ws2", {"chain_ws_issuers": 2}), ("ws1", {"chain_ws_issuers": 1})):
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            try:
+                table = torch.empty((N, d), dtype=tdt, device="cuda")
+                av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+                ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
+                for lo, hi in zip(cuts[:-1], cuts[1:]):
+                    ctx.saga_steps(dp, dg, gamma, sag, idx[lo:hi], table, av, z)
+                kern = ctx.last_kernel()
+                ctx.synchronize()
+            finally:
+                ctx.set_option("chain_no_ws", 0)
+                ctx.set_option("chain_ws_issuers", 0)
+            assert ("chain_ws_kernel" in kern) == (name != "dma"), kern
+            if name != "dma":
+                assert f"issuers{name[-1]}" in kern, kern
+            outs[name] = [t.cpu().numpy() for t in (z, av, table)]
+        for name in ("ws2", "ws1"):
+            for u, v, what in zip(outs["dma"], outs[name], ("z", "av", "table")):
+                assert np.array_equal(u, v), f"{name} differs from the DMA chain in {what} (N={N}, d={d})"
+        close(outs["ws2"][0], rz, dtype, scale=5000, what=f"ws saga z N={N}")
+        if loss == "logistic":   # (an interpolating least-squares problem drives its gradients -- the table -- to rounding level)
+            close(outs["ws2"][2], rt, dtype, scale=5000, what=f"ws saga table N={N}")
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("sag", [False, True])
 @pytest.mark.parametrize("shape", CHAIN_SHAPES)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Times the SVRG inner chain (d = 1024 f64 and f32) on cuda:0; prints us per update."""
+"""Where a step of chain_ws_kernel spends its cycles: a CIAO_WS_DBG=1 experiment build (tools/exp_build.sh) sums, per consumer
+wave, the cycles from arrival to a successful poll (exchange) and from there to the next arrival (compute), and counts poll
+retries / landed spins; per issuer wave, how often it ran into the consumers and what issuing a step's DMA costs."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,9 +16,8 @@ ctx = Context(0)
 for kv in os.environ.get("CIAO_OPTS", "").split(","):
     if "=" in kv:
         ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-out = []
 for dt in (torch.float64, torch.float32):
-    N, d, m = 200_000, int(os.environ.get("CIAO_D", "1024")), 400_000
+    N, d, m = 200_000, int(os.environ.get("CIAO_D", "1024")), 100_000
     A = torch.empty((N, d), dtype=dt, device="cuda"); b = torch.empty((N,), dtype=dt, device="cuda")
     ctx.synth_normal(A, 0, 1, 1 / np.sqrt(d))
     F = PackedF(L.LOSS_LS, A, b, float(N))
@@ -26,14 +27,17 @@ for dt in (torch.float64, torch.float32):
     av, z, zf, w = (torch.empty_like(x0) for _ in range(4))
     ctx.svrg_init(F, x0, av, z, zf, w)
     idx = ctx._idx(IndexStream(0).rand_indices(N, m))
+    dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
+    ctx.set_option("chain_dbg_ptr", dbg.data_ptr())
     ctx.svrg_inner(F, g, 1e-7, idx[:2000], av, z, zf, w); ctx.synchronize()
+    dbg.zero_()
     t0 = time.perf_counter(); ctx.svrg_inner(F, g, 1e-7, idx, av, z, zf, w); ctx.synchronize()
-    t2 = (time.perf_counter() - t0) / m * 1e6
-    # the same with the row dots of the last full pass reused (one dot product per step): a whole outer iteration, so the
-    # sweep over the N rows is in the time (N / m of a sweep per update: about 1 ns here)
-    ctx.svrg_init(F, x0, av, z, zf, w)
-    ctx.svrg_iterate(F, g, 1e-7, idx[:2000], False, av, z, zf, w, reuse_rowdots=True); ctx.synchronize()
-    t0 = time.perf_counter(); ctx.svrg_iterate(F, g, 1e-7, idx, False, av, z, zf, w, reuse_rowdots=True); ctx.synchronize()
-    t1 = (time.perf_counter() - t0) / m * 1e6
-    out.append(f"{'f64' if dt == torch.float64 else 'f32'} two dots {t2:.3f} one dot {t1:.3f} us/update")
-print(" | ".join(out))
+    us = (time.perf_counter() - t0) / m * 1e6
+    v = dbg.cpu().numpy().reshape(8, 8)
+    print(f"{'f64' if dt == torch.float64 else 'f32'} d={d}: {us:.3f} us/update with stamps; {ctx.last_kernel()}")
+    st = np.maximum(v[:4, 4], 1)
+    print(f"   consumers: exchange cycles/step {np.round(v[:4, 0] / st, 1).tolist()}  compute {np.round(v[:4, 1] / st, 1).tolist()}  "
+          f"poll retries/step {np.round(v[:4, 2] / st, 3).tolist()}  landed spins {v[:4, 3].tolist()}")
+    for q in range(2):
+        r = v[5 + q]
+        print(f"   issuer {q}: blocked {r[0]} times ({r[1]} spins), lifetime {r[2]} cycles = {r[2] / m:.1f}/step, issue {r[3] / m:.1f} cycles/step")
