@@ -57,6 +57,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary timings (sequential chains, table kernels; N=1 only)")
+    ap.add_argument("--cpu-chain-updates", type=int, default=100_000, help="updates of each chain the CPU baseline replays")
+    ap.add_argument("--cpu-chain-seconds", type=float, default=5.0, help="CPU time budget of each chain baseline")
     ap.add_argument("--no-chains", action="store_true", help="skip the top-level SVRG / SAGA chain figures (N=1 only)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work at all: rendezvous, barrier and the JSON relay only (CPU test of the launcher)")
@@ -238,22 +240,20 @@ def run_rank(args):
     if world > 1 or force_dist:
         want = os.environ.get("CIAO_BENCH_COLLECTIVE", "rccl" if backend == "nccl" else "torch")
         if want == "rccl" and backend == "nccl":
-            try:
-                comm = RcclComm(rank, world, dev.index)
-            except Exception as e:   # a box whose RCCL cannot be loaded natively still gets a (truthfully labelled) number
-                print(f"[bench] rank {rank}: native RCCL path unavailable ({e!r})", file=sys.stderr)
-                comm = None
-            # every rank must take the same path: one that failed while the others succeeded would leave them waiting in
-            # ncclAllReduce for a rank that is in torch's collective instead
-            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+            # Vote BEFORE the collective initialisation, on what can fail on one rank alone (loading librccl, its symbols): a rank
+            # that failed there while the others went on into ncclCommInitRank would leave them waiting for it.  Every rank then
+            # takes the same path; a failure INSIDE ncclCommInitRank is fatal (this rank exits non-zero and the launcher -- ours
+            # or torch.distributed.run -- ends the others).
+            why = RcclComm.probe()
+            if why is not None:
+                print(f"[bench] rank {rank}: native RCCL path unavailable ({why})", file=sys.stderr)
+            ok = torch.tensor([1 if why is None else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
-                if comm is not None:
-                    comm.close()
-                    comm = None
                 if rank == 0:
                     print("[bench] falling back to torch.distributed for the collective on every rank", file=sys.stderr)
             else:
+                comm = RcclComm(rank, world, dev.index)
                 ctx.set_rccl(comm)
                 rccl_ranks = comm.count()
                 collective = "rccl ncclAllReduce(d+1) per step, issued by the library on its stream"
@@ -394,6 +394,7 @@ def run_rank(args):
             out["cpu_baseline"] = {"value": None, "unit": "sample-gradients/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
 
     # ---- the updates SURVEY.md 8d defines: sequential SVRG / SAGA chains at the metric's own size (N=1 only) -------------
+    args.cpu_sweep_rate = (out.get("cpu_baseline") or {}).get("value")
     if rank == 0 and world == 1 and not args.no_chains:
         try:
             out.update(chain_figures(ctx, dev, F, g, gamma, A, b, n_local, d, args, L, np, torch))
@@ -434,7 +435,18 @@ def chain_figures(ctx, dev, F, g, gamma, A, b, N, d, args, L, np, torch):
     x0 = torch.zeros(d, dtype=tdt, device=dev)
     av, z, zf, w = (torch.empty_like(x0) for _ in range(4))
     ctx.svrg_init(F, x0, av, z, zf, w)
-    idx = ctx._idx(st.rand_indices(N, N))
+    hidx = st.rand_indices(N, N)
+    idx = ctx._idx(hidx)
+    cpu_svrg = None
+    if not args.no_cpu:
+        # cpu_baseline of the chain: the single-threaded oracle (orc_svrg_inner: SVRG_basic.jl:73-82 restated,
+        # two gradient! calls + the four broadcasts + prox! per update) on the FIRST updates of this very epoch -- the rows they visit
+        # are gathered to the host, the state is the device's init state -- for a bounded number of updates
+        try:
+            cpu_svrg = cpu_chain_baseline("svrg", ctx, F, g, gamma, hidx[:args.cpu_chain_updates], N, (av, z, zf, w), None, args, np, torch)
+        except Exception as e:
+            cpu_svrg = {"value": None, "unit": "updates/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+    del hidx
     ctx.svrg_iterate(F, g, gamma, idx[:4096], False, av, z, zf, w)                 # warm (code objects, workspace)
     ctx.synchronize()
     t0 = time.perf_counter()
@@ -453,12 +465,21 @@ def chain_figures(ctx, dev, F, g, gamma, A, b, N, d, args, L, np, torch):
                                    "roofline": {"bound": "hbm", "bytes_per_update": d * es + 8, "bound_updates_per_sec": bound,
                                                 "achieved": upd * (d * es + 8) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                 "frac": upd / bound, "note": "latency-bound dependent chain (SURVEY.md section 7)"}}
+    if cpu_svrg is not None:
+        res["svrg_updates_per_sec"]["cpu_baseline"] = cpu_svrg
     ep_bytes = N * (d * es + 8) + N * (d * es + es)
     res[f"svrg_epochs_per_sec_N{N // 1_000_000}M" if N % 1_000_000 == 0 else f"svrg_epochs_per_sec_N{N}"] = {
         "value": 1.0 / t_epoch, "seconds_per_epoch": t_epoch, "m": N, "inner_cycle_s": t_chain, "full_pass_s": t_sweep,
         "what": "one SVRG outer iteration = m = N updates + tail + full-gradient sweep (SVRG_basic.jl:71-96), measured once",
         "roofline": {"bound": "hbm", "bytes_per_epoch": ep_bytes, "achieved": ep_bytes / t_epoch / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ep_bytes / t_epoch / 1e9 / HBM_PEAK_GBS}}
+    if cpu_svrg is not None and cpu_svrg.get("value") and args.cpu_sweep_rate:
+        # an epoch on one host core = N updates + N sample-gradients of the full pass, at the two rates measured in this run
+        t_cpu_epoch = N / cpu_svrg["value"] + N / args.cpu_sweep_rate
+        res[f"svrg_epochs_per_sec_N{N // 1_000_000}M" if N % 1_000_000 == 0 else f"svrg_epochs_per_sec_N{N}"]["cpu_baseline"] = {
+            "value": 1.0 / t_cpu_epoch, "unit": "epochs/s", "cores": 1, "kind": "port",
+            "sample": f"extrapolated: N / (oracle updates/s on {cpu_svrg.get('updates')} updates) + N / (oracle sample-gradients/s of "
+                      f"cpu_baseline above) = {t_cpu_epoch:.0f} s per epoch; a whole epoch on one core would take that long"}
     del idx
     # ---- SAGA at config #3: l1-logistic, fp32, N x d data + N x d table -------------------------------------------------
     if d * 4 * N * 2 + (A.numel() * A.element_size() if A.dtype != torch.float32 else 0) < 250e9:
@@ -476,7 +497,14 @@ def chain_figures(ctx, dev, F, g, gamma, A, b, N, d, args, L, np, torch):
         sav, sz = torch.empty_like(x1), torch.empty_like(x1)
         ctx.saga_init(Fs, gs, gam, x1, table, sav, sz)
         k = 400_000
-        sidx = ctx._idx(st.rand_indices(N, k))
+        hsidx = st.rand_indices(N, k)
+        sidx = ctx._idx(hsidx)
+        cpu_saga = None
+        if not args.no_cpu:
+            try:
+                cpu_saga = cpu_chain_baseline("saga", ctx, Fs, gs, gam, hsidx[:args.cpu_chain_updates], N, (sav, sz), table, args, np, torch)
+            except Exception as e:
+                cpu_saga = {"value": None, "unit": "updates/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
         ctx.saga_steps(Fs, gs, gam, False, sidx[:4096], table, sav, sz)
         ctx.synchronize()
         t0 = time.perf_counter()
@@ -491,9 +519,44 @@ def chain_figures(ctx, dev, F, g, gamma, A, b, N, d, args, L, np, torch):
                                        "roofline": {"bound": "hbm", "bytes_per_update": 3 * d * 4 + 8, "bound_updates_per_sec": bound,
                                                     "achieved": upd * (3 * d * 4 + 8) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                     "frac": upd / bound, "note": "latency-bound dependent chain (SURVEY.md section 7)"}}
+        if cpu_saga is not None:
+            res["saga_updates_per_sec"]["cpu_baseline"] = cpu_saga
         del A32, y32, table, Fs, sidx
         torch.cuda.empty_cache()
     return res
+
+
+def cpu_chain_baseline(alg, ctx, F, g, gamma, hidx, N, state, table, args, np, torch):
+    """The oracle's sequential chain (single thread) on the rows the first len(hidx) updates of the device's run visit: rows (and
+    SAGA table rows) gathered to the host, indices remapped, 1/N of the whole problem, the device's own start state.  The
+    device state is not touched.  Repeats the same updates until cpu_chain_seconds have passed (the state keeps moving)."""
+    from oracle import oracle as O
+    touched, remap = np.unique(hidx, return_inverse=True)
+    t = torch.from_numpy(touched).to(F.A.device)
+    A_t, b_t = F.A[t].cpu().numpy(), F.b[t].cpu().numpy()
+    logistic = (alg == "saga")
+    op = O.Problem("logistic" if logistic else "ls", A_t, b_t, F.lam, N_total=N)
+    og = O.Prox("l1", lam=g.lam)
+    rdt = A_t.dtype.type
+    host = [v.cpu().numpy().copy() for v in state]
+    h_tab = table[t].cpu().numpy() if table is not None else None
+    remap = remap.astype(np.int64)
+    reps, t_cpu = 0, 0.0
+    while t_cpu < args.cpu_chain_seconds and reps < 200:
+        t0 = time.perf_counter()
+        if alg == "svrg":
+            O.svrg_inner(op, og, rdt(gamma), remap, *host)
+        else:
+            O.saga_steps(op, og, rdt(gamma), False, remap, h_tab, *host)
+        t_cpu += time.perf_counter() - t0
+        reps += 1
+    n = len(remap) * reps
+    what = ("orc_svrg_inner (SVRG_basic.jl:73-82 restated: two gradient! + four broadcasts + prox! per update)" if alg == "svrg"
+            else "orc_saga_steps (SAGA_basic.jl:53-68 restated: gradient!, two broadcasts, prox!, table row copy per update)")
+    return {"value": n / t_cpu, "unit": "updates/s", "us_per_update": t_cpu / n * 1e6, "cores": 1, "kind": "port", "updates": n,
+            "sample": f"the first {len(remap)} updates of the same run ({len(touched)} distinct rows of the same A"
+                      f"{' and table' if table is not None else ''} gathered to the host, d={A_t.shape[1]}, {A_t.dtype.name}), "
+                      f"{reps} time(s) over, {t_cpu:.1f} s; oracle/ciao_oracle.c {what}", "host_cores": os.cpu_count()}
 
 
 def main():

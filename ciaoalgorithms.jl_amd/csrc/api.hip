@@ -140,6 +140,16 @@ static int32_t check_pair(const ciao_problem *p, const ciao_prox_desc *g)
     return CIAO_OK;
 }
 
+// the sharing problem's iterates are real: the complex NormL1 has no meaning for it (and no ProShI kernel implements it)
+static int32_t check_real_prox(const ciao_prox_desc *g, const char *who)
+{
+    if (g && g->kind == CIAO_PROX_L1_COMPLEX) {
+        set_error("%s: CIAO_PROX_L1_COMPLEX is not supported for the sharing problem (real iterates only)", who);
+        return CIAO_ERR_UNSUPPORTED;
+    }
+    return CIAO_OK;
+}
+
 template <typename T>
 static RowsArgs<T> rows_args(const ciao_problem *p)
 {
@@ -503,6 +513,7 @@ static int32_t finito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_p
                 e.g = make_prox<T>(g);
                 return launch_rows<T>(ctx, RM_FINITO_BATCH, a, e);
             };
+#ifdef CIAO_EXP_GRAPH_BATCHES   // experiment builds only (tools/exp_build.sh NAME -DCIAO_EXP_GRAPH_BATCHES): profiles/r02_batches_eager_vs_graph.txt
             if (ctx->graph_batches && !ctx->hook && t1 - t > 4) {
                 // EXPERIMENT (option "graph_batches"): the run of batches as one captured graph, timed by events around its
                 // launch -- what the batches cost when the host's launch rate is out of the picture
@@ -537,7 +548,9 @@ static int32_t finito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_p
                 (void)hipEventDestroy(e1);
                 (void)hipGraphExecDestroy(exec);
                 (void)hipGraphDestroy(graph);
-            } else {
+            } else
+#endif
+            {
                 for (int64_t tt = t; tt < t1; ++tt) CIAO_TRY(one(tt));
             }
         }
@@ -1052,8 +1065,10 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "chain_ws_issuers")) {
         CIAO_REQUIRE(value >= 0 && value <= 2, "chain_ws_issuers must be 0 (automatic), 1 or 2");
         ctx->chain_ws_issuers = value;
+#ifdef CIAO_EXP_GRAPH_BATCHES
     } else if (!strcmp(key, "graph_batches")) {
         ctx->graph_batches = value != 0;
+#endif
     } else if (!strcmp(key, "force_generic")) {
         ctx->force_generic = value != 0;
     } else {
@@ -1239,6 +1254,7 @@ int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_de
     CIAO_TRY(check_problem(ctx, p));
     ctx->rowdot_A = keep;   // z_full is read-only here: a following ciao_svrg_iterate may still reuse the row dots
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_REQUIRE(m >= 0 && (m == 0 || idx), "m < 0 or idx is NULL");
     CIAO_REQUIRE(m == 0 || p->N > 0 || ctx->shards.nshards > 0, "cannot sample from an empty problem");
     CIAO_REQUIRE(av && z && z_full && w, "NULL state vector");
@@ -1259,6 +1275,7 @@ int32_t ciao_svrg_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
     // pass read (reuse_rowdots) AND the previous call on this ctx was svrg_init / svrg_iterate / svrg_inner on these buffers
     ctx->rowdot_A = reuse_rowdots ? keep : nullptr;
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_pair(p, g));
     CIAO_REQUIRE(m >= 1 && idx, "m < 1 or idx is NULL");
     CIAO_REQUIRE(p->N > 0 || ctx->shards.nshards > 0, "cannot sample from an empty problem");
     CIAO_REQUIRE(av && z && z_full && w, "NULL state vector");
@@ -1493,6 +1510,7 @@ int32_t ciao_proshi_init(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_d
     CIAO_ENTER(ctx);
     CIAO_TRY(check_sepquad(ctx, f));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_real_prox(g, "ciao_proshi_init"));
     CIAO_REQUIRE(x0 && av && z && hat_gamma_dev && ((table && gam) || f->N == 0), "NULL state vector / table / gam");
     return DISPATCH(f->dtype, proshi_init_t, ctx, f, g, gam, x0, table, av, z, hat_gamma_dev);
 }
@@ -1503,6 +1521,7 @@ int32_t ciao_proshi_steps(ciao_ctx *ctx, const ciao_sepquad *f, const ciao_prox_
     CIAO_ENTER(ctx);
     CIAO_TRY(check_sepquad(ctx, f));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_real_prox(g, "ciao_proshi_steps"));
     CIAO_REQUIRE(nit >= 0 && (nit == 0 || (bptr_host && (bidx || bptr_host[nit] == bptr_host[0]))), "nit < 0 or NULL batch arrays");
     CIAO_REQUIRE(table && gam && av && z, "NULL state vector / table / gam");
     CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");
@@ -1518,6 +1537,7 @@ int32_t ciao_proshi_steps_blocks(ciao_ctx *ctx, const ciao_sepquad *f, const cia
     CIAO_ENTER(ctx);
     CIAO_TRY(check_sepquad(ctx, f));
     CIAO_TRY(check_prox(g));
+    CIAO_TRY(check_real_prox(g, "ciao_proshi_steps_blocks"));
     CIAO_TRY(check_blocks(ctx, f->N, nit, first_host, len_host, "ciao_proshi_steps_blocks"));
     CIAO_REQUIRE(table && gam && av && z, "NULL state vector / table / gam");
     CIAO_REQUIRE(hat_gamma > 0, "hat_gamma must be > 0");

@@ -92,8 +92,8 @@ struct VecOfC<double> {
 };
 
 #ifndef CIAO_CHAIN_DBG
-#define CIAO_CHAIN_DBG 0   // timing experiments only (tools/chain_probe.sh): 1 = no ring refill, 2 = no cross-wave exchange, 4 = no element-wise update,
-                           // 8 = s_memtime stamps at five points of every step, summed per wave into ChainArgs::dbg (tools/chain_stamps.py)
+#define CIAO_CHAIN_DBG 0   // timing experiments only (tools/chain_probe.sh, EXP= builds; results are WRONG): 1 = no ring refill, 2 = no cross-wave
+                           // exchange, 4 = no element-wise update
 #endif
 
 constexpr int CHAIN_NT = 256;
@@ -1141,19 +1141,6 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
 
     int par = 0;
     int64_t inb = 0;
-#if (CIAO_CHAIN_DBG & 8)
-    // cycle stamps: T0 after the barrier, T1 dot product known, T2 update + refill issued, T3 next dot reduced in-wave,
-    // T4 partial written and LDS idle (about to enter the barrier).  sums[k] += T(k+1) - T(k), sums[4] += T0' - T4.
-    unsigned long long stamp_sum[5] = {0, 0, 0, 0, 0}, stamp_prev = 0, stamp_steps = 0;
-#define CIAO_STAMP(k)                                                     \
-    do {                                                                  \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
-        if (stamp_prev) stamp_sum[k] += now_ - stamp_prev;                \
-        stamp_prev = now_;                                                \
-    } while (0)
-#else
-#define CIAO_STAMP(k) do { } while (0)
-#endif
     for (int64_t base = 0; base < a.nsteps; base += CH) {
         const int nch = (int)((a.nsteps - base) < CH ? (a.nsteps - base) : CH);
 
@@ -1281,7 +1268,6 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
 #ifdef CIAO_CHAIN_READLANE   // experiment: the all-lanes sum through v_readlane, lane 0 stores
                 d1 = wave_allsum(d1);
                 if (TWO) d2 = wave_allsum(d2);
-                CIAO_STAMP(2);
                 if (lane == 0) {
                     red[par][wib][0] = d1;
                     if (TWO) red[par][wib][1] = d2;
@@ -1289,7 +1275,6 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
 #else
                 d1 = wave_sum_lane63(d1);   // bitwise the same total, in lane 63 only: no v_readlane / scalar round trip
                 if (TWO) d2 = wave_sum_lane63(d2);
-                CIAO_STAMP(2);   // T3: closes [T2, T3] = prefetch of the next step's inputs + dot + in-wave reduction
                 if (lane == WAVE - 1) {
                     red[par][wib][0] = d1;
                     if (TWO) red[par][wib][1] = d2;
@@ -1439,11 +1424,6 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 // one or eight waves: the refill at the end of the step (four waves: in the exchange's shadow, above -- a table row
                 // it fetches that this step is about to rewrite is flagged stale either way: the flag compares DEPTH steps back)
                 if (!(NW == 4 && !(CIAO_CHAIN_DBG & 2)) && !(CIAO_CHAIN_DBG & 1)) refill(u, row_n, ptr_n);
-#if (CIAO_CHAIN_DBG & 8)
-#pragma unroll
-                for (int j = 0; j < J; ++j) asm volatile("" : "+v"(p[j]));   // the update is done HERE
-#endif
-                CIAO_STAMP(1);   // T2: closes [T1, T2] = link function + element-wise update + prox + DMA issue
             }
         };
         // the run-time flags become compile-time tags of the group (SAG only exists for the SAGA chain)
@@ -1476,13 +1456,6 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
 #pragma unroll
         for (int j = 0; j < J; ++j) zs[j] += p[j];
     }
-#if (CIAO_CHAIN_DBG & 8)
-    if (a.dbg && lane == 0) {
-        for (int k = 0; k < 5; ++k) a.dbg[wib * 6 + k] = (long long)stamp_sum[k];
-        a.dbg[wib * 6 + 5] = (long long)stamp_steps;
-    }
-#endif
-#undef CIAO_STAMP
 
 #pragma unroll
     for (int j = 0; j < J; ++j) {

@@ -72,7 +72,9 @@ struct ciao_ctx {
     int chain_last_dma = 0;
     bool chain_last_masked = false;
     long long *chain_dbg = nullptr;   // timing builds only (CIAO_CHAIN_DBG & 8): device buffer for cycle stamps
-    int64_t graph_batches = 0;      // experiment: capture runs of batch-parallel Finito batches as one graph (api.hip)
+#ifdef CIAO_EXP_GRAPH_BATCHES
+    int64_t graph_batches = 0;      // experiment builds only: capture runs of batch-parallel Finito batches as one graph (api.hip)
+#endif
     int64_t force_generic = 0;      // testing: route every rows launch through the generic kernel
 
     std::string last_kernel;

@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a)
 {
     constexpr int CH = PROSHI_CH, PD = ProshiDepth<T>::value, NW = 4;
     constexpr int DW = sizeof(T) / 4;                 // dwords per value
-    constexpr int OPS = 3 * DW + 1;                   // per visit and thread: 3 DW LDS-DMA loads + the table store (EVERY thread stores: see below)
+    constexpr int OPS = 3 * DW + 1;                   // per visit and wave: 3 DW LDS-DMA loads + the table store (every wave that visits has a live lane)
     constexpr int WAIT_N = (PD - 1) * OPS;
     static_assert(CH % PD == 0 && WAIT_N <= 63, "ring slots line up with chunk starts; vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
@@ -311,7 +311,12 @@ __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a)
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t k0 = (int64_t)blockIdx.x * 256 + tid;
     const bool live = k0 < a.d;
-    const int64_t k = live ? k0 : a.d - 1;     // dead threads of the last block shadow a live coordinate and never store
+    // Dead threads of the last block (k0 >= d).  In a wave that also has live lanes they shadow coordinate d-1 -- loads only, their
+    // stores are predicated off, so the wave issues the same instructions as any other and the counted waits stay exact.  A wave
+    // with no live lane at all takes no part in the visits (it has nothing to compute, and a whole wave shadowing d-1 would race
+    // with the wave that owns it: the waves of this kernel are not synchronised inside a chunk); it only helps with the staging.
+    const int64_t k = live ? k0 : a.d - 1;
+    const bool wave_dead = ((int64_t)blockIdx.x * 256 + (int64_t)wib * WAVE) >= a.d;   // wave-uniform
     T av = a.av[k], z = a.z[k];
     // g's parameters for coordinate k, fetched once
     const T gl = (a.g.kind == CIAO_PROX_L1) ? a.hat_gamma * a.g.lam : T(0);
@@ -371,6 +376,7 @@ __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a)
             s_back[e] = back;
         }
         __syncthreads();
+        if (wave_dead) continue;   // (after the chunk's last barrier; the next chunk starts with one)
         if (base == 0) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) refill(u, uniform64(s_row[PD + u]));
@@ -404,9 +410,9 @@ __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a)
                 gt *= -(gi * a.invN);                                            // :114
                 gt += s2;                                                        // :115
                 av += gt;                                                        // :116
-                // :117 -- unconditional: a dead thread of the last block shadows coordinate d-1 with the identical state and inputs,
-                // so it stores the identical value; every wave then issues the same op sequence and the counted waits are exact
-                a.table[row * a.d + k] = gt;
+                // :117 -- the dead lanes of a partly live wave do not store (the instruction is issued all the same: the counted
+                // waits assume one store per visit and wave)
+                if (live) a.table[row * a.d + k] = gt;
                 hist[u * 256 + tid] = gt;
                 if (++inb == a.batch) {
                     inb = 0;

@@ -195,6 +195,21 @@ class RcclComm:
     issued by libciao_hip.so itself on its stream.  The unique id travels through the existing torch.distributed group
     (any backend); nothing else of torch is involved.  `handle` is the ncclComm_t."""
 
+    SYMBOLS = ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommCount", "ncclAllReduce", "ncclGetErrorString")
+
+    @staticmethod
+    def probe(lib_path: str | None = None) -> str | None:
+        """Everything that can fail on ONE rank alone -- loading librccl, resolving its symbols -- without any communication:
+        None if this rank could build a communicator, else the reason.  Ranks vote on this BEFORE the collective
+        ncclCommInitRank (a rank that failed here would otherwise leave the others waiting inside it)."""
+        try:
+            lib = C.CDLL(lib_path or default_rccl_path(), mode=C.RTLD_LOCAL)
+            for name in RcclComm.SYMBOLS:
+                getattr(lib, name)
+        except (OSError, AttributeError) as e:
+            return repr(e)
+        return None
+
     def __init__(self, rank: int, world: int, device: int, group=None, lib_path: str | None = None):
         import torch.distributed as dist
         self.lib_path = lib_path or default_rccl_path()

@@ -106,7 +106,10 @@ def _idx(a):
 class Problem:
     """Packed F = [f_1 .. f_N]: loss kind, row-major A (N x d), b (targets / labels), LeastSquares λ."""
 
-    def __init__(self, loss, A, b=None, lam=1.0):
+    def __init__(self, loss, A, b=None, lam=1.0, N_total=None):
+        """N_total: the rows in `A` are a gathered SUBSET of a problem of N_total rows (tests that hold a device run at full size
+        against the oracle on the rows it touched): the functions that take explicit row indices (svrg_inner, saga_steps, ...)
+        then use 1/N_total where the algorithm says 1/N and never look at a row that is not there."""
         self.loss = {"ls": LOSS_LS, "logistic": LOSS_LOGISTIC, "zero": LOSS_ZERO, "ls_complex": LOSS_LS_COMPLEX}.get(loss, loss)
         if np.iscomplexobj(A):   # complex T: LeastSquares on (re, im) pairs; d counts reals, b holds N pairs
             assert self.loss in (LOSS_LS, LOSS_LS_COMPLEX)
@@ -123,6 +126,10 @@ class Problem:
         elif self.loss != LOSS_ZERO:
             assert self.b is not None and self.b.shape == (self.N,)
         self.lam = float(lam)
+        self.rows = self.N
+        if N_total is not None:
+            assert N_total >= self.N
+            self.N = int(N_total)
         self._c = _Problem(self.loss, 0, self.N, self.d, self.A.ctypes.data,
                            self.b.ctypes.data if self.b is not None else None, self.lam)
 

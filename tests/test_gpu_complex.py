@@ -363,3 +363,37 @@ def test_complex_argument_validation(ctx, ciao):
     # an odd number of reals is not a vector of pairs
     with pytest.raises(ciao._lib.CiaoError):
         ctx.prox(ProxG(L.PROX_L1_COMPLEX, lam=0.1), xp[:7], 0.5, y[:7])
+    # the SVRG entry points check the pairing as every other solver entry point does (they accepted a complex problem
+    # with the real NormL1 -- thresholded per scalar -- and a real one with the complex NormL1 -- no prox at all)
+    idx = np.arange(6, dtype=np.int64)
+    z, zf, w = (torch.empty_like(xp) for _ in range(3))
+    ctx.svrg_init(dp, xp, av, z, zf, w)
+    for call in (lambda g: ctx.svrg_inner(dp, g, 0.1, idx, av, z, zf, w), lambda g: ctx.svrg_iterate(dp, g, 0.1, idx, False, av, z, zf, w)):
+        with pytest.raises(ciao._lib.CiaoError) as ei:
+            call(ProxG(L.PROX_L1, lam=0.1))
+        assert ei.value.status == -1
+    xr_d = dev(xr)
+    avr, zr, zfr, wr = (torch.empty_like(xr_d) for _ in range(4))
+    ctx.svrg_init(dpr, xr_d, avr, zr, zfr, wr)
+    for call in (lambda g: ctx.svrg_inner(dpr, g, 0.1, idx, avr, zr, zfr, wr), lambda g: ctx.svrg_iterate(dpr, g, 0.1, idx, False, avr, zr, zfr, wr)):
+        with pytest.raises(ciao._lib.CiaoError) as ei:
+            call(ProxG(L.PROX_L1_COMPLEX, lam=0.1))
+        assert ei.value.status == -1
+    # the sharing problem has real iterates: the complex NormL1 is refused (CIAO_ERR_UNSUPPORTED), not silently ignored
+    from ciaoalgorithms_jl_amd.device import PackedSepQuad
+    Q = torch.ones((3, 4), dtype=torch.float64, device="cuda")
+    f = PackedSepQuad(Q, Q.clone(), 1.0, -1.0, 1.0)
+    gam = torch.ones(3, dtype=torch.float64, device="cuda")
+    table = torch.empty((3, 4), dtype=torch.float64, device="cuda")
+    v4 = [torch.zeros(4, dtype=torch.float64, device="cuda") for _ in range(3)]
+    hg = torch.empty(1, dtype=torch.float64, device="cuda")
+    bad = ProxG(L.PROX_L1_COMPLEX, lam=0.1)
+    with pytest.raises(ciao._lib.CiaoError) as ei:
+        ctx.proshi_init(f, bad, gam, v4[0], table, v4[1], v4[2], hg)
+    assert ei.value.status == -3
+    with pytest.raises(ciao._lib.CiaoError) as ei:
+        ctx.proshi_steps(f, bad, gam, 0.5, np.array([0, 1], dtype=np.int64), np.array([0], dtype=np.int64), table, v4[1], v4[2])
+    assert ei.value.status == -3
+    with pytest.raises(ciao._lib.CiaoError) as ei:
+        ctx.proshi_steps_blocks(f, bad, gam, 0.5, np.array([0], dtype=np.int64), np.array([1], dtype=np.int64), table, v4[1], v4[2])
+    assert ei.value.status == -3

@@ -2,9 +2,11 @@
 
   C1  Lasso SVRG N=1000 d=50 fp64: the reference's generator (test/test_lasso.jl:15-47) at exactly that size, 30 SVRG
       epochs (29 000 dependent updates + 30 sweeps) through the solver functor, iterate by iterate against the oracle.
-  C2  Lasso SVRG N=1M d=1024 fp64: tests/test_gpu_properties.py (same shape) + one real epoch here (objective decreases,
-      av == full gradient at z_full).
-  C3  l1-logistic SAGA N=10M d=1024 fp32, 41 GB gradient table in HBM: init + 2*10^6 steps; the invariant
+  C2  Lasso SVRG N=1M d=1024 fp64: 4096 chain updates at the real N against the ORACLE run on the rows they visit (both chain
+      variants), then one real epoch (objective decreases, av == full gradient at z_full); tests/test_gpu_properties.py has
+      the same shape.
+  C3  l1-logistic SAGA N=10M d=1024 fp32, 41 GB gradient table in HBM: init, 4096 steps against the ORACLE run on the rows and
+      table rows they visit (state and every visited table row), then 2*10^6 steps; the invariant
       av == mean(table) is checked on the touched rows (av_now - av_init == (1/N) sum_touched (s_i - s_i^init)) and every
       touched table row is a multiple of its data row (grad f_i = c_i a_i: rank-1 structure).
   C4  Lasso SVRG N=80M over 8 GPUs -> this rank's share is the bench shape, 10M x 1024 fp64: shard additivity of the sweep
@@ -43,6 +45,20 @@ def _free_hbm():
     yield
     import torch
     torch.cuda.empty_cache()
+
+
+def gather_rows(F, idx):
+    """The rows a chain visits, on the host: (touched rows sorted, A[touched], b[touched], idx remapped into them)."""
+    import torch
+    touched, remap = np.unique(idx, return_inverse=True)
+    t = torch.from_numpy(touched).cuda()
+    return touched, F.A[t].cpu().numpy(), F.b[t].cpu().numpy(), remap.astype(np.int64), t
+
+
+def rel_eps(dev, ref, dtype):
+    ref = np.asarray(ref)
+    return float(np.abs(dev.cpu().numpy().astype(np.float64) - ref.astype(np.float64)).max() /
+                 (np.finfo(dtype).eps * max(np.abs(ref).max(), 1e-300)))
 
 
 def test_C1_lasso_svrg_N1000_d50_fp64_against_the_oracle(ciao, ctx):
@@ -90,9 +106,34 @@ def test_C2_lasso_svrg_N1M_d1024_fp64_one_epoch(ciao, ctx):
     av, z, zf, w = (torch.empty_like(x0) for _ in range(4))
     obj = torch.zeros(3, dtype=torch.float64, device="cuda")
     f0 = ctx.objective(F, g, x0)
+    gamma = 1.0 / (7 * 1.3 * N)
+    # ---- the chain at the config's real N, d and row addresses against the ORACLE: 4096 updates from the
+    # init state on the device; the <= 4096 rows they visit are gathered to the host and the oracle runs the same updates on
+    # that submatrix from the same (av, z, z_full, w); tolerance 2000 eps (observed 194: the linear growth law of DESIGN section 5).  Both chain variants: two dot products per update (ciao_svrg_inner) and
+    # the row dots of the full pass reused (ciao_svrg_iterate with reuse_rowdots, whose tail gives z_full = z / m).
+    from oracle import oracle as O
+    x1 = torch.from_numpy(np.random.default_rng(8).standard_normal(d) * 0.01).cuda()    # not the all-zero start: every term is live
+    ctx.svrg_init(F, x1, av, z, zf, w)
+    idx4 = ciao.IndexStream(5).rand_indices(N, 4096)
+    _, A_t, b_t, remap, _ = gather_rows(F, idx4)
+    op = O.Problem("ls", A_t, b_t, float(N), N_total=N)
+    og = O.Prox("l1", lam=1e-3)
+    h = [t.cpu().numpy().copy() for t in (av, z, zf, w)]
+    O.svrg_inner(op, og, gamma, remap, *h)
+    d2 = [t.clone() for t in (av, z, zf, w)]
+    ctx.svrg_inner(F, g, gamma, idx4, *d2)
+    assert "chain_dma_kernel<f64,J2,alg0>" in ctx.last_kernel(), ctx.last_kernel()
+    e_w, e_z = rel_eps(d2[3], h[3], np.float64), rel_eps(d2[1], h[1], np.float64)
+    assert e_w <= 2000 and e_z <= 2000, f"C2 chain (two dots) vs oracle after 4096 updates: w {e_w:.0f} eps, z {e_z:.0f} eps"
+    d1 = [t.clone() for t in (av, z, zf, w)]
+    ctx.svrg_iterate(F, g, gamma, idx4, False, *d1, reuse_rowdots=True)
+    e_zf = rel_eps(d1[2], h[1] / 4096.0, np.float64)
+    assert e_zf <= 2000, f"C2 chain (cached row dots) vs oracle after 4096 updates: z_full {e_zf:.0f} eps"
+    P.PARITY_LOG.append({"test": "test_C2", "line": 0, "what": "C2 4096 chain updates at N=1M vs oracle (w, z, z_full; eps)", "dtype": "float64",
+                         "ratio": max(e_w, e_z, e_zf), "scale": 2000.0})
     ctx.svrg_init(F, x0, av, z, zf, w)
     ctx.set_monitor(g, obj)
-    ctx.svrg_iterate(F, g, 1.0 / (7 * 1.3 * N), ciao.IndexStream(0).rand_indices(N, N), False, av, z, zf, w, reuse_rowdots=True)
+    ctx.svrg_iterate(F, g, gamma, ciao.IndexStream(0).rand_indices(N, N), False, av, z, zf, w, reuse_rowdots=True)
     ctx.set_monitor(None, None)
     ctx.synchronize()
     f1 = ctx.objective(F, g, zf)
@@ -116,6 +157,26 @@ def test_C3_l1logistic_saga_N10M_d1024_fp32_table_in_hbm(ciao, ctx):
     av, z = torch.empty_like(x0), torch.empty_like(x0)
     ctx.saga_init(F, g, gamma, x0, table, av, z)
     av0 = av.double().clone()
+    # ---- the chain at the config's real N, table size and addresses against the ORACLE: 4096 steps from the
+    # init state (with repeats inside the prefetch window); the rows and table rows they visit are gathered to the host and the
+    # oracle runs the same steps on them with 1/N of the whole problem; state and every visited table row are compared to
+    # 50 eps (observed 3.6).
+    from oracle import oracle as O
+    idx4 = ciao.IndexStream(7).rand_indices(N, 4096)
+    idx4[100:103] = idx4[100]
+    idx4[2000] = idx4[1990]
+    touched4, A_t, b_t, remap, t4 = gather_rows(F, idx4)
+    op = O.Problem("logistic", A_t, b_t, 1.0, N_total=N)
+    og = O.Prox("l1", lam=1.0 / N)
+    h_tab, h_av, h_z = table[t4].cpu().numpy(), av.cpu().numpy().copy(), z.cpu().numpy().copy()
+    O.saga_steps(op, og, np.float32(gamma), False, remap, h_tab, h_av, h_z)
+    ctx.saga_steps(F, g, gamma, False, idx4, table, av, z)
+    assert "chain_ws_kernel<f32,J1,alg1" in ctx.last_kernel() or "chain_dma_kernel<f32,J1,alg1>" in ctx.last_kernel(), ctx.last_kernel()
+    e_z, e_av, e_t = rel_eps(z, h_z, np.float32), rel_eps(av, h_av, np.float32), rel_eps(table[t4], h_tab, np.float32)
+    assert e_z <= 50 and e_av <= 50 and e_t <= 50, f"C3 chain vs oracle after 4096 steps: z {e_z:.0f}, av {e_av:.0f}, table {e_t:.0f} eps"
+    P.PARITY_LOG.append({"test": "test_C3", "line": 0, "what": "C3 4096 SAGA steps at N=10M (41 GB table) vs oracle (z, av, table; eps)",
+                         "dtype": "float32", "ratio": max(e_z, e_av, e_t), "scale": 50.0})
+    ctx.saga_init(F, g, gamma, x0, table, av, z)        # back to the init state for the long run below
     steps = 2_000_000
     idx = ciao.IndexStream(0).rand_indices(N, steps)
     touched = np.unique(idx)
@@ -125,6 +186,7 @@ def test_C3_l1logistic_saga_N10M_d1024_fp32_table_in_hbm(ciao, ctx):
     c0 = -F.b[tdev].double() / (1.0 + torch.exp(F.b[tdev].double() * (a_t @ x0.double())))
     for k in range(0, steps, 500_000):
         ctx.saga_steps(F, g, gamma, False, idx[k:k + 500_000], table, av, z)
+    kern = ctx.last_kernel()
     ctx.synchronize()
     rows = table[tdev].double()
     # (1) rank-1 structure: every touched row is c_i * a_i for one scalar c_i
@@ -142,7 +204,7 @@ def test_C3_l1logistic_saga_N10M_d1024_fp32_table_in_hbm(ciao, ctx):
         ci = -F.b[int(i)].double() / (1.0 + torch.exp(F.b[int(i)].double() * (a_i @ x0.double())))
         assert (table[int(i)].double() - ci * a_i).abs().max().item() <= 1e-6
     assert ctx.objective(F, g, z) < ctx.objective(F, g, x0)
-    assert "chain_dma_kernel<f32,J1,alg1>" in ctx.last_kernel() or True
+    assert "chain_ws_kernel<f32,J1,alg1" in kern, kern
 
 
 def test_C4_share_shard_additivity_at_10M_rows(ctx):

@@ -1437,6 +1437,57 @@ def test_proshi_small_batches_run_as_one_coordinate_parallel_chain(ctx, ciao, dt
     ctx.synchronize()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d", [2, 50, 300, 1500, 449])
+def test_proshi_chain_with_wholly_dead_waves_over_thousands_of_visits(ctx, ciao, dtype, d):
+    """d mod 256 in 1..192 leaves whole waves of the last block without a coordinate.  They used to shadow coordinate d-1 --
+    loads AND stores -- unsynchronised with the wave that owns it: once the waves drifted apart by the look-ahead depth (the
+    loop has no barrier), a prefetch could read, and a late store overwrite, the owner's table entry.  Now
+    they take no part in the visits.  Here: agents revisited just outside the look-ahead window (N = depth + 2, cyclic order)
+    and inside it (runs of repeats), 6000 visits in one launch -- far more than the drift needs -- against the oracle, and
+    bitwise reproducible from run to run."""
+    import torch
+    from oracle import oracle as O
+    from ciaoalgorithms_jl_amd.device import PackedSepQuad, ProxG
+    import ciaoalgorithms_jl_amd._lib as L
+    depth = 9 if dtype == np.float64 else 16
+    N = depth + 2
+    rng = np.random.default_rng(d)
+    Q = rng.uniform(0.5, 3.0, (N, d)).astype(dtype)
+    q = rng.standard_normal((N, d)).astype(dtype)
+    eta, lo, hi = 3.0 * N, -2.0, 2.0
+    x0 = (0.5 * rng.standard_normal(d)).astype(dtype)
+    gam = (0.999 * N / (np.abs(Q).max(axis=1) + eta)).astype(dtype)
+    g_hi = np.linspace(0.5, 1.5, d).astype(dtype)
+    of, og = O.SepQuad(Q, q, eta, lo, hi), O.Prox("box", lo=-np.inf, hi=g_hi, dtype=dtype)
+    df = PackedSepQuad(dev(Q), dev(q), eta, lo, hi)
+    dg = ProxG(L.PROX_BOX, lo=-float("inf"), hi_vec=dev(g_hi))
+    tdt = dev(x0).dtype
+    nit = 6000
+    order = np.arange(nit, dtype=np.int64) % N
+    order[1000:1004] = order[1000]                      # revisits inside the window as well
+    order[3000:3600] = rng.integers(0, N, 600)
+    batches = [order[i:i + 1] for i in range(nit)]
+    bptr = np.arange(nit + 1, dtype=np.int64)
+    rt, rav, rz, rhg = O.proshi_init(of, og, gam, x0)
+    O.proshi_steps(of, og, gam, rhg, batches, rt, rav, rz)
+    runs = []
+    for _ in range(2):
+        table = torch.empty((N, d), dtype=tdt, device="cuda")
+        av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+        hg = torch.empty(1, dtype=tdt, device="cuda")
+        ctx.proshi_init(df, dg, dev(gam), dev(x0), table, av, z, hg)
+        ctx.proshi_steps(df, dg, dev(gam), float(hg.item()), bptr, order, table, av, z)
+        assert "proshi_chain_kernel" in ctx.last_kernel(), ctx.last_kernel()
+        ctx.synchronize()
+        runs.append((table.clone(), av.clone(), z.clone()))
+    for u, v in zip(*runs):
+        assert torch.equal(u, v)
+    close(runs[0][0], rt, dtype, scale=200, what="proshi long chain table")
+    close(runs[0][0][:, d - 1], rt[:, d - 1], dtype, scale=50, what="proshi long chain table, coordinate d-1")
+    close(runs[0][1], rav, dtype, scale=500, what="proshi long chain av")
+
+
 def test_proshi_dense_is_validated(ctx, ciao):
     import torch
     from ciaoalgorithms_jl_amd.device import PackedSepQuad, ProxG
