@@ -30,6 +30,69 @@ def _timed(ctx, fn, reps=1):
     return (time.perf_counter() - t0) / reps
 
 
+def lambda_path(dev, Ks=(1, 2, 4, 8, 16, 32, 64, 128, 256), N=1_000_000, d=1024, m=40_000, alg="svrg"):
+    """K independent chains over the SAME data matrix, one context (= one HIP stream) each: a regularisation path (K values of
+    lambda) of SVRG inner cycles, or of SAGA solves with a table each.  A chain is one workgroup on one CU and is latency-bound
+    (25-30 GB/s); K of them run side by side as far as the HIP runtime gives the streams hardware queues of their own
+    (GPU_MAX_HW_QUEUES, read when the runtime starts).  Returns the aggregate updates/s per K with its fraction of the HBM
+    bound (d*s+8 bytes per SVRG update, 3*d*s+8 per SAGA update)."""
+    from ciaoalgorithms_jl_amd import _lib as L
+    from ciaoalgorithms_jl_amd.device import Context, ProxG
+    from ciaoalgorithms_jl_amd.sampling import IndexStream
+    tdt = torch.float64 if alg == "svrg" else torch.float32
+    es = 8 if alg == "svrg" else 4
+    boot = Context(dev.index)
+    F = _problem(boot, dev, N, d, tdt, alg != "svrg")
+    boot.synchronize()
+    x0 = torch.zeros(d, dtype=tdt, device=dev) if alg == "svrg" else torch.ones(d, dtype=tdt, device=dev)
+    hidx = IndexStream(0).rand_indices(N, m)
+    idx = boot._idx(hidx)
+    gamma = 1.0 / (7 * 1.3 * N) if alg == "svrg" else 1.0 / (3 * 0.25 * 1.3)
+    Kmax = max(Ks)
+    chains = []
+    for k in range(Kmax):
+        c = Context(dev.index, stream=torch.cuda.Stream(device=dev))
+        g = ProxG(L.PROX_L1, lam=(1e-3 if alg == "svrg" else 1.0 / N) * (1.0 + k / Kmax))
+        if alg == "svrg":
+            st = tuple(torch.empty_like(x0) for _ in range(4))
+            boot.svrg_init(F, x0, *st)
+            tab = None
+        else:
+            st = (torch.empty_like(x0), torch.empty_like(x0))
+            tab = torch.empty((N, d), dtype=tdt, device=dev)
+            boot.saga_init(F, g, gamma, x0, tab, *st)
+        chains.append((c, g, st, tab))
+    boot.synchronize()
+
+    def launch(c, g, st, tab, ix):
+        if alg == "svrg":
+            c.svrg_inner(F, g, gamma, ix, *st)
+        else:
+            c.saga_steps(F, g, gamma, False, ix, tab, *st)
+
+    for c, g, st, tab in chains:
+        launch(c, g, st, tab, idx[:512])
+    torch.cuda.synchronize(dev)
+    bytes_per = (d * es + 8) if alg == "svrg" else (3 * d * es + 8)
+    curve = []
+    for K in Ks:
+        t0 = time.perf_counter()
+        for c, g, st, tab in chains[:K]:
+            launch(c, g, st, tab, idx)
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter() - t0
+        agg = K * m / t
+        curve.append({"K": K, "updates_per_s": agg, "us_per_update_per_chain": t / m * 1e6, "alg_GBps": agg * bytes_per / 1e9,
+                      "frac_of_hbm_bound": agg * bytes_per / 8e12})
+    kern = chains[0][0].last_kernel()
+    for c, _, _, _ in chains:
+        c.close()
+    boot.close()
+    import os
+    return {"alg": alg, "N": N, "d": d, "dtype": "f64" if es == 8 else "f32", "m_per_chain": m, "kernel": kern,
+            "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default"), "curve": curve}
+
+
 def run(ctx, dev, quick=False):
     from ciaoalgorithms_jl_amd import _lib as L
     from ciaoalgorithms_jl_amd.device import ProxG

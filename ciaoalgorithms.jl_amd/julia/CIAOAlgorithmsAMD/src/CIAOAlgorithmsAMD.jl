@@ -96,6 +96,33 @@ struct PackedF{R}
     N::Int
     d::Int
 end
+# F or g is not a family the device path packs.  The functors' `fallback = :host` catches exactly this and hands the problem
+# to the REFERENCE's own loop (kul-optec/CIAOAlgorithms.jl: any ProximalOperators object, one operator call per sample, on the
+# host) -- never silently: a warning names the route.  The reference package is an optional dependency: tell the wrapper where
+# it is with `CIAOAlgorithmsAMD.use_reference!(CIAOAlgorithms)`.  (Python twin: solvers.py `_route`, host_route.py.)
+struct UnpackableOperator <: Exception
+    msg::String
+end
+Base.showerror(io::IO, e::UnpackableOperator) = print(io, "UnpackableOperator: ", e.msg)
+const REFERENCE = Ref{Any}(nothing)
+use_reference!(m::Module) = (REFERENCE[] = m; nothing)
+function host_route(name::Symbol, ::Type{R}, cfg::NamedTuple, x0; kwargs...) where {R}
+    REFERENCE[] === nothing &&
+        throw(ArgumentError("fallback = :host needs the reference package: `using CIAOAlgorithms; CIAOAlgorithmsAMD.use_reference!(CIAOAlgorithms)`"))
+    @warn "CIAOAlgorithmsAMD: this problem runs on the HOST route (the reference's own loop, one operator call per sample, no GPU): its F / g are not a family the device path packs"
+    ref_solver = getfield(REFERENCE[], name){R}(; cfg...)      # CIAOAlgorithms.SVRG{R}(; γ, maxit, ...) etc.: the same keywords
+    return ref_solver(x0; kwargs...)
+end
+# iterator(solver, x0; ...) on the device, or `nothing` when the problem is unpackable and the caller allowed the host route
+function device_iterator(solver, x0, fallback; kwargs...)
+    try
+        return iterator(solver, x0; kwargs...)
+    catch e
+        (e isa UnpackableOperator && fallback === :host) || rethrow()
+        return nothing
+    end
+end
+
 function pack_F(::Type{R}, F, N::Int, d::Int; cplx::Bool = false) where {R}
     F isa PackedF{R} && return F
     if F === nothing || all(f -> f isa ProximalOperators.Zero, F)
@@ -104,7 +131,7 @@ function pack_F(::Type{R}, F, N::Int, d::Int; cplx::Bool = false) where {R}
         # complex x0: rows of d/2 complex entries (real rows are widened: real A times complex x is what LeastSquares computes)
         lam = F[1].lambda
         n = d ÷ 2
-        all(f -> f.lambda == lam && size(f.A) == (1, n), F) || throw(ArgumentError("unpackable LeastSquares terms"))
+        all(f -> f.lambda == lam && size(f.A) == (1, n), F) || throw(UnpackableOperator("unpackable LeastSquares terms"))
         A = Matrix{Complex{R}}(undef, n, N); b = Vector{Complex{R}}(undef, N)
         for i in 1:N
             A[:, i] .= vec(F[i].A); b[i] = F[i].b[1]
@@ -112,10 +139,10 @@ function pack_F(::Type{R}, F, N::Int, d::Int; cplx::Bool = false) where {R}
         return PackedF{R}(LOSS_LS_COMPLEX, ROCArray(reshape(collect(reinterpret(reshape, R, A)), d, N)),      # 2 x n x N -> (re, im) interleaved rows
                           ROCArray(collect(reinterpret(R, b))), Float64(lam), N, d)
     elseif cplx
-        throw(ArgumentError("with a complex x0 the device path packs LeastSquares rows and Zero only"))
+        throw(UnpackableOperator("with a complex x0 the device path packs LeastSquares rows and Zero only"))
     elseif all(f -> f isa ProximalOperators.LeastSquares, F)
         lam = F[1].lambda
-        all(f -> f.lambda == lam && size(f.A) == (1, d), F) || throw(ArgumentError("unpackable LeastSquares terms"))
+        all(f -> f.lambda == lam && size(f.A) == (1, d), F) || throw(UnpackableOperator("unpackable LeastSquares terms"))
         A = Matrix{R}(undef, d, N); b = Vector{R}(undef, N)
         for i in 1:N
             A[:, i] .= vec(F[i].A); b[i] = F[i].b[1]
@@ -124,12 +151,12 @@ function pack_F(::Type{R}, F, N::Int, d::Int; cplx::Bool = false) where {R}
     elseif all(f -> f isa ProximalOperators.Precompose && f.f isa ProximalOperators.LogisticLoss, F)
         A = Matrix{R}(undef, d, N); y = Vector{R}(undef, N)
         for i in 1:N
-            size(F[i].L) == (1, d) || throw(ArgumentError("unpackable Precompose term"))
+            size(F[i].L) == (1, d) || throw(UnpackableOperator("unpackable Precompose term"))
             A[:, i] .= vec(F[i].L); y[i] = F[i].f.y[1]
         end
         return PackedF{R}(LOSS_LOGISTIC, ROCArray(A), ROCArray(y), 1.0, N, d)
     end
-    throw(ArgumentError("F is not a family the device path can pack (LeastSquares rows, Precompose(LogisticLoss) rows, Zero)"))
+    throw(UnpackableOperator("F is not a family the device path can pack (LeastSquares rows, Precompose(LogisticLoss) rows, Zero)"))
 end
 cproblem(p::PackedF{R}) where {R} =
     CiaoProblem(p.loss, dtype_code(R), p.N, p.d, p.d, p.N, dptr(p.A), dptr(p.b), p.lam)
@@ -138,7 +165,7 @@ function pack_g(::Type{R}, g, d::Int; cplx::Bool = false) where {R}
     g isa ProximalOperators.Zero && return (CiaoProxDesc(PROX_ZERO, 0, 0.0, -Inf, Inf, C_NULL, C_NULL), nothing)
     g isa ProximalOperators.NormL1 && g.lambda isa Real &&
         return (CiaoProxDesc(cplx ? PROX_L1_COMPLEX : PROX_L1, 0, Float64(g.lambda), -Inf, Inf, C_NULL, C_NULL), nothing)
-    cplx && throw(ArgumentError("with a complex x0 g must be Zero or NormL1 (IndBox has no complex form)"))
+    cplx && throw(UnpackableOperator("with a complex x0 g must be Zero or NormL1 (IndBox has no complex form)"))
     if g isa ProximalOperators.IndBox
         lo = g.lb isa Real ? nothing : ROCArray(R.(vec(g.lb)))
         hi = g.ub isa Real ? nothing : ROCArray(R.(vec(g.ub)))
@@ -146,7 +173,7 @@ function pack_g(::Type{R}, g, d::Int; cplx::Bool = false) where {R}
         return (CiaoProxDesc(PROX_BOX, 0, 0.0, g.lb isa Real ? Float64(g.lb) : -Inf, g.ub isa Real ? Float64(g.ub) : Inf,
                              dptr(lo), dptr(hi)), keep)
     end
-    throw(ArgumentError("g is not a family the device path supports (Zero, NormL1, IndBox)"))
+    throw(UnpackableOperator("g is not a family the device path supports (Zero, NormL1, IndBox)"))
 end
 
 # ---- L1 plugin API on packed operators (the ProximalOperators.jl calling convention, device arrays) ---------------------
@@ -292,14 +319,16 @@ function iterator(solver::SVRG{R}, x0::AbstractArray{C}; F = nothing, g = Proxim
     return SVRG_basic_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex), gd, keep, x0, N, L, μ, solver.γ, m, solver.plus)
 end
 
-function (solver::SVRG{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrComplex{R}}   # SVRG.jl:46-84
+function (solver::SVRG{R})(x0::AbstractArray{C}; fallback = nothing, kwargs...) where {R,C<:RealOrComplex{R}}   # SVRG.jl:46-84
     disp(it, state) = @printf "%5d | %.3e  \n" it state.γ
     maxit = solver.maxit
     if solver.plus && solver.maxit > 25
         maxit = 25
         @warn "exponential number of inner updates...reverted to 25 maximum iterations"
     end
-    iter = iterator(solver, x0; kwargs...)
+    iter = device_iterator(solver, x0, fallback; kwargs...)
+    iter === nothing && return host_route(:SVRG, R, (γ = solver.γ, maxit = solver.maxit, verbose = solver.verbose, freq = solver.freq,
+                                                      m = solver.m, plus = solver.plus), x0; kwargs...)
     num_iters, state_final = nothing, nothing
     for (it_, state_) in enumerate(Iterators.take(iter, maxit))
         solver.verbose && mod(it_, solver.freq) == 0 && disp(it_, state_)
@@ -384,9 +413,11 @@ function iterator(solver::SAGA{R}, x0::AbstractArray{C}; F = nothing, g = Proxim
     return SAGA_basic_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex), gd, keep, x0, N, L, solver.γ, solver.SAG_flag)
 end
 
-function (solver::SAGA{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrComplex{R}}   # SAGA.jl:44-73
+function (solver::SAGA{R})(x0::AbstractArray{C}; fallback = nothing, kwargs...) where {R,C<:RealOrComplex{R}}   # SAGA.jl:44-73
     disp(it, state) = @printf "%5d | %.3e  \n" it state.γ
-    iter = iterator(solver, x0; kwargs...)
+    iter = device_iterator(solver, x0, fallback; kwargs...)
+    iter === nothing && return host_route(:SAGA, R, (γ = solver.γ, maxit = solver.maxit, verbose = solver.verbose, freq = solver.freq,
+                                                      SAG_flag = solver.SAG_flag), x0; kwargs...)
     next = iterate(iter)
     next === nothing && return solution(nothing), nothing      # MethodError, as in the reference (SAGA.jl:72)
     state, _ = next
@@ -560,9 +591,13 @@ steps!(iter::FINITO_iterable, state::FINITO_state, n::Int) =
     iter.lfinito ? (foreach(_ -> iterate(iter, state), 1:n); n) : finito_steps!(iter, state, n)
 hatγ(state::FINITO_state) = state.hat_γ
 
-function (solver::Finito{R})(x0::AbstractArray{C}; kwargs...) where {R,C<:RealOrComplex{R}}   # Finito.jl:66-133
+function (solver::Finito{R})(x0::AbstractArray{C}; fallback = nothing, kwargs...) where {R,C<:RealOrComplex{R}}   # Finito.jl:66-133
     disp(it, state) = @printf "%5d | %.3e  \n" it hatγ(state)
-    iter = iterator(solver, x0; kwargs...)
+    iter = device_iterator(solver, x0, fallback; kwargs...)
+    iter === nothing && return host_route(:Finito, R, (γ = solver.γ, sweeping = solver.sweeping, LFinito = solver.LFinito,
+                                                        adaptive = solver.adaptive, minibatch = solver.minibatch, maxit = solver.maxit,
+                                                        verbose = solver.verbose, freq = solver.freq, α = solver.α, tol = solver.tol,
+                                                        tol_b = solver.tol_b), x0; kwargs...)
     next = iterate(iter)
     next === nothing && return solution(nothing), nothing      # MethodError, as in the reference (Finito.jl:132)
     state, _ = next

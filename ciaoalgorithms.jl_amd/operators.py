@@ -9,8 +9,9 @@ families the reference's own tests use and packs them:
     f_i = Zero()                                                      SVRG.jl:58 (default F)
     g   = NormL1(λ) | Zero() | IndBox(lo, hi)                         test/test_lasso.jl:59, SVRG.jl:49, test_sharing.jl:16
 
-Anything else raises TypeError -- there is no silent host fallback.  These classes only *describe* operators (they hold
-host data and constructor arguments); no arithmetic happens here.
+Anything else raises UnpackableOperator (a TypeError) -- there is no SILENT host fallback; `fallback="host"` on a solver call
+asks for the explicit one (host_route.py).  These classes only *describe* operators (they hold host data and constructor
+arguments); no arithmetic happens here (host_ops.py has the host route's).
 """
 from __future__ import annotations
 
@@ -19,6 +20,11 @@ import torch
 
 from . import _lib as L
 from .device import PackedF, ProxG, torch_dtype
+
+
+class UnpackableOperator(TypeError):
+    """F or g is not one of the families the device path packs.  The solvers' `fallback="host"` catches exactly this (and
+    nothing else: a dtype mismatch, a wrong length ... stay errors) and runs the problem on the host route (host_route.py)."""
 
 
 class Zero:
@@ -141,9 +147,9 @@ def pack_F(F, N: int, d: int, R, device=None, complex_pairs: bool = False) -> Pa
     if all(isinstance(f, LeastSquares) for f in F):
         lam = F[0].lam
         if any(f.lam != lam for f in F):
-            raise TypeError("LeastSquares terms with different λ cannot be packed")
+            raise UnpackableOperator("LeastSquares terms with different λ cannot be packed")
         if any(f.A.shape != (1, n) for f in F):
-            raise TypeError("only one-row LeastSquares terms (A_i of size 1 x d) are packable")
+            raise UnpackableOperator("only one-row LeastSquares terms (A_i of size 1 x d) are packable")
         A = np.concatenate([f.A for f in F], axis=0)
         b = np.concatenate([f.b for f in F], axis=0)
         if complex_pairs or np.iscomplexobj(A) or np.iscomplexobj(b):
@@ -156,19 +162,39 @@ def pack_F(F, N: int, d: int, R, device=None, complex_pairs: bool = False) -> Pa
             return PackedF.least_squares_complex(_dev(Ap, dtype, device), _dev(bp, dtype, device), lam)
         return PackedF.least_squares(_dev(A, dtype, device), _dev(b, dtype, device), lam)
     if complex_pairs:
-        raise TypeError("with a complex x0 the device path packs LeastSquares rows and Zero only")
+        raise UnpackableOperator("with a complex x0 the device path packs LeastSquares rows and Zero only")
     if all(isinstance(f, Precompose) and isinstance(f.f, LogisticLoss) for f in F):
         for f in F:
             if f.L.shape != (1, d) or f.f.y.shape != (1,) or f.f.mu != 1.0 or np.any(np.asarray(f.b) != 0):
-                raise TypeError("only Precompose(LogisticLoss([y_i], 1.0), a_i' (1 x d), mu) terms are packable")
+                raise UnpackableOperator("only Precompose(LogisticLoss([y_i], 1.0), a_i' (1 x d), mu) terms are packable")
         A = np.concatenate([f.L for f in F], axis=0)
         y = np.concatenate([f.f.y for f in F], axis=0)
         return PackedF.logistic(_dev(A, dtype, device), _dev(y, dtype, device))
     kinds = sorted({type(f).__name__ for f in F})
-    raise TypeError(f"F of kinds {kinds} is not a family the device path can pack (LeastSquares rows, Precompose(LogisticLoss) "
-                    f"rows, Zero).  An opaque operator object cannot be called per sample from a GPU kernel, and this path has no "
-                    f"host fallback on purpose (a silent CPU route would make every parity and performance statement about it void): "
-                    f"give F as one of those families, or as a device matrix via PackedF / pack_rows_from_host")
+    raise UnpackableOperator(f"F of kinds {kinds} is not a family the device path can pack (LeastSquares rows, "
+                             f"Precompose(LogisticLoss) rows, Zero).  An opaque operator object cannot be called per sample from a GPU "
+                             f"kernel, and there is no SILENT host route (it would make every parity and performance statement about "
+                             f"this path void): give F as one of those families or as a device matrix (PackedF / pack_rows_from_host), "
+                             f"or ask for the slow host route explicitly with fallback=\"host\"")
+
+
+def require_packable(F, g, complex_x0: bool = False):
+    """The family checks of pack_F / pack_g WITHOUT touching a device: raises UnpackableOperator exactly when they would.  The
+    solvers call it first, so that `fallback="host"` never allocates on (or needs) a GPU for a problem that cannot run there."""
+    if not (F is None or isinstance(F, PackedF)):
+        F = list(F)
+        ok = (all(isinstance(f, Zero) for f in F)
+              or (all(isinstance(f, LeastSquares) for f in F) and all(f.lam == F[0].lam and f.A.shape[0] == 1 for f in F))
+              or (not complex_x0 and all(isinstance(f, Precompose) and isinstance(f.f, LogisticLoss) and f.L.shape[0] == 1
+                                         and f.f.y.shape == (1,) and f.f.mu == 1.0 and not np.any(np.asarray(f.b) != 0) for f in F)))
+        if F and not ok:
+            kinds = sorted({type(f).__name__ for f in F})
+            raise UnpackableOperator(f"F of kinds {kinds} is not a family the device path can pack (one-row LeastSquares with one λ, "
+                                     f"Precompose(LogisticLoss) rows, Zero).  There is no SILENT host route; ask for the slow one "
+                                     f"explicitly with fallback=\"host\"")
+    if not (g is None or isinstance(g, (ProxG, Zero, NormL1)) or (isinstance(g, IndBox) and not complex_x0)):
+        raise UnpackableOperator(f"g of type {type(g).__name__} is not a family the device path supports (Zero, NormL1, IndBox); "
+                                 f"fallback=\"host\" runs any g with a prox(x, gamma) method on the host route")
 
 
 def pack_rows_from_host(chunks, N: int, d: int, R, loss: str = "ls", lam: float = 1.0, device=None, N_total=None, row0: int = 0) -> PackedF:
@@ -228,7 +254,7 @@ def pack_g(g, d: int, R, device=None, complex_pairs: bool = False) -> ProxG:
     if isinstance(g, NormL1):
         return ProxG(L.PROX_L1_COMPLEX if complex_pairs else L.PROX_L1, lam=g.lam)
     if complex_pairs:
-        raise TypeError(f"g of type {type(g).__name__} has no complex form on the device path (Zero, NormL1)")
+        raise UnpackableOperator(f"g of type {type(g).__name__} has no complex form on the device path (Zero, NormL1)")
     if isinstance(g, IndBox):
         lo_vec = hi_vec = None
         lo, hi = -float("inf"), float("inf")
@@ -241,7 +267,8 @@ def pack_g(g, d: int, R, device=None, complex_pairs: bool = False) -> ProxG:
         else:
             hi = float(g.hi)
         return ProxG(L.PROX_BOX, lo=lo, hi=hi, lo_vec=lo_vec, hi_vec=hi_vec)
-    raise TypeError(f"g of type {type(g).__name__} is not a family the device path supports (Zero, NormL1, IndBox)")
+    raise UnpackableOperator(f"g of type {type(g).__name__} is not a family the device path supports (Zero, NormL1, IndBox); "
+                             f"fallback=\"host\" runs any g with a prox(x, gamma) method on the host route")
 
 
 def pack_sharing_F(F, N: int, d: int, R, device=None):

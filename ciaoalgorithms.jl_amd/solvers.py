@@ -10,7 +10,9 @@ Python identifiers may be Greek, so `γ`, `μ`, `α` work as keywords exactly as
 
 Differences forced by the device boundary (documented in DESIGN.md):
   * the sampling stream is an explicit input (`stream=IndexStream(seed)`), see sampling.py;
-  * F must be one of the packable families (operators.py), or an already packed `PackedF` living on the device;
+  * F must be one of the packable families (operators.py), or an already packed `PackedF` living on the device; anything else
+    raises operators.UnpackableOperator unless the caller passes `fallback="host"`, which runs the same iterables on the host
+    with one operator call per sample (host_route.py: slow, announced with a warning, `state.backend == "host"`);
   * state vectors are torch device tensors; `solution(state)` returns the state's own tensor (identity, as in
     test/test_lasso.jl:185), and the solver returns it as a numpy array when x0 was a numpy array;
   * adaptive Finito (Finito_adaptive.jl) keeps its per-sample scalars in an N x 4 device
@@ -38,7 +40,8 @@ import torch
 
 from ._lib import ERR_UNSUPPORTED, CiaoError
 from .device import Context, PackedF, default_context, torch_dtype
-from .operators import pack_F, pack_g, pack_sharing_F
+from . import host_route as HR
+from .operators import UnpackableOperator, pack_F, pack_g, pack_sharing_F, require_packable
 from .sampling import IndexStream
 
 __all__ = ["SVRG", "SAGA", "SAG", "Finito", "Proshi", "iterator", "solution"]
@@ -615,6 +618,8 @@ def solution(state):
     if state is None:
         raise TypeError("solution(nothing): no method matching solution(::Nothing) -- the iterable ended before yielding "
                         "a state (invalid configuration, see the warning above)")
+    if getattr(state, "backend", None) == "host":                          # the explicit host route (host_route.py)
+        return HR.host_solution(state)
     if isinstance(state, Proshi_basic_state):                              # ProShI_basic.jl:127-132: shifts s IN PLACE
         state._it.ctx.proshi_solution(state._it.F, state.γ, state.z, state.s)
         return state.s
@@ -624,6 +629,25 @@ def solution(state):
 # ======================================================================================================================
 # L3: solver structs + functors + iterator()
 # ======================================================================================================================
+def _route(device_factory, host_factory, fallback, backend, F=None, g=None, x0=None):
+    """The device iterable; or the HOST route when the caller forces it (backend="host") or allows it (fallback="host") and
+    F / g are not a family the device path packs (operators.UnpackableOperator -- nothing else is caught).  Never silently:
+    host_route.announce() warns, and the states carry backend == "host"."""
+    if backend not in (None, "device", "host") or fallback not in (None, "host"):
+        raise ValueError('backend is "device" (default) or "host"; fallback is None (default) or "host"')
+    if backend == "host":
+        HR.announce('backend="host" was requested')
+        return host_factory()
+    try:
+        require_packable(F, g, complex_x0=bool(np.iscomplexobj(x0.detach().cpu().numpy() if isinstance(x0, torch.Tensor) else x0)))
+        return device_factory()
+    except UnpackableOperator as e:
+        if fallback != "host":
+            raise
+        HR.announce(f'fallback="host" was given and the device path cannot pack the problem ({str(e).split(".")[0]})')
+        return host_factory()
+
+
 class _Solver:
     _chunk = 1 << 20        # iterations per device launch in the functor's fast path ...
     _chunk_samples = 1 << 24   # ... capped so that one chunk's batch indices stay within 128 MiB (host scratch + HBM)
@@ -673,6 +697,9 @@ class _Solver:
                 disp(num_iters, state)
         sol = solution(state)
         it.ctx.synchronize()
+        if getattr(it, "backend", None) == "host":   # host route: numpy state; a torch x0 gets a (CPU) tensor back
+            out = sol.reshape(np.shape(it.x0))
+            return (torch.from_numpy(out) if isinstance(it.x0, torch.Tensor) else out), num_iters
         if isinstance(state, Proshi_basic_state):   # Array{Array{R,1}}: one x_i per agent (test_sharing.jl:45)
             return ([row for row in sol.cpu().numpy()] if it._numpy else sol), num_iters
         if it._complex:   # hand the (re, im) pairs back as the complex type x0 came in
@@ -716,10 +743,12 @@ class SVRG(_Solver):
         assert freq > 0
         self.R, self.γ, self.maxit, self.verbose, self.freq, self.m, self.plus = R, γ, int(maxit), verbose, int(freq), m, plus
 
-    def _iterable(self, x0, F=None, g=None, L=None, μ=None, mu=None, N=None, ctx=None, stream=None, shards=None):
+    def _iterable(self, x0, F=None, g=None, L=None, μ=None, mu=None, N=None, ctx=None, stream=None, shards=None,
+                  fallback=None, backend=None):
         μ = _pick(μ, mu, "μ")
         m = self.m if self.m is not None else N                            # SVRG.jl:59
-        return SVRG_basic_iterable(self.R, F, g, x0, N, L, μ, self.γ, m, self.plus, ctx=ctx, stream=stream, shards=shards)
+        return _route(lambda: SVRG_basic_iterable(self.R, F, g, x0, N, L, μ, self.γ, m, self.plus, ctx=ctx, stream=stream, shards=shards),
+                      lambda: HR.HostSVRG(self.R, F, g, x0, N, L, μ, self.γ, m, self.plus, stream=stream), fallback, backend, F, g, x0)
 
     def __call__(self, x0, **kw):                                          # SVRG.jl:46-84
         maxit = self.maxit
@@ -740,8 +769,9 @@ class SAGA(_Solver):
         assert freq > 0
         self.R, self.γ, self.maxit, self.verbose, self.freq, self.SAG_flag = R, γ, int(maxit), verbose, int(freq), SAG_flag
 
-    def _iterable(self, x0, F=None, g=None, L=None, N=None, ctx=None, stream=None, shards=None):
-        return SAGA_basic_iterable(self.R, F, g, x0, N, L, self.γ, self.SAG_flag, ctx=ctx, stream=stream, shards=shards)
+    def _iterable(self, x0, F=None, g=None, L=None, N=None, ctx=None, stream=None, shards=None, fallback=None, backend=None):
+        return _route(lambda: SAGA_basic_iterable(self.R, F, g, x0, N, L, self.γ, self.SAG_flag, ctx=ctx, stream=stream, shards=shards),
+                      lambda: HR.HostSAGA(self.R, F, g, x0, N, L, self.γ, self.SAG_flag, stream=stream), fallback, backend, F, g, x0)
 
     def __call__(self, x0, **kw):                                          # SAGA.jl:44-73
         stop, every = _split_drive_kw(kw)
@@ -771,15 +801,21 @@ class Finito(_Solver):
         self.minibatch, self.maxit, self.verbose, self.freq, self.α, self.tol, self.tol_b = (
             tuple(minibatch), int(maxit), verbose, int(freq), α, tol, tol_b)
 
-    def _iterable(self, x0, F=None, g=None, L=None, N=None, ctx=None, stream=None):   # Finito.jl:80-116
+    def _iterable(self, x0, F=None, g=None, L=None, N=None, ctx=None, stream=None, fallback=None, backend=None):   # Finito.jl:80-116
         if self.LFinito:
-            return FINITO_LFinito_iterable(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α,
-                                           ctx=ctx, stream=stream)
+            return _route(lambda: FINITO_LFinito_iterable(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α,
+                                                          ctx=ctx, stream=stream),
+                          lambda: HR.HostLFinito(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α, stream=stream),
+                          fallback, backend, F, g, x0)
         if self.adaptive:
+            if backend == "host":
+                raise NotImplementedError("the host route has no adaptive Finito")
             return FINITO_adaptive_iterable(self.R, F, g, x0, N, L, self.tol, self.tol_b, self.sweeping, self.α,
                                             ctx=ctx, stream=stream)
-        return FINITO_basic_iterable(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α,
-                                     ctx=ctx, stream=stream)
+        return _route(lambda: FINITO_basic_iterable(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α,
+                                                    ctx=ctx, stream=stream),
+                      lambda: HR.HostFinito(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α, stream=stream),
+                      fallback, backend, F, g, x0)
 
     def __call__(self, x0, **kw):                                          # Finito.jl:66-133
         stop, every = _split_drive_kw(kw)

@@ -624,3 +624,27 @@ def test_long_index_draws_are_generated_on_the_device(api, ciao, ctx):
     x, it = S.SAGA(np.float64, γ=1.0 / (3 * Li.max()), maxit=9000)(x0, F=F, g=g, N=N, ctx=ctx, stream=ciao.IndexStream(2))
     xr, _ = RS.saga(op, og, x0, maxit=9000, gamma=1.0 / (3 * Li.max()), stream=ciao.IndexStream(2))
     assert np.abs(x - xr).max() <= 1e-9 * max(np.abs(xr).max(), 1e-30) + 1e-13
+
+
+@pytest.mark.filterwarnings("ignore::RuntimeWarning")
+def test_host_route_follows_the_device_route_on_a_packable_problem(api):
+    """backend="host" forces the explicit host route (host_route.py) for a problem the device packs: same iterables, same
+    injected stream, so after the same number of iterations the two routes hold the same iterate up to rounding -- the host
+    route is the reference's loop, not a different algorithm.  (An unpackable problem: tests/test_host_route.py, no GPU.)"""
+    S, ops = api
+    F, g, L, x0, N, cost, f_star = lasso_problem(ops, np.float64)
+    F2, g2, L2, x02, x_star, N2 = logistic_problem(ops, np.float64)
+    cases = [(S.SVRG(np.float64, γ=1 / (7 * np.max(L)), maxit=40), dict(F=F, g=g, N=N), x0),
+             (S.SAGA(np.float64, maxit=400), dict(F=F, g=g, L=L, N=N), x0),
+             (S.SAG(np.float64, maxit=400), dict(F=F2, g=g2, L=L2, N=N2), x02),
+             (S.Finito(np.float64, sweeping=1, minibatch=(True, 2), maxit=300), dict(F=F2, g=g2, L=L2, N=N2), x02),
+             (S.Finito(np.float64, sweeping=3, maxit=300), dict(F=F, g=g, L=L, N=N), x0),
+             (S.Finito(np.float64, LFinito=True, sweeping=3, minibatch=(True, 2), maxit=100), dict(F=F2, g=g2, L=L2, N=N2), x02)]
+    for solver, kw, start in cases:
+        xd, nd = solver(start, stream=ciao_stream(11), **kw)
+        xh, nh = solver(start, stream=ciao_stream(11), backend="host", **kw)
+        assert nd == nh and xh.dtype == xd.dtype
+        assert np.abs(xd - xh).max() <= 1e-9 * max(np.abs(xh).max(), 1.0), (type(solver).__name__, np.abs(xd - xh).max())
+    it = S.iterator(S.SAGA(np.float64), x0, F=F, g=g, L=L, N=N, backend="host")
+    st = next(iter(it))
+    assert st.backend == "host" and it.x0 is x0
