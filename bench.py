@@ -236,10 +236,18 @@ def run_rank(args):
     gamma = 1.0 / (7.0 * L_max) if not logistic else 1.0 / (10.0 * L_max)   # test_lasso.jl:164 / test_logistic_l1.jl:126
 
     # ---- the collective: what is installed is what `config.collective` reports -----------------------------------------
-    collective, rccl_ranks, comm, hook = "none", None, None, None
+    collective, rccl_ranks, comm, hook, peers = "none", None, None, None, None
     if world > 1 or force_dist:
         want = os.environ.get("CIAO_BENCH_COLLECTIVE", "rccl" if backend == "nccl" else "torch")
-        if want == "rccl" and backend == "nccl":
+        if want == "peer":
+            # the one-shot peer all-reduce (csrc/peer_kernels.h): the sweep's finalize kernel writes the raw sum into every rank's
+            # mailbox, its epilogue waits for the flags -- no collective call, no extra launch.  Not the default until a node run
+            # has measured it against ncclAllReduce.
+            from ciaoalgorithms_jl_amd.parallel import PeerGroup
+            peers = PeerGroup(ctx, max_elems=2 * d)
+            ctx.set_peers(peers)
+            collective = "peer mailboxes over HIP IPC (one direct write per rank + flags), fused into finalize / epilogue: no collective call"
+        elif want == "rccl" and backend == "nccl":
             # Vote BEFORE the collective initialisation, on what can fail on one rank alone (loading librccl, its symbols): a rank
             # that failed there while the others went on into ncclCommInitRank would leave them waiting for it.  Every rank then
             # takes the same path; a failure INSIDE ncclCommInitRank is fatal (this rank exits non-zero and the launcher -- ours
@@ -257,7 +265,7 @@ def run_rank(args):
                 ctx.set_rccl(comm)
                 rccl_ranks = comm.count()
                 collective = "rccl ncclAllReduce(d+1) per step, issued by the library on its stream"
-        if comm is None:
+        if comm is None and peers is None:
             hook = AllReduceHook(dev)
             ctx.set_allreduce(hook)
             collective = (f"torch.distributed all_reduce(d+1) per step, backend {dist.get_backend()}"
@@ -296,12 +304,14 @@ def run_rank(args):
     kernel_name = ctx.last_kernel()
 
     # ---- the collective alone: K all-reduces of d+1 scalars back to back on the compute stream ---------------------------
-    allreduce_us = None
+    allreduce_us, allreduce_peer_us = None, None
     if world > 1 or force_dist:
         buf = torch.zeros(d + 1, dtype=tdt, device=dev)
         reps = 200
         try:
-            if comm is not None:
+            if peers is not None:
+                fn = lambda: ctx.peer_allreduce(buf)
+            elif comm is not None:
                 fn = lambda: comm.all_reduce(buf, ctx.stream)
             else:
                 fn = lambda: hook(buf.data_ptr(), d + 1, L.F64 if es == 8 else L.F32, ctx.stream.cuda_stream if ctx.stream else 0)
@@ -312,6 +322,29 @@ def run_rank(args):
             fence()
         except Exception as e:
             print(f"[bench] all-reduce microbenchmark failed: {e!r}", file=sys.stderr)
+        # ... and the peer exchange beside it, whatever collective the timed region used (as two kernels of its own here: the
+        # sweep fuses them into finalize / epilogue and pays no launch for them).  Set up and torn down around the measurement.
+        if peers is not None:
+            allreduce_peer_us = allreduce_us
+        else:
+            try:
+                from ciaoalgorithms_jl_amd.parallel import PeerGroup
+                saved_rccl, saved_hook = comm, hook
+                pg = PeerGroup(ctx, max_elems=2 * d)
+                ctx.set_peers(pg)
+                for _ in range(10):
+                    ctx.peer_allreduce(buf)
+                fence()
+                allreduce_peer_us = _timed_events(torch, ctx.stream or torch.cuda.current_stream(), lambda: ctx.peer_allreduce(buf), reps) * 1e6
+                fence()
+                ctx.set_peers(None)
+                pg.close()
+                if saved_rccl is not None:
+                    ctx.set_rccl(saved_rccl)
+                elif saved_hook is not None:
+                    ctx.set_allreduce(saved_hook)
+            except Exception as e:
+                print(f"[bench] peer all-reduce microbenchmark failed: {e!r}", file=sys.stderr)
 
     units = float(N_total) * args.steps                                  # sample-gradients processed by all ranks
     value = units / elapsed
@@ -355,6 +388,7 @@ def run_rank(args):
         # all-reduce of the d+1 scalars (BASELINE.md section 2 asks for that figure in microseconds)
         "step_overhead_us_beyond_sweep_kernel": (elapsed / args.steps - k_avg_s) * 1e6,
         "allreduce_us_per_step": allreduce_us,
+        "allreduce_us_per_step_peer_mailboxes": allreduce_peer_us,
         "rccl_ranks": rccl_ranks,
         "config": {"workload": f"{'l1_logistic' if logistic else 'lasso'}_svrg_fullgrad_prox_sweep",
                    "N_total": N_total, "rows_per_gpu": n_local, "d": d, "f": "LeastSquares(a_i,b_i,N)" if not logistic else "Precompose(LogisticLoss)",
@@ -412,6 +446,9 @@ def run_rank(args):
 
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if peers is not None:
+        ctx.set_peers(None)
+        peers.close()
     ctx.close()
     if comm is not None:
         comm.close()

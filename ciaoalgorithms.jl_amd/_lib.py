@@ -88,6 +88,9 @@ SIGNATURES = {
     "ciao_ipc_export": (_i32, [_vp, _vp, C.POINTER(_i64)]),
     "ciao_ipc_open": (_i32, [_vp, _i64, C.POINTER(_vp)]),
     "ciao_ipc_close": (_i32, [_vp, _i64]),
+    "ciao_peer_mailbox_create": (_i32, [_vp, _i64, C.POINTER(C.c_void_p), C.POINTER(_i64)]),
+    "ciao_peer_mailbox_destroy": (_i32, [_vp, _vp]),
+    "ciao_ctx_set_peers": (_i32, [_vp, _i32, _i32, C.POINTER(C.c_void_p), _i64]),
     "ciao_saga_init": (_i32, [_vp, _PP, _GP, _f64, _vp, _vp, _vp, _vp]),
     "ciao_saga_steps": (_i32, [_vp, _PP, _GP, _f64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "ciao_hat_gamma": (_i32, [_vp, _i32, _i64, _vp, C.POINTER(_f64)]),
@@ -108,6 +111,7 @@ SIGNATURES = {
     "ciao_synth_targets": (_i32, [_vp, _PP, _vp, _f64, _i32, _i64, C.c_uint64, _vp]),
     "ciao_sample_batches": (_i32, [C.c_uint64, C.c_uint64, _i64, _i64, _i64, _vp, C.POINTER(C.c_uint64)]),
     "ciao_sample_uniform": (_i32, [_vp, C.c_uint64, C.c_uint64, _i64, _i64, _vp]),
+    "ciao_peer_allreduce": (_i32, [_vp, _i32, _i64, _vp]),
 }
 
 _lib = None

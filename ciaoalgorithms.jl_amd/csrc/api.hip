@@ -911,6 +911,7 @@ int32_t ciao_ctx_destroy(ciao_ctx *ctx)
     if (ctx->idxbuf) (void)hipFree(ctx->idxbuf);
     if (ctx->scal) (void)hipFree(ctx->scal);
     if (ctx->errflag) (void)hipFree(ctx->errflag);
+    if (ctx->peer_counter) (void)hipFree(ctx->peer_counter);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     delete ctx;
     return CIAO_OK;
@@ -943,6 +944,11 @@ int32_t ciao_ctx_synchronize(ciao_ctx *ctx)
             set_error("internal: a wave of the wave-specialised chain kernel gave up waiting for another (chain_ws_kernel spin limit); "
                       "results since the last synchronize are invalid -- option chain_no_ws=1 selects the previous chain kernel");
             return CIAO_ERR_HIP;
+        }
+        if (flag == 4) {
+            set_error("peer all-reduce: a rank's flag never arrived (ciao_ctx_set_peers: every rank must make the same reductions in "
+                      "the same order); results since the last synchronize are invalid");
+            return CIAO_ERR_HOOK;
         }
         set_error("a sample index was outside [0, N): results since the last synchronize are invalid");
         return CIAO_ERR_ARG;
@@ -1004,6 +1010,90 @@ int32_t ciao_ctx_set_rccl(ciao_ctx *ctx, void *comm, const char *librccl_path)
     ctx->hook = rccl_hook;
     ctx->hook_user = ctx;
     return CIAO_OK;
+}
+
+// ---- one-shot peer all-reduce (peer_kernels.h) ---------------------------------------------------------------------------
+static int64_t peer_slot_bytes_for(int64_t max_elems) { return ((max_elems * 8 + 255) / 256) * 256; }
+
+int32_t ciao_peer_mailbox_create(ciao_ctx *ctx, int64_t max_elems, void **mailbox_out, int64_t *bytes_out)
+{
+    CIAO_ENTER(ctx);
+    CIAO_REQUIRE(mailbox_out && max_elems >= 1, "NULL argument or max_elems < 1");
+    const size_t bytes = (size_t)(PEER_HDR + 2 * PEER_MAX * peer_slot_bytes_for(max_elems));
+    void *m = nullptr;
+    // fine-grained device memory: written by the other GPUs over xGMI while this GPU's kernels read it
+    CIAO_HIP(hipExtMallocWithFlags(&m, bytes, hipDeviceMallocFinegrained));
+    CIAO_HIP(hipMemset(m, 0, bytes));
+    CIAO_HIP(hipDeviceSynchronize());
+    *mailbox_out = m;
+    if (bytes_out) *bytes_out = (int64_t)bytes;
+    return CIAO_OK;
+}
+
+int32_t ciao_peer_mailbox_destroy(ciao_ctx *ctx, void *mailbox)
+{
+    CIAO_ENTER(ctx);
+    if (mailbox) CIAO_HIP(hipFree(mailbox));
+    return CIAO_OK;
+}
+
+// the library's peer hook on an arbitrary buffer (chain-owner broadcasts, bench): the two halves as kernels of their own
+static int32_t peer_hook(void *user, void *buf, int64_t count, int32_t dtype, void *stream)
+{
+    ciao_ctx *ctx = static_cast<ciao_ctx *>(user);
+    if (count > ctx->peer_max_elems) {
+        set_error("the peer mailboxes hold %lld elements, this reduction has %lld", (long long)ctx->peer_max_elems, (long long)count);
+        return CIAO_ERR_ARG;
+    }
+    const PeerDev pd = peer_dev(ctx);
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    if (dtype == CIAO_F64) {
+        hipLaunchKernelGGL((peer_send_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double *)buf, count, pd);
+        hipLaunchKernelGGL((peer_recv_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (double *)buf, count, pd);
+    } else {
+        hipLaunchKernelGGL((peer_send_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)buf, count, pd);
+        hipLaunchKernelGGL((peer_recv_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (float *)buf, count, pd);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : CIAO_ERR_HIP;
+}
+
+int32_t ciao_ctx_set_peers(ciao_ctx *ctx, int32_t rank, int32_t world, void *const *mailboxes, int64_t max_elems)
+{
+    CIAO_ENTER(ctx);
+    if (!mailboxes || world <= 0) {   // off
+        if (ctx->hook == peer_hook) {
+            ctx->hook = nullptr;
+            ctx->hook_user = nullptr;
+        }
+        ctx->peer_world = 0;
+        return CIAO_OK;
+    }
+    CIAO_REQUIRE(world >= 1 && world <= PEER_MAX && rank >= 0 && rank < world, "world must be in 1..%d and rank in [0, world) (got %d, %d)",
+                 PEER_MAX, world, rank);
+    CIAO_REQUIRE(max_elems >= 1, "max_elems < 1");
+    for (int r = 0; r < world; ++r) CIAO_REQUIRE(mailboxes[r], "mailbox %d is NULL", r);
+    if (!ctx->peer_counter) {
+        CIAO_HIP(hipMalloc((void **)&ctx->peer_counter, sizeof(unsigned int)));
+        CIAO_HIP(hipMemset(ctx->peer_counter, 0, sizeof(unsigned int)));
+    }
+    for (int r = 0; r < PEER_MAX; ++r) ctx->peer_mail[r] = r < world ? static_cast<unsigned char *>(mailboxes[r]) : nullptr;
+    ctx->peer_world = world;
+    ctx->peer_rank = rank;
+    ctx->peer_seq = 0;   // fresh mailboxes (all flags zero) are expected: every rank calls this at the same point of its program
+    ctx->peer_max_elems = max_elems;
+    ctx->peer_slot_bytes = peer_slot_bytes_for(max_elems);
+    ctx->hook = peer_hook;
+    ctx->hook_user = ctx;
+    return CIAO_OK;
+}
+
+int32_t ciao_peer_allreduce(ciao_ctx *ctx, int32_t dtype, int64_t count, void *buf)
+{
+    CIAO_ENTER(ctx);
+    CIAO_REQUIRE(ctx->peer_world > 0, "no peers are set (ciao_ctx_set_peers)");
+    CIAO_REQUIRE(buf && count >= 1 && (dtype == CIAO_F64 || dtype == CIAO_F32), "NULL buffer, count < 1 or unknown dtype");
+    const int32_t st = peer_hook(ctx, buf, count, dtype, (void *)ctx->stream);
+    return st == 0 ? CIAO_OK : (st < 0 ? st : CIAO_ERR_HOOK);
 }
 
 int32_t ciao_ctx_set_monitor(ciao_ctx *ctx, const ciao_prox_desc *g, double *obj_dev)

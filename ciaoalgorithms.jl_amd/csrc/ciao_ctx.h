@@ -49,6 +49,14 @@ struct ciao_ctx {
     int (*rccl_allreduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*rccl_errstr)(int) = nullptr;
 
+    // one-shot peer all-reduce (ciao_ctx_set_peers; peer_kernels.h): world == 0 = off.  While set, ctx->hook is the library's own
+    // peer hook, so everything that asks "is this a row-sharded run?" keeps asking ctx->hook.
+    int peer_world = 0, peer_rank = 0;
+    unsigned int peer_seq = 0;                 // sequence number of the last reduction (the same on every rank)
+    int64_t peer_slot_bytes = 0, peer_max_elems = 0;
+    unsigned char *peer_mail[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned int *peer_counter = nullptr;      // device word: workgroups of the sending kernel that are done
+
     // tuning
     int64_t sweep_blocks_per_cu = 0;   // 0 = choose from the row size (rows_launch.inc)
     int64_t sweep_multi = 1;           // short rows (<= 4 KiB): several rows per wave per iteration (rows_multi_kernel)

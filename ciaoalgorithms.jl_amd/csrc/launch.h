@@ -8,6 +8,21 @@
 
 namespace ciao {
 
+// the next reduction's view of the peer mailboxes (advances the sequence number: every rank makes the same reductions in the
+// same order)
+inline PeerDev peer_dev(ciao_ctx *ctx)
+{
+    PeerDev p{};
+    p.world = ctx->peer_world;
+    p.rank = ctx->peer_rank;
+    p.seq = ++ctx->peer_seq;
+    p.slot_bytes = ctx->peer_slot_bytes;
+    for (int r = 0; r < PEER_MAX; ++r) p.mail[r] = ctx->peer_mail[r];
+    p.counter = ctx->peer_counter;
+    p.errflag = ctx->errflag;
+    return p;
+}
+
 // rows kernel + finalize (+ all-reduce hook) + epilogue.  Specialised in rows_f32.hip / rows_f64.hip.
 template <typename T>
 int32_t launch_rows(ciao_ctx *ctx, int mode, RowsArgs<T> &a, const Epilogue<T> &ep);

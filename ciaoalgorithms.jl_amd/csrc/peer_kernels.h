@@ -1,0 +1,141 @@
+// peer_kernels.h -- the one-shot peer all-reduce of the d+1 scalars of a sweep / batch ("tuned
+// alternative"; no counterpart in the reference, which has no collective at all).
+//
+// The message is 4-16 KB and the 8 GPUs of a node are fully connected (7 xGMI links per GPU): a ring is the wrong shape, the wire
+// time is a fraction of a microsecond and everything that matters is latency -- an RCCL call per reduction costs more than the
+// reduction.  So every rank owns a MAILBOX in its own HBM (fine-grained memory allocated by the library, mapped into the other
+// ranks by HIP IPC): two parities x one slot per rank.  A reduction with sequence number q:
+//   * the kernel that produced the rank's raw sum (finalize_kernel) stores it into slot [q & 1][rank] of EVERY rank's mailbox -- one
+//     direct write per peer, one xGMI link each -- and the LAST of its workgroups to finish (device-scope counter) then releases
+//     flag [q & 1][rank] = q in every mailbox (system scope);
+//   * the kernel that consumes the sum (the epilogue) waits in its own mailbox for the world's flags to read q (acquire, system
+//     scope), adds the slots IN RANK ORDER -- every rank forms the bitwise-identical sum -- and applies the epilogue.
+// No collective call, no extra launch: the two kernels exist anyway.  Two parities suffice: a rank can only write reduction q+2
+// after its epilogue of q+1 has seen every rank's flag q+1, which each rank set after ITS epilogue of q had read the slots of q.
+// The wait is bounded (errflag 4, then ciao_ctx_synchronize reports it): a rank that never arrives is an error, not a hung GPU.
+#pragma once
+
+#include "ciao_common.h"
+
+namespace ciao {
+
+constexpr int PEER_MAX = 8;
+constexpr int64_t PEER_HDR = 1024;        // flags: [2 parities][8 ranks] x 64 bytes
+constexpr unsigned int PEER_SPIN_LIMIT = 1u << 22;   // polls of ~1 us: seconds
+
+struct PeerDev {
+    int world, rank;                   // world == 0: no peers (single device, or the hook path)
+    unsigned int seq;                  // this reduction's sequence number (>= 1; the same on every rank)
+    int64_t slot_bytes;
+    unsigned char *mail[PEER_MAX];     // mail[r] = rank r's mailbox (mail[rank] = own; the others IPC-mapped)
+    unsigned int *counter;             // device-scope "workgroups done" counter of the sending kernel (this rank's own memory)
+    int *errflag;
+};
+
+__device__ __forceinline__ unsigned int *peer_flag(const PeerDev &p, int owner, int from)
+{
+    return reinterpret_cast<unsigned int *>(p.mail[owner] + (int64_t)(((p.seq & 1u) * PEER_MAX + (unsigned)from) * 64));
+}
+template <typename T>
+__device__ __forceinline__ T *peer_slot(const PeerDev &p, int owner, int from)
+{
+    return reinterpret_cast<T *>(p.mail[owner] + PEER_HDR + (int64_t)((p.seq & 1u) * PEER_MAX + (unsigned)from) * p.slot_bytes);
+}
+
+// element k of this rank's contribution -> every rank's mailbox
+template <typename T>
+__device__ __forceinline__ void peer_put(const PeerDev &p, int64_t k, T v)
+{
+    for (int r = 0; r < p.world; ++r) peer_slot<T>(p, r, p.rank)[k] = v;
+}
+
+// End of the sending kernel, called by EVERY thread of EVERY workgroup after its peer_put()s: the last workgroup to get here
+// publishes the flags.  (fence: this thread's stores are performed system-wide; barrier: the workgroup's are; the counter orders
+// the workgroups; the fence behind it orders the flags after everything the counter has seen.)
+__device__ __forceinline__ void peer_publish(const PeerDev &p)
+{
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int total = gridDim.x * gridDim.y;
+        const unsigned int old = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == total - 1) {
+            __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next reduction
+            __threadfence_system();
+            for (int r = 0; r < p.world; ++r) __hip_atomic_store(peer_flag(p, r, p.rank), p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// Start of the consuming kernel, called by every thread of a workgroup: returns false if a rank never arrived.
+__device__ __forceinline__ bool peer_wait(const PeerDev &p)
+{
+    __shared__ int peer_ok;
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        for (int r = 0; r < p.world && ok; ++r) {
+            unsigned int spins = 0;
+            while (__hip_atomic_load(peer_flag(p, p.rank, r), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != p.seq) {
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > PEER_SPIN_LIMIT) {
+                    *p.errflag = 4;
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        peer_ok = ok;
+    }
+    __syncthreads();
+    return peer_ok != 0;
+}
+
+// element k of the reduced sum: the world's slots of this rank's own mailbox, added in rank order (system-scope loads: the
+// slots were written by other GPUs)
+__device__ __forceinline__ double peer_load(const double *q)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__device__ __forceinline__ float peer_load(const float *q)
+{
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+template <typename T>
+__device__ __forceinline__ T peer_sum(const PeerDev &p, int64_t k)
+{
+    T s = peer_load(peer_slot<T>(p, p.rank, 0) + k);
+    for (int r = 1; r < p.world; ++r) s += peer_load(peer_slot<T>(p, p.rank, r) + k);
+    return s;
+}
+
+// the sending half on its own (the library's all-reduce hook on an arbitrary buffer: chain-owner broadcasts, bench): buf[0..count)
+template <typename T>
+__global__ void __launch_bounds__(256) peer_send_kernel(const T *__restrict__ buf, int64_t count, PeerDev p)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < count) peer_put(p, k, buf[k]);
+    peer_publish(p);
+}
+
+// the consuming half: the reduced sum into raw_out[0..count) (hook form), or the epilogue on it (fused form: count = d + 1,
+// the extra scalar at [d])
+template <typename T>
+__global__ void __launch_bounds__(256) peer_recv_kernel(T *__restrict__ raw_out, int64_t count, PeerDev p)
+{
+    if (!peer_wait(p)) return;
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < count) raw_out[k] = peer_sum<T>(p, k);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) peer_epilogue_kernel(int64_t d, Epilogue<T> ep, PeerDev p)
+{
+    if (!peer_wait(p)) return;
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ep.z_out && ep.g.kind == CIAO_PROX_L1_COMPLEX) {   // (re, im) pairs: thread k takes coordinates 2k and 2k+1
+        if (2 * k + 1 < d) epilogue_apply2(ep, 2 * k, peer_sum<T>(p, 2 * k), peer_sum<T>(p, 2 * k + 1), peer_sum<T>(p, d));
+        return;
+    }
+    if (k < d) epilogue_apply(ep, k, peer_sum<T>(p, k), peer_sum<T>(p, d));
+}
+
+}  // namespace ciao

@@ -12,6 +12,7 @@
 #pragma once
 
 #include "ciao_common.h"
+#include "peer_kernels.h"
 
 namespace ciao {
 
@@ -1283,7 +1284,7 @@ constexpr int FIN_THREADS = 256;
 template <typename T>
 __global__ void __launch_bounds__(FIN_THREADS)
     finalize_kernel(const T *__restrict__ partial, int64_t pstride, int nparts, const T *__restrict__ pextra,
-                    int64_t d, T *raw_out, Epilogue<T> ep)
+                    int64_t d, T *raw_out, Epilogue<T> ep, PeerDev peers)
 {
     constexpr int VEC = 16 / sizeof(T);
     using V = typename ChunkOf<T, VEC>::type;
@@ -1364,12 +1365,17 @@ __global__ void __launch_bounds__(FIN_THREADS)
                 if (raw_out) {
                     raw_out[col + w] = tot[w];
                     if (col + w == 0) raw_out[d] = extra;
+                    if (peers.world > 0) {   // the rank's raw sum straight into every rank's mailbox (peer_kernels.h)
+                        peer_put(peers, col + w, tot[w]);
+                        if (col + w == 0) peer_put(peers, d, extra);
+                    }
                 } else {
                     epilogue_apply_pre(ep, col + w, tot[w], extra, pa[w], pu[w], pv[w], pp[w]);
                 }
             }
         }
     }
+    if (peers.world > 0) peer_publish(peers);   // the last workgroup to get here releases this rank's flag in every mailbox
 }
 
 // epilogue on an already reduced (and all-reduced) raw sum: raw[0..d) + extra at raw[d]

@@ -261,6 +261,22 @@ class Context:
         L.check(self.lib.ciao_ctx_set_shards(self._h, C.byref(table) if table is not None else None))
         self.shards = table
 
+    def set_peers(self, group: "parallel.PeerGroup | None"):
+        """One-shot peer all-reduce (include/ciao_hip.h: ciao_ctx_set_peers): `group` is a parallel.PeerGroup whose mailboxes are
+        exchanged and mapped; None turns it off."""
+        if group is None:
+            self._peers_keepalive = None
+            L.check(self.lib.ciao_ctx_set_peers(self._h, 0, 0, None, 0))
+            return
+        self._peers_keepalive = group
+        arr = (C.c_void_p * group.world)(*group.mailboxes)
+        L.check(self.lib.ciao_ctx_set_peers(self._h, group.rank, group.world, arr, group.max_elems))
+
+    def peer_allreduce(self, t: torch.Tensor):
+        """In-place sum over the ranks of a float32 / float64 device tensor through the peer mailboxes (bench / tests)."""
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
+        L.check(self.lib.ciao_peer_allreduce(self._h, L.F64 if t.dtype == torch.float64 else L.F32, t.numel(), C.c_void_p(t.data_ptr())))
+
     def set_rccl(self, comm):
         """Native all-reduce: `comm` is a parallel.RcclComm (or None to clear).  The library then calls ncclAllReduce itself on
         its stream -- no Python callback per reduction (include/ciao_hip.h: ciao_ctx_set_rccl)."""

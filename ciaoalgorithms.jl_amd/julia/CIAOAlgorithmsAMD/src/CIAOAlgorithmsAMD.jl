@@ -227,6 +227,23 @@ function ipc_open(handle::Vector{UInt8}, offset::Integer)
     return out[]
 end
 ipc_close(p::Ptr{Cvoid}, offset::Integer) = check(ccall((:ciao_ipc_close, libciao), Int32, (Ptr{Cvoid}, Int64), p, offset))
+# One-shot peer all-reduce (include/ciao_hip.h: ciao_ctx_set_peers; csrc/peer_kernels.h): every rank creates a mailbox, exchanges
+# its IPC handle (ipc_export of the mailbox pointer / ipc_open, through whatever the host uses between processes: MPI.jl,
+# Distributed ...), and sets the table; the d-vector sums then travel by the kernels' own stores, no collective call.
+function peer_mailbox_create(max_elems::Integer)
+    out = Ref{Ptr{Cvoid}}(C_NULL); nbytes = Ref{Int64}(0)
+    check(ccall((:ciao_peer_mailbox_create, libciao), Int32, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}, Ref{Int64}), context().h, max_elems, out, nbytes))
+    return out[], nbytes[]
+end
+peer_mailbox_destroy(m::Ptr{Cvoid}) = check(ccall((:ciao_peer_mailbox_destroy, libciao), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), context().h, m))
+function ipc_export(p::Ptr{Cvoid})
+    handle = zeros(UInt8, 64); off = Ref{Int64}(0)
+    check(ccall((:ciao_ipc_export, libciao), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Ref{Int64}), p, handle, off))
+    return handle, off[]
+end
+set_peers!(rank::Integer, mailboxes::Vector{Ptr{Cvoid}}, max_elems::Integer) =      # rank is 0-based on the ABI
+    check(ccall((:ciao_ctx_set_peers, libciao), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Ptr{Cvoid}}, Int64), context().h, rank, length(mailboxes), mailboxes, max_elems))
+clear_peers!() = check(ccall((:ciao_ctx_set_peers, libciao), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Ptr{Cvoid}}, Int64), context().h, 0, 0, C_NULL, 0))
 set_option!(key::AbstractString, value::Integer) =
     check(ccall((:ciao_ctx_set_option, libciao), Int32, (Ptr{Cvoid}, Cstring, Int64), context().h, key, value))
 last_kernel() = unsafe_string(ccall((:ciao_ctx_last_kernel, libciao), Cstring, (Ptr{Cvoid},), context().h))

@@ -190,6 +190,53 @@ def default_rccl_path() -> str:
     return p if os.path.exists(p) else "librccl.so"
 
 
+class PeerGroup:
+    """The one-shot peer all-reduce (csrc/peer_kernels.h; SURVEY.md 8e "tuned alternative"): every rank creates a mailbox in its
+    own HBM, the HIP IPC handles travel through the torch.distributed group (any backend -- control plane only), every rank maps
+    the others' and hands the library the table (Context.set_peers).  From then on the d-vector sums of the sharded sweeps and
+    batches are exchanged by the kernels themselves: no collective call per reduction.  max_elems >= d + 1 (2 d for the sharded
+    chains' hand-over).  One node (world <= 8)."""
+
+    def __init__(self, ctx, max_elems: int, group=None):
+        import torch.distributed as dist
+        self.ctx, self.max_elems, self.group = ctx, int(max_elems), group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world > 8:
+            raise ValueError("peer mailboxes serve one node (at most 8 ranks)")
+        own = C.c_void_p()
+        nbytes = C.c_int64(0)
+        L.check(ctx.lib.ciao_peer_mailbox_create(ctx._h, self.max_elems, C.byref(own), C.byref(nbytes)))
+        self.own = own.value
+        h = (C.c_char * 64)()
+        off = C.c_int64(0)
+        L.check(ctx.lib.ciao_ipc_export(C.c_void_p(self.own), h, C.byref(off)))
+        every = [None] * self.world
+        dist.all_gather_object(every, (bytes(h), int(off.value)), group=group)
+        self._opened, self.mailboxes = [], []
+        for r, (hr, offr) in enumerate(every):
+            if r == self.rank:
+                self.mailboxes.append(self.own)
+                continue
+            out = C.c_void_p()
+            L.check(ctx.lib.ciao_ipc_open((C.c_char * 64).from_buffer_copy(hr), offr, C.byref(out)))
+            self._opened.append((out.value, offr))
+            self.mailboxes.append(out.value)
+        dist.barrier(group=group)          # every mailbox is mapped everywhere before the first reduction writes into one
+
+    def close(self):
+        import torch.distributed as dist
+        if getattr(self, "own", None) is None:
+            return
+        self.ctx.synchronize()
+        if dist.is_initialized():
+            dist.barrier(group=self.group)   # nobody is still writing into a mailbox that is about to be unmapped / freed
+        for ptr, off in self._opened:
+            self.ctx.lib.ciao_ipc_close(C.c_void_p(ptr), off)
+        self._opened = []
+        self.ctx.lib.ciao_peer_mailbox_destroy(self.ctx._h, C.c_void_p(self.own))
+        self.own = None
+
+
 class RcclComm:
     """An RCCL communicator of our own (one rank per process / GPU), for Context.set_rccl: the d-vector all-reduce is then
     issued by libciao_hip.so itself on its stream.  The unique id travels through the existing torch.distributed group

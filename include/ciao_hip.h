@@ -225,6 +225,20 @@ typedef struct {
  * ranks through one all-reduce of 2d scalars in which the non-owners contribute zeros; the tail and the full pass of
  * ciao_svrg_iterate then run sharded as usual.  (The a_i'z_full cache is not used across shards.) */
 CIAO_API int32_t ciao_ctx_set_shards(ciao_ctx *ctx, const ciao_shard_table *shards);
+/* ---- one-shot peer all-reduce (SURVEY.md sections 5 / 8e, the "tuned alternative" to ncclAllReduce; no reference counterpart) --
+ * The all-reduce of the d+1 scalars of a sweep / batch is latency, not bandwidth (4-16 KB over 7 direct xGMI links).  With
+ * peers set, the kernel that produces a rank's raw sum writes it straight into a slot of EVERY rank's mailbox and releases a
+ * flag, and the kernel that applies the epilogue waits for the world's flags and adds the slots in rank order (bitwise the
+ * same sum on every rank): no collective call and no extra launch per reduction (csrc/peer_kernels.h).
+ *   _mailbox_create: this rank's mailbox, fine-grained device memory for reductions of up to max_elems elements (d + 1, or
+ *                    2 d for the sharded chains' hand-over); share it with ciao_ipc_export / _open.  _destroy frees it.
+ *   ciao_ctx_set_peers: mailboxes[r] = rank r's mailbox as mapped on THIS device (mailboxes[rank] = its own); world <= 8.  Every
+ *                    rank calls it with freshly created mailboxes at the same point of its program and from then on makes
+ *                    the same reductions in the same order.  Replaces any all-reduce hook / RCCL communicator; NULL or world 0
+ *                    turns it off.  A rank whose flag never arrives is reported by ciao_ctx_synchronize (CIAO_ERR_HOOK). */
+CIAO_API int32_t ciao_peer_mailbox_create(ciao_ctx *ctx, int64_t max_elems, void **mailbox_out, int64_t *bytes_out);
+CIAO_API int32_t ciao_peer_mailbox_destroy(ciao_ctx *ctx, void *mailbox);
+CIAO_API int32_t ciao_ctx_set_peers(ciao_ctx *ctx, int32_t rank, int32_t world, void *const *mailboxes, int64_t max_elems);
 /* Sharing a device allocation with the chain owner's process (plain HIP IPC, no torch / AMDGPU.jl needed):
  * _export: handle_out = 64 bytes describing the allocation that contains dev_ptr, *offset_out = dev_ptr's offset in it;
  * _open (in the other process, on the device that will read it): *dev_ptr_out = the mapped pointer + offset;
@@ -380,6 +394,9 @@ CIAO_API int32_t ciao_sample_batches(uint64_t seed, uint64_t pos, int64_t N, int
  * DEVICE array out_dev[m] on the ctx's stream: an epoch's 10^7 indices cost the host a second and 80 MB of PCIe, the device
  * microseconds.  Needs 0 < N < 2^32. */
 CIAO_API int32_t ciao_sample_uniform(ciao_ctx *ctx, uint64_t seed, uint64_t pos, int64_t N, int64_t m, int64_t *out_dev);
+/* The peer all-reduce (ciao_ctx_set_peers) on a device buffer of its own, as two kernels (send, wait + add): what bench.py
+ * times as allreduce_us_per_step for that collective, and what tests hold against a host-staged sum. */
+CIAO_API int32_t ciao_peer_allreduce(ciao_ctx *ctx, int32_t dtype, int64_t count, void *buf);
 
 #endif /* CIAO_BENCH_API */
 

@@ -68,8 +68,23 @@ def test_two_ranks_on_the_one_gpu_real_step():
     assert j["n_gpus"] == 2 and j["config"]["N_total"] == 400000 and j["config"]["rows_per_gpu"] == 200000
     assert "gloo" in j["config"]["collective"] and "rccl" not in j["config"]["collective"].lower().replace("(= rccl)", "")
     assert j["rccl_ranks"] is None and j["allreduce_us_per_step"] is not None
+    assert j["allreduce_us_per_step_peer_mailboxes"] is not None, "the peer exchange is timed beside whatever collective ran"
     assert j["value"] > 0 and j["roofline"]["kernel_launches"] == 3
     assert j["config"]["launcher"] == "bench.py spawned the ranks"
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_one_gpu_real_step_through_the_peer_mailboxes():
+    """CIAO_BENCH_COLLECTIVE=peer: the sweep's reductions travel through the peer mailboxes (csrc/peer_kernels.h), fused into
+    finalize / epilogue; the line names that collective and reports its per-step cost."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--rows-per-gpu", "200000", "--no-cpu", "--no-extras", "--no-chains"],
+             {"CIAO_BENCH_BACKEND": "gloo", "CIAO_BENCH_COLLECTIVE": "peer"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["N_total"] == 400000
+    assert "peer mailboxes" in j["config"]["collective"] and j["rccl_ranks"] is None
+    assert j["allreduce_us_per_step"] is not None and j["allreduce_us_per_step"] == j["allreduce_us_per_step_peer_mailboxes"]
+    assert j["value"] > 0 and j["roofline"]["kernel_launches"] == 3
 
 
 def _torchrun(n, args, env_extra=None, timeout=600, port=29631):

@@ -217,3 +217,122 @@ def test_native_rccl_allreduce_one_rank():
     ok = q.get(timeout=300)
     p.join(timeout=60)
     assert all(v is True for v in ok.values()), ok
+
+
+def _peer_worker(rank, world, port, q):
+    """The one-shot peer all-reduce (csrc/peer_kernels.h) between two processes sharing the test box's GPU: real HIP IPC mappings
+    of each other's mailboxes, the kernels of both processes running side by side.  Every result is held BITWISE against the
+    host-staged hook path (the sum of two terms is the same in either order) and against the oracle."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    import ciao_loader
+    ciao_loader.load()
+    from ciaoalgorithms_jl_amd import _lib as L
+    from ciaoalgorithms_jl_amd.device import Context, PackedF, ProxG
+    from ciaoalgorithms_jl_amd.parallel import AllReduceHook, PeerGroup, shard_rows
+    from ciaoalgorithms_jl_amd.solvers import Finito
+    from ciaoalgorithms_jl_amd.sampling import IndexStream
+    from oracle import oracle as O
+    import problems as P
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = {}
+    try:
+        dev = torch.device("cuda", 0)
+        ctx = Context(0)
+        N, d = 403, 1024
+        A, b, x = P.synthetic("ls", N, d, np.float64, seed=12)
+        row0, n = shard_rows(N, rank, world)
+        F = PackedF(L.LOSS_LS, torch.from_numpy(A[row0:row0 + n]).to(dev), torch.from_numpy(b[row0:row0 + n]).to(dev), float(N),
+                    N_total=N, row0=row0)
+        g = ProxG(L.PROX_L1, lam=0.01)
+        og, op = O.Prox("l1", lam=0.01), O.Problem("ls", A, b, float(N))
+        xd = torch.from_numpy(x).to(dev)
+        Li = float(N) * np.sum(A * A, axis=1)
+
+        def workload():
+            out = {}
+            av, y = torch.empty_like(xd), torch.empty_like(xd)
+            xk = xd.clone()
+            for _ in range(5):                                    # five chained sweeps: both parities, increasing sequence numbers
+                ctx.proxgrad_step(F, g, 0.05 / N, xk, av, y)
+                xk, y = y, xk
+            out["sweeps"] = xk.cpu().numpy().copy()
+            out["objective"] = ctx.objective(F, g, xk)            # the raw-sum form of the reduction
+            for lf in (False, True):
+                solver = Finito(np.float64, maxit=8, sweeping=2, minibatch=(True, 64), LFinito=lf)
+                out[f"finito{int(lf)}"] = solver(np.zeros(d), F=F, g=g, L=Li, N=N, ctx=ctx, stream=IndexStream(0))[0]
+            ctx.synchronize()
+            return out
+
+        hook = AllReduceHook(dev)
+        ctx.set_allreduce(hook)
+        ref = workload()
+        ctx.set_allreduce(None)
+        pg = PeerGroup(ctx, max_elems=2 * d)
+        ctx.set_peers(pg)
+        # (1) the primitive on a buffer of its own, thirty times in a row
+        good = True
+        for k in range(30):
+            t = torch.full((d + 1,), float(rank + 1) * (k + 1), dtype=torch.float64, device=dev)
+            t[7] = 0.5 * (rank + 1)
+            ctx.peer_allreduce(t)
+            ctx.synchronize()
+            want = sum(float(r + 1) * (k + 1) for r in range(world))
+            good = good and float(t[0]) == want and float(t[d]) == want and float(t[7]) == 0.5 * sum(r + 1 for r in range(world))
+        ok["primitive"] = bool(good)
+        t32 = torch.full((100,), 1.5 + rank, dtype=torch.float32, device=dev)
+        ctx.peer_allreduce(t32)
+        ctx.synchronize()
+        ok["primitive_f32"] = bool(torch.all(t32 == sum(1.5 + r for r in range(world))))
+        # (2) the fused form inside sweeps / batches / the objective: bitwise the hook path's results
+        got = workload()
+        for key in ref:
+            ok[f"bitwise_{key}"] = bool(np.array_equal(np.asarray(ref[key]), np.asarray(got[key])))
+        rav = O.full_pass(op, x)
+        av1, y1 = torch.empty_like(xd), torch.empty_like(xd)
+        ctx.proxgrad_step(F, g, 0.05 / N, xd, av1, y1)
+        ok["av_vs_oracle"] = bool(np.abs(av1.cpu().numpy() - rav).max() <= 1e-10 * np.abs(rav).max())
+        # (3) replicas stay bitwise identical across ranks
+        gathered = [torch.zeros(d, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.from_numpy(got["sweeps"]))
+        ok["bitwise_replicas"] = all(torch.equal(gathered[0], t) for t in gathered)
+        # (4) a reduction longer than the mailboxes is refused, not truncated
+        try:
+            big = torch.zeros(2 * d + 5, dtype=torch.float64, device=dev)
+            ctx.peer_allreduce(big)
+            ok["oversize_refused"] = False
+        except L.CiaoError:
+            ok["oversize_refused"] = True
+        # (5) off again: the context is a single-device context as before
+        ctx.set_peers(None)
+        pg.close()
+        solo = PackedF(L.LOSS_LS, torch.from_numpy(A).to(dev), torch.from_numpy(b).to(dev), float(N))
+        ctx.proxgrad_step(solo, g, 0.05 / N, xd, av1, y1)
+        ctx.synchronize()
+        ok["single_again"] = bool(np.abs(av1.cpu().numpy() - rav).max() <= 1e-10 * np.abs(rav).max())
+        ctx.close()
+        q.put((rank, ok))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, {"exception": repr(e) + traceback.format_exc()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_allreduce_two_ranks_on_one_gpu():
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_peer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok in res:
+        assert all(v is True for v in ok.values()), f"rank {rank}: {ok}"

@@ -128,7 +128,7 @@ def test_every_ccall_of_the_julia_module_matches_the_abi(ciao):
                   "ciao_ctx_set_stream", "ciao_ctx_timing_enable", "ciao_ctx_timing_read",   # bench instrumentation
                   "ciao_svrg_inner",             # the inner cycle alone: Base.iterate always runs whole epochs
                   "ciao_lfinito_iterate",        # index-list form: LFinito's batches are always static row blocks (_blocks form)
-                  "ciao_synth_normal", "ciao_synth_targets", "ciao_sample_batches", "ciao_sample_uniform"}   # CIAO_BENCH_API section
+                  "ciao_synth_normal", "ciao_synth_targets", "ciao_sample_batches", "ciao_sample_uniform", "ciao_peer_allreduce"}   # CIAO_BENCH_API section
     # (the Julia host draws with Julia's own RNG, as the reference does: the injected splitmix stream is the Python mirror's)
     missing = set(ciao._lib.SIGNATURES) - bound - not_needed
     assert not missing, f"the Julia module binds no ccall for {sorted(missing)}"
