@@ -1471,6 +1471,303 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Complex chains on the LDS-DMA ring.  chain_cplx_reg_kernel requests the next row ONE step ahead, so one
+// HBM miss per step is exposed (1.6 us per SVRG update at 512 complex fp64 entries against 0.27 us for the real chain).  Here
+// the rows (and SAGA / Finito table rows) travel exactly as in chain_dma_kernel -- LDS-DMA DEPTH steps ahead, hand-counted
+// vmcnt waits, indices / b_i / gamma_i / hazard flags staged 1024 steps at a time -- and only the arithmetic is complex: thread t
+// owns the 16-byte chunks t + 256 j of every (re, im)-interleaved vector (one complex entry per chunk in fp64, two in fp32), the
+// complex dot product(s) are two (four) real wave sums and one exchange of 2 (4) values per wave, formulas and operation
+// order those of chain_cplx_reg_kernel (bitwise the same results: tests).  Rows of whole 16-byte chunks up to 16 KiB.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int CDMA_CHUNK = 512;
+
+template <typename T, int J, int ALG, bool MASKED>
+__global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
+{
+    constexpr int NW = CHAIN_NW, NT = CHAIN_NT;
+    using V = typename VecOfC<T>::type;
+    constexpr int VEC = 16 / sizeof(T), PC = VEC / 2;          // reals / complex entries per chunk
+    constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
+    constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
+    constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO);
+    constexpr int DEPTH = DmaDepth<J, HAS_TABLE>::value;
+    constexpr int CH = CDMA_CHUNK;   // (half the real chains' chunk: b_i is a pair here, and two 64 KiB rings leave 32 KiB for the staging)
+    constexpr int OPS_PER_STEP = HAS_TABLE ? (MASKED ? 2 * J : 3 * J) : J;
+    constexpr int WAIT_N = (DEPTH - 1) * OPS_PER_STEP;
+    constexpr int ROW_BYTES = J * NT * 16;
+    static_assert(CH % DEPTH == 0 && WAIT_N <= 63, "ring slots line up with chunk starts; vmcnt is a 6-bit counter");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned char *ringA = dsm;
+    unsigned char *ringT = ringA + DEPTH * ROW_BYTES;
+    unsigned char *cur = ringT + (HAS_TABLE ? DEPTH * ROW_BYTES : 0);
+    int64_t *s_row = reinterpret_cast<int64_t *>(cur);
+    cur += (CH + 2 * DEPTH) * sizeof(int64_t);
+    T *s_b = reinterpret_cast<T *>(cur);           // (re, im) of b_i per step
+    cur += 2 * CH * sizeof(T);
+    T *s_g = reinterpret_cast<T *>(cur);
+    cur += (PER_SAMPLE_GAM ? CH : 0) * sizeof(T);
+    int *s_stale = reinterpret_cast<int *>(cur);
+    cur += (HAS_TABLE ? CH : 0) * sizeof(int);
+    cur += (16 - (reinterpret_cast<uintptr_t>(cur) & 15)) & 15;
+    T(*red)[NW][4] = reinterpret_cast<T(*)[NW][4]>(cur);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t d = a.d;
+    const uint32_t ringA_off = (uint32_t)(uintptr_t)ringA, ringT_off = (uint32_t)(uintptr_t)ringT;
+    const int64_t nchunks = d / VEC;
+    bool ok[J];
+    int64_t cl[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int64_t c = tid + (int64_t)j * NT;
+        ok[j] = !MASKED || c < nchunks;
+        cl[j] = ok[j] ? c : 0;
+    }
+    T *pmem = (ALG == CA_SVRG) ? a.w : a.z;
+    const bool l1 = (a.g.kind == CIAO_PROX_L1_COMPLEX);
+    auto proxc = [&](T tau, T vr, T vi, T &yr, T &yi) {
+        if (l1) {
+            prox_cpair(tau * a.g.lam, vr, vi, yr, yi);
+        } else {
+            yr = vr;
+            yi = vi;
+        }
+    };
+    V av[J], p[J], q[J], zs[J];          // q: z_full (SVRG, LFinito); zs: the SVRG accumulator z
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int64_t c = cl[j];
+        av[j] = reinterpret_cast<const V *>(a.av)[c];
+        p[j] = reinterpret_cast<const V *>(pmem)[c];
+        q[j] = TWO ? reinterpret_cast<const V *>(a.zf)[c] : V(T(0));
+        zs[j] = (ALG == CA_SVRG) ? reinterpret_cast<const V *>(a.z)[c] : V(T(0));
+        if (!ok[j]) av[j] = p[j] = q[j] = zs[j] = V(T(0));
+    }
+    auto refill = [&](int u, int64_t r) {
+        const unsigned char *ap = reinterpret_cast<const unsigned char *>(a.A + r * a.ld);
+#pragma unroll
+        for (int j = 0; j < J; ++j) glds16(ap + cl[j] * 16, ringA_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
+        if (HAS_TABLE) {
+            const unsigned char *sp = reinterpret_cast<const unsigned char *>(a.table + r * d);
+#pragma unroll
+            for (int j = 0; j < J; ++j) glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
+        }
+    };
+    int par = 0;
+    int64_t inb = 0;
+    for (int64_t base = 0; base < a.nsteps; base += CH) {
+        const int nch = (int)((a.nsteps - base) < CH ? (a.nsteps - base) : CH);
+        __syncthreads();
+        int64_t hist = -1;
+        if (tid < DEPTH && base > 0) hist = s_row[CH + tid];
+        __syncthreads();
+        if (tid < DEPTH) s_row[tid] = hist;
+        for (int e = tid; e < nch + DEPTH; e += NT) {
+            int64_t st = base + e;
+            if (st > a.nsteps - 1) st = a.nsteps - 1;
+            int64_t r = a.idx[st];
+            if ((uint64_t)r >= (uint64_t)a.N) {
+                *a.errflag = 1;
+                r = 0;
+            }
+            s_row[DEPTH + e] = r;
+            if (e < nch) {
+                s_b[2 * e] = a.b[2 * r];
+                s_b[2 * e + 1] = a.b[2 * r + 1];
+                if (PER_SAMPLE_GAM) s_g[e] = a.gam ? a.gam[r] : a.gam_uniform;
+            }
+        }
+        __syncthreads();
+        if (HAS_TABLE) {
+            for (int e = tid; e < nch; e += NT) {
+                const int64_t r = s_row[DEPTH + e];
+                bool st = false;
+#pragma unroll
+                for (int k = 1; k <= DEPTH; ++k) st |= (s_row[DEPTH + e - k] == r);
+                s_stale[e] = st ? 1 : 0;
+            }
+            __syncthreads();
+        }
+        if (base == 0) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) refill(u, uniform64(s_row[DEPTH + u]));
+        }
+        wait_vmcnt<0>();
+        drain_vmcnt_visible();
+        for (int s0 = 0; s0 < nch; s0 += DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                const int s = s0 + u;
+                if (s >= nch) break;
+                wait_vmcnt<WAIT_N>();                                   // slot u's DMA (issued DEPTH steps ago) has landed
+                V ar[J], sr[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * NW + wib) * 64 + lane) * 16);
+                    if (HAS_TABLE) sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * NW + wib) * 64 + lane) * 16);
+                    if (MASKED && !ok[j]) {
+                        ar[j] = V(T(0));
+                        if (HAS_TABLE) sr[j] = V(T(0));
+                    }
+                }
+                const int64_t row = uniform64(s_row[DEPTH + s]);
+                const int64_t row_n = uniform64(s_row[DEPTH + s + DEPTH]);
+                const T br = s_b[2 * s], bi = s_b[2 * s + 1];
+                const T gi = PER_SAMPLE_GAM ? s_g[s] : T(1);
+                if (HAS_TABLE && __builtin_amdgcn_readfirstlane(s_stale[s])) {
+                    const V *sp = reinterpret_cast<const V *>(a.table + row * d);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) sr[j] = ok[j] ? sp[cl[j]] : V(T(0));
+                    drain_vmcnt_visible();
+                }
+                if (ALG == CA_LFINITO && inb == 0) {                    // Finito_LFinito.jl:92  z = prox(av)
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+#pragma unroll
+                        for (int c = 0; c < PC; ++c) {
+                            T yr, yi;
+                            proxc(a.hat_gamma, av[j][2 * c], av[j][2 * c + 1], yr, yi);
+                            p[j][2 * c] = yr;
+                            p[j][2 * c + 1] = yi;
+                        }
+                }
+                T s1r = T(0), s1i = T(0), s2r = T(0), s2i = T(0);
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int c = 0; c < PC; ++c) {
+                        const T xr = ar[j][2 * c], xi = ar[j][2 * c + 1];
+                        s1r += xr * p[j][2 * c] - xi * p[j][2 * c + 1];
+                        s1i += xr * p[j][2 * c + 1] + xi * p[j][2 * c];
+                        if (TWO) {
+                            s2r += xr * q[j][2 * c] - xi * q[j][2 * c + 1];
+                            s2i += xr * q[j][2 * c + 1] + xi * q[j][2 * c];
+                        }
+                    }
+                s1r = wave_sum_lane63(s1r);
+                s1i = wave_sum_lane63(s1i);
+                if (TWO) {
+                    s2r = wave_sum_lane63(s2r);
+                    s2i = wave_sum_lane63(s2i);
+                }
+                if (lane == WAVE - 1) {
+                    red[par][wib][0] = s1r;
+                    red[par][wib][1] = s1i;
+                    if (TWO) {
+                        red[par][wib][2] = s2r;
+                        red[par][wib][3] = s2i;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                           // raw barrier: must not drain the DMA queue
+                const T t0 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+                const T t1 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+                T t2 = T(0), t3 = T(0);
+                if (TWO) {
+                    t2 = (red[par][0][2] + red[par][1][2]) + (red[par][2][2] + red[par][3][2]);
+                    t3 = (red[par][0][3] + red[par][1][3]) + (red[par][2][3] + red[par][3][3]);
+                }
+                par ^= 1;
+                const T rpr = t0 - br, rpi = t1 - bi;                   // residual at p
+                const T rzr = t2 - br, rzi = t3 - bi;                   // residual at z_full (TWO)
+                const bool last_of_batch = (inb + 1 == a.batch) || (base + s + 1 == a.nsteps);
+                V *sp = HAS_TABLE ? reinterpret_cast<V *>(a.table + row * d) : nullptr;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    V tv = V(T(0));
+#pragma unroll
+                    for (int c = 0; c < PC; ++c) {
+                        const T xr = ar[j][2 * c], xi = ar[j][2 * c + 1];
+                        T pr = p[j][2 * c], pi = p[j][2 * c + 1];           // (vector elements cannot be bound by reference:
+                        T avr = av[j][2 * c], avi = av[j][2 * c + 1];       //  scalar copies, written back at the end of the entry)
+                        T gpr, gpi, gzr, gzi;
+                        cgrad_elem(xr, xi, rpr, rpi, a.lam, gpr, gpi);
+                        cgrad_elem(xr, xi, rzr, rzi, a.lam, gzr, gzi);
+                        if (ALG == CA_SVRG) {                                            // SVRG_basic.jl:74-81
+                            T tr = gzr - gpr, ti = gzi - gpi;
+                            tr -= avr;
+                            ti -= avi;
+                            tr *= a.gamma;
+                            ti *= a.gamma;
+                            tr += pr;
+                            ti += pi;
+                            proxc(a.gamma, tr, ti, pr, pi);
+                            zs[j][2 * c] += pr;
+                            zs[j][2 * c + 1] += pi;
+                        } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
+                            const T s_r = sr[j][2 * c], s_i = sr[j][2 * c + 1];
+                            const T delr = (gpr - s_r) * a.invN, deli = (gpi - s_i) * a.invN;
+                            T wr, wi;
+                            if (a.sag) {
+                                avr += delr;
+                                avi += deli;
+                                wr = pr - a.gamma * avr;
+                                wi = pi - a.gamma * avi;
+                            } else {
+                                wr = pr - a.gamma * (gpr - s_r + avr);
+                                wi = pi - a.gamma * (gpi - s_i + avi);
+                                avr += delr;
+                                avi += deli;
+                            }
+                            proxc(a.gamma, wr, wi, pr, pi);
+                            tv[2 * c] = gpr;
+                            tv[2 * c + 1] = gpi;
+                        } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
+                            const T s_r = sr[j][2 * c], s_i = sr[j][2 * c + 1];
+                            const T tr = pr - (gi * a.invN) * gpr, ti = pi - (gi * a.invN) * gpi;
+                            avr += (tr - s_r) * (a.hat_gamma / gi);
+                            avi += (ti - s_i) * (a.hat_gamma / gi);
+                            tv[2 * c] = tr;
+                            tv[2 * c + 1] = ti;
+                            if (last_of_batch) proxc(a.hat_gamma, avr, avi, pr, pi);
+                        } else {                                                         // Finito_LFinito.jl:93-98
+                            const T cc = a.hat_gamma * a.invN;
+                            avr += cc * gzr;
+                            avi += cc * gzi;
+                            avr -= cc * gpr;
+                            avi -= cc * gpi;
+                            avr += (a.hat_gamma / gi) * (pr - q[j][2 * c]);
+                            avi += (a.hat_gamma / gi) * (pi - q[j][2 * c + 1]);
+                        }
+                        p[j][2 * c] = pr;
+                        p[j][2 * c + 1] = pi;
+                        av[j][2 * c] = avr;
+                        av[j][2 * c + 1] = avi;
+                    }
+                    if (HAS_TABLE && ok[j]) sp[cl[j]] = tv;
+                    if (MASKED && !ok[j]) av[j] = p[j] = zs[j] = V(T(0));   // (dead chunks: keep the state exactly zero)
+                }
+                if (++inb == a.batch) inb = 0;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this lane's LDS reads of slot u are done before the DMA overwrites it
+                refill(u, row_n);
+            }
+        }
+    }
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if (!ok[j]) continue;
+        const int64_t c = cl[j];
+        reinterpret_cast<V *>(pmem)[c] = p[j];
+        reinterpret_cast<V *>(a.av)[c] = av[j];
+        if (ALG == CA_SVRG) reinterpret_cast<V *>(a.z)[c] = zs[j];
+    }
+}
+
+template <typename T, int J, int ALG>
+constexpr size_t chain_cdma_lds_bytes()
+{
+    constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
+    constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO);
+    constexpr int DEPTH = DmaDepth<J, HAS_TABLE>::value;
+    return (size_t)DEPTH * J * CHAIN_NT * 16 * (HAS_TABLE ? 2 : 1) + (CDMA_CHUNK + 2 * DEPTH) * sizeof(int64_t) + 2 * CDMA_CHUNK * sizeof(T) +
+           (PER_SAMPLE_GAM ? CDMA_CHUNK * sizeof(T) : 0) + (HAS_TABLE ? CDMA_CHUNK * sizeof(int) : 0) + 16 + 2 * CHAIN_NW * 4 * sizeof(T);
+}
+
 template <typename T, int J, int ALG, int NT, bool SHARDED = false>
 constexpr size_t chain_dma_lds_bytes()
 {

@@ -43,6 +43,11 @@ int32_t launch_dma(ciao_ctx *ctx, int J256, bool masked, ChainArgs<T> &a);
 template <typename T, int ALG, int LOSS>
 int32_t launch_ws(ciao_ctx *ctx, int J256, bool masked, ChainArgs<T> &a);
 
+// complex chains on the LDS-DMA ring (chain_cdma_kernel): rows of whole 16-byte chunks up to 16 KiB.  Specialised in
+// chain_cdma_f32.hip / chain_cdma_f64.hip.
+template <typename T>
+int32_t launch_cdma(ciao_ctx *ctx, int alg, int J, bool masked, ChainArgs<T> &a);
+
 // ProShI agent rows (init or one batch) + finalize + epilogue.  Specialised in rows_f32.hip / rows_f64.hip.
 template <typename T>
 int32_t launch_proshi(ciao_ctx *ctx, bool init, ProshiArgs<T> &a, const Epilogue<T> &ep);
