@@ -347,4 +347,14 @@ def run(ctx, dev, quick=False):
                                               "trials_per_step": trials / max(done, 1), "kernel": ctx.last_kernel()}
     del F, table
     torch.cuda.empty_cache()
+
+    # ---- K independent SVRG chains over the same A on K streams (a regularisation path): what the idle 255 CUs give through the
+    # existing API.  The HIP runtime's hardware queues bound the concurrency (4 by default; tools/lambda_path.py with
+    # GPU_MAX_HW_QUEUES=64 reaches 16x one chain: profiles/r03_lambda_path_streams.txt)
+    if not quick:
+        try:
+            out["lambda_path_svrg_K_streams"] = lambda_path(dev, Ks=(1, 2, 4, 8, 16, 32), N=500_000, m=20_000)
+        except Exception as e:
+            out["lambda_path_svrg_K_streams"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
     return out
