@@ -324,9 +324,13 @@ def run_rank(args):
             print(f"[bench] all-reduce microbenchmark failed: {e!r}", file=sys.stderr)
         # ... and the peer exchange beside it, whatever collective the timed region used (as two kernels of its own here: the
         # sweep fuses them into finalize / epilogue and pays no launch for them).  Set up and torn down around the measurement.
+        # On real peers (backend nccl, several GPUs) this is the FIRST time the mailboxes cross xGMI: it runs after the timed region,
+        # but a fault in it would still cost the whole line, so there it needs CIAO_BENCH_PEER_PROBE=1 (or CIAO_BENCH_COLLECTIVE=peer);
+        # the one-GPU rehearsals (gloo backend, CIAO_BENCH_FORCE_DIST) always run it.
+        probe = os.environ.get("CIAO_BENCH_PEER_PROBE", "1" if (backend != "nccl" or world == 1) else "0") == "1"
         if peers is not None:
             allreduce_peer_us = allreduce_us
-        else:
+        elif probe:
             try:
                 from ciaoalgorithms_jl_amd.parallel import PeerGroup
                 saved_rccl, saved_hook = comm, hook

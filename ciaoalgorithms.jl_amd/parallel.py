@@ -203,25 +203,50 @@ class PeerGroup:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         if self.world > 8:
             raise ValueError("peer mailboxes serve one node (at most 8 ranks)")
-        own = C.c_void_p()
-        nbytes = C.c_int64(0)
-        L.check(ctx.lib.ciao_peer_mailbox_create(ctx._h, self.max_elems, C.byref(own), C.byref(nbytes)))
-        self.own = own.value
-        h = (C.c_char * 64)()
-        off = C.c_int64(0)
-        L.check(ctx.lib.ciao_ipc_export(C.c_void_p(self.own), h, C.byref(off)))
+        # Every rank takes part in every collective below whatever happened to it locally: a rank that failed (allocation, export,
+        # mapping) says so in the object it contributes, and ALL ranks raise together -- none is left waiting for another.
+        self.own, self._opened, self.mailboxes = None, [], []
+        mine, err = None, None
+        try:
+            own = C.c_void_p()
+            nbytes = C.c_int64(0)
+            L.check(ctx.lib.ciao_peer_mailbox_create(ctx._h, self.max_elems, C.byref(own), C.byref(nbytes)))
+            self.own = own.value
+            h = (C.c_char * 64)()
+            off = C.c_int64(0)
+            L.check(ctx.lib.ciao_ipc_export(C.c_void_p(self.own), h, C.byref(off)))
+            mine = (bytes(h), int(off.value))
+        except Exception as e:   # noqa: BLE001 -- reported to every rank below
+            err = repr(e)
         every = [None] * self.world
-        dist.all_gather_object(every, (bytes(h), int(off.value)), group=group)
-        self._opened, self.mailboxes = [], []
-        for r, (hr, offr) in enumerate(every):
-            if r == self.rank:
-                self.mailboxes.append(self.own)
-                continue
-            out = C.c_void_p()
-            L.check(ctx.lib.ciao_ipc_open((C.c_char * 64).from_buffer_copy(hr), offr, C.byref(out)))
-            self._opened.append((out.value, offr))
-            self.mailboxes.append(out.value)
-        dist.barrier(group=group)          # every mailbox is mapped everywhere before the first reduction writes into one
+        dist.all_gather_object(every, (mine, err), group=group)
+        if all(e[1] is None for e in every):
+            try:
+                for r, ((hr, offr), _) in enumerate(every):
+                    if r == self.rank:
+                        self.mailboxes.append(self.own)
+                        continue
+                    out = C.c_void_p()
+                    L.check(ctx.lib.ciao_ipc_open((C.c_char * 64).from_buffer_copy(hr), offr, C.byref(out)))
+                    self._opened.append((out.value, offr))
+                    self.mailboxes.append(out.value)
+            except Exception as e:   # noqa: BLE001
+                err = repr(e)
+        # second round: every mailbox is mapped everywhere (or somebody failed) before the first reduction writes into one
+        votes = [None] * self.world
+        dist.all_gather_object(votes, err if err is not None else next((e[1] for e in every if e[1] is not None), None), group=group)
+        bad = [(r, v) for r, v in enumerate(votes) if v is not None]
+        if bad:
+            self._release()
+            raise RuntimeError(f"peer mailboxes could not be set up on every rank: {bad}")
+
+    def _release(self):
+        for ptr, off in self._opened:
+            self.ctx.lib.ciao_ipc_close(C.c_void_p(ptr), off)
+        self._opened = []
+        if self.own is not None:
+            self.ctx.lib.ciao_peer_mailbox_destroy(self.ctx._h, C.c_void_p(self.own))
+            self.own = None
 
     def close(self):
         import torch.distributed as dist
@@ -230,11 +255,7 @@ class PeerGroup:
         self.ctx.synchronize()
         if dist.is_initialized():
             dist.barrier(group=self.group)   # nobody is still writing into a mailbox that is about to be unmapped / freed
-        for ptr, off in self._opened:
-            self.ctx.lib.ciao_ipc_close(C.c_void_p(ptr), off)
-        self._opened = []
-        self.ctx.lib.ciao_peer_mailbox_destroy(self.ctx._h, C.c_void_p(self.own))
-        self.own = None
+        self._release()
 
 
 class RcclComm:
