@@ -1011,6 +1011,10 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
     // dependent path.  It costs one step of DMA lead, hence only with DEPTH >= 4.
     constexpr bool PIPE = DEPTH >= 4;
     constexpr int WAIT_N = (PIPE ? DEPTH - 2 : DEPTH - 1) * OPS_PER_STEP;
+    // four waves: the ring's refill is issued in the shadow of the exchange (between the partial reads' issue and their wait) --
+    // unless it is eight DMA instructions (table + row of 16 KiB): those outlast the shadow and are better left at the end of the
+    // step (Finito r = 1 at d = 4096 fp32: 0.87 us there, 1.04 in the shadow)
+    constexpr bool SHADOW_REFILL = (NW == 4) && (!HAS_TABLE || J <= 2);
     constexpr int ROW_BYTES = J * NT * 16;
     static_assert(!SHARDED || ALG == CA_SVRG || ALG == CA_SAGA, "only the SVRG and SAGA chains run over a shard table");
     // Chains without a table (SVRG, LFinito) need a step's row only as an ADDRESS: the staged entry is the row's address
@@ -1303,7 +1307,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                     constexpr bool SINGLE64 = (sizeof(T) == 8 && !TWO);
                     V rv[SINGLE64 ? 2 : (int)(NW * 2 * sizeof(T) / 16)];
                     if constexpr (SINGLE64) xchg_issue_single64(raddr, rv); else xchg_issue(raddr, rv);
-                    if (!(CIAO_CHAIN_DBG & 1)) refill(u, row_n, ptr_n);
+                    if (SHADOW_REFILL && !(CIAO_CHAIN_DBG & 1)) refill(u, row_n, ptr_n);
                     if (SVRG_ANY) {
                         if (u > 0 || s0 > 0 || base > 0) {   // compile-time true except in the first step of a ring revolution
 #pragma unroll
@@ -1423,7 +1427,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 if (++inb == a.batch) inb = 0;
                 // one or eight waves: the refill at the end of the step (four waves: in the exchange's shadow, above -- a table row
                 // it fetches that this step is about to rewrite is flagged stale either way: the flag compares DEPTH steps back)
-                if (!(NW == 4 && !(CIAO_CHAIN_DBG & 2)) && !(CIAO_CHAIN_DBG & 1)) refill(u, row_n, ptr_n);
+                if (!(SHADOW_REFILL && !(CIAO_CHAIN_DBG & 2)) && !(CIAO_CHAIN_DBG & 1)) refill(u, row_n, ptr_n);
             }
         };
         // the run-time flags become compile-time tags of the group (SAG only exists for the SAGA chain)

@@ -591,7 +591,7 @@ def test_packing_rows_from_a_host_matrix_stream(api, ctx, tmp_path):
         assert x.dtype == R and it == 4 and np.isfinite(x).all()
     with pytest.raises(ValueError):
         ops.pack_rows_from_host(iter([(ro[:10], b[:10])]), N, d, np.float64)
-    with pytest.raises(TypeError, match=r"no\s+host fallback|no host fallback"):
+    with pytest.raises(ops.UnpackableOperator, match=r"no SILENT host route"):      # (a TypeError; fallback="host" is the explicit route)
         S.SVRG(np.float64, γ=0.1, maxit=2)(np.zeros(d), F=[object()] * 3, N=3, ctx=ctx)
 
 
