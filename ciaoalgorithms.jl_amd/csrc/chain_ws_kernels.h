@@ -32,9 +32,13 @@
 // `s_waitcnt vmcnt(K*J)` after its stores means its stores of K steps ago have been written (stores are its only vector-memory
 // operations, so the counter is theirs), hence "step s complete" implies every table store of steps <= s-2-K is in memory, and
 // a table row DMA issued when C steps were complete is fresh unless the row was a sample of steps [C-1-K, t).  The stager
-// flags every step whose row occurs among the previous R+K+1 steps (a superset); a flagged step ignores its ring slot and
+// flags every step whose row occurs among the previous R+K+3 steps (a superset: +1 for the deferred store, +2 of margin); a flagged step ignores its ring slot and
 // re-reads the row: each thread reads back the bytes it stored itself, in program order (as chain_dma_kernel does).
-// The arithmetic of a step is chain_dma_kernel's, operation for operation: results are bitwise identical (tests).
+// The arithmetic of a step is chain_dma_kernel's, operation for operation: results are bitwise identical (tests; tools/ws_soak.py:
+// 2 x 10^7 steps, the whole 8 GB table).  What a step leaves behind that the next dot product does not need -- the table row's
+// store, SVRG's z += w -- is issued in the NEXT step's exchange, between the poll's issue and its wait.
+// Dispatch (chain_launch.inc): SAGA / SAG on rows of 2-8 KiB.  The kernel also instantiates for SVRG (it was measured: 10 % slower
+// than chain_dma_kernel there, profiles/r03_chain_step_instruction_classes.md), which is why those units are not built.
 #pragma once
 
 #include "chain_kernels.h"
@@ -105,6 +109,7 @@ __device__ __forceinline__ void ws_spin(unsigned int &spins, int *errflag)
 {
     if (++spins > WS_SPIN_LIMIT) {
         *errflag = 3;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // an issuer's LDS-DMA in flight must have landed before its wave is gone
         __builtin_amdgcn_endpgm();
     }
 }
