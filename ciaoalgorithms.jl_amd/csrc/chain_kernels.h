@@ -1293,6 +1293,10 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                     for (int j = 0; j < J; ++j) {
                         q1[j] = a.gamma * x.ar[j];
                         q2[j] = p[j] - gav[j];
+                        // four waves: computed HERE, before the barrier (the empty asm is volatile and stays in front of the
+                        // volatile wait below; hipcc otherwise sinks half of these eight instructions behind the exchange,
+                        // onto the dependent path)
+                        if constexpr (NW == 4) asm volatile("" : "+v"(q1[j]), "+v"(q2[j]));
                     }
                 }
                 if constexpr (NW == 4 && !(CIAO_CHAIN_DBG & 2)) {
