@@ -30,12 +30,14 @@ def _timed(ctx, fn, reps=1):
     return (time.perf_counter() - t0) / reps
 
 
-def lambda_path(dev, Ks=(1, 2, 4, 8, 16, 32, 64, 128, 256), N=1_000_000, d=1024, m=40_000, alg="svrg"):
-    """K independent chains over the SAME data matrix, one context (= one HIP stream) each: a regularisation path (K values of
-    lambda) of SVRG inner cycles, or of SAGA solves with a table each.  A chain is one workgroup on one CU and is latency-bound
-    (25-30 GB/s); K of them run side by side as far as the HIP runtime gives the streams hardware queues of their own
-    (GPU_MAX_HW_QUEUES, read when the runtime starts).  Returns the aggregate updates/s per K with its fraction of the HBM
-    bound (d*s+8 bytes per SVRG update, 3*d*s+8 per SAGA update)."""
+def lambda_path(dev, Ks=(1, 2, 4, 8, 16, 32, 64, 128, 256), N=1_000_000, d=1024, m=40_000, alg="svrg", mode="streams"):
+    """K independent chains over the SAME data matrix: a regularisation path (K values of lambda, an index stream each) of SVRG
+    inner cycles, or of SAGA solves with a table each.  A chain is one workgroup on one CU and is latency-bound (25-30 GB/s).
+    mode "streams": one context (= one HIP stream) per chain -- they run side by side as far as the HIP runtime gives the streams
+    hardware queues of their own (GPU_MAX_HW_QUEUES, read when the runtime starts).  mode "batch": one context, the K calls
+    recorded and launched as ONE grid of K workgroups (Context.chain_batch; include/ciao_hip.h ciao_ctx_chain_batch_begin).
+    Returns the aggregate updates/s per K with its fraction of the HBM bound (d*s+8 bytes per SVRG update,
+    3*d*s+8 per SAGA update)."""
     from ciaoalgorithms_jl_amd import _lib as L
     from ciaoalgorithms_jl_amd.device import Context, ProxG
     from ciaoalgorithms_jl_amd.sampling import IndexStream
@@ -45,13 +47,12 @@ def lambda_path(dev, Ks=(1, 2, 4, 8, 16, 32, 64, 128, 256), N=1_000_000, d=1024,
     F = _problem(boot, dev, N, d, tdt, alg != "svrg")
     boot.synchronize()
     x0 = torch.zeros(d, dtype=tdt, device=dev) if alg == "svrg" else torch.ones(d, dtype=tdt, device=dev)
-    hidx = IndexStream(0).rand_indices(N, m)
-    idx = boot._idx(hidx)
-    gamma = 1.0 / (7 * 1.3 * N) if alg == "svrg" else 1.0 / (3 * 0.25 * 1.3)
     Kmax = max(Ks)
+    idxs = [boot._idx(IndexStream(k).rand_indices(N, m)) for k in range(Kmax)]
+    gamma = 1.0 / (7 * 1.3 * N) if alg == "svrg" else 1.0 / (3 * 0.25 * 1.3)
     chains = []
     for k in range(Kmax):
-        c = Context(dev.index, stream=torch.cuda.Stream(device=dev))
+        c = Context(dev.index, stream=torch.cuda.Stream(device=dev)) if mode == "streams" else boot
         g = ProxG(L.PROX_L1, lam=(1e-3 if alg == "svrg" else 1.0 / N) * (1.0 + k / Kmax))
         if alg == "svrg":
             st = tuple(torch.empty_like(x0) for _ in range(4))
@@ -70,26 +71,32 @@ def lambda_path(dev, Ks=(1, 2, 4, 8, 16, 32, 64, 128, 256), N=1_000_000, d=1024,
         else:
             c.saga_steps(F, g, gamma, False, ix, tab, *st)
 
-    for c, g, st, tab in chains:
-        launch(c, g, st, tab, idx[:512])
+    for k, (c, g, st, tab) in enumerate(chains):
+        launch(c, g, st, tab, idxs[k][:512])
     torch.cuda.synchronize(dev)
     bytes_per = (d * es + 8) if alg == "svrg" else (3 * d * es + 8)
     curve = []
     for K in Ks:
         t0 = time.perf_counter()
-        for c, g, st, tab in chains[:K]:
-            launch(c, g, st, tab, idx)
+        if mode == "batch":
+            with boot.chain_batch():
+                for k, (c, g, st, tab) in enumerate(chains[:K]):
+                    launch(c, g, st, tab, idxs[k])
+        else:
+            for k, (c, g, st, tab) in enumerate(chains[:K]):
+                launch(c, g, st, tab, idxs[k])
         torch.cuda.synchronize(dev)
         t = time.perf_counter() - t0
         agg = K * m / t
         curve.append({"K": K, "updates_per_s": agg, "us_per_update_per_chain": t / m * 1e6, "alg_GBps": agg * bytes_per / 1e9,
                       "frac_of_hbm_bound": agg * bytes_per / 8e12})
     kern = chains[0][0].last_kernel()
-    for c, _, _, _ in chains:
-        c.close()
+    if mode == "streams":
+        for c, _, _, _ in chains:
+            c.close()
     boot.close()
     import os
-    return {"alg": alg, "N": N, "d": d, "dtype": "f64" if es == 8 else "f32", "m_per_chain": m, "kernel": kern,
+    return {"alg": alg, "mode": mode, "N": N, "d": d, "dtype": "f64" if es == 8 else "f32", "m_per_chain": m, "kernel": kern,
             "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default"), "curve": curve}
 
 
@@ -368,5 +375,11 @@ def run(ctx, dev, quick=False):
             out["lambda_path_svrg_K_streams"] = lambda_path(dev, Ks=(1, 2, 4, 8, 16, 32), N=500_000, m=20_000)
         except Exception as e:
             out["lambda_path_svrg_K_streams"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        # ... and as ONE launch of K workgroups (Context.chain_batch): every CU runs a chain
+        try:
+            out["lambda_path_svrg_K_batched"] = lambda_path(dev, Ks=(1, 16, 64, 256, 1024), N=500_000, m=20_000, mode="batch")
+        except Exception as e:
+            out["lambda_path_svrg_K_batched"] = {"error": repr(e)}
         torch.cuda.empty_cache()
     return out

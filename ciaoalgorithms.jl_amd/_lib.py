@@ -91,6 +91,8 @@ SIGNATURES = {
     "ciao_peer_mailbox_create": (_i32, [_vp, _i64, C.POINTER(C.c_void_p), C.POINTER(_i64)]),
     "ciao_peer_mailbox_destroy": (_i32, [_vp, _vp]),
     "ciao_ctx_set_peers": (_i32, [_vp, _i32, _i32, C.POINTER(C.c_void_p), _i64]),
+    "ciao_ctx_chain_batch_begin": (_i32, [_vp]),
+    "ciao_ctx_chain_batch_end": (_i32, [_vp, _i32]),
     "ciao_saga_init": (_i32, [_vp, _PP, _GP, _f64, _vp, _vp, _vp, _vp]),
     "ciao_saga_steps": (_i32, [_vp, _PP, _GP, _f64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "ciao_hat_gamma": (_i32, [_vp, _i32, _i64, _vp, C.POINTER(_f64)]),

@@ -912,6 +912,9 @@ int32_t ciao_ctx_destroy(ciao_ctx *ctx)
     if (ctx->scal) (void)hipFree(ctx->scal);
     if (ctx->errflag) (void)hipFree(ctx->errflag);
     if (ctx->peer_counter) (void)hipFree(ctx->peer_counter);
+    if (ctx->batch_dev) (void)hipFree(ctx->batch_dev);
+    if (ctx->batch_host) (void)hipHostFree(ctx->batch_host);
+    if (ctx->batch_ev) (void)hipEventDestroy(ctx->batch_ev);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     delete ctx;
     return CIAO_OK;
@@ -1096,6 +1099,91 @@ int32_t ciao_peer_allreduce(ciao_ctx *ctx, int32_t dtype, int64_t count, void *b
     return st == 0 ? CIAO_OK : (st < 0 ? st : CIAO_ERR_HOOK);
 }
 
+// ---- a batch of independent chains in one launch per kernel ---------------------------------------------------------------
+int32_t ciao_ctx_chain_batch_begin(ciao_ctx *ctx)
+{
+    CIAO_ENTER(ctx);   // (refuses a second begin)
+    ctx->batch.clear();
+    ctx->batch_open = 1;
+    return CIAO_OK;
+}
+
+int32_t ciao_ctx_chain_batch_end(ciao_ctx *ctx, int32_t launch)
+{
+    CIAO_ENTER_BATCHABLE(ctx);
+    CIAO_REQUIRE(ctx->batch_open, "no chain batch is open on this ctx");
+    ctx->batch_open = 0;
+    std::vector<ciao_chain_rec> recs;
+    recs.swap(ctx->batch);
+    if (!launch || recs.empty()) return CIAO_OK;
+    const size_t K = recs.size();
+    // No chain may write what another one touches: sort the state ranges by their start and compare each with the ones that begin
+    // inside it (read-only ranges -- a shared z_full, say -- may overlap)
+    {
+        struct Rg { const unsigned char *lo, *hi; bool wr; size_t chain; };
+        std::vector<Rg> rg;
+        rg.reserve(K * 5);
+        for (size_t c = 0; c < K; ++c)
+            for (int k = 0; k < 5; ++k)
+                if (recs[c].hi[k] > recs[c].lo[k]) rg.push_back({recs[c].lo[k], recs[c].hi[k], recs[c].wr[k], c});
+        std::sort(rg.begin(), rg.end(), [](const Rg &x, const Rg &y) { return x.lo < y.lo; });
+        for (size_t i = 0; i < rg.size(); ++i)
+            for (size_t j = i + 1; j < rg.size() && rg[j].lo < rg[i].hi; ++j)
+                if (rg[i].chain != rg[j].chain && (rg[i].wr || rg[j].wr)) {
+                    set_error("chains %zu and %zu of the batch overlap in a state vector / table that one of them writes: the chains of a "
+                              "batch run concurrently and must own their av / z / w (SVRG: w, z; SAGA: z, av, table)", rg[i].chain, rg[j].chain);
+                    return CIAO_ERR_ARG;
+                }
+    }
+    // group by kernel (first appearance first); the argument blocks of a group are contiguous in the staging buffer
+    std::vector<std::vector<size_t>> groups;
+    for (size_t c = 0; c < K; ++c) {
+        size_t gi = 0;
+        for (; gi < groups.size(); ++gi) {
+            const ciao_chain_rec &f = recs[groups[gi][0]];
+            if (f.kern == recs[c].kern && f.block == recs[c].block && f.lds == recs[c].lds && f.args.size() == recs[c].args.size()) break;
+        }
+        if (gi == groups.size()) groups.emplace_back();
+        groups[gi].push_back(c);
+    }
+    size_t total = 0;
+    for (const auto &g : groups) total += (g.size() * recs[g[0]].args.size() + 255) & ~(size_t)255;
+    CIAO_TRY(ensure(ctx, &ctx->batch_dev, &ctx->batch_dev_bytes, total));
+    if (!ctx->batch_ev) CIAO_HIP(hipEventCreateWithFlags(&ctx->batch_ev, hipEventDisableTiming));
+    CIAO_HIP(hipEventSynchronize(ctx->batch_ev));   // the previous batch's staging copy has been read (no-op for a fresh event)
+    if (ctx->batch_host_bytes < total) {
+        if (ctx->batch_host) (void)hipHostFree(ctx->batch_host);
+        ctx->batch_host = nullptr;
+        ctx->batch_host_bytes = 0;
+        CIAO_HIP(hipHostMalloc(&ctx->batch_host, total, hipHostMallocDefault));
+        ctx->batch_host_bytes = total;
+    }
+    std::vector<size_t> off(groups.size());
+    size_t at = 0;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        off[gi] = at;
+        const size_t ab = recs[groups[gi][0]].args.size();
+        for (size_t k = 0; k < groups[gi].size(); ++k)
+            memcpy(static_cast<unsigned char *>(ctx->batch_host) + at + k * ab, recs[groups[gi][k]].args.data(), ab);
+        at += (groups[gi].size() * ab + 255) & ~(size_t)255;
+    }
+    CIAO_HIP(hipMemcpyAsync(ctx->batch_dev, ctx->batch_host, total, hipMemcpyHostToDevice, ctx->stream));
+    CIAO_HIP(hipEventRecord(ctx->batch_ev, ctx->stream));
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        ciao_chain_rec &f = recs[groups[gi][0]];
+        // the by-value argument: the first chain's block with `multi` (its first field, whatever T) -> this group's blocks
+        const void *multi = static_cast<unsigned char *>(ctx->batch_dev) + off[gi];
+        memcpy(f.args.data(), &multi, sizeof multi);
+        void *kargs[1] = {f.args.data()};
+        CIAO_HIP(hipLaunchKernel(f.kern, dim3((unsigned)groups[gi].size()), dim3(f.block), kargs, f.lds, ctx->stream));
+    }
+    char nm[256];
+    snprintf(nm, sizeof nm, "chain batch: %zu chains in %zu launch(es); first: %s grid=%zu", K, groups.size(),
+             recs[groups[0][0]].name.c_str(), groups[0].size());
+    ctx->last_kernel = nm;
+    return CIAO_OK;
+}
+
 int32_t ciao_ctx_set_monitor(ciao_ctx *ctx, const ciao_prox_desc *g, double *obj_dev)
 {
     CIAO_ENTER(ctx);
@@ -1118,8 +1206,10 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "split_max_rows")) {
         CIAO_REQUIRE(value >= -1, "split_max_rows must be >= -1");
         ctx->split_max_rows = value;
-    } else if (!strcmp(key, "chain_dbg_ptr")) {   // timing builds (tools/chain_stamps.py): device int64[24]
+#ifdef CIAO_WS_DBG   // experiment builds only (EXTRA=-DCIAO_WS_DBG=1): device int64[8 waves][8] for chain_ws_kernel's cycle sums
+    } else if (!strcmp(key, "chain_dbg_ptr")) {
         ctx->chain_dbg = reinterpret_cast<long long *>((uintptr_t)value);
+#endif
     } else if (!strcmp(key, "small_i")) {
         CIAO_REQUIRE(value == 0 || value == 8 || value == 16, "small_i must be 0, 8 or 16");
         ctx->small_i = value;
@@ -1339,7 +1429,8 @@ int32_t ciao_svrg_init(ciao_ctx *ctx, const ciao_problem *p, const void *x0, voi
 int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
                         const int64_t *idx, const void *av, void *z, const void *z_full, void *w)
 {
-    CIAO_ENTER(ctx);
+    CIAO_ENTER_BATCHABLE(ctx);
+    CIAO_REQUIRE(!ctx->batch_open || (!ctx->hook && ctx->shards.nshards == 0), "a chain batch cannot run on a row-sharded problem");
     const void *keep = ctx->rowdot_A;
     CIAO_TRY(check_problem(ctx, p));
     ctx->rowdot_A = keep;   // z_full is read-only here: a following ciao_svrg_iterate may still reuse the row dots
@@ -1391,7 +1482,8 @@ int32_t ciao_saga_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_des
 int32_t ciao_saga_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int32_t sag,
                         int64_t nsteps, const int64_t *idx, void *table, void *av, void *z)
 {
-    CIAO_ENTER(ctx);
+    CIAO_ENTER_BATCHABLE(ctx);
+    CIAO_REQUIRE(!ctx->batch_open || (!ctx->hook && ctx->shards.nshards == 0), "a chain batch cannot run on a row-sharded problem");
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
     CIAO_TRY(check_pair(p, g));

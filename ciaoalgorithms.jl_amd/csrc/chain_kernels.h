@@ -28,6 +28,10 @@ enum ChainAlg {
 
 template <typename T>
 struct ChainArgs {
+    // A batch of independent chains in ONE launch (ciao_ctx_chain_batch_begin / _end): workgroup k runs multi[k] (device memory) and
+    // everything else of the by-value argument is ignored.  nullptr: the one chain described by the fields below.  First field,
+    // so that the host can patch it into a recorded argument block whatever T is.
+    const ChainArgs<T> *multi;
     const T *A;
     const T *b;
     int64_t ld, d;
@@ -46,7 +50,7 @@ struct ChainArgs {
     T *av, *z, *zf, *w;
     int64_t N;             // rows the indices may address (index validation): local rows, or N_total with a shard table
     int *errflag;          // device word set to 1 on an out-of-range index
-    long long *dbg;        // CIAO_CHAIN_DBG & 8 builds only: [wave][6] cycle sums (option "chain_dbg_ptr")
+    long long *dbg;        // CIAO_WS_DBG experiment builds only: [wave][8] cycle sums of chain_ws_kernel (option "chain_dbg_ptr")
     // Row-sharded problem (ciao_ctx_set_shards; SURVEY.md 8e "one chain on one GPU pulling remote rows over xGMI"): the rows
     // live in nshards allocations, shard k = global rows [sh_row0[k], sh_row0[k+1]); the pointers may be peer-mapped memory of
     // other GPUs.  idx then holds GLOBAL rows.  nshards = 0: A / b / table above are the whole problem.
@@ -56,6 +60,28 @@ struct ChainArgs {
     T *shT[CIAO_MAX_SHARDS];
     int64_t sh_row0[CIAO_MAX_SHARDS + 1];
 };
+
+// A batch of chains (ChainArgs::multi): workgroup k takes its own argument block.  Word by word through v_readfirstlane, so that
+// every field is in scalar registers exactly as a kernel argument would be (the inline asm of the chain kernels names SGPRs).
+template <typename T>
+__device__ __forceinline__ void chain_args_fetch(ChainArgs<T> &a)
+{
+    static_assert(sizeof(ChainArgs<T>) % 4 == 0, "whole dwords");
+    if (!a.multi) return;
+    const unsigned int *src = reinterpret_cast<const unsigned int *>(a.multi + blockIdx.x);
+    unsigned int w[sizeof(ChainArgs<T>) / 4];
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(ChainArgs<T>) / 4; ++i) w[i] = (unsigned int)__builtin_amdgcn_readfirstlane((int)src[i]);
+    __builtin_memcpy(&a, w, sizeof a);
+    // pointers read from memory are generic to the compiler (flat loads / stores, which count on BOTH memory counters and break
+    // the hand-counted waits): say that they are global, as it knows of a kernel argument's
+    auto glob = [](auto *&p) {
+        using P = std::remove_reference_t<decltype(*p)>;
+        p = (P *)(__attribute__((address_space(1))) P *)(uintptr_t)p;
+    };
+    glob(a.A), glob(a.b), glob(a.idx), glob(a.gam), glob(a.table), glob(a.g.lo_vec), glob(a.g.hi_vec);
+    glob(a.av), glob(a.z), glob(a.zf), glob(a.w), glob(a.errflag), glob(a.dbg);
+}
 
 // global row -> (shard, local row) for the contiguous block partition; all values wave-uniform
 template <typename T>
@@ -92,7 +118,7 @@ struct VecOfC<double> {
 };
 
 #ifndef CIAO_CHAIN_DBG
-#define CIAO_CHAIN_DBG 0   // timing experiments only (tools/chain_probe.sh, EXP= builds; results are WRONG): 1 = no ring refill, 2 = no cross-wave
+#define CIAO_CHAIN_DBG 0   // timing experiments only (EXP= builds, tools/exp_build.sh; results are WRONG): 1 = no ring refill, 2 = no cross-wave
                            // exchange, 4 = no element-wise update
 #endif
 
@@ -990,8 +1016,16 @@ struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at 0.4-0.9 u
 // while staging and kept in LDS, table rows are addressed through the shard table.  A separate instantiation, so that the
 // single-allocation chain keeps its instruction count (an always-present shard search cost it 0.07 us per SAGA step).
 template <typename T, int J, int ALG, int LOSS, bool MASKED, int NT, bool SHARDED = false>
-__global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
+__global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
 {
+    // a batch of chains: this workgroup's own argument block.  (`a` is a private copy whose fields all end up in scalar registers;
+    // what is indexed per LANE -- the shard table, never part of a batch -- is read from the kernel argument itself.)
+#ifdef CIAO_NO_CHAIN_BATCH   // A/B experiment builds only: the kernel argument used in place (batches then run chain 0 K times)
+    const ChainArgs<T> &a = a_in;
+#else
+    ChainArgs<T> a = a_in;
+    chain_args_fetch(a);
+#endif
     constexpr int NW = NT / WAVE;
     static_assert(NW == 1 || NW == 4 || NW == 8, "one, four or eight waves");
     using V = typename VecOfC<T>::type;
@@ -1056,6 +1090,8 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
     // chunk ownership: thread t owns 16-byte chunks t + 256*j; with MASKED those at or beyond the row's end are dead (their
     // state stays zero, their loads are redirected to chunk 0 and discarded, their stores are predicated off)
     const int64_t nchunks = d / VEC;
+    T box_lo = a.g.lo, box_hi = a.g.hi;   // as VALUES (a select between "&a.g.lo" and the bound vector would keep `a` in memory)
+    asm volatile("" : "+v"(box_lo), "+v"(box_hi));
     bool ok[J];
     int64_t cl[J];   // chunk to address: own chunk, or 0 when dead
 #pragma unroll
@@ -1086,8 +1122,8 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
             plo[j][v] = -INFINITY;
             phi[j][v] = INFINITY;
             if (a.g.kind == CIAO_PROX_BOX && ok[j]) {   // dead chunks keep -inf/+inf: their zeros stay zeros
-                plo[j][v] = a.g.lo_vec ? a.g.lo_vec[c * VEC + v] : a.g.lo;
-                phi[j][v] = a.g.hi_vec ? a.g.hi_vec[c * VEC + v] : a.g.hi;
+                plo[j][v] = a.g.lo_vec ? a.g.lo_vec[c * VEC + v] : box_lo;
+                phi[j][v] = a.g.hi_vec ? a.g.hi_vec[c * VEC + v] : box_hi;
             }
         }
     }
@@ -1109,7 +1145,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 glds16s(ap, (uint32_t)cl[j] * 16u, ringA_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
         }
         if (HAS_TABLE) {
-            const unsigned char *sp = reinterpret_cast<const unsigned char *>(table_row<SHARDED>(a, r));
+            const unsigned char *sp = reinterpret_cast<const unsigned char *>(table_row<SHARDED>(SHARDED ? a_in : a, r));
 #pragma unroll
             for (int j = 0; j < J; ++j)
                 glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
@@ -1165,9 +1201,9 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
             const T *arow, *bp;
             if (SHARDED) {   // global row -> (shard, local row): the shard's base may be another GPU's memory
                 int64_t local;
-                const int k = shard_of(a, r, local);
-                arow = a.shA[k] + local * a.ld;
-                bp = a.shb[k] ? a.shb[k] + local : nullptr;
+                const int k = shard_of(a_in, r, local);
+                arow = a_in.shA[k] + local * a.ld;
+                bp = a_in.shb[k] ? a_in.shb[k] + local : nullptr;
             } else {
                 arow = a.A + r * a.ld;
                 bp = a.b ? a.b + r : nullptr;
@@ -1249,7 +1285,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                 if (HAS_TABLE && __builtin_amdgcn_readfirstlane(x.stale)) {
                     // an intervening step rewrote this table row after its DMA was issued: re-read it from memory (this
                     // very thread stored these bytes, so program order makes them visible)
-                    const V *sp = reinterpret_cast<const V *>(table_row<SHARDED>(a, row));
+                    const V *sp = reinterpret_cast<const V *>(table_row<SHARDED>(SHARDED ? a_in : a, row));
 #pragma unroll
                     for (int j = 0; j < J; ++j) x.sr[j] = ok[j] ? sp[cl[j]] : V(T(0));
                     drain_vmcnt_visible();   // retire it HERE, or hipcc puts a draining vmcnt(0) on the common path
@@ -1371,7 +1407,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                                 if (!(NW == 4 && !(CIAO_CHAIN_DBG & 2))) zs[j][v] += p[j][v];   // four waves: in the next step's exchange shadow
                             }
                     } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
-                        V *sp = reinterpret_cast<V *>(table_row<SHARDED>(a, row));
+                        V *sp = reinterpret_cast<V *>(table_row<SHARDED>(SHARDED ? a_in : a, row));
                         const T gl = a.gamma * plam;
                         const T cp = gp.coef();
                         const T ngam = -a.gamma;
@@ -1395,7 +1431,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a)
                         const T gi = x.gi;
                         const T ncc = -(gi * a.invN) * gp.coef();   // t = z - (gamma_i/N) * c * a
                         const T rr = a.hat_gamma / gi;
-                        V *sp = reinterpret_cast<V *>(table_row<SHARDED>(a, row));
+                        V *sp = reinterpret_cast<V *>(table_row<SHARDED>(SHARDED ? a_in : a, row));
     #pragma unroll
                         for (int j = 0; j < J; ++j) {
                             V tv;

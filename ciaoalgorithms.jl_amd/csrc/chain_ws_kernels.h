@@ -202,7 +202,7 @@ __device__ __forceinline__ void gstore16s(void *sbase, uint32_t voff, V data)
 }
 
 #ifndef CIAO_WS_DBG
-#define CIAO_WS_DBG 0   // timing experiments only: 1 = per-wave cycle sums and spin counts into ChainArgs::dbg [wave][8] (tools/ws_stamps.py);
+#define CIAO_WS_DBG 0   // timing experiments only: 1 = per-wave cycle sums and spin counts into ChainArgs::dbg [wave][8] (read back through option "chain_dbg_ptr");
                         // 2 = the issuers issue no DMA (WRONG results: what the consumers alone would do)
 #endif
 

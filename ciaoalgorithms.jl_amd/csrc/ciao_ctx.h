@@ -10,6 +10,17 @@
 #define CIAO_BENCH_API 1
 #include "../../include/ciao_hip.h"
 
+// one recorded chain of an open batch (ciao_ctx_chain_batch_begin): the launch it would have been
+struct ciao_chain_rec {
+    const void *kern = nullptr;          // the kernel (host function pointer)
+    unsigned block = 0;
+    size_t lds = 0;
+    std::vector<unsigned char> args;     // its ChainArgs<T>
+    const unsigned char *lo[5] = {}, *hi[5] = {};   // byte ranges of av, z, z_full, w, table ...
+    bool wr[5] = {};                                //   ... and whether the chain writes them
+    std::string name;
+};
+
 struct ciao_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -79,13 +90,23 @@ struct ciao_ctx {
     int chain_last_one_wave = 0;    // E of the single-wave register-ring chain the last launch took, 0 = four waves
     int chain_last_dma = 0;
     bool chain_last_masked = false;
-    long long *chain_dbg = nullptr;   // timing builds only (CIAO_CHAIN_DBG & 8): device buffer for cycle stamps
+    long long *chain_dbg = nullptr;   // experiment builds only (CIAO_WS_DBG): device buffer for chain_ws_kernel's cycle sums
 #ifdef CIAO_EXP_GRAPH_BATCHES
     int64_t graph_batches = 0;      // experiment builds only: capture runs of batch-parallel Finito batches as one graph (api.hip)
 #endif
     int64_t force_generic = 0;      // testing: route every rows launch through the generic kernel
 
     std::string last_kernel;
+
+    // a batch of independent chains for one launch per kernel (ciao_ctx_chain_batch_begin / _end): while open, the chain entry
+    // points record instead of launching
+    int batch_open = 0;
+    std::vector<ciao_chain_rec> batch;
+    void *batch_dev = nullptr;           // the launched batch's argument blocks (device) ...
+    size_t batch_dev_bytes = 0;
+    void *batch_host = nullptr;          // ... and their pinned staging copy
+    size_t batch_host_bytes = 0;
+    hipEvent_t batch_ev = nullptr;       // the staging copy of the previous batch has been read
 
     // optional HIP-event timing of the dominant kernel (bench.py roofline)
     bool timing = false;
@@ -138,8 +159,14 @@ struct DeviceGuard {
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
-#define CIAO_ENTER(ctx)                     \
+// (while a chain batch is open only the entry points that record into it -- CIAO_ENTER_BATCHABLE -- may be called)
+#define CIAO_ENTER_BATCHABLE(ctx)           \
     CIAO_REQUIRE((ctx), "ctx is NULL");     \
+    ::ciao::DeviceGuard _ciao_dg((ctx)->device)
+#define CIAO_ENTER(ctx)                                                                                                           \
+    CIAO_REQUIRE((ctx), "ctx is NULL");                                                                                           \
+    CIAO_REQUIRE(!(ctx)->batch_open, "a chain batch is open on this ctx (ciao_ctx_chain_batch_begin): only ciao_svrg_inner and "  \
+                                     "ciao_saga_steps may be called before ciao_ctx_chain_batch_end");                            \
     ::ciao::DeviceGuard _ciao_dg((ctx)->device)
 
 }  // namespace ciao

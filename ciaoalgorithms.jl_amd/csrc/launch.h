@@ -23,6 +23,37 @@ inline PeerDev peer_dev(ciao_ctx *ctx)
     return p;
 }
 
+// An open chain batch (ciao_ctx_chain_batch_begin): the launch of a chain kernel is RECORDED -- kernel, block, LDS, argument block,
+// the byte ranges of its state and which of them it writes -- and made by ciao_ctx_chain_batch_end, one launch per kernel with one
+// workgroup per chain.  Only the chains without a Finito batch structure are taken (SVRG inner cycles, SAGA / SAG steps).
+template <typename T, int ALG>
+inline int32_t chain_batch_record(ciao_ctx *ctx, const void *kern, unsigned block, size_t lds, const ChainArgs<T> &a)
+{
+    constexpr bool svrg = (ALG == CA_SVRG || ALG == CA_SVRGC);
+    if (!(svrg || ALG == CA_SAGA) || a.nshards > 0) {
+        set_error("a chain batch takes SVRG inner cycles and SAGA / SAG steps of unsharded problems only");
+        return CIAO_ERR_UNSUPPORTED;
+    }
+    ciao_chain_rec r;
+    r.kern = kern;
+    r.block = block;
+    r.lds = lds;
+    r.args.assign(reinterpret_cast<const unsigned char *>(&a), reinterpret_cast<const unsigned char *>(&a) + sizeof a);
+    const size_t vb = (size_t)a.d * sizeof(T);
+    auto range = [&](int k, const void *p, size_t bytes, bool w) {
+        r.lo[k] = static_cast<const unsigned char *>(p);
+        r.hi[k] = p ? r.lo[k] + bytes : r.lo[k];
+        r.wr[k] = w;
+    };
+    range(0, a.av, vb, !svrg);
+    range(1, a.z, vb, true);
+    range(2, a.zf, vb, false);
+    range(3, a.w, vb, svrg);
+    range(4, svrg ? nullptr : a.table, (size_t)a.N * vb, true);
+    ctx->batch.push_back(std::move(r));
+    return CIAO_OK;
+}
+
 // rows kernel + finalize (+ all-reduce hook) + epilogue.  Specialised in rows_f32.hip / rows_f64.hip.
 template <typename T>
 int32_t launch_rows(ciao_ctx *ctx, int mode, RowsArgs<T> &a, const Epilogue<T> &ep);

@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
             const V *ap = reinterpret_cast<const V *>(a.A + row * a.ld);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-#ifdef CIAO_PLAIN_LOADS   // timing experiment (tools/sweep_probe.sh): default-policy loads instead of non-temporal ones
+#ifdef CIAO_PLAIN_LOADS   // timing experiment (EXP= build): default-policy loads instead of non-temporal ones
                 r[k] = ap[k * WAVE + lane];
 #else
                 // every row is read exactly once per sweep: non-temporal loads keep the stream out of L2/MALL and run

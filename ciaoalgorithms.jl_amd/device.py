@@ -178,6 +178,26 @@ class ProxG:
         return C.byref(self._c)
 
 
+class _ChainBatch:
+    """Context manager of Context.chain_batch()."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        L.check(self.ctx.lib.ciao_ctx_chain_batch_begin(self.ctx._h))
+        self.ctx._batch_keep = []
+        return self.ctx
+
+    def __exit__(self, et, ev, tb):
+        keep, self.ctx._batch_keep = self.ctx._batch_keep, None
+        st = self.ctx.lib.ciao_ctx_chain_batch_end(self.ctx._h, 1 if et is None else 0)
+        self.ctx._batch_last_idx = keep      # (the launch reads them: alive until the next batch or the ctx goes)
+        if et is None:
+            L.check(st)
+        return False
+
+
 class Context:
     """One device + one HIP stream + the library's private workspace (ciao_ctx).  Not thread-safe."""
 
@@ -193,6 +213,7 @@ class Context:
         handle = C.c_void_p(stream.cuda_stream) if stream is not None else None
         L.check(self.lib.ciao_ctx_create(self.device, handle, C.byref(self._h)))
         self._hook_keepalive = None
+        self._batch_keep = None        # index tensors of an open chain batch (kept alive until its launch is enqueued)
         self.shards = None
 
     # -- lifetime ----------------------------------------------------------------------------------------------------
@@ -343,8 +364,18 @@ class Context:
         L.check(self.lib.ciao_svrg_init(self._h, p.ref, self._vec(x0, p, "x0"), self._vec(av, p, "av"), self._vec(z, p, "z"),
                                         self._vec(z_full, p, "z_full"), self._vec(w, p, "w")))
 
+    def chain_batch(self):
+        """`with ctx.chain_batch(): ...` -- the svrg_inner / saga_steps calls inside are recorded and launched TOGETHER on leaving
+        the block, one workgroup per chain (include/ciao_hip.h: ciao_ctx_chain_batch_begin / _end): several independent solves
+        over the same rows (a regularisation path, folds, restarts) on as many compute units.  The chains must own their state
+        vectors / tables; each one's results are bitwise those of the same call made alone.  An exception inside the block
+        drops the records."""
+        return _ChainBatch(self)
+
     def svrg_inner(self, p, g, gamma, idx, av, z, z_full, w):
         idx = self._idx(idx)
+        if self._batch_keep is not None:
+            self._batch_keep.append(idx)
         L.check(self.lib.ciao_svrg_inner(self._h, p.ref, g.ref, float(gamma), idx.numel(), _ptr(idx), self._vec(av, p, "av"),
                                          self._vec(z, p, "z"), self._vec(z_full, p, "z_full"), self._vec(w, p, "w")))
         return idx
@@ -366,6 +397,8 @@ class Context:
 
     def saga_steps(self, p, g, gamma, sag, idx, table, av, z):
         idx = self._idx(idx)
+        if self._batch_keep is not None:
+            self._batch_keep.append(idx)
         L.check(self.lib.ciao_saga_steps(self._h, p.ref, g.ref, float(gamma), 1 if sag else 0, idx.numel(), _ptr(idx),
                                          self._vec(table, p, "table", p.N * p.d), self._vec(av, p, "av"), self._vec(z, p, "z")))
         return idx

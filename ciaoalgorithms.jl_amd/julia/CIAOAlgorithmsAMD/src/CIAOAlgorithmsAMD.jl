@@ -244,6 +244,27 @@ end
 set_peers!(rank::Integer, mailboxes::Vector{Ptr{Cvoid}}, max_elems::Integer) =      # rank is 0-based on the ABI
     check(ccall((:ciao_ctx_set_peers, libciao), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Ptr{Cvoid}}, Int64), context().h, rank, length(mailboxes), mailboxes, max_elems))
 clear_peers!() = check(ccall((:ciao_ctx_set_peers, libciao), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Ptr{Cvoid}}, Int64), context().h, 0, 0, C_NULL, 0))
+# Several independent chains in ONE launch (include/ciao_hip.h: ciao_ctx_chain_batch_begin / _end): the `saga_steps!` calls made
+# inside `chain_batch() do ... end` -- a regularisation path or folds: iterables over the same rows, a state each -- are recorded
+# and run together, one workgroup (one compute unit) per chain; each state ends bitwise as if its call had been made alone.
+# No counterpart in the reference, which solves one problem per call.
+const BATCH_OPEN = Ref(false)
+const BATCH_KEEP = Any[]          # the index arrays of the recorded calls: alive until the launch is enqueued
+function chain_batch(f)
+    check(ccall((:ciao_ctx_chain_batch_begin, libciao), Int32, (Ptr{Cvoid},), context().h))
+    BATCH_OPEN[] = true
+    ok = false
+    try
+        f()
+        ok = true
+    finally
+        BATCH_OPEN[] = false
+        st = ccall((:ciao_ctx_chain_batch_end, libciao), Int32, (Ptr{Cvoid}, Int32), context().h, Int32(ok))
+        empty!(BATCH_KEEP)        # (frees are stream-ordered: behind the launch)
+        ok && check(st)
+    end
+    return nothing
+end
 set_option!(key::AbstractString, value::Integer) =
     check(ccall((:ciao_ctx_set_option, libciao), Int32, (Ptr{Cvoid}, Cstring, Int64), context().h, key, value))
 last_kernel() = unsafe_string(ccall((:ciao_ctx_last_kernel, libciao), Cstring, (Ptr{Cvoid},), context().h))
@@ -409,6 +430,7 @@ end
 # `nsteps` consecutive reference iterations in one launch (the functor uses this; Base.iterate uses nsteps = 1)
 function saga_steps!(iter::SAGA_basic_iterable{R}, state::SAGA_basic_state{R}, draws::Vector{Int}) where {R}
     idx = to_dev_idx(draws)
+    BATCH_OPEN[] && push!(BATCH_KEEP, idx)
     p, g = Ref(cproblem(iter.F)), Ref(iter.g)
     check(ccall((:ciao_saga_steps, libciao), Int32,
                 (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Int32, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),

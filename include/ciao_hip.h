@@ -255,6 +255,20 @@ CIAO_API int32_t ciao_saga_init(ciao_ctx *ctx, const ciao_problem *p, const ciao
 CIAO_API int32_t ciao_saga_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int32_t sag,
                         int64_t nsteps, const int64_t *idx, void *table, void *av, void *z);
 
+/* ---- several independent chains at once ----------------------------------------------------------------------- */
+/* A chain (the SVRG inner cycle SVRG_basic.jl:73-82, the SAGA / SAG steps SAGA_basic.jl:53-68) is one workgroup on one of the
+ * GPU's 256 compute units: sequential by definition.  A host that runs SEVERAL solves over the same rows -- a
+ * regularisation path (g = NormL1(lambda_k)), cross-validation folds (index streams over different row subsets), restarts --
+ * has that many independent chains.  Between _begin and _end the calls of ciao_svrg_inner and ciao_saga_steps on this ctx are
+ * RECORDED instead of launched (every other entry point returns CIAO_ERR_ARG meanwhile); _end(launch = 1) checks that no chain
+ * writes state another one touches (SVRG writes w, z; SAGA z, av and its table; CIAO_ERR_ARG otherwise), and launches them as one
+ * grid per kernel variant with one workgroup per chain, on the ctx's stream; _end(launch = 0) drops the records.  Each chain's
+ * results are bitwise those of the same call made alone.  Takes the chains of the LDS-DMA kernels: real scalars, rows of whole
+ * 16-byte chunks of at most 32 KiB, 16-byte aligned, unsharded (CIAO_ERR_UNSUPPORTED from the recording call otherwise: the batch
+ * stays open and that call is not part of it).  No counterpart in the reference, which solves one problem per call. */
+CIAO_API int32_t ciao_ctx_chain_batch_begin(ciao_ctx *ctx);
+CIAO_API int32_t ciao_ctx_chain_batch_end(ciao_ctx *ctx, int32_t launch);
+
 /* ---- Finito / MISO  (Finito/Finito_basic.jl) ---------------------------------------------------------------- */
 /* hat_gamma = 1 / sum_i (1/gam_i)  over the LOCAL rows then all-reduced (Finito_basic.jl:82). Synchronises. */
 CIAO_API int32_t ciao_hat_gamma(ciao_ctx *ctx, int32_t dtype, int64_t N, const void *gam, double *hat_gamma_host);

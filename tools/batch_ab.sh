@@ -1,0 +1,16 @@
+#!/bin/bash
+# chain batches (ON the GPU box): the chain parity tests and the batch tests, the single-chain timings (must not have moved), then
+# the aggregate curve of K chains in one launch against K streams.
+set -o pipefail
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_chain_batch.py tests/test_gpu_parity.py -q -m gpu -x -k "batch or svrg or saga or finito or chain or wave_spec" > gpurun_out/batch_tests.log 2>&1
+rc=$?
+tail -5 gpurun_out/batch_tests.log
+[ $rc -eq 0 ] || exit $rc
+{
+echo "single chain: $(python tools/chain_time.py) || $(python tools/saga_time.py | tail -1)"
+echo "single chain, saga on chain_dma_kernel: $(CIAO_OPTS=chain_no_ws=1 python tools/saga_time.py | tail -1)"
+echo "== SVRG, K chains in one launch"; python tools/lambda_path.py svrg batch 2>&1 >/dev/null | grep "K="
+echo "== SAGA (N=200k, a table per chain), K chains in one launch"; CIAO_N=200000 python tools/lambda_path.py saga batch 2>&1 >/dev/null | grep "K="
+echo "== SVRG, K streams (default hardware queues)"; CIAO_KS=1,4,16,64,256 python tools/lambda_path.py svrg 2>&1 >/dev/null | grep "K="
+} 2>&1 | grep -v amdgpu.ids | tee gpurun_out/batch_ab.txt

@@ -1,13 +1,11 @@
 #!/bin/bash
-# A/B of chain changes on ONE box: the product library against build/prev/libciao_hip.so (the previous library), after the chain
-# parity tests.  us per update: SVRG (two dot products / cached row dots), fp64 and fp32, N=200k d=1024; SAGA at BASELINE config #3.
+# A/B of a chain-kernel change on ONE box: the product library against an experiment build of the alternative
+# (tools/exp_build.sh NAME "FLAGS" ...; CIAO_AB_LIB=build/NAME/libciao_hip.so).  us per update: SVRG (two dot products / cached row
+# dots, fp64 and fp32, d = 1024), SAGA at BASELINE config #3 on the wave-specialised kernel and on chain_dma_kernel.
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "svrg or saga or finito or chain or wave_spec" > gpurun_out/chain_tests.log 2>&1
-rc=$?
-tail -3 gpurun_out/chain_tests.log
-[ $rc -eq 0 ] || exit $rc
-for rep in 1 2; do
-  echo "product : $(python tools/chain_time.py) || $(python tools/saga_time.py | tail -1)"
-  echo "prev    : $(CIAO_HIP_LIB=$PWD/build/prev/libciao_hip.so python tools/chain_time.py) || $(CIAO_HIP_LIB=$PWD/build/prev/libciao_hip.so python tools/saga_time.py | tail -1)"
+B="${CIAO_AB_LIB:-$PWD/build/nobatch/libciao_hip.so}"
+for rep in 1 2 3; do
+  echo "product : $(python tools/chain_time.py) || ws $(python tools/saga_time.py | tail -1 | cut -c1-60) || dma $(CIAO_OPTS=chain_no_ws=1 python tools/saga_time.py | tail -1 | cut -c1-60)"
+  echo "other   : $(CIAO_HIP_LIB=$B python tools/chain_time.py) || ws $(CIAO_HIP_LIB=$B python tools/saga_time.py | tail -1 | cut -c1-60) || dma $(CIAO_HIP_LIB=$B CIAO_OPTS=chain_no_ws=1 python tools/saga_time.py | tail -1 | cut -c1-60)"
 done 2>&1 | grep -v amdgpu.ids | tee gpurun_out/chain_ab.txt
