@@ -342,16 +342,23 @@ static int32_t svrg_inner_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_pro
     return launch_chain<T>(ctx, CA_SVRG, a);
 }
 
+// SVRG_basic.jl:84-92: z_full = z / m; basic: w = z_full; z = 0; av = (1/N) sum_i grad f_i(z_full)
 template <typename T>
-static int32_t svrg_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
-                              const int64_t *idx, int32_t plus, int32_t reuse_rowdots, void *av, void *z, void *z_full, void *w)
+static int32_t svrg_epoch_tail_t(ciao_ctx *ctx, const ciao_problem *p, int64_t m, int32_t plus, void *av, void *z, void *z_full, void *w)
 {
-    CIAO_TRY(svrg_inner_t<T>(ctx, p, g, gamma, m, idx, av, z, z_full, w, reuse_rowdots != 0));
     ctx->rowdot_A = nullptr;   // z_full is about to change
     hipLaunchKernelGGL((svrg_tail_kernel<T>), dim3((unsigned)((p->d + 255) / 256)), dim3(256), 0, ctx->stream, p->d, (T)m,
                        (int)plus, (T *)z, (T *)z_full, (T *)w);
     CIAO_HIP(hipGetLastError());
     return full_gradient_t<T>(ctx, p, z_full, av, true);
+}
+
+template <typename T>
+static int32_t svrg_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
+                              const int64_t *idx, int32_t plus, int32_t reuse_rowdots, void *av, void *z, void *z_full, void *w)
+{
+    CIAO_TRY(svrg_inner_t<T>(ctx, p, g, gamma, m, idx, av, z, z_full, w, reuse_rowdots != 0));
+    return svrg_epoch_tail_t<T>(ctx, p, m, plus, av, z, z_full, w);
 }
 
 template <typename T>
@@ -1465,6 +1472,15 @@ int32_t ciao_svrg_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
                  "the SVRG inner cycle is a sequential chain: on a row-sharded problem it needs a shard table (ciao_ctx_set_shards)");
     CIAO_TRY(check_shards(ctx, p, false));
     return DISPATCH(p->dtype, svrg_iterate_t, ctx, p, g, gamma, m, idx, plus, reuse_rowdots, av, z, z_full, w);
+}
+
+int32_t ciao_svrg_epoch_tail(ciao_ctx *ctx, const ciao_problem *p, int64_t m, int32_t plus, void *av, void *z, void *z_full, void *w)
+{
+    CIAO_ENTER(ctx);
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_REQUIRE(m >= 1, "m < 1");
+    CIAO_REQUIRE(av && z && z_full && w, "NULL state vector");
+    return DISPATCH(p->dtype, svrg_epoch_tail_t, ctx, p, m, plus, av, z, z_full, w);
 }
 
 int32_t ciao_saga_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, const void *x0,

@@ -390,6 +390,11 @@ class Context:
                                            self._vec(z_full, p, "z_full"), self._vec(w, p, "w")))
         return idx
 
+    def svrg_epoch_tail(self, p, m, plus, av, z, z_full, w):
+        """SVRG_basic.jl:84-92 on their own: z_full = z / m; w = z_full unless plus; z = 0; av = full gradient at z_full."""
+        L.check(self.lib.ciao_svrg_epoch_tail(self._h, p.ref, int(m), 1 if plus else 0, self._vec(av, p, "av"), self._vec(z, p, "z"),
+                                              self._vec(z_full, p, "z_full"), self._vec(w, p, "w")))
+
     # -- SAGA / SAG ----------------------------------------------------------------------------------------------------
     def saga_init(self, p, g, gamma, x0, table, av, z):
         L.check(self.lib.ciao_saga_init(self._h, p.ref, g.ref, float(gamma), self._vec(x0, p, "x0"),

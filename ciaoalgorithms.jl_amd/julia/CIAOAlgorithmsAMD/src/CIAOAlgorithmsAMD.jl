@@ -349,6 +349,31 @@ function Base.iterate(iter::SVRG_basic_iterable{R}, state::SVRG_basic_state{R}) 
 end
 solution(state::SVRG_basic_state) = state.z_full                                            # SVRG_basic.jl:99
 
+# K SVRG solves over the same rows (a regularisation path: iterables that differ in g) advanced by ONE reference iteration each:
+# the K inner cycles (:73-82) recorded and launched as one chain batch -- one workgroup, one compute unit, per solve -- then every
+# solve's epoch tail (:84-93).  Each state ends bitwise as Base.iterate(iter, state) leaves it with TRUST_SVRG_STATE[] = false.
+function iterate_together!(iters::Vector{SVRG_basic_iterable{R}}, states::Vector{SVRG_basic_state{R}}) where {R}
+    chain_batch() do
+        for (iter, state) in zip(iters, states)
+            idx = to_dev_idx(rand(1:iter.N, state.m))                                       # :73
+            push!(BATCH_KEEP, idx)
+            p, g = Ref(cproblem(iter.F)), Ref(iter.g)
+            check(ccall((:ciao_svrg_inner, libciao), Int32,
+                        (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                        context().h, p, g, Float64(state.γ), state.m, dptr(idx),
+                        dptr(state.av), dptr(state.z), dptr(state.z_full), dptr(state.w)))
+        end
+    end
+    for (iter, state) in zip(iters, states)
+        p = Ref(cproblem(iter.F))
+        check(ccall((:ciao_svrg_epoch_tail, libciao), Int32,
+                    (Ptr{Cvoid}, Ref{CiaoProblem}, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    context().h, p, state.m, Int32(iter.plus), dptr(state.av), dptr(state.z), dptr(state.z_full), dptr(state.w)))
+        iter.plus && (state.m *= 2)                                                         # :93
+    end
+    return states
+end
+
 function iterator(solver::SVRG{R}, x0::AbstractArray{C}; F = nothing, g = ProximalOperators.Zero(), L = nothing,
                   μ = nothing, N) where {R,C<:RealOrComplex{R}}
     d = nreals(x0)                      # reals: twice the length of a complex x0

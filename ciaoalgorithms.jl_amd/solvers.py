@@ -44,7 +44,7 @@ from . import host_route as HR
 from .operators import UnpackableOperator, pack_F, pack_g, pack_sharing_F, require_packable
 from .sampling import IndexStream
 
-__all__ = ["SVRG", "SAGA", "SAG", "Finito", "Proshi", "iterator", "solution"]
+__all__ = ["SVRG", "SAGA", "SAG", "Finito", "Proshi", "iterator", "solution", "solve_together"]
 
 
 def _pick(greek, ascii_, name):
@@ -846,6 +846,66 @@ class Proshi(_Solver):
 
 
 Proshi_basic_iterable._chunkable = True
+
+
+def solve_together(iterables, maxit):
+    """K independent SVRG or SAGA / SAG solves over device-resident rows, advanced in LOCKSTEP: `iterables` are what
+    `iterator(solver, x0, F=..., g=..., N=..., ctx=ctx)` returns, all on the same ctx (typically the same packed F with a g -- a
+    lambda of the regularisation path -- and a sampling stream each).  The reference solves one problem per call and a chain is
+    one workgroup on one of the GPU's 256 compute units; here the K sequential chains of every outer step are recorded and
+    launched as ONE chain batch (Context.chain_batch; include/ciao_hip.h: ciao_ctx_chain_batch_begin), one workgroup per solve.
+    Returns ([solution_k], num_iters) with the functors' counting (the init state is iteration 1, SVRG.jl:69-83).
+
+    Each solve ends bitwise as its own `solver(maxit=maxit)(x0, ...)` would -- for SVRG with the row-dot cache off
+    (`ctx.set_option("svrg_cache_rowdots", 0)`: a batch's inner cycles recompute a_i'z_full, include/ciao_hip.h:
+    ciao_svrg_epoch_tail), for SAGA / SAG as is."""
+    its = list(iterables)
+    if not its:
+        return [], 0
+    kinds = {type(it) for it in its}
+    if len(kinds) != 1 or not kinds <= {SVRG_basic_iterable, SAGA_basic_iterable}:
+        raise TypeError("solve_together takes SVRG iterables or SAGA / SAG iterables (one kind), built by iterator(solver, x0, ...)")
+    ctx = its[0].ctx
+    if any(it.ctx is not ctx for it in its) or any(getattr(it, "shards", None) is not None for it in its):
+        raise ValueError("the solves of a batch share one ctx and are unsharded")
+    states = []
+    for it in its:
+        iter(it)
+        it._started = True
+        it._state = it._init()
+        if it._state is None:
+            raise ValueError("an iterable of the batch has an invalid configuration (see the warning above)")
+        states.append(it._state)
+    num_iters = 1
+    svrg = kinds == {SVRG_basic_iterable}
+    chunk = _Solver._chunk
+    while num_iters < maxit:
+        if svrg:                                                           # SVRG_basic.jl:71-96, once per solve
+            drawn = [it._draw(it.N, st.m)[0] for it, st in zip(its, states)]                       # :73
+            with ctx.chain_batch():
+                for it, st, idx in zip(its, states, drawn):
+                    ctx.svrg_inner(it.F, it.g, st.γ, idx, st.av, st.z, st.z_full, st.w)            # :74-82
+            for it, st in zip(its, states):
+                ctx.svrg_epoch_tail(it.F, st.m, it.plus, st.av, st.z, st.z_full, st.w)             # :84-92
+                st._tok = None
+                if it.plus:
+                    st.m *= 2                                                                      # :93
+            num_iters += 1
+        else:                                                              # SAGA_basic.jl:53-68, n iterations per solve and launch
+            n = min(maxit - num_iters, chunk)
+            drawn = [it._draw(it.N, n) for it in its]                                              # :55
+            with ctx.chain_batch():
+                for it, st, (idx, _) in zip(its, states, drawn):
+                    ctx.saga_steps(it.F, it.g, st.γ, it.SAG, idx, st.s, st.av, st.z)
+            for st, (_, last) in zip(states, drawn):
+                st.ind = last + 1
+            num_iters += n
+    ctx.synchronize()
+    outs = []
+    for it, st in zip(its, states):
+        sol = solution(st)
+        outs.append(sol.cpu().numpy().reshape(np.shape(it.x0)) if it._numpy else sol)
+    return outs, num_iters
 
 
 def iterator(solver, x0, **kw):

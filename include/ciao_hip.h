@@ -199,6 +199,12 @@ CIAO_API int32_t ciao_svrg_inner(ciao_ctx *ctx, const ciao_problem *p, const cia
  * (solvers.py: torch's in-place version counters of z_full, A and b). */
 CIAO_API int32_t ciao_svrg_iterate(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
                           const int64_t *idx, int32_t plus, int32_t reuse_rowdots, void *av, void *z, void *z_full, void *w);
+/* The second half of ciao_svrg_iterate on its own, :84-92: z_full = z / m; basic (plus == 0): w = z_full; z = 0; then the full
+ * pass av = (1/N) sum_i grad f_i(z_full).  ciao_svrg_inner followed by this IS ciao_svrg_iterate with reuse_rowdots == 0, bit for
+ * bit; it exists for hosts that run the inner cycles of several solves as one chain batch (ciao_ctx_chain_batch_begin) and
+ * finish each solve's outer iteration afterwards. */
+CIAO_API int32_t ciao_svrg_epoch_tail(ciao_ctx *ctx, const ciao_problem *p, int64_t m, int32_t plus, void *av, void *z,
+                             void *z_full, void *w);
 
 /* ---- the sequential chains on a row-sharded problem ("one chain on one GPU pulling remote rows over xGMI") --
  * The inner loops of SVRG and SAGA are one dependent chain and do not shard: on a problem whose rows do not fit one GPU

@@ -214,3 +214,83 @@ def test_many_more_chains_than_compute_units(ctx):
             ctx.svrg_inner(F, gs[k], 0.2 / F.N, idx[k], av, zk, zf, wk)
             ctx.synchronize()
             assert torch.isfinite(wk).all() and torch.equal(wk, W[k]) and torch.equal(zk, Z[k]), f"d={d} chain {k}"
+
+
+# ======================================================================================================================
+# the host mirror's lockstep driver: K solver runs through the reference-style API, their chains batched
+# ======================================================================================================================
+def _path_problem(ops, dtype, N=600, d=256, seed=5):
+    rng = np.random.default_rng(seed)
+    A = (rng.standard_normal((N, d)) / np.sqrt(d)).astype(dtype)
+    xt = rng.standard_normal(d) * (rng.random(d) < 0.1)
+    b = (A @ xt + 0.01 * rng.standard_normal(N)).astype(dtype)
+    F = [ops.LeastSquares(A[i:i + 1, :], b[i:i + 1], float(N)) for i in range(N)]     # test_lasso.jl:52-54
+    Lc = N * (A.astype(np.float64) ** 2).sum(1)
+    return A, b, F, Lc
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_svrg_regularisation_path_solved_together_is_bitwise_the_solves_alone(ctx, dtype):
+    """SVRG (SVRG.jl:46-84) for six values of lambda over the same rows: solve_together == six functor calls, bit for bit"""
+    import ciaoalgorithms_jl_amd.operators as ops
+    import ciaoalgorithms_jl_amd.solvers as S
+    from ciaoalgorithms_jl_amd.sampling import IndexStream
+    A, b, F, Lc = _path_problem(ops, dtype)
+    N, d = A.shape
+    lams = [0.3, 0.1, 0.03, 0.01, 0.003, 0.001]
+    gam = dtype(1 / (7 * Lc.max()))                                                   # test_lasso.jl:164
+    x0 = np.zeros(d, dtype)
+    ctx.set_option("svrg_cache_rowdots", 0)        # a batch's inner cycles recompute a_i'z_full: compare with solves that do too
+    try:
+        alone = [S.SVRG(dtype, γ=gam, maxit=6)(x0, F=F, g=ops.NormL1(l), N=N, ctx=ctx, stream=IndexStream(k))
+                 for k, l in enumerate(lams)]
+        its = [S.iterator(S.SVRG(dtype, γ=gam), x0, F=F, g=ops.NormL1(l), N=N, ctx=ctx, stream=IndexStream(k)) for k, l in enumerate(lams)]
+        xs, n = S.solve_together(its, maxit=6)
+    finally:
+        ctx.set_option("svrg_cache_rowdots", 1)
+    assert n == 6 and all(a[1] == 6 for a in alone)
+    for k, (x, (xa, _)) in enumerate(zip(xs, alone)):
+        assert x.dtype == dtype and np.isfinite(x).all() and np.array_equal(x, xa), f"lambda #{k}"
+    # more regularisation, smaller solution: the path is a path
+    l1 = [float(np.abs(x).sum()) for x in xs]
+    assert l1[0] < l1[-1]
+    # ... and with the row-dot cache ON the separate solves agree to rounding (a different, equally valid summation order)
+    xa, _ = S.SVRG(dtype, γ=gam, maxit=6)(x0, F=F, g=ops.NormL1(lams[2]), N=N, ctx=ctx, stream=IndexStream(2))
+    eps = np.finfo(dtype).eps
+    assert np.abs(xa - xs[2]).max() <= 2000 * eps * max(np.abs(xa).max(), 1e-30)
+
+
+@pytest.mark.parametrize("sag", [False, True], ids=["saga", "sag"])
+def test_saga_solves_together_are_bitwise_the_solves_alone(ctx, sag):
+    """SAGA / SAG (SAGA.jl:44-73) for four lambdas, 3000 iterations each: the lockstep driver == the functor"""
+    import ciaoalgorithms_jl_amd.operators as ops
+    import ciaoalgorithms_jl_amd.solvers as S
+    from ciaoalgorithms_jl_amd.sampling import IndexStream
+    dtype = np.float64
+    A, b, F, Lc = _path_problem(ops, dtype, N=400, d=128, seed=9)
+    N, d = A.shape
+    lams = [0.1, 0.03, 0.01, 0.003]
+    x0 = np.zeros(d, dtype)
+    mk = lambda: S.SAGA(dtype, maxit=3000, SAG_flag=sag)
+    alone = [mk()(x0, F=F, g=ops.NormL1(l), N=N, L=Lc, ctx=ctx, stream=IndexStream(10 + k)) for k, l in enumerate(lams)]
+    its = [S.iterator(mk(), x0, F=F, g=ops.NormL1(l), N=N, L=Lc, ctx=ctx, stream=IndexStream(10 + k)) for k, l in enumerate(lams)]
+    xs, n = S.solve_together(its, maxit=3000)
+    assert n == 3000
+    for k, (x, (xa, na)) in enumerate(zip(xs, alone)):
+        assert na == 3000 and np.isfinite(x).all() and np.array_equal(x, xa), f"lambda #{k}"
+    assert its[0]._state.ind >= 1
+
+
+def test_solve_together_refuses_mixed_and_foreign_iterables(ctx):
+    import ciaoalgorithms_jl_amd.operators as ops
+    import ciaoalgorithms_jl_amd.solvers as S
+    A, b, F, Lc = _path_problem(ops, np.float64, N=50, d=32)
+    x0 = np.zeros(32)
+    a = S.iterator(S.SVRG(γ=1e-3), x0, F=F, g=ops.NormL1(0.1), N=50, ctx=ctx)
+    c = S.iterator(S.SAGA(γ=1e-3), x0, F=F, g=ops.NormL1(0.1), N=50, ctx=ctx)
+    f = S.iterator(S.Finito(γ=1e-3), x0, F=F, g=ops.NormL1(0.1), N=50, L=Lc, ctx=ctx)
+    with pytest.raises(TypeError, match="one kind"):
+        S.solve_together([a, c], maxit=3)
+    with pytest.raises(TypeError, match="one kind"):
+        S.solve_together([f], maxit=3)
+    assert S.solve_together([], maxit=3) == ([], 0)
