@@ -1299,11 +1299,47 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                         d1 = fmad(x.ar[j][v], p[j][v], d1);
                         if (TWO) d2 = fmad(x.ar[j][v], zf[j][v], d2);
                     }
+                V q1[J], q2[J];
                 if constexpr (NW == 1) {
                     // ONE wave owns the whole row: the reduced dot is broadcast from lane 63 through an SGPR, and the LDS
-                    // exchange (write, lgkmcnt(0), barrier, read: the largest piece of a four-wave step) does not exist
-                    d1 = readlane(wave_sum_lane63(d1), WAVE - 1);
-                    if (TWO) d2 = readlane(wave_sum_lane63(d2), WAVE - 1);
+                    // exchange (write, lgkmcnt(0), barrier, read: the largest piece of a four-wave step) does not exist.
+                    // The sums go stage by stage -- with two dot products two independent dependency chains, each filling the
+                    // other's latencies (one after the other, what hipcc makes of two calls, they cost twice six dependent
+                    // stages) -- and between the stages, instead of wait states, what the update needs that does not depend on
+                    // the dots: SVRG's q2 = w - gamma*av and q1 = gamma*a_i, element by element.  The empty asm statements
+                    // keep that order; the additions are wave_sum_lane63's, in its order: bitwise the same sums.
+                    int nq = 0;   // elements of (q2, q1) placed so far (compile-time after unrolling)
+                    constexpr int NQ = SVRG_ANY ? 2 * J * VEC : 0, PER = (NQ + 5) / 6;
+                    auto fill = [&](int n) {
+                        for (int e = 0; e < n && nq < NQ; ++e, ++nq) {
+                            const int k = nq >> 1, j = k / VEC, v = k % VEC;
+                            if (nq & 1) {
+                                q1[j][v] = a.gamma * x.ar[j][v];
+                                asm volatile("" : "+v"(q1[j][v]));
+                            } else {
+                                q2[j][v] = p[j][v] - gav[j][v];
+                                asm volatile("" : "+v"(q2[j][v]));
+                            }
+                        }
+                    };
+                    auto stage = [&](auto f) {
+                        d1 = f(d1);
+                        asm volatile("" : "+v"(d1));
+                        if (TWO) {
+                            d2 = f(d2);
+                            asm volatile("" : "+v"(d2));
+                        }
+                        fill(PER);
+                    };
+                    stage([](T v) { return v + dpp_mov<0xB1>(v); });
+                    stage([](T v) { return v + dpp_mov<0x4E>(v); });
+                    stage([](T v) { return v + dpp_mov<0x141>(v); });
+                    stage([](T v) { return v + dpp_mov<0x140>(v); });
+                    stage([](T v) { return v + dpp_rows<0x142, 0xA>(v); });
+                    stage([](T v) { return v + dpp_rows<0x143, 0xC>(v); });
+                    fill(NQ);
+                    d1 = readlane(d1, WAVE - 1);
+                    if (TWO) d2 = readlane(d2, WAVE - 1);
                 } else {
 #ifdef CIAO_CHAIN_READLANE   // experiment: the all-lanes sum through v_readlane, lane 0 stores
                 d1 = wave_allsum(d1);
@@ -1323,8 +1359,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                 }
                 // work that does not need the dot product goes between the LDS write and the barrier, where it overlaps the
                 // other waves' arrival:  temp = gamma*(a*dc - av) + w  =  (gamma*a)*dc + (w - gamma*av)
-                V q1[J], q2[J];
-                if (SVRG_ANY) {
+                if (SVRG_ANY && NW != 1) {
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
                         q1[j] = a.gamma * x.ar[j];
