@@ -480,6 +480,19 @@ template <typename T>
 static int32_t finito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
                               int64_t nit, const BatchSrc &src, void *table, void *av, void *z)
 {
+    if (ctx->batch_open && nit > 0) {
+        // recorded into a chain batch: the whole call must be ONE chain launch -- every iteration's batch of the same small size
+        // (a second launch of the same solve would have to wait for the first: not something a batch can express)
+        const int64_t r0 = src.size(0);
+        bool uniform = !src.blocks() && r0 >= 1;
+        for (int64_t tt = 1; uniform && tt < nit; ++tt) uniform = src.size(tt) == r0;
+        if (!uniform || !batch_as_chain<T>(ctx, p, r0)) {
+            set_error("a chain batch takes Finito steps whose batches all have the same size, small enough to run as a sequential "
+                      "chain (index-list form; option chain_max_batch), got %lld iterations starting with a batch of %lld",
+                      (long long)nit, (long long)r0);
+            return CIAO_ERR_UNSUPPORTED;
+        }
+    }
     int64_t t = 0;
     while (t < nit) {
         const int64_t r = src.size(t);
@@ -1572,7 +1585,8 @@ static int32_t check_blocks(const ciao_ctx *ctx, int64_t N, int64_t n, const int
 int32_t ciao_finito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, const void *gam, double hat_gamma,
                           int64_t nit, const int64_t *bptr_host, const int64_t *bidx, void *table, void *av, void *z)
 {
-    CIAO_ENTER(ctx);
+    CIAO_ENTER_BATCHABLE(ctx);
+    CIAO_REQUIRE(!ctx->batch_open || (!ctx->hook && ctx->shards.nshards == 0), "a chain batch cannot run on a row-sharded problem");
     CIAO_TRY(check_problem(ctx, p));
     CIAO_TRY(check_prox(g));
     CIAO_TRY(check_pair(p, g));

@@ -165,8 +165,8 @@ struct DeviceGuard {
     ::ciao::DeviceGuard _ciao_dg((ctx)->device)
 #define CIAO_ENTER(ctx)                                                                                                           \
     CIAO_REQUIRE((ctx), "ctx is NULL");                                                                                           \
-    CIAO_REQUIRE(!(ctx)->batch_open, "a chain batch is open on this ctx (ciao_ctx_chain_batch_begin): only ciao_svrg_inner and "  \
-                                     "ciao_saga_steps may be called before ciao_ctx_chain_batch_end");                            \
+    CIAO_REQUIRE(!(ctx)->batch_open, "a chain batch is open on this ctx (ciao_ctx_chain_batch_begin): only ciao_svrg_inner, "    \
+                                     "ciao_saga_steps and ciao_finito_steps may be called before ciao_ctx_chain_batch_end");      \
     ::ciao::DeviceGuard _ciao_dg((ctx)->device)
 
 }  // namespace ciao

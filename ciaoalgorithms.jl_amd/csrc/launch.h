@@ -30,8 +30,8 @@ template <typename T, int ALG>
 inline int32_t chain_batch_record(ciao_ctx *ctx, const void *kern, unsigned block, size_t lds, const ChainArgs<T> &a)
 {
     constexpr bool svrg = (ALG == CA_SVRG || ALG == CA_SVRGC);
-    if (!(svrg || ALG == CA_SAGA) || a.nshards > 0) {
-        set_error("a chain batch takes SVRG inner cycles and SAGA / SAG steps of unsharded problems only");
+    if (!(svrg || ALG == CA_SAGA || ALG == CA_FINITO) || a.nshards > 0) {
+        set_error("a chain batch takes SVRG inner cycles, SAGA / SAG steps and small-batch Finito steps of unsharded problems only");
         return CIAO_ERR_UNSUPPORTED;
     }
     ciao_chain_rec r;

@@ -365,7 +365,7 @@ class Context:
                                         self._vec(z_full, p, "z_full"), self._vec(w, p, "w")))
 
     def chain_batch(self):
-        """`with ctx.chain_batch(): ...` -- the svrg_inner / saga_steps calls inside are recorded and launched TOGETHER on leaving
+        """`with ctx.chain_batch(): ...` -- the svrg_inner / saga_steps / small-batch finito_steps calls inside are recorded and launched TOGETHER on leaving
         the block, one workgroup per chain (include/ciao_hip.h: ciao_ctx_chain_batch_begin / _end): several independent solves
         over the same rows (a regularisation path, folds, restarts) on as many compute units.  The chains must own their state
         vectors / tables; each one's results are bitwise those of the same call made alone.  An exception inside the block
@@ -422,6 +422,8 @@ class Context:
     def finito_steps(self, p, g, gam, hat_gamma, bptr: np.ndarray, bidx, table, av, z):
         bptr = np.ascontiguousarray(bptr, dtype=np.int64)
         bidx = self._idx(bidx)
+        if self._batch_keep is not None:
+            self._batch_keep.append(bidx)
         assert bptr[0] == 0 and bptr[-1] == bidx.numel()
         L.check(self.lib.ciao_finito_steps(self._h, p.ref, g.ref, self._vec(gam, p, "gam", p.N), float(hat_gamma),
                                            len(bptr) - 1, C.c_void_p(bptr.ctypes.data), _ptr(bidx),

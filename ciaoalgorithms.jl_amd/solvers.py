@@ -849,7 +849,7 @@ Proshi_basic_iterable._chunkable = True
 
 
 def solve_together(iterables, maxit):
-    """K independent SVRG or SAGA / SAG solves over device-resident rows, advanced in LOCKSTEP: `iterables` are what
+    """K independent SVRG, SAGA / SAG or small-batch Finito solves over device-resident rows, advanced in LOCKSTEP: `iterables` are what
     `iterator(solver, x0, F=..., g=..., N=..., ctx=ctx)` returns, all on the same ctx (typically the same packed F with a g -- a
     lambda of the regularisation path -- and a sampling stream each).  The reference solves one problem per call and a chain is
     one workgroup on one of the GPU's 256 compute units; here the K sequential chains of every outer step are recorded and
@@ -858,13 +858,15 @@ def solve_together(iterables, maxit):
 
     Each solve ends bitwise as its own `solver(maxit=maxit)(x0, ...)` would -- for SVRG with the row-dot cache off
     (`ctx.set_option("svrg_cache_rowdots", 0)`: a batch's inner cycles recompute a_i'z_full, include/ciao_hip.h:
-    ciao_svrg_epoch_tail), for SAGA / SAG as is."""
+    ciao_svrg_epoch_tail), for SAGA / SAG and Finito as is (Finito: batches small enough to run as a chain, i.e. the default
+    minibatch of one sample up to option chain_max_batch; larger batches are batch-parallel kernels that fill the GPU alone)."""
     its = list(iterables)
     if not its:
         return [], 0
     kinds = {type(it) for it in its}
-    if len(kinds) != 1 or not kinds <= {SVRG_basic_iterable, SAGA_basic_iterable}:
-        raise TypeError("solve_together takes SVRG iterables or SAGA / SAG iterables (one kind), built by iterator(solver, x0, ...)")
+    if len(kinds) != 1 or not kinds <= {SVRG_basic_iterable, SAGA_basic_iterable, FINITO_basic_iterable}:
+        raise TypeError("solve_together takes SVRG iterables, SAGA / SAG iterables or basic Finito iterables (one kind), built by "
+                        "iterator(solver, x0, ...)")
     ctx = its[0].ctx
     if any(it.ctx is not ctx for it in its) or any(getattr(it, "shards", None) is not None for it in its):
         raise ValueError("the solves of a batch share one ctx and are unsharded")
@@ -891,6 +893,13 @@ def solve_together(iterables, maxit):
                 if it.plus:
                     st.m *= 2                                                                      # :93
             num_iters += 1
+        elif kinds == {FINITO_basic_iterable}:                             # Finito_basic.jl:91-121, n iterations per solve and launch
+            n = min(maxit - num_iters, max(1, min(chunk, _Solver._chunk_samples // max(it.batch for it in its))))
+            drawn = [_next_batches_packed(it, st, n) for it, st in zip(its, states)]               # :95-108 (index lists, whatever the sweeping)
+            with ctx.chain_batch():
+                for it, st, (bptr, bidx) in zip(its, states, drawn):
+                    ctx.finito_steps(it.F, it.g, st.γ, st.hat_γ, bptr, bidx, st.s, st.av, st.z)    # :109-118
+            num_iters += n
         else:                                                              # SAGA_basic.jl:53-68, n iterations per solve and launch
             n = min(maxit - num_iters, chunk)
             drawn = [it._draw(it.N, n) for it in its]                                              # :55

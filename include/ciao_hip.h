@@ -265,9 +265,11 @@ CIAO_API int32_t ciao_saga_steps(ciao_ctx *ctx, const ciao_problem *p, const cia
 /* A chain (the SVRG inner cycle SVRG_basic.jl:73-82, the SAGA / SAG steps SAGA_basic.jl:53-68) is one workgroup on one of the
  * GPU's 256 compute units: sequential by definition.  A host that runs SEVERAL solves over the same rows -- a
  * regularisation path (g = NormL1(lambda_k)), cross-validation folds (index streams over different row subsets), restarts --
- * has that many independent chains.  Between _begin and _end the calls of ciao_svrg_inner and ciao_saga_steps on this ctx are
+ * has that many independent chains.  Between _begin and _end the calls of ciao_svrg_inner, ciao_saga_steps and ciao_finito_steps
+ * (index-list form, every iteration's batch of the same size, small enough to run as a sequential chain: option "chain_max_batch";
+ * the default Finito has batches of one sample, Finito.jl:50) on this ctx are
  * RECORDED instead of launched (every other entry point returns CIAO_ERR_ARG meanwhile); _end(launch = 1) checks that no chain
- * writes state another one touches (SVRG writes w, z; SAGA z, av and its table; CIAO_ERR_ARG otherwise), and launches them as one
+ * writes state another one touches (SVRG writes w, z; SAGA and Finito z, av and their table; CIAO_ERR_ARG otherwise), and launches them as one
  * grid per kernel variant with one workgroup per chain, on the ctx's stream; _end(launch = 0) drops the records.  Each chain's
  * results are bitwise those of the same call made alone.  Takes the chains of the LDS-DMA kernels: real scalars, rows of whole
  * 16-byte chunks of at most 32 KiB, 16-byte aligned, unsharded (CIAO_ERR_UNSUPPORTED from the recording call otherwise: the batch

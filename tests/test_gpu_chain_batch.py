@@ -288,9 +288,59 @@ def test_solve_together_refuses_mixed_and_foreign_iterables(ctx):
     x0 = np.zeros(32)
     a = S.iterator(S.SVRG(γ=1e-3), x0, F=F, g=ops.NormL1(0.1), N=50, ctx=ctx)
     c = S.iterator(S.SAGA(γ=1e-3), x0, F=F, g=ops.NormL1(0.1), N=50, ctx=ctx)
-    f = S.iterator(S.Finito(γ=1e-3), x0, F=F, g=ops.NormL1(0.1), N=50, L=Lc, ctx=ctx)
+    f = S.iterator(S.Finito(γ=1e-3, LFinito=True), x0, F=F, g=ops.NormL1(0.1), N=50, L=Lc, ctx=ctx)
     with pytest.raises(TypeError, match="one kind"):
         S.solve_together([a, c], maxit=3)
     with pytest.raises(TypeError, match="one kind"):
         S.solve_together([f], maxit=3)
     assert S.solve_together([], maxit=3) == ([], 0)
+
+
+@pytest.mark.parametrize("sweeping,r", [(1, 1), (2, 1), (3, 4), (1, 3)], ids=["random-r1", "cyclic-r1", "shuffled-r4", "random-r3"])
+def test_finito_solves_together_are_bitwise_the_solves_alone(ctx, sweeping, r):
+    """Finito (Finito.jl:66-133; the default minibatch of one sample and small minibatches: sequential chains) for four lambdas"""
+    import ciaoalgorithms_jl_amd.operators as ops
+    import ciaoalgorithms_jl_amd.solvers as S
+    from ciaoalgorithms_jl_amd.sampling import IndexStream
+    dtype = np.float64
+    # (static batches, Finito_basic.jl:52-58, must divide N here: a shorter last batch would make a solve's steps two dependent
+    #  launches, which a chain batch refuses)
+    A, b, F, Lc = _path_problem(ops, dtype, N=404 if sweeping != 1 else 403, d=128, seed=11)
+    N, d = A.shape
+    lams = [0.1, 0.03, 0.01, 0.003]
+    x0 = np.zeros(d, dtype)
+    mk = lambda: S.Finito(dtype, maxit=2500, sweeping=sweeping, minibatch=(r > 1, r))
+    alone = [mk()(x0, F=F, g=ops.NormL1(l), N=N, L=Lc, ctx=ctx, stream=IndexStream(20 + k)) for k, l in enumerate(lams)]
+    assert "chain_dma_kernel" in ctx.last_kernel()
+    its = [S.iterator(mk(), x0, F=F, g=ops.NormL1(l), N=N, L=Lc, ctx=ctx, stream=IndexStream(20 + k)) for k, l in enumerate(lams)]
+    xs, n = S.solve_together(its, maxit=2500)
+    assert n == 2500 and "chain batch: 4 chains in 1 launch(es)" in ctx.last_kernel()
+    for k, (x, (xa, na)) in enumerate(zip(xs, alone)):
+        assert na == 2500 and np.isfinite(x).all() and np.array_equal(x, xa), f"lambda #{k}"
+
+
+def test_finito_steps_with_large_or_ragged_batches_are_refused_by_a_chain_batch(ctx):
+    import torch
+    import ciaoalgorithms_jl_amd._lib as L
+    from ciaoalgorithms_jl_amd._lib import CiaoError
+    from ciaoalgorithms_jl_amd.device import ProxG
+    F = _problem(600, 256, np.float64)
+    g = ProxG(L.PROX_L1, lam=1e-3)
+    gam = torch.full((F.N,), 0.5, dtype=torch.float64, device="cuda")
+    hg = ctx.hat_gamma(gam)
+    x0 = torch.zeros(F.d, dtype=torch.float64, device="cuda")
+    table = torch.empty((F.N, F.d), dtype=torch.float64, device="cuda")
+    av, z = torch.empty_like(x0), torch.empty_like(x0)
+    ctx.finito_init(F, g, gam, hg, x0, table, av, z)
+    big = np.arange(0, 401, 200, dtype=np.int64)                 # two batches of 200: batch-parallel kernels, not a chain
+    with pytest.raises(CiaoError, match="same size, small enough"):
+        with ctx.chain_batch():
+            ctx.finito_steps(F, g, gam, hg, big, np.arange(400, dtype=np.int64), table, av, z)
+    ragged = np.array([0, 2, 3], dtype=np.int64)                 # a batch of 2, then one of 1: two dependent launches
+    with pytest.raises(CiaoError, match="same size, small enough"):
+        with ctx.chain_batch():
+            ctx.finito_steps(F, g, gam, hg, ragged, np.arange(3, dtype=np.int64), table, av, z)
+    with ctx.chain_batch():                                      # a single solve in a batch is fine
+        ctx.finito_steps(F, g, gam, hg, np.arange(0, 41, 2, dtype=np.int64), np.arange(40, dtype=np.int64), table, av, z)
+    ctx.synchronize()
+    assert torch.isfinite(z).all() and "chain batch: 1 chains" in ctx.last_kernel()
