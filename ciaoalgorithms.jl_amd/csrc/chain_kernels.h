@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(CHAIN_BIG_NT) chain_cplx_kernel(ChainArgs<T> a
     const bool l1 = (a.g.kind == CIAO_PROX_L1_COMPLEX);
     auto proxc = [&](T tau, T vr, T vi, T &yr, T &yi) {
         if (l1) {
-            prox_cpair(tau * a.g.lam, vr, vi, yr, yi);
+            prox_cpair_chain(tau * a.g.lam, vr, vi, yr, yi);
         } else {
             yr = vr;
             yi = vi;
@@ -711,7 +711,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cplx_reg_kernel(ChainArgs<T> a
     const bool l1 = (a.g.kind == CIAO_PROX_L1_COMPLEX);
     auto proxc = [&](T tau, T vr, T vi, T &yr, T &yi) {
         if (l1) {
-            prox_cpair(tau * a.g.lam, vr, vi, yr, yi);
+            prox_cpair_chain(tau * a.g.lam, vr, vi, yr, yi);
         } else {
             yr = vr;
             yi = vi;
@@ -1610,7 +1610,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
     const bool l1 = (a.g.kind == CIAO_PROX_L1_COMPLEX);
     auto proxc = [&](T tau, T vr, T vi, T &yr, T &yi) {
         if (l1) {
-            prox_cpair(tau * a.g.lam, vr, vi, yr, yi);
+            prox_cpair_chain(tau * a.g.lam, vr, vi, yr, yi);
         } else {
             yr = vr;
             yi = vi;
