@@ -261,10 +261,26 @@ def run_rank(args):
                 if rank == 0:
                     print("[bench] falling back to torch.distributed for the collective on every rank", file=sys.stderr)
             else:
-                comm = RcclComm(rank, world, dev.index)
-                ctx.set_rccl(comm)
-                rccl_ranks = comm.count()
-                collective = "rccl ncclAllReduce(d+1) per step, issued by the library on its stream"
+                # ... and a second vote AFTER the collective initialisation: a rank whose ncclCommInitRank returned an error (the
+                # others' then did too, or will time out inside it) must not leave the rest on a communicator it is not part of
+                err = None
+                try:
+                    comm = RcclComm(rank, world, dev.index)
+                    rccl_ranks = comm.count()
+                except Exception as e:   # noqa: BLE001 -- whatever went wrong, every rank has to hear of it
+                    err, comm = repr(e), None
+                    print(f"[bench] rank {rank}: native RCCL communicator failed ({err})", file=sys.stderr)
+                ok = torch.tensor([1 if err is None else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    if comm is not None:
+                        comm.close()
+                    comm, rccl_ranks = None, None
+                    if rank == 0:
+                        print("[bench] falling back to torch.distributed for the collective on every rank", file=sys.stderr)
+                else:
+                    ctx.set_rccl(comm)
+                    collective = "rccl ncclAllReduce(d+1) per step, issued by the library on its stream"
         if comm is None and peers is None:
             hook = AllReduceHook(dev)
             ctx.set_allreduce(hook)
