@@ -1370,6 +1370,14 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                         if constexpr (NW == 4) asm volatile("" : "+v"(q1[j]), "+v"(q2[j]));
                     }
                 }
+                // Finito / LFinito: the per-sample stepsize's two scalars -- hat_gamma / gamma_i (a division: ten instructions) and
+                // gamma_i / N -- need nothing of this step either: issued here, in front of the exchange, instead of behind it
+                T pre_rr = T(0), pre_gn = T(0);
+                if (ALG == CA_FINITO || ALG == CA_LFINITO) {
+                    pre_rr = a.hat_gamma / x.gi;
+                    pre_gn = x.gi * a.invN;
+                    if constexpr (NW != 1) asm volatile("" : "+v"(pre_rr), "+v"(pre_gn));
+                }
                 if constexpr (NW == 4 && !(CIAO_CHAIN_DBG & 2)) {
                     // The exchange with its reads in two halves, and in between -- while the partials travel from LDS, about
                     // ninety cycles in which this wave has nothing else to do -- everything of the step that does not need
@@ -1463,9 +1471,8 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                             if (ok[j]) sp[cl[j]] = gnv;
                         }
                     } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
-                        const T gi = x.gi;
-                        const T ncc = -(gi * a.invN) * gp.coef();   // t = z - (gamma_i/N) * c * a
-                        const T rr = a.hat_gamma / gi;
+                        const T ncc = -pre_gn * gp.coef();   // t = z - (gamma_i/N) * c * a
+                        const T rr = pre_rr;                  // hat_gamma / gamma_i
                         V *sp = reinterpret_cast<V *>(table_row<SHARDED>(SHARDED ? a_in : a, row));
     #pragma unroll
                         for (int j = 0; j < J; ++j) {
@@ -1486,9 +1493,8 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                         }
                     } else {                                                         // Finito_LFinito.jl:93-98
                         const GradCoef<T> gzf = grad_coef_t<T, LOSS>(d2, bi, a.lam);
-                        const T gi = x.gi;
                         const T dc = (a.hat_gamma * a.invN) * (gzf.coef() - gp.coef());
-                        const T rr = a.hat_gamma / gi;
+                        const T rr = pre_rr;                  // hat_gamma / gamma_i
     #pragma unroll
                         for (int j = 0; j < J; ++j)
     #pragma unroll
