@@ -1291,6 +1291,14 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                     drain_vmcnt_visible();   // retire it HERE, or hipcc puts a draining vmcnt(0) on the common path
                 }
 
+                // Finito / LFinito: the per-sample stepsize's two scalars -- hat_gamma / gamma_i (a division: ten instructions) and
+                // gamma_i / N -- need nothing of this step: written HERE, in front of the wave sum, they fill the wait states of its
+                // DPP stages and the exchange's first shadow instead of standing behind the exchange
+                T pre_rr = T(0), pre_gn = T(0);
+                if (ALG == CA_FINITO || ALG == CA_LFINITO) {
+                    pre_rr = a.hat_gamma / x.gi;
+                    pre_gn = x.gi * a.invN;
+                }
                 T d1 = T(0), d2 = T(0);
 #pragma unroll
                 for (int j = 0; j < J; ++j)
@@ -1370,13 +1378,8 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                         if constexpr (NW == 4) asm volatile("" : "+v"(q1[j]), "+v"(q2[j]));
                     }
                 }
-                // Finito / LFinito: the per-sample stepsize's two scalars -- hat_gamma / gamma_i (a division: ten instructions) and
-                // gamma_i / N -- need nothing of this step either: issued here, in front of the exchange, instead of behind it
-                T pre_rr = T(0), pre_gn = T(0);
                 if (ALG == CA_FINITO || ALG == CA_LFINITO) {
-                    pre_rr = a.hat_gamma / x.gi;
-                    pre_gn = x.gi * a.invN;
-                    if constexpr (NW != 1) asm volatile("" : "+v"(pre_rr), "+v"(pre_gn));
+                    if constexpr (NW != 1) asm volatile("" : "+v"(pre_rr), "+v"(pre_gn));   // (computed above, complete by here)
                 }
                 if constexpr (NW == 4 && !(CIAO_CHAIN_DBG & 2)) {
                     // The exchange with its reads in two halves, and in between -- while the partials travel from LDS, about
