@@ -126,6 +126,8 @@ def test_null_arguments_are_rejected_before_any_launch(ciao):
     assert lib.ciao_ctx_create(0, None, None) == ciao._lib.ERR_ARG
     assert lib.ciao_full_gradient(None, None, None, None) == ciao._lib.ERR_ARG
     assert lib.ciao_ctx_synchronize(None) == ciao._lib.ERR_ARG
+    assert lib.ciao_ctx_chain_batch_begin(None) == ciao._lib.ERR_ARG and lib.ciao_ctx_chain_batch_end(None, 1) == ciao._lib.ERR_ARG
+    assert lib.ciao_svrg_epoch_tail(None, None, 1, 0, None, None, None, None) == ciao._lib.ERR_ARG
     assert lib.ciao_ctx_destroy(None) == ciao._lib.OK
 
 
