@@ -1166,10 +1166,8 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
         for (int j = 0; j < J; ++j) {
             x.ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * NW + wib) * 64 + lane) * 16);
             if (HAS_TABLE) x.sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * NW + wib) * 64 + lane) * 16);
-            if (MASKED && !ok[j]) {
-                x.ar[j] = V(T(0));
-                if (HAS_TABLE) x.sr[j] = V(T(0));
-            }
+            // (MASKED: the dead chunks are zeroed by mask_dead() when the step that USES them begins -- zeroing them here would
+            // make the wave wait for these reads right after issuing them, a whole LDS latency at the top of every step)
         }
         x.row = s_row[DEPTH + s];
         x.row_n = s_row[DEPTH + s + DEPTH];
@@ -1177,6 +1175,17 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
         x.bi = s_b[s];
         x.gi = PER_SAMPLE_GAM ? s_g[s] : T(1);
         x.stale = HAS_TABLE ? s_stale[s] : 0;
+    };
+
+    auto mask_dead = [&](StepIn &x) {   // rows shorter than the threads' reach: what the ring holds for the dead chunks is discarded
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                if (!ok[j]) {
+                    x.ar[j] = V(T(0));
+                    if (HAS_TABLE) x.sr[j] = V(T(0));
+                }
+        }
     };
 
     int par = 0;
@@ -1260,6 +1269,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                 if (CHK && s >= nch) return;
                 StepIn &x = in[PIPE ? (u & 1) : 0];
                 if (PIPE) {
+                    mask_dead(x);                // read one step ago: long here
                     if (!CHK || s + 1 < nch) {   // next step's inputs: retire its DMA (one step less lead), read, do not wait
                         wait_vmcnt<WAIT_N>();
                         fetch(in[(u + 1) & 1], (u + 1) % DEPTH, s + 1);
@@ -1267,6 +1277,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                 } else {
                     wait_vmcnt<WAIT_N>();
                     fetch(x, u, s);
+                    mask_dead(x);
                 }
                 const int64_t row = uniform64(x.row);
                 const int64_t row_n = uniform64(x.row_n);
