@@ -2481,7 +2481,15 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
                 const int s = s0 + u;
                 if (s >= nch || stop) break;
                 StepIn &x = in[PIPE ? (u & 1) : 0];
+                auto mask_dead = [&]() {
+                    if constexpr (MASKED) {
+#pragma unroll
+                        for (int j = 0; j < J; ++j)
+                            if (!ok[j]) x.ar[j] = x.sr[j] = V(T(0));
+                    }
+                };
                 if (PIPE) {
+                    mask_dead();   // read one step ago
                     if (s + 1 < nch) {
                         wait_vmcnt<WAIT_N>();
                         fetch(in[(u + 1) & 1], (u + 1) % DEPTH, s + 1);
@@ -2489,6 +2497,7 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
                 } else {
                     wait_vmcnt<WAIT_N>();
                     fetch(x, u, s);
+                    mask_dead();
                 }
                 const int64_t row = uniform64(x.row);
                 const int64_t row_n = uniform64(x.row_n);

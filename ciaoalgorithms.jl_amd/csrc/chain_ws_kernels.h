@@ -456,16 +456,24 @@ __global__ void __launch_bounds__((WS_NCW + 1 + NISS) * WAVE) chain_ws_kernel(Ch
         for (int j = 0; j < J; ++j) {
             x.ar[j] = *reinterpret_cast<const V *>(ringA + slot * ROW_BYTES + ((j * NW + wib) * 64 + lane) * 16);
             if (HAS_TABLE) x.sr[j] = *reinterpret_cast<const V *>(ringT + slot * ROW_BYTES + ((j * NW + wib) * 64 + lane) * 16);
-            if (MASKED && !ok[j]) {
-                x.ar[j] = V(T(0));
-                if (HAS_TABLE) x.sr[j] = V(T(0));
-            }
+            // (MASKED: the dead chunks are zeroed when the step that uses them begins, mask_dead() -- here the wave would have to
+            // wait for the reads it has just issued)
         }
         const WsRec<T> *rc = &rec[s & (WS_RR - 1)];
         x.bi = rc->bi;
         x.gi = (ALG == CA_SVRGC) ? rc->gi : T(1);
         x.tptr = HAS_TABLE ? rc->tptr : nullptr;
         x.stale = HAS_TABLE ? rc->stale : 0;
+    };
+    auto mask_dead = [&](StepIn &x) {   // rows shorter than the consumers' reach: what the ring holds for the dead chunks is discarded
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                if (!ok[j]) {
+                    x.ar[j] = V(T(0));
+                    if (HAS_TABLE) x.sr[j] = V(T(0));
+                }
+        }
     };
     auto wait_landed = [&](int64_t need) {   // rows of steps < need are in the ring (and their records staged before them)
         if (need > nsteps) need = nsteps;
@@ -514,6 +522,7 @@ __global__ void __launch_bounds__((WS_NCW + 1 + NISS) * WAVE) chain_ws_kernel(Ch
             if (u == 0) wait_landed(s0 + HALF + 1);          // the prefetches of the first half reach step s0 + HALF
             if (u == HALF) wait_landed(s0 + R + 1);          // ... of the second half, step s0 + R
             StepIn &x = in[u & 1];
+            mask_dead(x);   // read in the previous step's first shadow: long here
             const T bi = x.bi;
             T *const tptr = HAS_TABLE ? reinterpret_cast<T *>((uintptr_t)uniform64((int64_t)(uintptr_t)x.tptr)) : nullptr;
             const bool has_prev = (u > 0) || (s0 > 0);   // compile-time true except in the first step of a revolution

@@ -14,7 +14,7 @@ ctx = Context(0)
 for kv in os.environ.get("CIAO_OPTS", "").split(","):
     if "=" in kv:
         ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-d = 1024
+d = int(os.environ.get("CIAO_D", "1024"))
 for N in (100_000, 1_000_000, 10_000_000):
     A = torch.empty((N, d), dtype=torch.float32, device="cuda"); y = torch.empty((N,), dtype=torch.float32, device="cuda")
     ctx.synth_normal(A, 0, 1, 1 / np.sqrt(d))
