@@ -1593,7 +1593,10 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
     constexpr int DEPTH = DmaDepth<J, HAS_TABLE>::value;
     constexpr int CH = CDMA_CHUNK;   // (half the real chains' chunk: b_i is a pair here, and two 64 KiB rings leave 32 KiB for the staging)
     constexpr int OPS_PER_STEP = HAS_TABLE ? (MASKED ? 2 * J : 3 * J) : J;
-    constexpr int WAIT_N = (DEPTH - 1) * OPS_PER_STEP;
+    // PIPE: the LDS reads of step s+1's ring slot are issued at the top of step s (one step less DMA lead), so that they have
+    // landed when step s+1 begins instead of being waited for right after their issue (chain_dma_kernel does the same)
+    constexpr bool PIPE = DEPTH >= 4;
+    constexpr int WAIT_N = (PIPE ? DEPTH - 2 : DEPTH - 1) * OPS_PER_STEP;
     constexpr int ROW_BYTES = J * NT * 16;
     static_assert(CH % DEPTH == 0 && WAIT_N <= 63, "ring slots line up with chunk starts; vmcnt is a 6-bit counter");
 
@@ -1697,21 +1700,42 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
         }
         wait_vmcnt<0>();
         drain_vmcnt_visible();
+        struct SlotIn {
+            V ar[J], sr[J];
+        };
+        SlotIn in[2];
+        auto fetch = [&](SlotIn &x, int u) {   // plain LDS reads of ring slot u; the caller has retired its DMA
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                x.ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * NW + wib) * 64 + lane) * 16);
+                if (HAS_TABLE) x.sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * NW + wib) * 64 + lane) * 16);
+            }
+        };
+        if (PIPE) fetch(in[0], 0);
         for (int s0 = 0; s0 < nch; s0 += DEPTH) {
 #pragma unroll
             for (int u = 0; u < DEPTH; ++u) {
                 const int s = s0 + u;
                 if (s >= nch) break;
-                wait_vmcnt<WAIT_N>();                                   // slot u's DMA (issued DEPTH steps ago) has landed
-                V ar[J], sr[J];
-#pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    ar[j] = *reinterpret_cast<const V *>(ringA + (((u * J + j) * NW + wib) * 64 + lane) * 16);
-                    if (HAS_TABLE) sr[j] = *reinterpret_cast<const V *>(ringT + (((u * J + j) * NW + wib) * 64 + lane) * 16);
-                    if (MASKED && !ok[j]) {
-                        ar[j] = V(T(0));
-                        if (HAS_TABLE) sr[j] = V(T(0));
+                SlotIn &x = in[PIPE ? (u & 1) : 0];   // (DEPTH is even: the buffers alternate across revolutions too)
+                if (PIPE) {
+                    if (s + 1 < nch) {
+                        wait_vmcnt<WAIT_N>();                           // slot u+1's DMA (issued DEPTH-1 steps ago) has landed
+                        fetch(in[(u + 1) & 1], (u + 1) % DEPTH);
                     }
+                } else {
+                    wait_vmcnt<WAIT_N>();                               // slot u's DMA (issued DEPTH steps ago) has landed
+                    fetch(x, u);
+                }
+                V(&ar)[J] = x.ar;
+                V(&sr)[J] = x.sr;
+                if (MASKED) {   // dead chunks: what the ring holds for them is discarded
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+                        if (!ok[j]) {
+                            ar[j] = V(T(0));
+                            if (HAS_TABLE) sr[j] = V(T(0));
+                        }
                 }
                 const int64_t row = uniform64(s_row[DEPTH + s]);
                 const int64_t row_n = uniform64(s_row[DEPTH + s + DEPTH]);
