@@ -1020,12 +1020,8 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
 {
     // a batch of chains: this workgroup's own argument block.  (`a` is a private copy whose fields all end up in scalar registers;
     // what is indexed per LANE -- the shard table, never part of a batch -- is read from the kernel argument itself.)
-#ifdef CIAO_NO_CHAIN_BATCH   // A/B experiment builds only: the kernel argument used in place (batches then run chain 0 K times)
-    const ChainArgs<T> &a = a_in;
-#else
     ChainArgs<T> a = a_in;
     chain_args_fetch(a);
-#endif
     constexpr int NW = NT / WAVE;
     static_assert(NW == 1 || NW == 4 || NW == 8, "one, four or eight waves");
     using V = typename VecOfC<T>::type;
