@@ -538,6 +538,38 @@ def chain_figures(ctx, dev, F, g, gamma, A, b, N, d, args, L, np, torch):
             "sample": f"extrapolated: N / (oracle updates/s on {cpu_svrg.get('updates')} updates) + N / (oracle sample-gradients/s of "
                       f"cpu_baseline above) = {t_cpu_epoch:.0f} s per epoch; a whole epoch on one core would take that long"}
     del idx
+    # ---- the same inner cycle for 256 INDEPENDENT solves at once (a regularisation path: a lambda, an index stream and a state
+    # each) over the same resident rows, recorded and launched as one chain batch -- one workgroup per solve.  Not the figure
+    # above (that is one solve, sequential by definition): what the GPU's other 255 compute units are worth to a host that has
+    # several solves.
+    try:
+        K, mk = 256, 40_000
+        W = torch.zeros((K, d), dtype=tdt, device=dev)
+        Z = torch.zeros((K, d), dtype=tdt, device=dev)
+        gs_k = [ProxG(L.PROX_L1, lam=g.lam * (1.0 + k / K)) for k in range(K)]
+        idxs = [ctx._idx(IndexStream(1000 + k).rand_indices(N, mk)) for k in range(K)]
+
+        def batch(m_):
+            with ctx.chain_batch():
+                for k in range(K):                       # av and z_full shared (read-only), w and z per solve
+                    ctx.svrg_inner(F, gs_k[k], gamma, idxs[k][:m_], av, Z[k], zf, W[k])
+            ctx.synchronize()
+
+        batch(512)
+        t0 = time.perf_counter()
+        batch(mk)
+        tb = time.perf_counter() - t0
+        updb = K * mk / tb
+        res["svrg_updates_per_sec_256_solves"] = {
+            "value": updb, "us_per_update_per_solve": tb / mk * 1e6, "solves": K, "m_per_solve": mk, "N": N, "d": d, "dtype": args.dtype,
+            "what": "256 independent SVRG inner cycles (SVRG_basic.jl:73-82 each) over the same rows in ONE launch (ciao_ctx_chain_batch_begin "
+                    "/ _end): aggregate updates/s; each solve bitwise what its own call computes (tests/test_gpu_chain_batch.py)",
+            "kernel": ctx.last_kernel(),
+            "roofline": {"bound": "hbm", "bytes_per_update": d * es + 8, "achieved": updb * (d * es + 8) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": updb * (d * es + 8) / 1e9 / HBM_PEAK_GBS}}
+        del W, Z, idxs
+    except Exception as e:   # noqa: BLE001 -- a secondary figure must not cost the line
+        res["svrg_updates_per_sec_256_solves"] = {"error": repr(e)}
     # ---- SAGA at config #3: l1-logistic, fp32, N x d data + N x d table -------------------------------------------------
     if d * 4 * N * 2 + (A.numel() * A.element_size() if A.dtype != torch.float32 else 0) < 250e9:
         A32 = torch.empty((N, d), dtype=torch.float32, device=dev)
