@@ -90,6 +90,23 @@ def test_C1_lasso_svrg_N1000_d50_fp64_against_the_oracle(ciao, ctx):
     assert 0 <= gap < 0.05 * gap0
     P.PARITY_LOG.append({"test": "test_C1", "line": 0, "what": "C1 worst relative iterate error over 30 states", "dtype": "float64",
                          "ratio": worst / np.finfo(np.float64).eps, "scale": 1e-11 / np.finfo(np.float64).eps})
+    # the two paths' wall time for the same 29 epochs (recorded, not asserted: a 400 KB problem is one workgroup's worth of work;
+    # VERDICT r2 "weak" 3 -- the device needed 11.9 ms against the oracle's 8.4 in round 2)
+    import time
+    def timed(make, n=30):
+        it = iter(make())
+        next(it)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n - 1):
+            next(it)
+        ctx.synchronize()
+        return time.perf_counter() - t0
+    t_dev = min(timed(lambda: S.iterator(S.SVRG(np.float64, γ=gamma), x0, F=F, g=g, N=N, ctx=ctx, stream=ciao.IndexStream(0))) for _ in range(3))
+    t_ref = min(timed(lambda: RS.SVRGIterable(O.Problem("ls", A, b, float(N)), O.Prox("l1", lam=lam), x0, gamma=gamma,
+                                              stream=ciao.IndexStream(0))) for _ in range(3))
+    P.PARITY_LOG.append({"test": "test_C1", "line": 1, "what": f"C1 wall time of 29 epochs: device {t_dev * 1e3:.2f} ms, oracle on one host core "
+                                                              f"{t_ref * 1e3:.2f} ms", "dtype": "float64", "ratio": t_dev / t_ref, "scale": 1e9})
 
 
 def test_C2_lasso_svrg_N1M_d1024_fp64_one_epoch(ciao, ctx):
