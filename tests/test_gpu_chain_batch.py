@@ -344,3 +344,27 @@ def test_finito_steps_with_large_or_ragged_batches_are_refused_by_a_chain_batch(
         ctx.finito_steps(F, g, gam, hg, np.arange(0, 41, 2, dtype=np.int64), np.arange(40, dtype=np.int64), table, av, z)
     ctx.synchronize()
     assert torch.isfinite(z).all() and "chain batch: 1 chains" in ctx.last_kernel()
+
+
+def test_svrg_plus_plus_solved_together_doubles_m_like_the_solves_alone(ctx):
+    """SVRG++ (SVRG.jl:31-38 plus=true: no w = z_full at the epoch's end, m doubles, SVRG_basic.jl:85,93) through the lockstep driver"""
+    import ciaoalgorithms_jl_amd.operators as ops
+    import ciaoalgorithms_jl_amd.solvers as S
+    from ciaoalgorithms_jl_amd.sampling import IndexStream
+    dtype = np.float64
+    A, b, F, Lc = _path_problem(ops, dtype, N=300, d=64, seed=21)
+    N, d = A.shape
+    lams = [0.05, 0.01, 0.002]
+    gam = 1 / (7 * Lc.max())
+    x0 = np.zeros(d, dtype)
+    mk = lambda: S.SVRG(dtype, γ=gam, m=40, plus=True, maxit=6)
+    ctx.set_option("svrg_cache_rowdots", 0)
+    try:
+        alone = [mk()(x0, F=F, g=ops.NormL1(l), N=N, ctx=ctx, stream=IndexStream(30 + k)) for k, l in enumerate(lams)]
+        its = [S.iterator(mk(), x0, F=F, g=ops.NormL1(l), N=N, ctx=ctx, stream=IndexStream(30 + k)) for k, l in enumerate(lams)]
+        xs, n = S.solve_together(its, maxit=6)
+    finally:
+        ctx.set_option("svrg_cache_rowdots", 1)
+    assert n == 6 and all(it._state.m == 40 * 2 ** 5 for it in its)
+    for k, (x, (xa, na)) in enumerate(zip(xs, alone)):
+        assert na == 6 and np.isfinite(x).all() and np.array_equal(x, xa), f"lambda #{k}"
