@@ -12,6 +12,7 @@
 // comparing indices at prefetch time and re-read at use time (same thread wrote it: program order).
 #pragma once
 
+#include <cstddef>
 #include <type_traits>
 
 #include "ciao_common.h"
@@ -83,27 +84,54 @@ __device__ __forceinline__ void chain_args_fetch(ChainArgs<T> &a)
     glob(a.av), glob(a.z), glob(a.zf), glob(a.w), glob(a.errflag), glob(a.dbg);
 }
 
-// global row -> (shard, local row) for the contiguous block partition; all values wave-uniform
+// Where global row r of a row-sharded problem lives: its data row, its b entry (or nullptr), its table row.
+// The shard table (33 qwords: shA[8] | shb[8] | shT[8] | sh_row0[9]) is copied to LDS once per kernel and searched THERE, with the
+// row's own (per-lane) shard number as an index.  Two other ways were measured and dropped: indexing the kernel argument's arrays
+// with the shard number makes the compiler copy the whole argument block to scratch memory and read it from there (round 3: 520
+// bytes of scratch, 320 instructions per SAGA step against 154); a chain of selects over compile-time indexes keeps all 66 scalar
+// registers of the table live through the whole kernel, and everything else spills to VGPR lanes (80-200 spilled SGPRs; the
+// sharded SAGA step 0.44 us against 0.38 unsharded, and the wave-specialised kernel 0.39 against 0.36 with the search in its stager).
+constexpr int SHARD_QW = 4 * CIAO_MAX_SHARDS + 1;
 template <typename T>
-__device__ __forceinline__ int shard_of(const ChainArgs<T> &a, int64_t r, int64_t &local)
+struct ShardRow {
+    const T *arow;
+    const T *bp;
+    T *trow;
+};
+// Lane j < 33 copies qword j of the table straight from the kernel-argument segment (a vector load from constant memory: no
+// scalar registers at all; the chain kernels take their ChainArgs as the one kernel argument, at offset 0, and a chain over a
+// shard table is never part of a batch, whose arguments would live elsewhere).
+template <typename T>
+__device__ __forceinline__ void shard_table_to_lds(int64_t *s_sh, int tid)
 {
-    int k = 0;
-#pragma unroll
-    for (int j = 1; j < CIAO_MAX_SHARDS; ++j) k += (j < a.nshards && r >= a.sh_row0[j]) ? 1 : 0;
-    local = r - a.sh_row0[k];
-    return k;
+    static_assert(offsetof(ChainArgs<T>, shb) == offsetof(ChainArgs<T>, shA) + 8 * CIAO_MAX_SHARDS &&
+                  offsetof(ChainArgs<T>, shT) == offsetof(ChainArgs<T>, shA) + 16 * CIAO_MAX_SHARDS &&
+                  offsetof(ChainArgs<T>, sh_row0) == offsetof(ChainArgs<T>, shA) + 24 * CIAO_MAX_SHARDS, "the table is 33 contiguous qwords");
+    const unsigned char __attribute__((address_space(4))) *ka =
+        (const unsigned char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    if (tid < SHARD_QW) s_sh[tid] = reinterpret_cast<const int64_t __attribute__((address_space(4))) *>(ka + offsetof(ChainArgs<T>, shA))[tid];
 }
-// address of the table row of global row r (uniform): one multiply without shards, a short scalar search with them
-template <bool SHARDED, typename T>
-__device__ __forceinline__ T *table_row(const ChainArgs<T> &a, int64_t r)
+template <typename T>
+__device__ __forceinline__ ShardRow<T> shard_resolve(const int64_t *s_sh, int nshards, int64_t r, int64_t ld, int64_t d)
 {
-    if constexpr (!SHARDED) return a.table + r * a.d;
-    int64_t local;
-    const int k = shard_of(a, r, local);
-    T *base = a.shT[0];
+    const int64_t *row0 = s_sh + 3 * CIAO_MAX_SHARDS;
+    int k = 0;   // sh_row0 ascends: the number of shards that start at or before r, minus one
 #pragma unroll
-    for (int j = 1; j < CIAO_MAX_SHARDS; ++j) base = (j == k) ? a.shT[j] : base;
-    return base + local * a.d;
+    for (int j = 1; j < CIAO_MAX_SHARDS; ++j) k += (j < nshards && r >= row0[j]) ? 1 : 0;
+    const int64_t local = r - row0[k];
+    const T *A = reinterpret_cast<const T *>((uintptr_t)s_sh[k]);
+    const T *b = reinterpret_cast<const T *>((uintptr_t)s_sh[CIAO_MAX_SHARDS + k]);
+    T *tb = reinterpret_cast<T *>((uintptr_t)s_sh[2 * CIAO_MAX_SHARDS + k]);
+    // pointers read from LDS are generic to the compiler; these are global memory (local or peer-mapped)
+    auto glob = [](auto *p) {
+        using P = std::remove_pointer_t<decltype(p)>;
+        return (P *)(__attribute__((address_space(1))) P *)(uintptr_t)p;
+    };
+    ShardRow<T> o;
+    o.arow = glob(A) + local * ld;
+    o.bp = b ? glob(b) + local : nullptr;
+    o.trow = tb ? glob(tb) + local * d : nullptr;
+    return o;
 }
 
 template <typename T>
@@ -1018,8 +1046,7 @@ struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at 0.4-0.9 u
 template <typename T, int J, int ALG, int LOSS, bool MASKED, int NT, bool SHARDED = false>
 __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
 {
-    // a batch of chains: this workgroup's own argument block.  (`a` is a private copy whose fields all end up in scalar registers;
-    // what is indexed per LANE -- the shard table, never part of a batch -- is read from the kernel argument itself.)
+    // a batch of chains: this workgroup's own argument block (`a` is a private copy whose fields all end up in scalar registers)
     ChainArgs<T> a = a_in;
     chain_args_fetch(a);
     constexpr int NW = NT / WAVE;
@@ -1039,6 +1066,9 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
     // PIPE: the LDS reads of step s+1 (its ring slot and its staged scalars) are issued at the top of step s and land
     // while step s reduces its dot product, so only one LDS round trip (the 4-partial exchange) stays on the
     // dependent path.  It costs one step of DMA lead, hence only with DEPTH >= 4.
+    // (eight waves -- 32 KiB rows, 256 registers per wave -- spill 50-190 registers with the two register sets and are still the
+    // fastest of what was measured: fp64 d = 4096 0.570 us per SVRG update against 0.590 without PIPE (no spill) and 0.755 on four
+    // waves with twice the chunks per thread, profiles/r04_chain_32k_ab.txt)
     constexpr bool PIPE = DEPTH >= 4;
     constexpr int WAIT_N = (PIPE ? DEPTH - 2 : DEPTH - 1) * OPS_PER_STEP;
     // four waves: the ring's refill is issued in the shadow of the exchange (between the partial reads' issue and their wait) --
@@ -1050,7 +1080,9 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
     // Chains without a table (SVRG, LFinito) need a step's row only as an ADDRESS: the staged entry is the row's address
     // itself (resolved while staging, with full parallelism), which takes the 64-bit multiply -- nine scalar instructions -- out
     // of every step.  Chains with a table also need the row index (table row, hazard flags): they keep it and compute
-    // the address in the step, or -- over a shard table -- stage the address in a second array.
+    // the address in the step, or -- over a shard table (STAGE_PTR) -- stage BOTH addresses: s_row holds the TABLE row's address
+    // (which identifies the sample as well as its index does: the hazard flags compare it) and s_ptr the data row's, so that a
+    // step never searches the shard table.
     constexpr bool PTR_IN_ROW = !HAS_TABLE;
     constexpr bool STAGE_PTR = SHARDED && HAS_TABLE;
     static_assert(CH % DEPTH == 0 && DEPTH % 2 == 0, "ring slots must line up with chunk starts; ping-pong needs even DEPTH");
@@ -1075,11 +1107,14 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
     cur += (HAS_TABLE ? CH : 0) * sizeof(int);
     cur += (16 - (reinterpret_cast<uintptr_t>(cur) & 15)) & 15;
     T(*red)[NW][2] = reinterpret_cast<T(*)[NW][2]>(cur);
+    cur += 2 * NW * 2 * sizeof(T);
+    int64_t *s_sh = reinterpret_cast<int64_t *>(cur);   // SHARDED: the shard table (shard_resolve)
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t d = a.d;
+    if constexpr (SHARDED) shard_table_to_lds<T>(s_sh, tid);   // (the staging's first __syncthreads orders it before its readers)
     const uint32_t ringA_off = (uint32_t)(uintptr_t)ringA;   // LDS byte offsets (low 32 bits of the flat address)
     const uint32_t ringT_off = (uint32_t)(uintptr_t)ringT;
 
@@ -1087,7 +1122,8 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
     // state stays zero, their loads are redirected to chunk 0 and discarded, their stores are predicated off)
     const int64_t nchunks = d / VEC;
     T box_lo = a.g.lo, box_hi = a.g.hi;   // as VALUES (a select between "&a.g.lo" and the bound vector would keep `a` in memory)
-    asm volatile("" : "+v"(box_lo), "+v"(box_hi));
+    T gam_u = a.gam_uniform;              // ... likewise (fp64: 16 bytes of scratch and a flat load per staged step otherwise)
+    asm volatile("" : "+v"(box_lo), "+v"(box_hi), "+v"(gam_u));
     bool ok[J];
     int64_t cl[J];   // chunk to address: own chunk, or 0 when dead
 #pragma unroll
@@ -1129,7 +1165,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
 #pragma unroll
     for (int j = 0; j < J; ++j) gav[j] = a.gamma * av[j];
 
-    // issue the DMA of row r (at address ap) into ring slot u: J (+J) wave-instructions of 1 KiB each
+    // issue the DMA of row r (at address ap; STAGE_PTR: r IS its table row's address) into ring slot u: J (+J) wave-instructions of 1 KiB each
     auto refill = [&](int u, int64_t r, const unsigned char *ap) {
         // table-free chains: base in SGPRs + 32-bit lane offset (-3 % per SVRG step); with a table ring beside it the plain
         // 64-bit VGPR addresses schedule better (measured: SAGA 0.416 us against 0.422 / 0.430 with the scalar base)
@@ -1141,11 +1177,18 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                 glds16s(ap, (uint32_t)cl[j] * 16u, ringA_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
         }
         if (HAS_TABLE) {
-            const unsigned char *sp = reinterpret_cast<const unsigned char *>(table_row<SHARDED>(SHARDED ? a_in : a, r));
+            const unsigned char *sp = STAGE_PTR ? reinterpret_cast<const unsigned char *>((uintptr_t)r)
+                                                : reinterpret_cast<const unsigned char *>(a.table + r * a.d);
 #pragma unroll
             for (int j = 0; j < J; ++j)
                 glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
         }
+    };
+
+    // the table row of the sample a step knows as `row`: its index, or (STAGE_PTR) the row's address itself
+    auto trow_of = [&](int64_t row) -> T * {
+        if constexpr (STAGE_PTR) return reinterpret_cast<T *>((uintptr_t)row);
+        else return a.table + row * a.d;
     };
 
     // everything step s needs from LDS: its ring slot and its staged scalars (two register sets, ping-pong by step parity)
@@ -1204,21 +1247,22 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                 r = 0;
             }
             const T *arow, *bp;
-            if (SHARDED) {   // global row -> (shard, local row): the shard's base may be another GPU's memory
-                int64_t local;
-                const int k = shard_of(a_in, r, local);
-                arow = a_in.shA[k] + local * a.ld;
-                bp = a_in.shb[k] ? a_in.shb[k] + local : nullptr;
+            int64_t ident = r;   // what the steps and the hazard flags know the sample by
+            if (SHARDED) {   // global row -> its shard's memory (which may be another GPU's)
+                const ShardRow<T> sr = shard_resolve<T>(s_sh, a.nshards, r, a.ld, a.d);
+                arow = sr.arow;
+                bp = sr.bp;
+                if (STAGE_PTR) ident = (int64_t)(uintptr_t)sr.trow;
             } else {
                 arow = a.A + r * a.ld;
                 bp = a.b ? a.b + r : nullptr;
             }
-            s_row[DEPTH + e] = PTR_IN_ROW ? (int64_t)(uintptr_t)arow : r;
+            s_row[DEPTH + e] = PTR_IN_ROW ? (int64_t)(uintptr_t)arow : ident;
             if (STAGE_PTR) s_ptr[DEPTH + e] = reinterpret_cast<const unsigned char *>(arow);
             if (e < nch) {
                 s_b[e] = bp ? *bp : T(0);
                 if (PER_SAMPLE_GAM) {
-                    const T gv = a.gam ? a.gam[r] : a.gam_uniform;
+                    const T gv = a.gam ? a.gam[r] : gam_u;
                     // SVRG with cached row dots: what the step needs of a_i'z_full is the link-function coefficient at it,
                     // which does not depend on the chain -- evaluated HERE, 256 steps at a time, instead of once per step on
                     // the chain's only wave per SIMD (for the logistic loss that is an exp and a division per step)
@@ -1292,7 +1336,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                 if (HAS_TABLE && __builtin_amdgcn_readfirstlane(x.stale)) {
                     // an intervening step rewrote this table row after its DMA was issued: re-read it from memory (this
                     // very thread stored these bytes, so program order makes them visible)
-                    const V *sp = reinterpret_cast<const V *>(table_row<SHARDED>(SHARDED ? a_in : a, row));
+                    const V *sp = reinterpret_cast<const V *>(trow_of(row));
 #pragma unroll
                     for (int j = 0; j < J; ++j) x.sr[j] = ok[j] ? sp[cl[j]] : V(T(0));
                     drain_vmcnt_visible();   // retire it HERE, or hipcc puts a draining vmcnt(0) on the common path
@@ -1460,7 +1504,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                                 if (!(NW == 4 && !(CIAO_CHAIN_DBG & 2))) zs[j][v] += p[j][v];   // four waves: in the next step's exchange shadow
                             }
                     } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
-                        V *sp = reinterpret_cast<V *>(table_row<SHARDED>(SHARDED ? a_in : a, row));
+                        V *sp = reinterpret_cast<V *>(trow_of(row));
                         const T gl = a.gamma * plam;
                         const T cp = gp.coef();
                         const T ngam = -a.gamma;
@@ -1483,7 +1527,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                     } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
                         const T ncc = -pre_gn * gp.coef();   // t = z - (gamma_i/N) * c * a
                         const T rr = pre_rr;                  // hat_gamma / gamma_i
-                        V *sp = reinterpret_cast<V *>(table_row<SHARDED>(SHARDED ? a_in : a, row));
+                        V *sp = reinterpret_cast<V *>(trow_of(row));
     #pragma unroll
                         for (int j = 0; j < J; ++j) {
                             V tv;
@@ -1591,6 +1635,9 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
     constexpr int OPS_PER_STEP = HAS_TABLE ? (MASKED ? 2 * J : 3 * J) : J;
     // PIPE: the LDS reads of step s+1's ring slot are issued at the top of step s (one step less DMA lead), so that they have
     // landed when step s+1 begins instead of being waited for right after their issue (chain_dma_kernel does the same)
+    // (eight waves -- 32 KiB rows, 256 registers per wave -- spill 50-190 registers with the two register sets and are still the
+    // fastest of what was measured: fp64 d = 4096 0.570 us per SVRG update against 0.590 without PIPE (no spill) and 0.755 on four
+    // waves with twice the chunks per thread, profiles/r04_chain_32k_ab.txt)
     constexpr bool PIPE = DEPTH >= 4;
     constexpr int WAIT_N = (PIPE ? DEPTH - 2 : DEPTH - 1) * OPS_PER_STEP;
     constexpr int ROW_BYTES = J * NT * 16;
@@ -1897,7 +1944,7 @@ constexpr size_t chain_dma_lds_bytes()
     constexpr bool STAGE_PTR = SHARDED && HAS_TABLE;
     return (size_t)DEPTH * J * NT * 16 * (HAS_TABLE ? 2 : 1) + (STAGE_PTR ? 2 : 1) * (CHAIN_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
            CHAIN_CHUNK * sizeof(T) * (PER_SAMPLE_GAM ? 2 : 1) + (HAS_TABLE ? CHAIN_CHUNK * sizeof(int) : 0) + 16 +
-           2 * NW * 2 * sizeof(T);
+           2 * NW * 2 * sizeof(T) + (SHARDED ? SHARD_QW * sizeof(int64_t) : 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2344,6 +2391,9 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
     constexpr int DEPTH = DmaDepth<(J * NT + 255) / 256, true>::value;
     constexpr int CH = AF_CHUNK;
     constexpr int OPS_PER_STEP = (MASKED ? 2 * J : 3 * J) + 1;   // MASKED: predicated table stores are not counted (chain_dma_kernel)
+    // (eight waves -- 32 KiB rows, 256 registers per wave -- spill 50-190 registers with the two register sets and are still the
+    // fastest of what was measured: fp64 d = 4096 0.570 us per SVRG update against 0.590 without PIPE (no spill) and 0.755 on four
+    // waves with twice the chunks per thread, profiles/r04_chain_32k_ab.txt)
     constexpr bool PIPE = DEPTH >= 4;
     constexpr int WAIT_N = (PIPE ? DEPTH - 2 : DEPTH - 1) * OPS_PER_STEP;
     constexpr int ROW_BYTES = J * NT * 16;

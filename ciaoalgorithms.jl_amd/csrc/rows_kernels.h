@@ -78,7 +78,9 @@ constexpr int ROWS_WAVES = ROWS_BLOCK / WAVE;
 // +1 for the Finito table row) and ~44 (f32) / ~76 (f64) registers of addressing / dot-product temporaries.
 template <int ES, int K, int MODE, int PF>
 struct RowsWaves {
-    static constexpr int budget = 4 * K * (2 + PF) + ((MODE == RM_FINITO_BATCH || MODE == RM_AFINITO_INIT) ? 2 * K + 16 : 0) + (ES == 8 ? 76 : 44);
+    // (the adaptive init of 16 KiB fp64 rows keeps a second probe's worth of scalars: at two waves per SIMD it spilled 18 registers)
+    static constexpr int budget = 4 * K * (2 + PF) + ((MODE == RM_FINITO_BATCH || MODE == RM_AFINITO_INIT) ? 2 * K + 16 : 0) + (ES == 8 ? 76 : 44) +
+                                  ((MODE == RM_AFINITO_INIT && K == 16 && ES == 8) ? 24 : 0);
     static constexpr int raw = 512 / ((budget + 7) / 8 * 8);
     static constexpr int value = raw < 1 ? 1 : (raw > 8 ? 8 : raw);
 };
@@ -579,6 +581,8 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
         acc[i] = T(0);
     }
     T ex = T(0);
+    T gam_u = a.gam_uniform;   // as a VALUE (see fetch)
+    asm volatile("" : "+v"(gam_u));
     s1s[lane] = T(0);   // rows of a short last group are never written: their (unused, times-zero) scalars must be finite
     ggs[lane] = T(1);
     const int64_t ngroups = (a.nrows + G - 1) / G;
@@ -604,9 +608,17 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
 #endif
             v[i] = on ? val : T(0);
         }
-        // volatile: hipcc otherwise sinks these two loads down to their use, behind the prefetch
-        bi = (a.b && myrow < nrg) ? *reinterpret_cast<const volatile T *>(a.b + rb + myrow) : T(0);
-        gi = (MODE == RM_FINITO_INIT && a.gam && myrow < nrg) ? *reinterpret_cast<const volatile T *>(a.gam + rb + myrow) : a.gam_uniform;
+        // volatile: hipcc otherwise sinks these two loads down to their use, behind the prefetch.  Through GLOBAL-address-space
+        // pointers, unconditionally per lane (a lane without a row reads the group's first row's scalar and drops it): a
+        // volatile load through a generic pointer is a FLAT instruction, and a per-lane `cond ? *p : value` made the compiler
+        // select between p and a scratch-memory copy of the value (8-16 bytes of scratch in every variant of this kernel)
+        typedef const volatile __attribute__((address_space(1))) T *gvol;
+        const int64_t rsel = rb + (myrow < nrg ? myrow : 0);
+        T bv = T(0), gv = gam_u;
+        if (a.b) bv = *reinterpret_cast<gvol>((uintptr_t)(a.b + rsel));
+        if (MODE == RM_FINITO_INIT && a.gam) gv = *reinterpret_cast<gvol>((uintptr_t)(a.gam + rsel));
+        bi = myrow < nrg ? bv : T(0);
+        gi = myrow < nrg ? gv : gam_u;
     };
     T av[SMALL_I], avn[SMALL_I];
     T bcur = T(0), gcur = T(1), bnext = T(0), gnext = T(1);

@@ -102,3 +102,46 @@
 
 OMP_SWEEP(double, f64, exp)
 OMP_SWEEP(float, f32, expf)
+
+/* Raw sums of a row shard on all cores (see ciao_oracle.h): a checker for the sharded configs at their real size.  The
+ * dot products and the products c_i a_ik are formed in double whatever R is, the sums are kept in long double (x87 80-bit):
+ * the value is the exact-arithmetic sum to well below one eps(R) of its own magnitude even after 10^7 cancelling terms. */
+#define OMP_SHARD(R, S, EXPF)                                                                                  \
+    EXPORT int orc_shard_sums_omp_##S(const orc_problem *p, int64_t rows, const R *x, long double *acc)        \
+    {                                                                                                          \
+        const int64_t d = p->d;                                                                                \
+        const R *A = (const R *)p->A, *b = (const R *)p->b;                                                    \
+        const double lam = p->lam;                                                                             \
+        int nt = 1;                                                                                            \
+        _Pragma("omp parallel")                                                                                \
+        {                                                                                                      \
+            _Pragma("omp single") nt = omp_get_num_threads();                                                  \
+        }                                                                                                      \
+        long double *priv = (long double *)calloc((size_t)nt * (size_t)d, sizeof(long double));                \
+        _Pragma("omp parallel num_threads(nt)")                                                                \
+        {                                                                                                      \
+            int t = omp_get_thread_num();                                                                      \
+            long double *a2 = priv + (size_t)t * (size_t)d;                                                        \
+            int64_t lo = rows * t / nt, hi = rows * (t + 1) / nt;                                              \
+            for (int64_t i = lo; i < hi; ++i) {                                                                \
+                const R *a = A + i * d;                                                                        \
+                double dot = 0.0;                                                                              \
+                for (int64_t k = 0; k < d; ++k) dot += (double)a[k] * (double)x[k];                            \
+                double c;                                                                                      \
+                if (p->loss == ORC_LOSS_LS)                                                                    \
+                    c = lam * (dot - (double)b[i]);                                                            \
+                else if (p->loss == ORC_LOSS_LOGISTIC)                                                         \
+                    c = -(double)b[i] / (1.0 + exp((double)b[i] * dot));                                       \
+                else                                                                                           \
+                    c = 0.0;                                                                                   \
+                for (int64_t k = 0; k < d; ++k) a2[k] += (long double)(c * (double)a[k]);                      \
+            }                                                                                                  \
+        }                                                                                                      \
+        for (int64_t k = 0; k < d; ++k)                                                                        \
+            for (int t = 0; t < nt; ++t) acc[k] += priv[(size_t)t * (size_t)d + (size_t)k];                    \
+        free(priv);                                                                                            \
+        return nt;                                                                                             \
+    }
+
+OMP_SHARD(double, f64, exp)
+OMP_SHARD(float, f32, expf)

@@ -53,6 +53,7 @@ typedef struct {
     R orc_gradient_##S(int loss, int64_t d, const R *a, const R *bp, R lam, const R *x, R *y);                 \
     void orc_prox_##S(const orc_prox_desc *g, int64_t d, const R *x, R gamma, R *y);                           \
     void orc_full_pass_##S(const orc_problem *p, const R *x, R *av, R *tmp);                                   \
+    void orc_shard_pass_##S(const orc_problem *p, int64_t rows, const R *x, R *av, R *tmp);                    \
     void orc_svrg_init_##S(const orc_problem *p, const R *x0, R *av, R *z, R *z_full, R *w);                   \
     void orc_svrg_inner_##S(const orc_problem *p, const orc_prox_desc *g, R gamma, int64_t m,                  \
                             const int64_t *idx, const R *av, R *z, const R *z_full, R *w);                     \
@@ -97,6 +98,13 @@ ORC_DECL(float, f32)
  * av = (1/N) sum_i grad f_i(x);  returns the number of threads used. */
 int orc_full_pass_omp_f64(const orc_problem *p, const double *x, double *av);
 int orc_full_pass_omp_f32(const orc_problem *p, const float *x, float *av);
+
+/* All-cores raw sums of a row shard, for checks at sizes one core cannot sweep in seconds:  acc[k] += sum_i c_i(x) a_ik over
+ * the `rows` rows stored in p->A (NOT divided by N; acc is long double and is continued, so slabs can be chained).  Every thread
+ * sums a contiguous block of rows into a private d-vector of R; the privates are added into acc in thread order.  Not the
+ * reference's summation order -- a high-accuracy value of the same sum; returns the number of threads used. */
+int orc_shard_sums_omp_f64(const orc_problem *p, int64_t rows, const double *x, long double *acc);
+int orc_shard_sums_omp_f32(const orc_problem *p, int64_t rows, const float *x, long double *acc);
 
 #ifdef __cplusplus
 }

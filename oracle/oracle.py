@@ -196,6 +196,24 @@ def full_pass_omp(p: Problem, x):
     return av, nt
 
 
+def shard_pass(p: Problem, x, av):
+    """av += sum over the rows HELD by `p` of grad f_i(x) / p.N, sequentially (p built with N_total = the whole problem's
+    row count): the reference's full pass restricted to a row range, continued in `av` (SVRG_basic.jl:88-92)."""
+    tmp = np.empty(p.d, p.dtype)
+    getattr(lib(), f"orc_shard_pass_{_sfx(p.dtype)}")(p.ref, C.c_int64(p.rows), _p(_chk(x, p.dtype, (p.d,))),
+                                                    _p(_chk(av, p.dtype, (p.d,))), _p(tmp))
+    return av
+
+
+def shard_sums_omp(p: Problem, x, acc):
+    """acc[k] += sum over the rows held by `p` of c_i(x) a_ik (raw, not divided by N) on all host cores, long double sums;
+    `acc` is a contiguous np.longdouble d-vector that is continued (slabs chain).  Returns the thread count."""
+    assert acc.dtype == np.longdouble and acc.shape == (p.d,) and acc.flags.c_contiguous
+    fn = getattr(lib(), f"orc_shard_sums_omp_{_sfx(p.dtype)}")
+    fn.restype = C.c_int
+    return fn(p.ref, C.c_int64(p.rows), _p(_chk(x, p.dtype, (p.d,))), C.c_void_p(acc.ctypes.data))
+
+
 def svrg_init(p: Problem, x0):
     av, z, z_full, w = (np.empty(p.d, p.dtype) for _ in range(4))
     getattr(lib(), f"orc_svrg_init_{_sfx(p.dtype)}")(p.ref, _p(_chk(x0, p.dtype, (p.d,))), _p(av), _p(z), _p(z_full), _p(w))

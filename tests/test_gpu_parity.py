@@ -688,10 +688,12 @@ def test_short_rows_run_the_chains_on_one_wave(ctx, ciao, dtype, d):
 # ----------------------------------------------------------------------------------------------------------------------
 # SAGA / SAG
 # ----------------------------------------------------------------------------------------------------------------------
-# rows of 2-8 KiB (fp64: 4-8 KiB) take chain_ws_kernel, the wave-specialised chain (consumer / stager / issuer waves, barrier-free
-# exchange); option chain_no_ws=1 keeps them on chain_dma_kernel.  Same arithmetic, operation for operation.
-WS_CASES = [(np.float64, 1024), (np.float64, 1000), (np.float64, 600), (np.float64, 520), (np.float32, 1024), (np.float32, 2048),
-            (np.float32, 1500), (np.float32, 1000), (np.float32, 516), (np.float32, 700)]
+# rows of 2-4 KiB take chain_ws_kernel, the wave-specialised chain (consumer / stager / issuer waves, barrier-free exchange); fp64
+# rows of up to 4 KiB of an unsharded problem run on ONE wave instead and reach it with option chain_four_waves=1 (or over a shard
+# table); option chain_no_ws=1 keeps everything on chain_dma_kernel, where rows beyond 4 KiB always run (round 4: the 8 KiB
+# variants were slower -- fp64 3.5x, it spilled -- and are not built).  Same arithmetic, operation for operation.
+WS_CASES = [(np.float64, 512), (np.float64, 400), (np.float64, 260), (np.float64, 1024), (np.float32, 1024), (np.float32, 2048),
+            (np.float32, 1000), (np.float32, 516), (np.float32, 700)]
 
 
 @pytest.mark.parametrize("dtype,d", WS_CASES)
@@ -718,9 +720,13 @@ def test_wave_specialised_saga_is_bitwise_the_dma_chain(ctx, ciao, dtype, d, sag
         rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
         O.saga_steps(op, og, dtype(gamma), sag, idx, rt, rav, rz)
         outs = {}
+        rowb = d * np.dtype(dtype).itemsize
+        four = dtype == np.float64 and rowb <= 4096          # fp64 rows of up to 4 KiB: off the one-wave kernel, for all three routes
+        takes_ws = rowb <= 4096 and (four or rowb > 2048)
         for name, opts in (("dma", {"chain_no_ws": 1}), ("ws2", {"chain_ws_issuers": 2}), ("ws1", {"chain_ws_issuers": 1})):
             for k, v in opts.items():
                 ctx.set_option(k, v)
+            ctx.set_option("chain_four_waves", 1 if four else 0)
             try:
                 table = torch.empty((N, d), dtype=tdt, device="cuda")
                 av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
@@ -732,8 +738,9 @@ def test_wave_specialised_saga_is_bitwise_the_dma_chain(ctx, ciao, dtype, d, sag
             finally:
                 ctx.set_option("chain_no_ws", 0)
                 ctx.set_option("chain_ws_issuers", 0)
-            assert ("chain_ws_kernel" in kern) == (name != "dma"), kern
-            if name != "dma":
+                ctx.set_option("chain_four_waves", 0)
+            assert ("chain_ws_kernel" in kern) == (name != "dma" and takes_ws), kern
+            if name != "dma" and takes_ws:
                 assert f"issuers{name[-1]}" in kern, kern
             outs[name] = [t.cpu().numpy() for t in (z, av, table)]
         for name in ("ws2", "ws1"):
