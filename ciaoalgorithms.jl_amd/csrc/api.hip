@@ -207,9 +207,18 @@ static void chain_shards(const ciao_ctx *ctx, const ciao_problem *p, ChainArgs<T
 
 // Row-sharded chains: after the owner's chain, vectors u and v (d each) are all-reduced with the non-owners contributing
 // zeros, so every rank ends with the owner's values (the sum adds exact zeros: bitwise the owner's).
+// `nsteps` = the length of the chain the owner runs first: the other ranks enqueue their half of the reduction at once and WAIT in
+// it for the owner's whole chain kernel -- seconds at 10^7 steps.  RCCL and a host hook tolerate any skew; the peer mailboxes'
+// wait is bounded in wall-clock time, so this one reduction is given the chain's worth of it (2 us per step is several times
+// the slowest chain, remote rows included) on top of the ordinary limit.
 template <typename T>
-static int32_t broadcast_from_owner(ciao_ctx *ctx, int64_t d, void *u, void *v)
+static int32_t broadcast_from_owner(ciao_ctx *ctx, int64_t d, void *u, void *v, int64_t nsteps)
 {
+    struct Once {
+        ciao_ctx *c;
+        ~Once() { c->peer_wait_s_once = 0; }
+    } once{ctx};
+    ctx->peer_wait_s_once = ctx->peer_timeout_s + 60 + nsteps / 500000;
     const size_t bytes = (size_t)d * sizeof(T);
     CIAO_TRY(ensure(ctx, &ctx->sumbuf, &ctx->sumbuf_bytes, 2 * bytes + sizeof(T)));
     char *buf = (char *)ctx->sumbuf;
@@ -332,7 +341,7 @@ static int32_t svrg_inner_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_pro
             chain_shards<T>(ctx, p, a, false);
             CIAO_TRY(launch_chain<T>(ctx, CA_SVRG, a));
         }
-        return ctx->hook ? broadcast_from_owner<T>(ctx, p->d, z, w) : CIAO_OK;
+        return ctx->hook ? broadcast_from_owner<T>(ctx, p->d, z, w, m) : CIAO_OK;
     }
     // a_i'z_full for every row is already known if the last full pass on this ctx was the one at this z_full
     if (use_rowdots && ctx->rowdot_A == p->A && ctx->rowdot_x == z_full && ctx->rowdot_N == p->N && ctx->rowdot_A) {
@@ -393,7 +402,7 @@ static int32_t saga_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_pro
             chain_shards<T>(ctx, p, a, true);
             CIAO_TRY(launch_chain<T>(ctx, CA_SAGA, a));
         }
-        return ctx->hook ? broadcast_from_owner<T>(ctx, p->d, z, av) : CIAO_OK;
+        return ctx->hook ? broadcast_from_owner<T>(ctx, p->d, z, av, nsteps) : CIAO_OK;
     }
     return launch_chain<T>(ctx, CA_SAGA, a);
 }
@@ -1083,11 +1092,12 @@ static int32_t peer_hook(void *user, void *buf, int64_t count, int32_t dtype, vo
 int32_t ciao_ctx_set_peers(ciao_ctx *ctx, int32_t rank, int32_t world, void *const *mailboxes, int64_t max_elems)
 {
     CIAO_ENTER(ctx);
-    if (!mailboxes || world <= 0) {   // off
+    if (!mailboxes || world <= 0) {   // off: what the peers displaced (a user hook, the RCCL communicator) is back in place
         if (ctx->hook == peer_hook) {
-            ctx->hook = nullptr;
-            ctx->hook_user = nullptr;
+            ctx->hook = ctx->peer_saved ? ctx->peer_saved_hook : nullptr;
+            ctx->hook_user = ctx->peer_saved ? ctx->peer_saved_user : nullptr;
         }
+        ctx->peer_saved = false;
         ctx->peer_world = 0;
         return CIAO_OK;
     }
@@ -1102,9 +1112,27 @@ int32_t ciao_ctx_set_peers(ciao_ctx *ctx, int32_t rank, int32_t world, void *con
     for (int r = 0; r < PEER_MAX; ++r) ctx->peer_mail[r] = r < world ? static_cast<unsigned char *>(mailboxes[r]) : nullptr;
     ctx->peer_world = world;
     ctx->peer_rank = rank;
-    ctx->peer_seq = 0;   // fresh mailboxes (all flags zero) are expected: every rank calls this at the same point of its program
+    // The sequence number lives WITH the mailboxes: this rank's own mailbox holds, per parity, the number of the last reduction every
+    // rank published, so a group that is set again (off and on; another ctx) continues after the largest of them instead of
+    // restarting at 1 and meeting flags of an earlier life that happen to equal the new numbers.  Every rank made the
+    // same reductions, so every rank reads the same maximum; fresh mailboxes read 0.
+    {
+        CIAO_HIP(hipStreamSynchronize(ctx->stream));
+        unsigned int flags[2 * PEER_MAX * 16];
+        static_assert(sizeof flags == PEER_HDR, "the header is two parities of eight 64-byte flag lines");
+        CIAO_HIP(hipMemcpy(flags, mailboxes[rank], sizeof flags, hipMemcpyDeviceToHost));
+        unsigned int last = 0;
+        for (int par = 0; par < 2; ++par)
+            for (int r = 0; r < world; ++r) last = flags[(par * PEER_MAX + r) * 16] > last ? flags[(par * PEER_MAX + r) * 16] : last;
+        ctx->peer_seq = last;
+    }
     ctx->peer_max_elems = max_elems;
     ctx->peer_slot_bytes = peer_slot_bytes_for(max_elems);
+    if (ctx->hook != peer_hook) {   // remember what is displaced (set twice in a row: the first one's memory stands)
+        ctx->peer_saved_hook = ctx->hook;
+        ctx->peer_saved_user = ctx->hook_user;
+        ctx->peer_saved = true;
+    }
     ctx->hook = peer_hook;
     ctx->hook_user = ctx;
     return CIAO_OK;
@@ -1262,6 +1290,9 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
         ctx->chain_no_dma = value != 0;
     } else if (!strcmp(key, "chain_no_ws")) {
         ctx->chain_no_ws = value != 0;
+    } else if (!strcmp(key, "peer_timeout_s")) {
+        CIAO_REQUIRE(value >= 1 && value <= 86400, "peer_timeout_s must be in 1..86400");
+        ctx->peer_timeout_s = value;
     } else if (!strcmp(key, "chain_ws_issuers")) {
         CIAO_REQUIRE(value >= 0 && value <= 2, "chain_ws_issuers must be 0 (automatic), 1 or 2");
         ctx->chain_ws_issuers = value;

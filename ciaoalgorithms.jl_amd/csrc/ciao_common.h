@@ -182,7 +182,11 @@ template <typename T>
 __device__ __forceinline__ void prox_cpair_chain(T gl, T vr, T vi, T &yr, T &yi)
 {
     const T n2 = fmad(vr, vr, vi * vi);
-    if (n2 > gl * gl) {
+    // (the floor: with gl = 0 or tiny a SUBNORMAL n2 would pass the test, v_rsq of a flushed subnormal is inf, and gl * inf = NaN;
+    // below the smallest normal number the coordinate is 0 to the stated error.  gl is a per-chain constant: the max is hoisted.)
+    constexpr T tiny = sizeof(T) == 8 ? T(2.2250738585072014e-308) : T(1.17549435e-38f);
+    const T thr = gl * gl > tiny ? gl * gl : tiny;
+    if (n2 > thr) {
         const T s = T(1) - gl * frsqrt(n2);
         yr = vr * s;
         yi = vi * s;

@@ -67,6 +67,12 @@ struct ciao_ctx {
     int64_t peer_slot_bytes = 0, peer_max_elems = 0;
     unsigned char *peer_mail[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned int *peer_counter = nullptr;      // device word: workgroups of the sending kernel that are done
+    int64_t peer_timeout_s = 30;               // option peer_timeout_s: how long a reduction waits for a rank (wall clock)
+    int64_t peer_wait_s_once = 0;              // set around ONE reduction that has to wait longer (the chain owner's broadcast)
+    // what ciao_ctx_set_peers displaced, put back when the peers are turned off
+    ciao_allreduce_fn peer_saved_hook = nullptr;
+    void *peer_saved_user = nullptr;
+    bool peer_saved = false;
 
     // tuning
     int64_t sweep_blocks_per_cu = 0;   // 0 = choose from the row size (rows_launch.inc)

@@ -20,6 +20,9 @@ inline PeerDev peer_dev(ciao_ctx *ctx)
     for (int r = 0; r < PEER_MAX; ++r) p.mail[r] = ctx->peer_mail[r];
     p.counter = ctx->peer_counter;
     p.errflag = ctx->errflag;
+    // the chain owner's broadcast sets peer_wait_s_once for the one reduction that has to outwait a whole chain kernel
+    const int64_t wait_s = ctx->peer_wait_s_once > ctx->peer_timeout_s ? ctx->peer_wait_s_once : ctx->peer_timeout_s;
+    p.wait_ticks = (unsigned long long)wait_s * PEER_TICKS_PER_S;
     return p;
 }
 
@@ -69,8 +72,8 @@ int32_t launch_chain(ciao_ctx *ctx, int alg, ChainArgs<T> &a);
 template <typename T, int ALG, int LOSS>
 int32_t launch_dma(ciao_ctx *ctx, int J256, bool masked, ChainArgs<T> &a);
 
-// the wave-specialised chain (chain_ws_kernels.h: consumer / stager / issuer waves, barrier-free exchange) for SVRG, SVRG with
-// cached row dots and SAGA / SAG on 4 / 8 / 16 KiB rows.  Defined in chain_ws_launch.inc, instantiated in chain_ws{0,1,3}_f32/f64.hip.
+// the wave-specialised chain (chain_ws_kernels.h: consumer / stager / issuer waves, barrier-free exchange) for SAGA / SAG on rows
+// of up to 4 KiB.  Defined in chain_ws_launch.inc, instantiated in chain_ws1_f32/f64.hip.
 template <typename T, int ALG, int LOSS>
 int32_t launch_ws(ciao_ctx *ctx, int J256, bool masked, ChainArgs<T> &a);
 

@@ -12,7 +12,8 @@
 //     scope), adds the slots IN RANK ORDER -- every rank forms the bitwise-identical sum -- and applies the epilogue.
 // No collective call, no extra launch: the two kernels exist anyway.  Two parities suffice: a rank can only write reduction q+2
 // after its epilogue of q+1 has seen every rank's flag q+1, which each rank set after ITS epilogue of q had read the slots of q.
-// The wait is bounded (errflag 4, then ciao_ctx_synchronize reports it): a rank that never arrives is an error, not a hung GPU.
+// The wait is bounded in wall-clock time (errflag 4, then ciao_ctx_synchronize reports it): a rank that never arrives is an error, not
+// a hung GPU.
 #pragma once
 
 #include "ciao_common.h"
@@ -21,7 +22,9 @@ namespace ciao {
 
 constexpr int PEER_MAX = 8;
 constexpr int64_t PEER_HDR = 1024;        // flags: [2 parities][8 ranks] x 64 bytes
-constexpr unsigned int PEER_SPIN_LIMIT = 1u << 22;   // polls of ~1 us: seconds
+constexpr unsigned long long PEER_TICKS_PER_S = 100000000ull;   // s_memrealtime: the 100 MHz constant clock
+constexpr int64_t PEER_WAIT_S_DEFAULT = 30;   // a reduction between ranks that run the same kernels: far more than any skew
+                                              // (option peer_timeout_s; the chain owner's broadcast waits for a whole chain, launch.h)
 
 struct PeerDev {
     int world, rank;                   // world == 0: no peers (single device, or the hook path)
@@ -30,6 +33,7 @@ struct PeerDev {
     unsigned char *mail[PEER_MAX];     // mail[r] = rank r's mailbox (mail[rank] = own; the others IPC-mapped)
     unsigned int *counter;             // device-scope "workgroups done" counter of the sending kernel (this rank's own memory)
     int *errflag;
+    unsigned long long wait_ticks;     // how long peer_wait() waits for a rank before it gives up (realtime ticks)
 };
 
 __device__ __forceinline__ unsigned int *peer_flag(const PeerDev &p, int owner, int from)
@@ -74,10 +78,14 @@ __device__ __forceinline__ bool peer_wait(const PeerDev &p)
     if (threadIdx.x == 0) {
         int ok = 1;
         for (int r = 0; r < p.world && ok; ++r) {
-            unsigned int spins = 0;
+            // bounded by WALL-CLOCK time, not by a poll count (a non-owner of a sharded chain waits here for the
+            // owner's whole chain kernel -- seconds at 10^7 steps -- and a count of ~1 us polls gave up on a correct run)
+            unsigned long long t0 = 0;
             while (__hip_atomic_load(peer_flag(p, p.rank, r), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != p.seq) {
                 __builtin_amdgcn_s_sleep(32);
-                if (++spins > PEER_SPIN_LIMIT) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (t0 == 0) t0 = now ? now : 1ull;
+                if (now - t0 > p.wait_ticks) {
                     *p.errflag = 4;
                     ok = 0;
                     break;

@@ -184,6 +184,64 @@ def test_complex_svrg_epochs(ctx, ciao, ctype, shape):
 
 
 @pytest.mark.parametrize("ctype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("n", [128, 300, 512, 1000, 2048])
+def test_complex_lds_dma_chain_is_dispatched_and_bitwise_the_register_ring(ctx, ciao, ctype, n):
+    """aligned complex rows of up to 16 KiB run chain_cdma_kernel (the LDS-DMA ring of the real chains with complex
+    arithmetic); option chain_no_dma=1 keeps them on chain_cplx_reg_kernel / chain_cplx_kernel.  Same formulas in the same
+    order: SVRG inner cycle, SAGA and SAG steps end BITWISE equal on both in fp64 (one entry per 16-byte chunk: the same entries per
+    thread) and to rounding in fp32 (two entries per chunk: other partial sums), unmasked and masked shapes; the dispatch is
+    asserted through ciao_ctx_last_kernel."""
+    import torch
+    from oracle import oracle as O
+    R = RTYPE[ctype]
+    N = 40
+    A, b, x0 = P.synthetic_complex(N, n, ctype, seed=n)
+    op, dp = cmake(A, b, float(N))
+    og, dg = cg(0.01)
+    gamma = 1.0 / (7 * float(N) * np.max(np.sum(np.abs(A.astype(np.complex128)) ** 2, axis=1)))
+    xp = O.as_pairs(x0)
+    tdt = dev(xp).dtype
+    rowb = 2 * n * np.dtype(R).itemsize
+    idx = ciao.IndexStream(n).rand_indices(N, 300)
+    idx[50:53] = idx[49]
+    outs = {}
+    for no_dma in (0, 1):
+        ctx.set_option("chain_no_dma", no_dma)
+        try:
+            av, z, zf, w = (torch.empty(2 * n, dtype=tdt, device="cuda") for _ in range(4))
+            ctx.svrg_init(dp, dev(xp), av, z, zf, w)
+            ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
+            k_svrg = ctx.last_kernel()
+            res = [w.clone(), z.clone()]
+            for sag in (False, True):
+                table = torch.empty((N, 2 * n), dtype=tdt, device="cuda")
+                sav, sz = torch.empty(2 * n, dtype=tdt, device="cuda"), torch.empty(2 * n, dtype=tdt, device="cuda")
+                ctx.saga_init(dp, dg, gamma, dev(xp), table, sav, sz)
+                ctx.saga_steps(dp, dg, gamma, sag, idx, table, sav, sz)
+                res += [sz.clone(), sav.clone(), table.clone()]
+            k_saga = ctx.last_kernel()
+            ctx.synchronize()
+        finally:
+            ctx.set_option("chain_no_dma", 0)
+        on_ring = (no_dma == 0 and rowb <= 16384)
+        for k in (k_svrg, k_saga):
+            assert ("chain_cdma_kernel" in k) == on_ring, (no_dma, rowb, k)
+            if on_ring:
+                assert ("masked" in k) == (rowb % 4096 != 0), k
+            else:
+                assert "chain_cplx" in k, k
+        outs[no_dma] = res
+    for u, v, what in zip(outs[0], outs[1], ("svrg w", "svrg z", "saga z", "saga av", "saga table", "sag z", "sag av", "sag table")):
+        if ctype == np.complex128:   # one complex entry per 16-byte chunk: both kernels give a thread the same entries, in the same order
+            assert torch.equal(u, v), f"chain_cdma_kernel differs from the complex register-ring chain in {what} (n={n}, {ctype.__name__})"
+        else:                        # fp32: a chunk holds TWO entries, so the threads' partial dot products group differently
+            close(u, v.cpu().numpy(), R, scale=200, what=f"chain_cdma_kernel vs the complex register-ring chain: {what} (n={n})")
+    rav, rz, rzf, rw = O.svrg_init(op, xp)
+    O.svrg_inner(op, og, R(gamma), idx, rav, rz, rzf, rw)
+    close(outs[0][0], rw, R, scale=200, what="complex LDS-DMA chain svrg w vs oracle")
+
+
+@pytest.mark.parametrize("ctype", [np.complex128, np.complex64])
 @pytest.mark.parametrize("sag", [False, True])
 @pytest.mark.parametrize("shape", CSHAPES)
 def test_complex_saga_steps(ctx, ciao, ctype, sag, shape):

@@ -307,8 +307,118 @@ def _peer_worker(rank, world, port, q):
             ok["oversize_refused"] = False
         except L.CiaoError:
             ok["oversize_refused"] = True
-        # (5) off again: the context is a single-device context as before
+        # (5) ADVICE r3 (medium): the ONE chain of a row-sharded SVRG / SAGA solve with the peers set.  The owner runs the chain
+        # over both shards; the other rank enqueues its half of the owner's broadcast at once and waits IN the mailbox for the whole
+        # chain kernel (a wall-clock bound now, lengthened for this one reduction by the chain's length; it used to be a poll
+        # count).  Against the oracle on the whole problem, and bitwise the owner's state on every rank.
+        from ciaoalgorithms_jl_amd.parallel import ShardGroup
+        from ciaoalgorithms_jl_amd import solvers as S
+        from oracle import ref_solvers as RS
+        gamma = 1.0 / (7 * float(Li.max()))
+        grp = ShardGroup(ctx, owner=0)
+        it = iter(S.iterator(S.SVRG(np.float64, γ=gamma), np.zeros(d), F=F, g=g, N=N, ctx=ctx, stream=IndexStream(3), shards=grp))
+        rit = iter(RS.SVRGIterable(op, og, np.zeros(d), gamma=gamma, stream=IndexStream(3)))
+        worst = 0.0
+        for _ in range(4):
+            sd, sr = next(it), next(rit)
+            worst = max(worst, float(np.abs(sd.z_full.cpu().numpy() - sr.z_full).max() / max(np.abs(sr.z_full).max(), 1e-30)))
+        ctx.synchronize()
+        ok["sharded_svrg_over_peers_vs_oracle"] = bool(worst <= 1e-11)
+        gathered = [torch.zeros(d, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, sd.z_full.cpu())
+        ok["sharded_svrg_over_peers_replicas_bitwise"] = all(torch.equal(gathered[0], t) for t in gathered)
+        grp.close()
+        grp2 = ShardGroup(ctx, owner=1)          # the OTHER rank owns the SAGA chain: rank 0 is the one that waits
+        sit = iter(S.iterator(S.SAGA(np.float64, γ=gamma), np.zeros(d), F=F, g=g, N=N, ctx=ctx, stream=IndexStream(5), shards=grp2))
+        rsit = iter(RS.SAGAIterable(op, og, np.zeros(d), gamma=gamma, stream=IndexStream(5)))
+        ss = sr = None
+        for _ in range(300):
+            ss, sr = next(sit), next(rsit)
+        ctx.synchronize()
+        ok["sharded_saga_over_peers_vs_oracle"] = bool(np.abs(ss.z.cpu().numpy() - sr.z).max() <= 1e-11 * max(np.abs(sr.z).max(), 1e-30))
+        ok["sharded_saga_over_peers_table_shard"] = bool(np.abs(ss.s.cpu().numpy() - sr.s[row0:row0 + n]).max() <= 1e-11 * np.abs(sr.s).max())
+        grp2.close()
+        # a long chain (1.5M steps: about half a second of kernel) that the waiting rank has to sit out
+        idxl = IndexStream(11).rand_indices(N, 1_500_000)
+        grp3 = ShardGroup(ctx, owner=0)
+        avs, zs, zfs, ws = (torch.empty(d, dtype=torch.float64, device=dev) for _ in range(4))
+        ctx.svrg_init(F, xd, avs, zs, zfs, ws)
+        grp3.install(F)
+        ctx.svrg_inner(F, g, gamma, idxl, avs, zs, zfs, ws)
+        ctx.synchronize()                                            # raises if a rank gave up waiting (error word 4)
+        wall = [torch.zeros(d, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(wall, ws.cpu())
+        ok["long_sharded_chain_over_peers_waited_out"] = all(torch.equal(wall[0], t) for t in wall) and bool(torch.isfinite(ws).all())
+        grp3.close()
+        # (6) config #5's batch unit through the mailboxes: Finito, d = 4096 fp32, static batches of 1024 = 512
+        # rows per rank, per-sample stepsizes, against the oracle on the whole problem -- in Float64 on the same Float32 data (the
+        # accuracy statement) and in Float32 (the table rows; z / av within the reference fold's own loss, tests/test_gpu_configs.py C5)
+        N5, d5, r5, nb5 = 8192, 4096, 1024, 6
+        A5, b5, _ = P.synthetic("ls", N5, d5, np.float32, seed=55)
+        # round-robin row ownership (rank owns the global rows i with i % world == rank): every contiguous batch of 1024 has 512 members
+        # on each rank, as DESIGN section 7 prescribes for config #5's static batches
+        n5 = N5 // world
+        F5 = PackedF(L.LOSS_LS, torch.from_numpy(np.ascontiguousarray(A5[rank::world])).to(dev),
+                     torch.from_numpy(np.ascontiguousarray(b5[rank::world])).to(dev), float(N5), N_total=N5, cyclic=(rank, world))
+        g5 = ProxG(L.PROX_L1, lam=1e-3)
+        gam5 = (0.999 / 1.3 * (1.0 + 0.1 * ((np.arange(N5) * 0.6180339887498949) % 1.0))).astype(np.float32)
+        hg5 = np.float32(1.0 / np.sum(1.0 / gam5.astype(np.float64)))
+        gam5d = torch.from_numpy(np.ascontiguousarray(gam5[rank::world])).to(dev)
+        x05 = torch.zeros(d5, dtype=torch.float32, device=dev)
+        tab5 = torch.empty((n5, d5), dtype=torch.float32, device=dev)
+        av5, z5 = torch.empty_like(x05), torch.empty_like(x05)
+        pg5 = PeerGroup(ctx, max_elems=d5 + 1)
+        ctx.set_peers(pg5)
+        ctx.finito_init(F5, g5, gam5d, float(hg5), x05, tab5, av5, z5)
+        ctx.synchronize()
+        st_tab = [torch.zeros((n5, d5), dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(st_tab, tab5.cpu())
+        h_tab = np.empty((N5, d5), np.float32)
+        for r in range(world):
+            h_tab[r::world] = st_tab[r].numpy()
+        h_av, h_z = av5.cpu().numpy().copy(), z5.cpu().numpy().copy()
+        w_tab, w_av, w_z = h_tab.astype(np.float64), h_av.astype(np.float64), h_z.astype(np.float64)
+        og5 = O.Prox("l1", lam=1e-3)
+        first5 = (np.arange(1, nb5 + 1, dtype=np.int64) % (N5 // r5)) * r5       # cyclic order starts at batch 2 (Finito_basic.jl:99)
+        batches5 = [np.arange(f, f + r5) for f in first5]
+        O.finito_steps(O.Problem("ls", A5, b5, float(N5)), og5, gam5, hg5, batches5, h_tab, h_av, h_z)
+        O.finito_steps(O.Problem("ls", A5.astype(np.float64), b5.astype(np.float64), float(N5)), og5, gam5.astype(np.float64), float(hg5),
+                       batches5, w_tab, w_av, w_z)
+        lo5, ln5 = F5.local_blocks(first5, first5 + r5)
+        ctx.finito_steps_blocks(F5, g5, gam5d, float(hg5), lo5, ln5, tab5, av5, z5)
+        kern5 = ctx.last_kernel()
+        ctx.synchronize()
+        e32 = np.finfo(np.float32).eps
+        def eps_of(dev_t, ref):
+            return float(np.abs(dev_t.cpu().numpy().astype(np.float64) - ref).max() / (e32 * max(np.abs(ref).max(), 1e-300)))
+        ok["c5_batch_kernel"] = "rows_split_kernel<f32,J4,mode4>" in kern5 and bool((ln5 == r5 // world).all())
+        ok["c5_batches_over_peers_vs_f64_oracle"] = eps_of(z5, w_z) <= 16 and eps_of(av5, w_av) <= 16 and eps_of(tab5, w_tab[rank::world]) <= 8
+        ok["c5_batches_over_peers_vs_f32_oracle"] = eps_of(tab5, h_tab[rank::world].astype(np.float64)) <= 20 and \
+            eps_of(z5, h_z.astype(np.float64)) <= 0.5 * nb5 * r5
+        zs5 = [torch.zeros(d5, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(zs5, z5.cpu())
+        ok["c5_replicas_bitwise"] = all(torch.equal(zs5[0], t) for t in zs5)
+        # (7) ADVICE r3 (low): the same group turned off and on again continues its sequence numbers (flags of the earlier
+        # reductions are still in the mailboxes and would match a restarted count), and what the peers displaced is back after "off"
         ctx.set_peers(None)
+        ctx.set_peers(pg5)
+        t7 = torch.full((d5 + 1,), float(rank + 1), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            t7.fill_(float(rank + 1))
+            ctx.peer_allreduce(t7)
+        ctx.synchronize()
+        ok["peers_reused_after_off_on"] = bool(torch.all(t7 == sum(float(r + 1) for r in range(world))))
+        ctx.set_peers(None)
+        pg5.close()
+        ctx.set_allreduce(hook)
+        ctx.set_peers(pg)
+        ctx.set_peers(None)                                          # "off" puts the displaced hook back
+        calls0 = hook.calls
+        ctx.proxgrad_step(F, g, 0.05 / N, xd, av1, y1)
+        ctx.synchronize()
+        ok["displaced_hook_restored"] = hook.calls == calls0 + 1 and bool(np.abs(av1.cpu().numpy() - rav).max() <= 1e-10 * np.abs(rav).max())
+        ctx.set_allreduce(None)
+        # (8) off again: the context is a single-device context as before
         pg.close()
         solo = PackedF(L.LOSS_LS, torch.from_numpy(A).to(dev), torch.from_numpy(b).to(dev), float(N))
         ctx.proxgrad_step(solo, g, 0.05 / N, xd, av1, y1)
