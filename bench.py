@@ -21,17 +21,30 @@ host callback per reduction).  CIAO_BENCH_COLLECTIVE=torch routes it through tor
 instead; CIAO_BENCH_BACKEND=gloo exists only to rehearse several ranks on ONE GPU (host-staged).  `config.collective`
 reports what actually ran.
 
-Prints ONE JSON line (rank 0).  `value` = sample-gradient(+prox) evaluations of the SWEEP per second over all ranks,
-inputs resident in HBM before the timed region.  An *update* in SURVEY.md section 8d's sense is one step of the
-sequential SVRG / SAGA inner loops; those are latency-bound dependent chains and are reported separately at top level
-(`svrg_updates_per_sec`, `saga_updates_per_sec`, `svrg_epochs_per_sec_N10M`), each with its own roofline fraction.
+Prints ONE JSON line (rank 0), kept under 6 KB so that the tail of a driver's log holds all of it.  `value` = per-sample
+grad+prox updates of the SWEEP per second over all ranks (one update = one row's gradient into the aggregate + its share of the
+fused prox), inputs resident in HBM before the timed region; `epochs_per_sec` = sweeps per second.  The other three kinds of
+update SURVEY.md section 8d defines are reported at top level of the same line, measured after the timed region on rank 0, each
+as {value, roofline{...frac}, cpu_baseline{...}}:
+    svrg_updates_per_sec       one step of the SVRG inner cycle (S3), from ONE real outer iteration m = N at the metric's size
+    svrg_epochs_per_sec_N10M   that outer iteration as a whole (m = N updates + tail + full-gradient sweep)
+    saga_updates_per_sec       one SAGA step (G3) at BASELINE config #3 (N x 1024 fp32 + the N x 1024 table), and in fp64
+    finito_samples_per_sec     one sample of a Finito batch (F3) at BASELINE config #5's per-rank shape (1.25M x 4096 fp32 + table):
+                               batches of 4096, and the 512-row share one rank of eight has of such a batch
 `roofline` is for the dominant kernel (the rows sweep), timed with HIP events on the stream it is launched on;
-`cpu_baseline` is the single-threaded CPU oracle on a bounded sample of the same rows.
+`cpu_baseline` is the single-threaded CPU oracle on a bounded sample of the same rows (also with --gpus N > 1: rank 0 times it
+after the timed region while the other ranks wait at the final barrier).  The secondary timings (`extra`) go to a side file
+(gpurun_out/bench_extras.json when that directory exists, else bench_extras.json beside this script) and to stderr.
+
+Before a rank allocates its 82 GB, `collective_preflight` sends 1 KB through every collective path that is going to be used
+(torch.distributed, the library's own ncclAllReduce, the peer mailboxes when asked for), each stage under a watchdog: a path that
+fails is recorded and the next one is taken on every rank alike; if none works the rank exits non-zero with the record on stderr.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -39,6 +52,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+METRIC = "grad+prox updates/sec"          # BASELINE.json's metric; the timed region is the full-gradient + prox sweep (its roofline row)
+UNIT = "updates/s"
 
 
 def parse(argv=None):
@@ -59,7 +74,9 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary timings (sequential chains, table kernels; N=1 only)")
     ap.add_argument("--cpu-chain-updates", type=int, default=100_000, help="updates of each chain the CPU baseline replays")
     ap.add_argument("--cpu-chain-seconds", type=float, default=5.0, help="CPU time budget of each chain baseline")
-    ap.add_argument("--no-chains", action="store_true", help="skip the top-level SVRG / SAGA chain figures (N=1 only)")
+    ap.add_argument("--no-chains", action="store_true", help="skip the top-level SVRG / SAGA / Finito update figures")
+    ap.add_argument("--chain-rows", type=int, default=None, help="rows of the chain figures' SAGA / Finito problems (default: the configs' sizes)")
+    ap.add_argument("--preflight-seconds", type=float, default=120.0, help="watchdog of each collective preflight stage")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work at all: rendezvous, barrier and the JSON relay only (CPU test of the launcher)")
     return ap.parse_args(argv)
@@ -133,15 +150,86 @@ def spawn_ranks(args):
 # ======================================================================================================================
 # one rank
 # ======================================================================================================================
+class Preflight:
+    """1 KB through each collective path BEFORE the big allocation, one stage at a time, each under a watchdog.
+
+    A stage that raises is recorded ("failed: ...") and the caller takes the next path; a stage that HANGS cannot be recovered
+    from inside the process (a collective has no timeout of its own here), so its watchdog prints the record to stderr and ends
+    the process with exit code 3 -- the launcher (ours, or torch.distributed.run) then ends the other ranks.  Nothing here
+    re-executes a process that has touched the GPU: a dead rank is a dead run, reported."""
+
+    def __init__(self, rank, seconds):
+        self.rank, self.seconds, self.rec = rank, float(seconds), {}
+
+    def stage(self, name, fn):
+        done = threading.Event()
+
+        def dog():
+            if not done.wait(self.seconds):
+                self.rec[name] = f"timeout after {self.seconds:.0f} s"
+                print(f"[bench] rank {self.rank}: collective_preflight " + json.dumps(self.rec), file=sys.stderr, flush=True)
+                os._exit(3)
+
+        threading.Thread(target=dog, daemon=True).start()
+        try:
+            note = fn()
+            self.rec[name] = "ok" if not note else f"ok ({note})"
+        except Exception as e:   # noqa: BLE001 -- whatever went wrong is the record
+            self.rec[name] = ("failed: " + repr(e))[:160]
+        finally:
+            done.set()
+        return self.rec[name].startswith("ok")
+
+    def give_up(self, why):
+        self.rec["fatal"] = why
+        print(f"[bench] rank {self.rank}: collective_preflight " + json.dumps(self.rec), file=sys.stderr, flush=True)
+        return 3
+
+
+def _vote(dist, torch, ok, dev=None):
+    """Every rank learns whether EVERY rank succeeded (MIN over the ranks), through the control plane that stage 1 has shown to work."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dev is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
 def dry_rank(args):
-    """The launcher's plumbing without a GPU: process group (gloo), barrier, MAX over ranks, rank 0 prints the line."""
+    """The launcher's plumbing without a GPU: process group (gloo), the collective preflight's control flow, barrier, MAX over
+    ranks, rank 0 prints the line."""
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    pf = Preflight(rank, args.preflight_seconds)
+    collective = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+        def torch_stage():
+            t = torch.ones(256, dtype=torch.float32)
+            dist.all_reduce(t)
+            assert float(t[0]) == world, (float(t[0]), world)
+            return "gloo, dry run"
+
+        if not pf.stage("torch", torch_stage):
+            return pf.give_up("the control plane itself does not work")
+        # the native-RCCL stage as the real run takes it: a rank-local failure (here: forced), a vote, the same fallback on every rank
+        forced = os.environ.get("CIAO_BENCH_FORCE_RCCL_FAIL")      # "all", or the number of the one rank that fails (tests)
+        mine = forced is None or (forced != "all" and str(rank) != forced)
+
+        def rccl_stage():
+            if not mine:
+                raise RuntimeError("forced by CIAO_BENCH_FORCE_RCCL_FAIL")
+            return "not attempted: dry run"
+
+        ok = pf.stage("rccl", rccl_stage)
+        if not _vote(dist, torch, ok):
+            if ok:
+                pf.rec["rccl"] = "ok here, failed on another rank"
+            collective = "gloo(dry run); native RCCL failed the preflight: every rank fell back to torch.distributed"
+        else:
+            collective = "gloo(dry run)"
         dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
@@ -150,9 +238,10 @@ def dry_rank(args):
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": "sweep_sample_gradients_per_sec", "value": None, "unit": "sample-gradients/s", "n_gpus": world,
+        print(json.dumps({"metric": METRIC, "value": None, "unit": UNIT, "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "dry_run": True, "max_rank_seconds": float(el.item()),
-                          "config": {"workload": "launcher_dry_run", "collective": "gloo(dry run)" if world > 1 else "none",
+                          "collective_preflight": pf.rec,
+                          "config": {"workload": "launcher_dry_run", "collective": collective,
                                      "launcher": "bench.py spawned the ranks" if os.environ.get("CIAO_BENCH_SPAWNED") else
                                      ("external launcher (WORLD_SIZE set)" if world > 1 else "single process")}}),
               flush=True)
@@ -215,18 +304,99 @@ def run_rank(args):
         if "=" in kv:
             ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
-    # ---- synthetic problem, generated on the device, keyed by the GLOBAL (row, col): SURVEY.md section 8d ------------
     n_local, d = args.rows_per_gpu, args.d
     N_total = n_local * world
     row0 = rank * n_local
     assert shard_rows(N_total, rank, world) == (row0, n_local)
+    logistic = args.loss == "logistic"
+
+    # ---- collective preflight (before the big allocation) and the choice of the collective: what is installed is what
+    # `config.collective` reports ------------------------------------------------------------------------------------------
+    pf = Preflight(rank, args.preflight_seconds)
+    collective, rccl_ranks, comm, hook, peers = "none", None, None, None, None
+    if world > 1 or force_dist:
+        from ciaoalgorithms_jl_amd.parallel import PeerGroup
+        want = os.environ.get("CIAO_BENCH_COLLECTIVE", "rccl" if backend == "nccl" else "torch")
+        small = torch.ones(256, dtype=torch.float32, device=dev)
+
+        def torch_stage():
+            small.fill_(1.0)
+            dist.all_reduce(small)
+            torch.cuda.synchronize()
+            assert float(small[0]) == world, (float(small[0]), world)
+            return f"backend {dist.get_backend()}"
+
+        if not pf.stage("torch", torch_stage):
+            return pf.give_up("torch.distributed, the control plane of every other stage, does not work")
+        if want == "rccl" and backend == "nccl":
+            # what can fail on one rank alone (loading librccl, its symbols; ncclCommInitRank returning an error) is voted on, so
+            # that every rank takes the same path; a rank that HANGS inside ncclCommInitRank is ended by the stage's watchdog
+            def rccl_stage():
+                nonlocal comm, rccl_ranks
+                if os.environ.get("CIAO_BENCH_FORCE_RCCL_FAIL") in ("all", str(rank)):
+                    raise RuntimeError("forced by CIAO_BENCH_FORCE_RCCL_FAIL")
+                why = RcclComm.probe()
+                if why is not None:
+                    raise RuntimeError(why)
+                comm = RcclComm(rank, world, dev.index)
+                rccl_ranks = comm.count()
+                small.fill_(1.0)
+                comm.all_reduce(small, ctx.stream)
+                ctx.synchronize()
+                assert float(small[0]) == world, (float(small[0]), world)
+                return f"{rccl_ranks} ranks"
+
+            ok = pf.stage("rccl", rccl_stage)
+            if _vote(dist, torch, ok, dev):
+                ctx.set_rccl(comm)
+                collective = "rccl ncclAllReduce(d+1) per step, issued by the library on its stream"
+            else:
+                if ok:
+                    pf.rec["rccl"] = "ok here, failed on another rank"
+                if comm is not None:
+                    comm.close()
+                comm, rccl_ranks = None, None
+                if rank == 0:
+                    print("[bench] native RCCL failed the preflight: torch.distributed carries the collective on every rank", file=sys.stderr)
+        elif want == "peer":
+            # the one-shot peer all-reduce (csrc/peer_kernels.h): the sweep's finalize kernel writes the raw sum into every rank's
+            # mailbox, its epilogue waits for the flags -- no collective call, no extra launch.  Not the default until a node run
+            # has measured it against ncclAllReduce.
+            def peer_stage():
+                nonlocal peers
+                peers = PeerGroup(ctx, max_elems=2 * d)
+                ctx.set_peers(peers)
+                small.fill_(1.0)
+                ctx.peer_allreduce(small)
+                ctx.synchronize()
+                assert float(small[0]) == world, (float(small[0]), world)
+
+            ok = pf.stage("peer", peer_stage)
+            if _vote(dist, torch, ok, dev):
+                collective = "peer mailboxes over HIP IPC (one direct write per rank + flags), fused into finalize / epilogue: no collective call"
+            else:
+                if ok:
+                    pf.rec["peer"] = "ok here, failed on another rank"
+                try:
+                    ctx.set_peers(None)
+                    if peers is not None:
+                        peers.close()
+                except Exception:   # noqa: BLE001
+                    pass
+                peers = None
+        if comm is None and peers is None:
+            hook = AllReduceHook(dev)
+            ctx.set_allreduce(hook)
+            collective = (f"torch.distributed all_reduce(d+1) per step, backend {dist.get_backend()}"
+                          + (" (= RCCL)" if dist.get_backend() == "nccl" else " (host-staged: one-GPU rehearsal, not xGMI)"))
+
+    # ---- synthetic problem, generated on the device, keyed by the GLOBAL (row, col): SURVEY.md section 8d ------------
     A = torch.empty((n_local, d), dtype=tdt, device=dev)
     b = torch.empty((n_local,), dtype=tdt, device=dev)
     ctx.synth_normal(A, row0, seed=0, scale=1.0 / np.sqrt(d))            # ||a_i||^2 ~ 1
     rng = np.random.default_rng(0)
     x_true = rng.standard_normal(d) * (rng.random(d) < 0.05)
     x_true_d = torch.from_numpy(x_true).to(dev, tdt)
-    logistic = args.loss == "logistic"
     lam_f = 1.0 if logistic else float(N_total)                          # LeastSquares(.., R(N)) test_lasso.jl:54
     F = PackedF(L.LOSS_LOGISTIC if logistic else L.LOSS_LS, A, b, lam_f, N_total=N_total, row0=row0)
     ctx.synth_targets(F, x_true_d, noise=0.01 if not logistic else 0.1, labels=logistic, seed=0, b_out=b)
@@ -234,58 +404,6 @@ def run_rank(args):
     g = ProxG(L.PROX_L1, lam=lam_g)
     L_max = (lam_f if not logistic else 0.25) * 1.3                      # ||a_i||^2 <= ~1.3 for d = 1024
     gamma = 1.0 / (7.0 * L_max) if not logistic else 1.0 / (10.0 * L_max)   # test_lasso.jl:164 / test_logistic_l1.jl:126
-
-    # ---- the collective: what is installed is what `config.collective` reports -----------------------------------------
-    collective, rccl_ranks, comm, hook, peers = "none", None, None, None, None
-    if world > 1 or force_dist:
-        want = os.environ.get("CIAO_BENCH_COLLECTIVE", "rccl" if backend == "nccl" else "torch")
-        if want == "peer":
-            # the one-shot peer all-reduce (csrc/peer_kernels.h): the sweep's finalize kernel writes the raw sum into every rank's
-            # mailbox, its epilogue waits for the flags -- no collective call, no extra launch.  Not the default until a node run
-            # has measured it against ncclAllReduce (VERDICT r2 item 2).
-            from ciaoalgorithms_jl_amd.parallel import PeerGroup
-            peers = PeerGroup(ctx, max_elems=2 * d)
-            ctx.set_peers(peers)
-            collective = "peer mailboxes over HIP IPC (one direct write per rank + flags), fused into finalize / epilogue: no collective call"
-        elif want == "rccl" and backend == "nccl":
-            # Vote BEFORE the collective initialisation, on what can fail on one rank alone (loading librccl, its symbols): a rank
-            # that failed there while the others went on into ncclCommInitRank would leave them waiting for it.  Every rank then
-            # takes the same path; a failure INSIDE ncclCommInitRank is fatal (this rank exits non-zero and the launcher -- ours
-            # or torch.distributed.run -- ends the others).
-            why = RcclComm.probe()
-            if why is not None:
-                print(f"[bench] rank {rank}: native RCCL path unavailable ({why})", file=sys.stderr)
-            ok = torch.tensor([1 if why is None else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                if rank == 0:
-                    print("[bench] falling back to torch.distributed for the collective on every rank", file=sys.stderr)
-            else:
-                # ... and a second vote AFTER the collective initialisation: a rank whose ncclCommInitRank returned an error (the
-                # others' then did too, or will time out inside it) must not leave the rest on a communicator it is not part of
-                err = None
-                try:
-                    comm = RcclComm(rank, world, dev.index)
-                    rccl_ranks = comm.count()
-                except Exception as e:   # noqa: BLE001 -- whatever went wrong, every rank has to hear of it
-                    err, comm = repr(e), None
-                    print(f"[bench] rank {rank}: native RCCL communicator failed ({err})", file=sys.stderr)
-                ok = torch.tensor([1 if err is None else 0], dtype=torch.int32, device=dev)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok.item()) == 0:
-                    if comm is not None:
-                        comm.close()
-                    comm, rccl_ranks = None, None
-                    if rank == 0:
-                        print("[bench] falling back to torch.distributed for the collective on every rank", file=sys.stderr)
-                else:
-                    ctx.set_rccl(comm)
-                    collective = "rccl ncclAllReduce(d+1) per step, issued by the library on its stream"
-        if comm is None and peers is None:
-            hook = AllReduceHook(dev)
-            ctx.set_allreduce(hook)
-            collective = (f"torch.distributed all_reduce(d+1) per step, backend {dist.get_backend()}"
-                          + (" (= RCCL)" if dist.get_backend() == "nccl" else " (host-staged: one-GPU rehearsal, not xGMI)"))
     xa = torch.zeros(d, dtype=tdt, device=dev)                           # x0 = 0 (test_lasso.jl:60)
     xb = torch.empty_like(xa)
     av = torch.empty_like(xa)
@@ -339,34 +457,39 @@ def run_rank(args):
         except Exception as e:
             print(f"[bench] all-reduce microbenchmark failed: {e!r}", file=sys.stderr)
         # ... and the peer exchange beside it, whatever collective the timed region used (as two kernels of its own here: the
-        # sweep fuses them into finalize / epilogue and pays no launch for them).  Set up and torn down around the measurement.
-        # On real peers (backend nccl, several GPUs) this is the FIRST time the mailboxes cross xGMI: it runs after the timed region,
-        # but a fault in it would still cost the whole line, so there it needs CIAO_BENCH_PEER_PROBE=1 (or CIAO_BENCH_COLLECTIVE=peer);
-        # the one-GPU rehearsals (gloo backend, CIAO_BENCH_FORCE_DIST) always run it.
+        # sweep fuses them into finalize / epilogue and pays no launch for them).  On real peers (backend nccl, several GPUs) this is
+        # the FIRST time the mailboxes cross xGMI: it runs after the timed region, but a fault in it would still cost the whole line,
+        # so there it needs CIAO_BENCH_PEER_PROBE=1 (or CIAO_BENCH_COLLECTIVE=peer); the one-GPU rehearsals always run it.
         probe = os.environ.get("CIAO_BENCH_PEER_PROBE", "1" if (backend != "nccl" or world == 1) else "0") == "1"
         if peers is not None:
             allreduce_peer_us = allreduce_us
         elif probe:
-            try:
-                from ciaoalgorithms_jl_amd.parallel import PeerGroup
-                saved_rccl, saved_hook = comm, hook
+            pg, good = None, False
+
+            def peer_probe():
+                nonlocal pg, allreduce_peer_us
                 pg = PeerGroup(ctx, max_elems=2 * d)
-                ctx.set_peers(pg)
+                ctx.set_peers(pg)           # displaces the RCCL communicator / the hook; "off" below puts it back (ciao_ctx_set_peers)
                 for _ in range(10):
                     ctx.peer_allreduce(buf)
                 fence()
                 allreduce_peer_us = _timed_events(torch, ctx.stream or torch.cuda.current_stream(), lambda: ctx.peer_allreduce(buf), reps) * 1e6
                 fence()
-                ctx.set_peers(None)
-                pg.close()
-                if saved_rccl is not None:
-                    ctx.set_rccl(saved_rccl)
-                elif saved_hook is not None:
-                    ctx.set_allreduce(saved_hook)
-            except Exception as e:
-                print(f"[bench] peer all-reduce microbenchmark failed: {e!r}", file=sys.stderr)
 
-    units = float(N_total) * args.steps                                  # sample-gradients processed by all ranks
+            try:
+                good = pf.stage("peer_probe", peer_probe)
+            finally:   # whatever happened in between: peers off (the displaced collective is back in place), mailboxes unmapped
+                try:
+                    ctx.set_peers(None)
+                    if pg is not None:
+                        pg.close()
+                except Exception as e:   # noqa: BLE001
+                    print(f"[bench] peer probe teardown failed: {e!r}", file=sys.stderr)
+            # the ranks agree on whether the probe worked before anything else uses the collective again
+            if not _vote(dist, torch, good, dev):
+                allreduce_peer_us = None
+
+    units = float(N_total) * args.steps                                  # per-sample grad+prox updates processed by all ranks
     value = units / elapsed
     alg_bytes = n_local * (d * es + es)                                  # per launch: rows + b_i  
     k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
@@ -382,18 +505,17 @@ def run_rank(args):
         counted = tj.get("kernels", {}).get(tkey, {}).get("rocprof_name")
         if traffic is not None and counted and counted.split("<")[0] != kernel_name.split("<")[0]:
             traffic = None   # the dominant kernel has changed since the counter pass: do not present a stale figure
-        traffic_src = {"file": "profiles/pmc_traffic.json", "measured_at": tj.get("measured_at"), "kernel_counted": counted,
-                       "static": True} if traffic else None
+        traffic_src = f"static: profiles/pmc_traffic.json ({tj.get('measured_at')}, {counted})" if traffic else None
     except Exception:
         traffic = None
 
     out = {
-        "metric": "sweep_sample_gradients_per_sec",
-        "metric_definition": "sample-gradient(+fused prox) evaluations per second of the SVRG full-gradient + prox sweep "
-                             "(SURVEY.md 8a row S4; BASELINE.md's roofline row).  One SVRG/SAGA inner-loop *update* (SURVEY.md "
-                             "8d) is a step of a dependent chain: see svrg_updates_per_sec / saga_updates_per_sec.",
+        "metric": METRIC,
+        "metric_definition": "the SVRG full-gradient + prox sweep (SVRG_basic.jl:87-92): one update = one row's gradient into the aggregate "
+                             "+ its share of the fused prox; value = N_total * steps / time.  The dependent-chain updates of SURVEY 8d "
+                             "are the *_per_sec entries below.",
         "value": value,
-        "unit": "sample-gradients/s",
+        "unit": UNIT,
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -403,13 +525,14 @@ def run_rank(args):
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "sweeps_per_sec": args.steps / elapsed,
+        "epochs_per_sec": args.steps / elapsed,
         # everything in a step that is not the sweep kernel: finalize + epilogue, launch gaps and -- with several ranks -- the
         # all-reduce of the d+1 scalars (BASELINE.md section 2 asks for that figure in microseconds)
         "step_overhead_us_beyond_sweep_kernel": (elapsed / args.steps - k_avg_s) * 1e6,
         "allreduce_us_per_step": allreduce_us,
         "allreduce_us_per_step_peer_mailboxes": allreduce_peer_us,
         "rccl_ranks": rccl_ranks,
+        "collective_preflight": pf.rec if (world > 1 or force_dist) else None,
         "config": {"workload": f"{'l1_logistic' if logistic else 'lasso'}_svrg_fullgrad_prox_sweep",
                    "N_total": N_total, "rows_per_gpu": n_local, "d": d, "f": "LeastSquares(a_i,b_i,N)" if not logistic else "Precompose(LogisticLoss)",
                    "g": f"NormL1({lam_g:g})", "gamma": gamma, "parallelism": f"rows_sharded_x{world}",
@@ -420,8 +543,9 @@ def run_rank(args):
                      "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_n, "algorithmic_bytes_per_launch": alg_bytes},
     }
 
-    # ---- cpu_baseline: the single-threaded oracle (reference-shaped sequential pass) on a bounded sample -------------
-    if rank == 0 and world == 1 and not args.no_cpu:
+    # ---- everything below runs on rank 0 only, after the timed region; with several ranks the others wait at the final barrier ----
+    # cpu_baseline: the single-threaded oracle (reference-shaped sequential pass) on a bounded sample of this rank's rows
+    if rank == 0 and not args.no_cpu:
         try:
             from oracle import oracle as O
             n_s = min(args.cpu_rows, n_local)
@@ -438,34 +562,55 @@ def run_rank(args):
             t2 = time.perf_counter()
             _, nt = O.full_pass_omp(op, x_h)
             t_omp = time.perf_counter() - t2
-            out["cpu_baseline"] = {"value": n_s * reps / t_cpu, "unit": "sample-gradients/s", "cores": 1, "kind": "port",
+            out["cpu_baseline"] = {"value": n_s * reps / t_cpu, "unit": UNIT, "cores": 1, "kind": "port",
                                    "sample": f"first {n_s} rows of the same A (d={d}, {args.dtype}), {reps} sequential full passes, "
-                                             f"{t_cpu:.1f} s; oracle/ciao_oracle.c orc_full_pass (SVRG_basic.jl:87-92 restated)",
+                                             f"{t_cpu:.1f} s; orc_full_pass (SVRG_basic.jl:87-92 restated)",
                                    "all_cores": {"value": n_s / t_omp, "cores": int(nt), "kind": "openmp sweep (not the reference's shape)"},
                                    "host_cores": os.cpu_count()}
             del A_h, b_h, op
         except Exception as e:  # the baseline must never cost us the bench line
-            out["cpu_baseline"] = {"value": None, "unit": "sample-gradients/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+            out["cpu_baseline"] = {"value": None, "unit": UNIT, "cores": 1, "kind": "port", "sample": f"failed: {e!r}"[:200]}
 
-    # ---- the updates SURVEY.md 8d defines: sequential SVRG / SAGA chains at the metric's own size (N=1 only) -------------
+    # the updates SURVEY.md 8d defines: the sequential SVRG / SAGA chains and the Finito batch, at the configs' own sizes
     args.cpu_sweep_rate = (out.get("cpu_baseline") or {}).get("value")
-    if rank == 0 and world == 1 and not args.no_chains:
+    if rank == 0 and not args.no_chains:
+        cctx = ctx
         try:
-            out.update(chain_figures(ctx, dev, F, g, gamma, A, b, n_local, d, args, L, np, torch))
+            if world > 1 or force_dist:
+                # this rank's shard as a problem of its own (N = the shard's rows), on a context without a collective: the chains
+                # are one dependent chain and do not shard
+                cctx = Context(dev.index)
+                Fc = PackedF(F.loss, A, b, 1.0 if logistic else float(n_local))
+                gam_c = gamma * (N_total / n_local) if not logistic else gamma
+            else:
+                Fc, gam_c = F, gamma
+            out.update(chain_figures(cctx, dev, Fc, g, gam_c, A, b, n_local, d, args, L, np, torch))
         except Exception as e:
-            out["chain_figures_error"] = repr(e)
+            out["chain_figures_error"] = repr(e)[:300]
+        finally:
+            if cctx is not ctx:
+                cctx.close()
 
     if not args.no_extras and world == 1 and rank == 0:
+        ex_dir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT
+        ex_path = os.path.join(ex_dir, "bench_extras.json")
         try:
             import bench_extras
             del A, b, F
             torch.cuda.empty_cache()
-            out["extra"] = bench_extras.run(ctx, dev)
+            extra = bench_extras.run(ctx, dev)
         except Exception as e:
-            out["extra"] = {"error": repr(e)}
+            extra = {"error": repr(e)}
+        try:
+            with open(ex_path, "w") as fh:
+                json.dump(extra, fh, indent=1)
+            out["extras_file"] = os.path.relpath(ex_path, ROOT)
+        except Exception as e:   # noqa: BLE001
+            out["extras_file"] = f"not written: {e!r}"[:120]
+        print("[bench] extra " + json.dumps(extra), file=sys.stderr, flush=True)
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(_compact(out), separators=(",", ":")), flush=True)
     if peers is not None:
         ctx.set_peers(None)
         peers.close()
@@ -478,11 +623,30 @@ def run_rank(args):
     return 0
 
 
+def _compact(o, nd=6):
+    """Floats to `nd` significant digits: the line has to fit the tail of a log."""
+    if isinstance(o, float):
+        return float(f"{o:.{nd}g}")
+    if isinstance(o, dict):
+        return {k: _compact(v, nd) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_compact(v, nd) for v in o]
+    return o
+
+
+def _roof(rate, bytes_per_unit):
+    return {"bound": "hbm", "achieved": rate * bytes_per_unit / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": rate * bytes_per_unit / 1e9 / HBM_PEAK_GBS, "bytes_per_unit": bytes_per_unit}
+
+
 def chain_figures(ctx, dev, F, g, gamma, A, b, N, d, args, L, np, torch):
-    """One REAL SVRG outer iteration (SVRG_basic.jl:71-96: m = N dependent updates + the full pass) on the resident
-    problem, and SAGA steps at BASELINE config #3's size (N rows x d fp32 + the N x d gradient table).  Each figure carries
-    the bandwidth bound it is measured against (S3 d*s+8, G3 3*d*s+8 bytes per update); the chains are
-    dependent (step k+1 reads the iterate step k wrote), so the bound is not reachable by construction."""
+    """The three other kinds of update of SURVEY.md 8d, each {value, roofline, cpu_baseline}:
+    * ONE real SVRG outer iteration (SVRG_basic.jl:71-96: m = N dependent updates + the full pass) on the resident problem;
+    * SAGA steps (SAGA_basic.jl:53-68) in fp64 on the resident rows + an N x d table, and at BASELINE config #3's size (N x d fp32 + table);
+    * Finito batches (Finito_basic.jl:109-118) at BASELINE config #5's per-rank shape (1.25M x 4096 fp32 + table): r = 4096 and the
+      512-row share one rank of eight has of such a batch.
+    Bytes per update from SURVEY.md 8d (S3 d*s+8, G3 3*d*s+8, F3 3*d*s+s+8); the chains are dependent (step k+1 reads the iterate step k
+    wrote), so their bound is not reachable by construction."""
     from ciaoalgorithms_jl_amd.device import PackedF, ProxG
     from ciaoalgorithms_jl_amd.sampling import IndexStream
     res = {}
@@ -496,13 +660,12 @@ def chain_figures(ctx, dev, F, g, gamma, A, b, N, d, args, L, np, torch):
     idx = ctx._idx(hidx)
     cpu_svrg = None
     if not args.no_cpu:
-        # cpu_baseline of the chain: the single-threaded oracle (orc_svrg_inner: SVRG_basic.jl:73-82 restated,
-        # two gradient! calls + the four broadcasts + prox! per update) on the FIRST updates of this very epoch -- the rows they visit
-        # are gathered to the host, the state is the device's init state -- for a bounded number of updates
+        # cpu_baseline of the chain: the single-threaded oracle (orc_svrg_inner: SVRG_basic.jl:73-82 restated) on the FIRST updates of
+        # this very epoch -- the rows they visit gathered to the host, the device's init state -- for a bounded number of updates
         try:
             cpu_svrg = cpu_chain_baseline("svrg", ctx, F, g, gamma, hidx[:args.cpu_chain_updates], N, (av, z, zf, w), None, args, np, torch)
         except Exception as e:
-            cpu_svrg = {"value": None, "unit": "updates/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+            cpu_svrg = {"value": None, "unit": "updates/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"[:200]}
     del hidx
     ctx.svrg_iterate(F, g, gamma, idx[:4096], False, av, z, zf, w)                 # warm (code objects, workspace)
     ctx.synchronize()
@@ -516,103 +679,161 @@ def chain_figures(ctx, dev, F, g, gamma, A, b, N, d, args, L, np, torch):
     t_sweep = time.perf_counter() - t1
     t_chain = max(t_epoch - t_sweep, 1e-9)
     upd = N / t_chain
-    bound = HBM_PEAK_GBS * 1e9 / (d * es + 8)
-    res["svrg_updates_per_sec"] = {"value": upd, "us_per_update": 1e6 / upd, "m": N, "N": N, "d": d, "dtype": args.dtype,
-                                   "what": "SVRG inner cycle (SVRG_basic.jl:73-82), one dependent chain on one workgroup",
-                                   "roofline": {"bound": "hbm", "bytes_per_update": d * es + 8, "bound_updates_per_sec": bound,
-                                                "achieved": upd * (d * es + 8) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                "frac": upd / bound, "note": "latency-bound dependent chain (SURVEY.md section 7)"}}
+    res["svrg_updates_per_sec"] = {"value": upd, "us_per_update": 1e6 / upd, "m": N, "d": d, "dtype": args.dtype,
+                                   "what": "SVRG inner cycle (SVRG_basic.jl:73-82): one dependent chain on one workgroup, latency-bound",
+                                   "roofline": _roof(upd, d * es + 8)}
     if cpu_svrg is not None:
         res["svrg_updates_per_sec"]["cpu_baseline"] = cpu_svrg
     ep_bytes = N * (d * es + 8) + N * (d * es + es)
-    res[f"svrg_epochs_per_sec_N{N // 1_000_000}M" if N % 1_000_000 == 0 else f"svrg_epochs_per_sec_N{N}"] = {
-        "value": 1.0 / t_epoch, "seconds_per_epoch": t_epoch, "m": N, "inner_cycle_s": t_chain, "full_pass_s": t_sweep,
-        "what": "one SVRG outer iteration = m = N updates + tail + full-gradient sweep (SVRG_basic.jl:71-96), measured once",
-        "roofline": {"bound": "hbm", "bytes_per_epoch": ep_bytes, "achieved": ep_bytes / t_epoch / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": ep_bytes / t_epoch / 1e9 / HBM_PEAK_GBS}}
+    ekey = f"svrg_epochs_per_sec_N{N // 1_000_000}M" if N % 1_000_000 == 0 else f"svrg_epochs_per_sec_N{N}"
+    res[ekey] = {"value": 1.0 / t_epoch, "seconds_per_epoch": t_epoch, "inner_cycle_s": t_chain, "full_pass_s": t_sweep,
+                 "what": "one SVRG outer iteration: m = N updates + tail + full-gradient sweep (SVRG_basic.jl:71-96), measured once",
+                 "roofline": _roof(1.0 / t_epoch, ep_bytes)}
     if cpu_svrg is not None and cpu_svrg.get("value") and args.cpu_sweep_rate:
         # an epoch on one host core = N updates + N sample-gradients of the full pass, at the two rates measured in this run
         t_cpu_epoch = N / cpu_svrg["value"] + N / args.cpu_sweep_rate
-        res[f"svrg_epochs_per_sec_N{N // 1_000_000}M" if N % 1_000_000 == 0 else f"svrg_epochs_per_sec_N{N}"]["cpu_baseline"] = {
-            "value": 1.0 / t_cpu_epoch, "unit": "epochs/s", "cores": 1, "kind": "port",
-            "sample": f"extrapolated: N / (oracle updates/s on {cpu_svrg.get('updates')} updates) + N / (oracle sample-gradients/s of "
-                      f"cpu_baseline above) = {t_cpu_epoch:.0f} s per epoch; a whole epoch on one core would take that long"}
+        res[ekey]["cpu_baseline"] = {"value": 1.0 / t_cpu_epoch, "unit": "epochs/s", "cores": 1, "kind": "port",
+                                     "sample": f"extrapolated from the two oracle rates of this run: {t_cpu_epoch:.0f} s per epoch on one core"}
     del idx
-    # ---- the same inner cycle for 256 INDEPENDENT solves at once (a regularisation path: a lambda, an index stream and a state
-    # each) over the same resident rows, recorded and launched as one chain batch -- one workgroup per solve.  Not the figure
-    # above (that is one solve, sequential by definition): what the GPU's other 255 compute units are worth to a host that has
-    # several solves.
-    try:
-        K, mk = 256, 40_000
-        W = torch.zeros((K, d), dtype=tdt, device=dev)
-        Z = torch.zeros((K, d), dtype=tdt, device=dev)
-        gs_k = [ProxG(L.PROX_L1, lam=g.lam * (1.0 + k / K)) for k in range(K)]
-        idxs = [ctx._idx(IndexStream(1000 + k).rand_indices(N, mk)) for k in range(K)]
+    Ns = args.chain_rows or N
 
-        def batch(m_):
-            with ctx.chain_batch():
-                for k in range(K):                       # av and z_full shared (read-only), w and z per solve
-                    ctx.svrg_inner(F, gs_k[k], gamma, idxs[k][:m_], av, Z[k], zf, W[k])
-            ctx.synchronize()
-
-        batch(512)
-        t0 = time.perf_counter()
-        batch(mk)
-        tb = time.perf_counter() - t0
-        updb = K * mk / tb
-        res["svrg_updates_per_sec_256_solves"] = {
-            "value": updb, "us_per_update_per_solve": tb / mk * 1e6, "solves": K, "m_per_solve": mk, "N": N, "d": d, "dtype": args.dtype,
-            "what": "256 independent SVRG inner cycles (SVRG_basic.jl:73-82 each) over the same rows in ONE launch (ciao_ctx_chain_batch_begin "
-                    "/ _end): aggregate updates/s; each solve bitwise what its own call computes (tests/test_gpu_chain_batch.py)",
-            "kernel": ctx.last_kernel(),
-            "roofline": {"bound": "hbm", "bytes_per_update": d * es + 8, "achieved": updb * (d * es + 8) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": updb * (d * es + 8) / 1e9 / HBM_PEAK_GBS}}
-        del W, Z, idxs
-    except Exception as e:   # noqa: BLE001 -- a secondary figure must not cost the line
-        res["svrg_updates_per_sec_256_solves"] = {"error": repr(e)}
-    # ---- SAGA at config #3: l1-logistic, fp32, N x d data + N x d table -------------------------------------------------
-    if d * 4 * N * 2 + (A.numel() * A.element_size() if A.dtype != torch.float32 else 0) < 250e9:
-        A32 = torch.empty((N, d), dtype=torch.float32, device=dev)
-        y32 = torch.empty((N,), dtype=torch.float32, device=dev)
-        ctx.synth_normal(A32, 0, seed=1, scale=1.0 / np.sqrt(d))
-        rng = np.random.default_rng(1)
-        xt = torch.from_numpy(rng.standard_normal(d) * (rng.random(d) < 0.05)).to(dev, torch.float32)
-        Fs = PackedF(L.LOSS_LOGISTIC, A32, y32, 1.0)
-        ctx.synth_targets(Fs, xt, noise=0.1, labels=True, seed=1, b_out=y32)
-        gs = ProxG(L.PROX_L1, lam=1.0 / N)
-        gam = 1.0 / (3 * 0.25 * 1.3)
-        table = torch.empty((N, d), dtype=torch.float32, device=dev)
-        x1 = torch.ones(d, dtype=torch.float32, device=dev)
+    def saga_figure(Fs, gs, gam, x1, tag, kern_note):
+        sdt = Fs.A.dtype
+        ses = 8 if sdt == torch.float64 else 4
+        table = torch.empty((Fs.N, d), dtype=sdt, device=dev)
         sav, sz = torch.empty_like(x1), torch.empty_like(x1)
         ctx.saga_init(Fs, gs, gam, x1, table, sav, sz)
         k = 400_000
-        hsidx = st.rand_indices(N, k)
+        hsidx = st.rand_indices(Fs.N, k)
         sidx = ctx._idx(hsidx)
         cpu_saga = None
         if not args.no_cpu:
             try:
-                cpu_saga = cpu_chain_baseline("saga", ctx, Fs, gs, gam, hsidx[:args.cpu_chain_updates], N, (sav, sz), table, args, np, torch)
+                cpu_saga = cpu_chain_baseline("saga", ctx, Fs, gs, gam, hsidx[:args.cpu_chain_updates], Fs.N, (sav, sz), table, args, np, torch)
             except Exception as e:
-                cpu_saga = {"value": None, "unit": "updates/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+                cpu_saga = {"value": None, "unit": "updates/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"[:200]}
         ctx.saga_steps(Fs, gs, gam, False, sidx[:4096], table, sav, sz)
         ctx.synchronize()
         t0 = time.perf_counter()
         ctx.saga_steps(Fs, gs, gam, False, sidx, table, sav, sz)
         ctx.synchronize()
-        ts = time.perf_counter() - t0
-        upd = k / ts
-        bound = HBM_PEAK_GBS * 1e9 / (3 * d * 4 + 8)
-        res["saga_updates_per_sec"] = {"value": upd, "us_per_update": 1e6 / upd, "steps": k, "N": N, "d": d, "dtype": "f32",
-                                       "what": "SAGA step (SAGA_basic.jl:53-68) at BASELINE config #3 (l1-logistic, table in HBM)",
-                                       "kernel": ctx.last_kernel(),
-                                       "roofline": {"bound": "hbm", "bytes_per_update": 3 * d * 4 + 8, "bound_updates_per_sec": bound,
-                                                    "achieved": upd * (3 * d * 4 + 8) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                    "frac": upd / bound, "note": "latency-bound dependent chain (SURVEY.md section 7)"}}
+        upd = k / (time.perf_counter() - t0)
+        fig = {"value": upd, "us_per_update": 1e6 / upd, "steps": k, "N": Fs.N, "d": d, "dtype": tag, "what": kern_note,
+               "kernel": ctx.last_kernel().split(" grid")[0], "roofline": _roof(upd, 3 * d * ses + 8)}
         if cpu_saga is not None:
-            res["saga_updates_per_sec"]["cpu_baseline"] = cpu_saga
-        del A32, y32, table, Fs, sidx
+            fig["cpu_baseline"] = cpu_saga
+        del table, sidx
         torch.cuda.empty_cache()
+        return fig
+
+    # ---- SAGA in fp64 (the reference's default R, SAGA.jl:108-109) on the resident rows: Lasso, an N x d fp64 table beside A ---------
+    saga64 = None
+    if tdt == torch.float64 and 2 * N * d * 8 < 200e9:
+        try:
+            g64 = 1.0 / (3.0 * 1.3 * F.lam) if F.loss == L.LOSS_LS else 1.0 / (3 * 0.25 * 1.3)
+            saga64 = saga_figure(F, g, g64, torch.zeros(d, dtype=tdt, device=dev), "f64",
+                                 "SAGA step (SAGA_basic.jl:53-68) in fp64 on the metric's own rows + an N x d table")
+        except Exception as e:   # noqa: BLE001
+            saga64 = {"error": repr(e)[:200]}
+    # ---- SAGA at config #3: l1-logistic, fp32, N x d data + N x d table -------------------------------------------------
+    if d * 4 * Ns * 2 + A.numel() * A.element_size() < 250e9:
+        A32 = torch.empty((Ns, d), dtype=torch.float32, device=dev)
+        y32 = torch.empty((Ns,), dtype=torch.float32, device=dev)
+        ctx.synth_normal(A32, 0, seed=1, scale=1.0 / np.sqrt(d))
+        rng = np.random.default_rng(1)
+        xt = torch.from_numpy(rng.standard_normal(d) * (rng.random(d) < 0.05)).to(dev, torch.float32)
+        Fs = PackedF(L.LOSS_LOGISTIC, A32, y32, 1.0)
+        ctx.synth_targets(Fs, xt, noise=0.1, labels=True, seed=1, b_out=y32)
+        res["saga_updates_per_sec"] = saga_figure(Fs, ProxG(L.PROX_L1, lam=1.0 / Ns), 1.0 / (3 * 0.25 * 1.3), torch.ones(d, dtype=torch.float32, device=dev),
+                                                  "f32", "SAGA step (SAGA_basic.jl:53-68) at BASELINE config #3 (l1-logistic, table in HBM)")
+        if saga64 is not None:
+            res["saga_updates_per_sec"]["f64"] = saga64
+        del A32, y32, Fs
+        torch.cuda.empty_cache()
+    elif saga64 is not None:
+        res["saga_updates_per_sec"] = saga64
+
+    # ---- Finito at config #5's per-rank shape: 1.25M x 4096 fp32 + the table; batches of 4096 and the 512-row share ---------------
+    try:
+        res["finito_samples_per_sec"] = finito_figure(ctx, dev, args, L, np, torch)
+    except Exception as e:   # noqa: BLE001 -- a figure must not cost the line
+        res["finito_samples_per_sec"] = {"error": repr(e)[:200]}
     return res
+
+
+def finito_figure(ctx, dev, args, L, np, torch):
+    """One sample of a Finito batch (Finito_basic.jl:109-118; SURVEY 8d: 3*d*s + s + 8 bytes per sample): static cyclic batches
+    (`ciao_finito_steps_blocks`) at BASELINE config #5's per-rank shape."""
+    from ciaoalgorithms_jl_amd.device import PackedF, ProxG
+    N5, d5 = (args.chain_rows or 1_250_000), 4096
+    A5 = torch.empty((N5, d5), dtype=torch.float32, device=dev)
+    b5 = torch.empty((N5,), dtype=torch.float32, device=dev)
+    ctx.synth_normal(A5, 0, seed=5, scale=1.0 / np.sqrt(d5))
+    rng = np.random.default_rng(5)
+    xt = torch.from_numpy(rng.standard_normal(d5) * (rng.random(d5) < 0.05)).to(dev, torch.float32)
+    F5 = PackedF(L.LOSS_LS, A5, b5, float(N5))
+    ctx.synth_targets(F5, xt, noise=0.01, labels=False, seed=5, b_out=b5)
+    g5 = ProxG(L.PROX_L1, lam=1e-3)
+    gam = (0.999 / 1.3 * (1.0 + 0.1 * torch.frac(torch.arange(N5, device=dev, dtype=torch.float64) * 0.6180339887498949))).float()
+    hg = ctx.hat_gamma(gam)                                                   # gamma_i = alpha N / L_i, per sample (Finito_basic.jl:69)
+    x0 = torch.zeros(d5, dtype=torch.float32, device=dev)
+    table = torch.empty((N5, d5), dtype=torch.float32, device=dev)
+    av, z = torch.empty_like(x0), torch.empty_like(x0)
+    ctx.finito_init(F5, g5, gam, hg, x0, table, av, z)
+    bytes_per = 3 * d5 * 4 + 4 + 8
+    fig = {}
+    for r, nb, key in ((4096, 200, None), (512, 600, "share_512_rows")):
+        nblk = N5 // r
+        first = (np.arange(1, nb + 1, dtype=np.int64) % nblk) * r            # cyclic: the first step uses batch 2 (Finito_basic.jl:99)
+        length = np.full(nb, r, np.int64)
+        ctx.finito_steps_blocks(F5, g5, gam, hg, first[:8], length[:8], table, av, z)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        ctx.finito_steps_blocks(F5, g5, gam, hg, first, length, table, av, z)
+        ctx.synchronize()
+        t = time.perf_counter() - t0
+        # the rows kernel's own duration from HIP events, in a pass of its own (an event pair per launch costs the batches 3-6 us each)
+        ctx.timing_enable(True)
+        ctx.timing_read()
+        ctx.finito_steps_blocks(F5, g5, gam, hg, first[:50], length[:50], table, av, z)
+        k_ms, k_n = ctx.timing_read()
+        ctx.timing_enable(False)
+        rate = nb * r / t
+        e = {"value": rate, "batch": r, "us_per_batch": t / nb * 1e6, "rows_kernel_us": k_ms / max(k_n, 1) * 1e3,
+             "kernel": ctx.last_kernel().split(" grid")[0], "roofline": _roof(rate, bytes_per)}
+        if key is None:
+            fig.update(e)
+            fig.update({"N": N5, "d": d5, "dtype": "f32",
+                        "what": "one sample of a Finito batch (Finito_basic.jl:109-118) at BASELINE config #5's per-rank shape, static batches"})
+        else:
+            e["what"] = "the 512 rows one rank of eight holds of a 4096-batch (no collective in this figure)"
+            fig[key] = e
+    if not args.no_cpu:
+        try:
+            from oracle import oracle as O
+            r, nbc = 4096, 2
+            rows = torch.arange(r, (nbc + 1) * r, device=dev)
+            A_t, b_t, gam_t = A5[rows].cpu().numpy(), b5[rows].cpu().numpy(), gam[rows].cpu().numpy()
+            h_tab, h_av, h_z = table[rows].cpu().numpy(), av.cpu().numpy().copy(), z.cpu().numpy().copy()
+            op = O.Problem("ls", A_t, b_t, float(N5), N_total=N5)
+            og = O.Prox("l1", lam=1e-3)
+            batches = [np.arange(k * r, (k + 1) * r) for k in range(nbc)]
+            reps, t_cpu = 0, 0.0
+            while t_cpu < args.cpu_chain_seconds and reps < 200:
+                t1 = time.perf_counter()
+                O.finito_steps(op, og, gam_t, np.float32(hg), batches, h_tab, h_av, h_z)
+                t_cpu += time.perf_counter() - t1
+                reps += 1
+            n = reps * nbc * r
+            fig["cpu_baseline"] = {"value": n / t_cpu, "unit": "samples/s", "cores": 1, "kind": "port", "samples": n,
+                                   "sample": f"the first {nbc} batches of 4096 of the same run (rows and table rows gathered to the host, d=4096, float32), "
+                                             f"{reps} time(s) over, {t_cpu:.1f} s; orc_finito_steps (Finito_basic.jl:109-118 restated)",
+                                   "host_cores": os.cpu_count()}
+        except Exception as e:   # noqa: BLE001
+            fig["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"[:200]}
+    del A5, b5, table, F5
+    torch.cuda.empty_cache()
+    return fig
 
 
 def cpu_chain_baseline(alg, ctx, F, g, gamma, hidx, N, state, table, args, np, torch):
@@ -623,7 +844,7 @@ def cpu_chain_baseline(alg, ctx, F, g, gamma, hidx, N, state, table, args, np, t
     touched, remap = np.unique(hidx, return_inverse=True)
     t = torch.from_numpy(touched).to(F.A.device)
     A_t, b_t = F.A[t].cpu().numpy(), F.b[t].cpu().numpy()
-    logistic = (alg == "saga")
+    logistic = (F.loss == O.LOSS_LOGISTIC)
     op = O.Problem("logistic" if logistic else "ls", A_t, b_t, F.lam, N_total=N)
     og = O.Prox("l1", lam=g.lam)
     rdt = A_t.dtype.type
@@ -640,12 +861,11 @@ def cpu_chain_baseline(alg, ctx, F, g, gamma, hidx, N, state, table, args, np, t
         t_cpu += time.perf_counter() - t0
         reps += 1
     n = len(remap) * reps
-    what = ("orc_svrg_inner (SVRG_basic.jl:73-82 restated: two gradient! + four broadcasts + prox! per update)" if alg == "svrg"
-            else "orc_saga_steps (SAGA_basic.jl:53-68 restated: gradient!, two broadcasts, prox!, table row copy per update)")
+    what = "orc_svrg_inner (SVRG_basic.jl:73-82 restated)" if alg == "svrg" else "orc_saga_steps (SAGA_basic.jl:53-68 restated)"
     return {"value": n / t_cpu, "unit": "updates/s", "us_per_update": t_cpu / n * 1e6, "cores": 1, "kind": "port", "updates": n,
-            "sample": f"the first {len(remap)} updates of the same run ({len(touched)} distinct rows of the same A"
-                      f"{' and table' if table is not None else ''} gathered to the host, d={A_t.shape[1]}, {A_t.dtype.name}), "
-                      f"{reps} time(s) over, {t_cpu:.1f} s; oracle/ciao_oracle.c {what}", "host_cores": os.cpu_count()}
+            "sample": f"the first {len(remap)} updates of the same run ({len(touched)} rows{' + table rows' if table is not None else ''} "
+                      f"gathered to the host, d={A_t.shape[1]}, {A_t.dtype.name}), {reps}x, {t_cpu:.1f} s; {what}",
+            "host_cores": os.cpu_count()}
 
 
 def main():

@@ -507,9 +507,13 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
         }
     };
 
-    // One row at a time per workgroup.  (A two-deep register pipeline -- next row in flight while this one is reduced --
-    // was measured and bought nothing: 29.1 vs 28.5 us at r = 2048, 5.1 vs 5.5 TB/s at r = 65536; with one workgroup per
-    // CU the chip already has 256 rows in flight, and the per-batch cost is launch + finalize, not row latency.)
+    // One row at a time per workgroup.  Measured and dropped, both bitwise neutral: a two-deep register pipeline (next row in
+    // flight while this one is reduced: 29.1 vs 28.5 us at r = 2048, 5.1 vs 5.5 TB/s at r = 65536), and -- for short batches of 2-4
+    // rows per workgroup, BASELINE config #5's 512-row share -- ALL of a workgroup's rows and table rows requested before the first
+    // is reduced (round 4, profiles/r04_c5_pre_ab.txt: 13.71 -> 13.59 us at r = 512, 18.39 -> 18.23 at r = 1024).  Every further
+    // row per workgroup costs 2.4 us either way: 256 rows x 48 KB in 2.4 us is 5.2 TB/s, the HBM's mixed read/write ceiling (one
+    // CU streams ~20 GB/s of it), so the rows are bandwidth, not latency; what is left of a batch is its fixed part -- two kernel
+    // boundaries and two dependent memory round trips (rows -> partials -> finalize), 8.9 us at d = 4096.
     RowIn cur;
     for (int64_t q = blockIdx.x; q < a.nrows; q += gridDim.x) {
         issue(cur, q);

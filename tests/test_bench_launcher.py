@@ -30,6 +30,41 @@ def test_direct_invocation_spawns_n_ranks(n):
     assert "gloo" in j["config"]["collective"]          # the line says what ran, not what the product path would use
 
 
+def test_eight_ranks_dry_run_with_the_collective_preflight():
+    """The node run's shape without a GPU: eight ranks, the preflight's control flow (stage, vote, record) in the line."""
+    r = _run(["--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["metric"] == "grad+prox updates/sec" and j["unit"] == "updates/s"
+    assert j["collective_preflight"]["torch"].startswith("ok") and j["collective_preflight"]["rccl"].startswith("ok")
+    assert len(lines[0]) < 6000, "the line must fit the tail of a log"
+
+
+@pytest.mark.parametrize("who", ["1", "all"])
+def test_a_failed_native_rccl_preflight_still_ends_in_a_line(who):
+    """One rank (or every rank) fails the native-RCCL stage: the vote sends EVERY rank to torch.distributed, the run completes and
+    the line carries the record of what failed."""
+    r = _run(["--gpus", "3", "--dry-run", "--steps", "2", "--warmup", "1"], {"CIAO_BENCH_FORCE_RCCL_FAIL": who})
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 3
+    rec = j["collective_preflight"]
+    assert rec["torch"].startswith("ok")
+    assert ("failed" in rec["rccl"]) if who == "all" else ("failed on another rank" in rec["rccl"]), rec   # rank 0's own view
+    assert "fell back to torch.distributed" in j["config"]["collective"]
+
+
+def test_a_hung_preflight_stage_ends_the_rank_with_the_record():
+    """The watchdog of a stage: a collective that never returns costs the run, not the node -- the rank prints the record and exits 3."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; pf = bench.Preflight(0, 0.5); "
+            "pf.stage('torch', lambda: None); pf.stage('rccl', lambda: time.sleep(30)); print('not reached')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "not reached" not in r.stdout
+    assert "collective_preflight" in r.stderr and '"torch": "ok"' in r.stderr and "timeout after" in r.stderr
+
+
 def test_rank_under_an_external_launcher_does_not_respawn():
     """With WORLD_SIZE set (torch.distributed.run) the process IS a rank: world 1 here, so it just prints its line."""
     r = _run(["--gpus", "1", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0"})
@@ -71,6 +106,27 @@ def test_two_ranks_on_the_one_gpu_real_step():
     assert j["allreduce_us_per_step_peer_mailboxes"] is not None, "the peer exchange is timed beside whatever collective ran"
     assert j["value"] > 0 and j["roofline"]["kernel_launches"] == 3
     assert j["config"]["launcher"] == "bench.py spawned the ranks"
+    # first-contact hardening: the preflight record of the paths that were used, and rank 0's cpu_baseline also with several ranks
+    assert j["collective_preflight"]["torch"].startswith("ok") and j["collective_preflight"]["peer_probe"].startswith("ok"), j["collective_preflight"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_rank0_reports_cpu_baseline_and_the_update_figures():
+    """With --gpus N > 1 rank 0 still times the CPU baseline and the chain / Finito figures (on its own shard, on a context without a
+    collective) after the timed region, while the other rank waits at the final barrier."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--rows-per-gpu", "200000", "--no-extras", "--cpu-rows", "20000",
+              "--cpu-seconds", "0.5", "--cpu-chain-seconds", "0.5", "--cpu-chain-updates", "2000", "--chain-rows", "100000"],
+             {"CIAO_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] == 1
+    for key in ("svrg_updates_per_sec", "saga_updates_per_sec", "finito_samples_per_sec"):
+        assert j[key]["value"] > 0 and 0 < j[key]["roofline"]["frac"] < 1 and j[key]["cpu_baseline"]["value"] > 0, (key, j[key])
+    assert j["saga_updates_per_sec"]["f64"]["value"] > 0
+    assert j["finito_samples_per_sec"]["share_512_rows"]["value"] > 0
+    assert any(k.startswith("svrg_epochs_per_sec_N") for k in j)
+    assert len(line) < 6000, len(line)
 
 
 @pytest.mark.gpu
