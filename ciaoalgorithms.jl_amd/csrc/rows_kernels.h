@@ -735,6 +735,282 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The BATCH modes on rows shorter than a wave's reach (rows_smallb_kernel; round 4): Finito batches (FINITO_BATCH) and LFinito's
+// batch sweep (GRAD2) over an index list or a row block of rows of up to 256 elements -- tabular-size d, the shape of the
+// reference's own problems scaled in N (test/test_lasso.jl:15, test/test_logistic_l1.jl:12-26), which used to fall to the
+// scalar generic kernel at 0.5-1.6 TB/s.  Same geometry as rows_small_kernel: a wave takes G rows per iteration, element
+// (lane, i) of the G*d elements always belongs to the same row-in-group and column, products through the wave's private LDS
+// area, Q = 64/G lanes add up a row's products and combine by shuffles, the row's scalars travel back through LDS, accumulators per
+// (lane, i) in registers, columns combined once at the end.  What the batch modes add:
+//   * the rows of a group may lie ANYWHERE (index list; padded rows): lane r < G resolves row r of the group -- index, bounds
+//     check, element offsets of the data row and the table row, b_i, gamma_i -- and parks them in LDS, TWO groups ahead of their
+//     use (three rotating buffers), so that neither the index load nor these scalars are ever waited for; an element's address
+//     is its row's offset (one LDS read) plus its column;
+//   * GRAD2: a second dot product per row (a second product area) and extra += hat_gamma / gamma_i per row;
+//   * FINITO_BATCH: the table row travels with the data row (same element mapping), t = z - (gamma_i/N) grad, acc += (t - s_i)
+//     hat_gamma / gamma_i, s_i = t (Finito_basic.jl:110-117).
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int MODE, int SMALL_I, bool GATHER>
+constexpr size_t smallb_wave_bytes()
+{
+    // (GATHER: offA[3][64] i64 | offT[3][64] i64 |) prod[GE] (| prod2[GE]) | s1[64] | cg[64] | rr[64] | bis[3][64] | gis[3][64]
+    return (size_t)(MODE == RM_GRAD2 ? 2 : 1) * WAVE * SMALL_I * sizeof(T) + 3 * WAVE * sizeof(T) + (GATHER ? 2 * 3 * WAVE * sizeof(int64_t) : 0) +
+           2 * 3 * WAVE * sizeof(T);
+}
+
+// GATHER = false: a dense row block (no index list, ld == d): the group's rows -- and table rows -- are ONE contiguous stretch, an
+// element's address is the group's base plus its own number, and only b_i / gamma_i go through the staging.
+template <typename T, int MODE, int SMALL_I, bool GATHER>
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_smallb_kernel(RowsArgs<T> a)
+{
+    static_assert(MODE == RM_GRAD2 || MODE == RM_FINITO_BATCH, "the batch modes");
+    constexpr bool TWO = (MODE == RM_GRAD2), TABLE = (MODE == RM_FINITO_BATCH);
+    constexpr int GE = WAVE * SMALL_I;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smallb_raw[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int d = (int)a.d;
+    unsigned char *area = smallb_raw + (size_t)wib * smallb_wave_bytes<T, MODE, SMALL_I, GATHER>();
+    int64_t *offA = reinterpret_cast<int64_t *>(area);                 // [3][64]: 8-byte aligned pieces first
+    int64_t *offT = offA + (GATHER ? 3 * WAVE : 0);
+    T *prod = reinterpret_cast<T *>(offT + (GATHER ? 3 * WAVE : 0));
+    T *prod2 = prod + (TWO ? GE : 0);
+    T *s1s = prod2 + GE;
+    T *cgs = s1s + WAVE;
+    T *rrs = cgs + WAVE;
+    T *bis = rrs + WAVE;                                               // [3][64]
+    T *gis = bis + 3 * WAVE;
+    int G = GE / d;
+    if (G > WAVE) G = WAVE;
+    const int used = G * d;
+    const T s2 = (a.loss == CIAO_LOSS_LS) ? a.lam : (a.loss == CIAO_LOSS_LOGISTIC ? T(1) : T(0));
+    int qs = 0;
+    while ((2 << qs) * G <= WAVE) ++qs;
+    const int Q = 1 << qs;
+    const int myrow = lane >> qs, myq = lane & (Q - 1);
+
+    bool live[SMALL_I];
+    int rrow[SMALL_I], col[SMALL_I];
+    T xcol[SMALL_I], x2col[TWO ? SMALL_I : 1], acc[SMALL_I];
+#pragma unroll
+    for (int i = 0; i < SMALL_I; ++i) {
+        const int e = lane + WAVE * i;
+        live[i] = e < used;
+        rrow[i] = live[i] ? e / d : 0;
+        col[i] = live[i] ? e - rrow[i] * d : 0;
+        xcol[i] = live[i] ? a.x1[col[i]] : T(0);
+        if (TWO) x2col[i] = live[i] ? a.x2[col[i]] : T(0);
+        acc[i] = T(0);
+    }
+    T ex = T(0);
+    T gam_u = a.gam_uniform;   // as a VALUE (rows_small_kernel: a select against a global load would park it in scratch)
+    asm volatile("" : "+v"(gam_u));
+    s1s[lane] = T(0);
+    cgs[lane] = T(0);
+    rrs[lane] = T(0);
+    const int64_t ngroups = (a.nrows + G - 1) / G;
+    const int64_t nwaves = (int64_t)gridDim.x * ROWS_WAVES;
+    typedef const volatile __attribute__((address_space(1))) T *gvol;
+    typedef const volatile __attribute__((address_space(1))) int64_t *gvol64;
+
+    // Lane r < G resolves row r of a group in three steps that are spread over three iterations, so that none of their loads is
+    // ever waited for: the row's INDEX (three groups ahead), then b_i and gamma_i at that row (two groups ahead), then everything
+    // parked in an LDS buffer (three rotate: this group's, the next's, the one after).  Rows beyond the batch's end stand in for
+    // their group's first row (their elements are masked out of everything).  Volatile global loads: they must be ISSUED where
+    // they stand.
+    auto load_row = [&](int64_t gg) -> int64_t {
+        if (lane >= G || gg >= ngroups) return 0;
+        int64_t q = gg * G + lane;
+        if (q >= a.nrows) q = gg * G;
+        return a.idx ? *reinterpret_cast<gvol64>((uintptr_t)(a.idx + q)) : a.row0 + q;
+    };
+    auto check_row = [&](int64_t row) -> int64_t {
+        if (a.idx && (uint64_t)row >= (uint64_t)a.N) {
+            *a.errflag = 1;
+            row = 0;
+        }
+        return row;
+    };
+    auto load_scal = [&](int64_t row, T &bq, T &gq) {
+        bq = T(0);
+        gq = gam_u;
+        if (lane < G) {
+            if (a.b) bq = *reinterpret_cast<gvol>((uintptr_t)(a.b + row));
+            if (a.gam) gq = *reinterpret_cast<gvol>((uintptr_t)(a.gam + row));
+        }
+    };
+    auto park = [&](int buf, int64_t row, T bq, T gq) {
+        if (lane < G) {
+            if (GATHER) {
+                offA[buf * WAVE + lane] = row * a.ld;
+                offT[buf * WAVE + lane] = row * (int64_t)d;
+            }
+            bis[buf * WAVE + lane] = bq;
+            gis[buf * WAVE + lane] = gq;
+        }
+    };
+    // the elements of group g (staged in `buf`): data row and, for the Finito batch, table row, one element-wise load each
+    auto fetch = [&](T(&v)[SMALL_I], T(&sv)[TABLE ? SMALL_I : 1], int64_t g, int buf) {
+        const int64_t left = a.nrows - g * G;
+        const int nrg = left < G ? (int)left : G;
+        const int64_t gbase = (a.row0 + g * G) * (int64_t)d;   // dense: the group's first element (ld == d)
+#pragma unroll
+        for (int i = 0; i < SMALL_I; ++i) {
+            const bool on = live[i] && rrow[i] < nrg;
+            const int r = on ? rrow[i] : 0;
+            const int c = on ? col[i] : 0;
+            const int64_t ea = GATHER ? offA[buf * WAVE + r] + c : gbase + (on ? lane + WAVE * i : 0);
+            const T val = a.A ? __builtin_nontemporal_load(a.A + ea) : T(0);
+            v[i] = on ? val : T(0);
+            if (TABLE) {
+                const int64_t et = GATHER ? offT[buf * WAVE + r] + c : ea;
+                const T tval = __builtin_nontemporal_load(a.table + et);
+                sv[i] = on ? tval : T(0);
+            }
+        }
+    };
+
+    T av[SMALL_I], avn[SMALL_I], sv[TABLE ? SMALL_I : 1], svn[TABLE ? SMALL_I : 1];
+    int64_t g = (int64_t)blockIdx.x * ROWS_WAVES + wib;
+    int cur = 0;   // LDS buffer of group g; (cur + 1) % 3 = group g + nwaves, (cur + 2) % 3 = group g + 2 nwaves
+    int64_t rowp = 0;   // lane r < G: row r of the group after next (its index has arrived; scalars and parking still to come)
+    if (g < ngroups) {
+        // the start of the pipeline with as few DEPENDENT round trips as the data allow (a wave of a single batch often has one
+        // group in all, and this is then its whole memory latency): indices first; a dense block's elements need nothing else and
+        // travel with the scalars, gathered rows need their offsets parked before their elements can be requested
+        const int64_t r0 = check_row(load_row(g)), r1 = check_row(load_row(g + nwaves));
+        rowp = check_row(load_row(g + 2 * nwaves));
+        T b0, g0, b1, g1;
+        if (!GATHER) fetch(av, sv, g, 0);
+        load_scal(r0, b0, g0);
+        load_scal(r1, b1, g1);
+        if (GATHER) {
+            park(0, r0, T(0), T(0));                         // offsets now (the indices are here), scalars when they arrive
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's own LDS writes (no other wave touches its area)
+            fetch(av, sv, g, 0);
+        }
+        park(0, r0, b0, g0);
+        park(1, r1, b1, g1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    for (; g < ngroups; g += nwaves) {
+        const int64_t left = a.nrows - g * G;
+        const int nr = left < G ? (int)left : G;
+        const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
+        const int64_t rown = load_row(g + 3 * nwaves);   // index: three groups ahead
+        T bq, gq;
+        load_scal(rowp, bq, gq);                          // scalars: two groups ahead (that index came in an iteration ago)
+#pragma unroll
+        for (int i = 0; i < SMALL_I; ++i) {
+            prod[lane + WAVE * i] = av[i] * xcol[i];
+            if (TWO) prod2[lane + WAVE * i] = av[i] * x2col[i];
+        }
+        const bool more = g + nwaves < ngroups;
+        if (more) fetch(avn, svn, g + nwaves, nxt);   // its descriptors were staged an iteration ago
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+            const bool rowlive = myrow < nr;
+            const int mr = rowlive ? myrow : 0;
+            const T *pr = prod + mr * d;
+            const T *pr2 = prod2 + mr * d;
+            T d0 = T(0), d1 = T(0), e0 = T(0), e1 = T(0);
+            int k = myq;
+            for (; k + Q < d; k += 2 * Q) {
+                d0 += pr[k];
+                d1 += pr[k + Q];
+                if (TWO) {
+                    e0 += pr2[k];
+                    e1 += pr2[k + Q];
+                }
+            }
+            if (k < d) {
+                d0 += pr[k];
+                if (TWO) e0 += pr2[k];
+            }
+            T dot = d0 + d1, dot2 = e0 + e1;
+            for (int m = Q >> 1; m > 0; m >>= 1) {
+                dot += __shfl_xor(dot, m, WAVE);
+                if (TWO) dot2 += __shfl_xor(dot2, m, WAVE);
+            }
+            if (rowlive && myq == 0) {
+                const T bi = bis[cur * WAVE + myrow], gi = gis[cur * WAVE + myrow];
+                const GradCoef<T> gc = grad_coef(a.loss, dot, bi, a.lam);
+                if (TWO) {                                    // Finito_LFinito.jl:93-98
+                    s1s[myrow] = gc.coef() - grad_coef(a.loss, dot2, bi, a.lam).coef();
+                    ex += a.hat_gamma / gi;
+                } else {                                      // Finito_basic.jl:110-117
+                    s1s[myrow] = gc.s1;
+                    cgs[myrow] = gi * a.invN;
+                    rrs[myrow] = a.hat_gamma / gi;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < SMALL_I; ++i) {
+            if (TWO) {
+                acc[i] += s1s[rrow[i]] * av[i];              // unconditional: dead elements carry a = 0 and a finite scalar
+                continue;
+            }
+            if (!(live[i] && rrow[i] < nr)) continue;
+            const T s1 = s1s[rrow[i]];
+            const T tv = xcol[i] - cgs[rrow[i]] * ((av[i] * s1) * s2);   // GradCoef::elem, as the wave- / workgroup-per-row kernels
+            acc[i] += (tv - sv[i]) * rrs[rrow[i]];
+            const int64_t et = GATHER ? offT[cur * WAVE + rrow[i]] + col[i] : (a.row0 + g * G) * (int64_t)d + lane + WAVE * i;
+            __builtin_nontemporal_store(tv, a.table + et);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row scalars and this group's descriptors are rewritten next
+        park(nx2, rowp, bq, gq);                             // (buffer nx2 held the group before this one: nobody reads it any more)
+        rowp = check_row(rown);
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < SMALL_I; ++i) {
+                av[i] = avn[i];
+                if (TABLE) sv[i] = svn[i];
+            }
+        }
+        cur = nxt;
+    }
+
+    // columns: element (lane, i) -> prod[e]; lane c then adds rows 0..G-1 of column c in row order (as rows_small_kernel)
+#pragma unroll
+    for (int i = 0; i < SMALL_I; ++i)
+        if (live[i]) prod[lane + WAVE * i] = acc[i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    T colsum[(256 + WAVE - 1) / WAVE];
+#pragma unroll
+    for (int q = 0; q < (256 + WAVE - 1) / WAVE; ++q) {
+        const int c = lane + WAVE * q;
+        T sacc = T(0);
+        if (c < d)
+            for (int r = 0; r < G; ++r) sacc += prod[r * d + c];
+        colsum[q] = sacc;
+    }
+    ex = wave_allsum(ex);
+    __syncthreads();   // every wave is done with its private area; the block's area now holds the per-wave column sums
+    __shared__ T red_extra_smallb[ROWS_WAVES];
+    T *base = reinterpret_cast<T *>(smallb_raw);
+#pragma unroll
+    for (int q = 0; q < (256 + WAVE - 1) / WAVE; ++q) {
+        const int c = lane + WAVE * q;
+        if (c < d) base[wib * d + c] = colsum[q];
+    }
+    if (lane == 0) red_extra_smallb[wib] = ex;
+    __syncthreads();
+    T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
+    for (int c = threadIdx.x; c < d; c += ROWS_BLOCK) {
+        T sacc = base[c];
+        for (int w = 1; w < ROWS_WAVES; ++w) sacc += base[w * d + c];
+        pout[c] = sacc;
+    }
+    if (threadIdx.x == 0) {
+        T e2 = T(0);
+        for (int w = 0; w < ROWS_WAVES; ++w) e2 += red_extra_smallb[w];
+        a.pextra[blockIdx.x] = e2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Short-row variant of the gradient sweeps (GRAD / GRAD2): R rows per wave per iteration.
 // The chip streams fastest with about 8 KiB of loads in flight per wave at one block per CU (tools/tune_sweep.py); a
 // 4 KiB (d=1024 fp32) or shorter row leaves a wave with too little in flight and too much per-row latency (dot ->

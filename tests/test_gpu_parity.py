@@ -857,6 +857,93 @@ def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, path):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d", [3, 5, 50, 100, 255])
+@pytest.mark.parametrize("pad", [0, 3])
+def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
+    """Rows of tabular size (d = 3 ... 255, the shape of the reference's own problems: test/test_lasso.jl:15,
+    test/test_logistic_l1.jl:12-26) in all five modes of the batch-parallel kernels, dense and padded row stride, N = 6000 (dozens
+    of row groups per wave, several workgroups): the full gradient, SAGA init and Finito init on rows_small_kernel, Finito
+    batches (index lists AND row blocks) and LFinito's batch sweep (index lists AND row blocks) on rows_smallb_kernel (round 4;
+    they used to run the scalar generic kernel) -- each against the oracle, the two batch forms of the same batches bitwise equal."""
+    import torch
+    from oracle import oracle as O
+    N, r = 6000, 700
+    loss = "logistic" if d % 2 else "ls"
+    A, b, x0 = P.synthetic(loss, N, d, dtype, seed=d)
+    lam_f = float(N) if loss == "ls" else 1.0
+    op, dp = make(loss, A, b, lam_f, dtype, pad=pad)
+    og, dg = make_g("l1", dtype, d, lam=0.02)
+    Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1)
+    gam = (0.999 * N / np.maximum(Li, 1e-3 * Li.max())).astype(dtype)
+    tdt = dev(x0).dtype
+    dgam = dev(gam)
+    hg = ctx.hat_gamma(dgam)
+    ctx.set_option("chain_max_batch", 0)
+    try:
+        # ---- modes 0, 2, 3: full gradient, SAGA init, Finito init
+        av = torch.empty(d, dtype=tdt, device="cuda")
+        ctx.full_gradient(dp, dev(x0), av)
+        assert "rows_small_kernel" in ctx.last_kernel(), ctx.last_kernel()
+        close(av, O.full_pass(op, x0), dtype, scale=200, what=f"small rows full gradient d={d}")
+        table = torch.empty((N, d), dtype=tdt, device="cuda")
+        sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+        ctx.saga_init(dp, dg, 0.1 / max(Li.max(), 1.0), dev(x0), table, sav, sz)
+        assert "rows_small_kernel" in ctx.last_kernel() or "prox" in ctx.last_kernel(), ctx.last_kernel()
+        rt, rav, rz = O.saga_init(op, og, dtype(0.1 / max(Li.max(), 1.0)), x0)
+        close(table, rt, dtype, scale=50, what="small rows saga_init table")
+        close(sav, rav, dtype, scale=200, what="small rows saga_init av")
+        z = torch.empty(d, dtype=tdt, device="cuda")
+        rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
+        ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
+        assert "rows_small_kernel" in ctx.last_kernel(), ctx.last_kernel()
+        close(table, rt, dtype, scale=50, what="small rows finito_init table")
+        close(av, rav, dtype, scale=200, what="small rows finito_init av")
+        # ---- mode 4: Finito batches -- random index lists, then static blocks given BOTH as index lists and as row blocks
+        st = ciao.IndexStream(d)
+        rnd = [st.sample_without_replacement(N, r) for _ in range(4)]
+        bptr = np.arange(len(rnd) + 1, dtype=np.int64) * r
+        ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(rnd), table, av, z)
+        assert "rows_smallb_kernel" in ctx.last_kernel() and "mode4" in ctx.last_kernel(), ctx.last_kernel()
+        O.finito_steps(op, og, gam, rhg, rnd, rt, rav, rz)
+        close(z, rz, dtype, scale=20000, what=f"small rows finito z, index lists ({ctx.last_kernel()})")
+        close(table, rt, dtype, scale=2000, what="small rows finito table, index lists")
+        nb = -(-N // r)
+        order = [(t + 1) % nb for t in range(nb + 2)]                     # cyclic: the first step uses batch 2 (Finito_basic.jl:99)
+        static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in order]   # the last block is short (6000 = 8 * 700 + 400)
+        t2, av2, z2 = table.clone(), av.clone(), z.clone()
+        bp = np.zeros(len(static) + 1, np.int64)
+        np.cumsum([len(x) for x in static], out=bp[1:])
+        ctx.finito_steps(dp, dg, dgam, hg, bp, np.concatenate(static), table, av, z)
+        ctx.finito_steps_blocks(dp, dg, dgam, hg, np.array([x[0] for x in static]), np.array([len(x) for x in static]), t2, av2, z2)
+        assert "rows_smallb_kernel" in ctx.last_kernel(), ctx.last_kernel()
+        assert torch.equal(z, z2) and torch.equal(av, av2) and torch.equal(table, t2), "row blocks and the same batches as index lists differ"
+        O.finito_steps(op, og, gam, rhg, static, rt, rav, rz)
+        close(z, rz, dtype, scale=20000, what="small rows finito z, row blocks")
+        close(table, rt, dtype, scale=2000, what="small rows finito table, row blocks")
+        inv = (table.double() / dgam.double()[:, None]).sum(dim=0).cpu().numpy() * hg
+        close(av, inv, dtype, scale=200, what="small rows finito av invariant")
+        # ---- mode 1: LFinito iterations (full pass + the batch sweep with two dot products per row), lists and blocks
+        lav, lz, lzf = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(3))
+        rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
+        ctx.lfinito_init(dp, hg, dev(x0), lav, lz, lzf)
+        blocks = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in range(nb)]
+        bp = np.zeros(nb + 1, np.int64)
+        np.cumsum([len(x) for x in blocks], out=bp[1:])
+        lav2, lz2, lzf2 = lav.clone(), lz.clone(), lzf.clone()
+        for it in range(2):
+            ctx.lfinito_iterate(dp, dg, dgam, hg, bp, np.concatenate(blocks), lav, lz, lzf)
+            assert "rows_smallb_kernel" in ctx.last_kernel() and "mode1" in ctx.last_kernel(), ctx.last_kernel()
+            ctx.lfinito_iterate_blocks(dp, dg, dgam, hg, np.array([x[0] for x in blocks]), np.array([len(x) for x in blocks]), lav2, lz2, lzf2)
+            O.lfinito_iterate(op, og, gam, rhg, blocks, rav, rz, rzf)
+            assert torch.equal(lz, lz2) and torch.equal(lav, lav2) and torch.equal(lzf, lzf2)
+            close(lz, rz, dtype, scale=20000, what=f"small rows lfinito z it {it} ({ctx.last_kernel()})")
+            close(lav, rav, dtype, scale=20000, what=f"small rows lfinito av it {it}")
+    finally:
+        ctx.set_option("chain_max_batch", -1)
+    ctx.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape,r", [((6, 3), 1), ((8, 5), 2), ((8, 5), 3), ((50, 50), 7), ((64, 1024), 16), ((300, 64), 100),
                                      ((20, 1500), 1), ((17, 2048), 2), ((1300, 1024), 600), ((50, 1001), 6)])
 @pytest.mark.parametrize("path", ["chain", "block_per_row", "wave_per_row"])

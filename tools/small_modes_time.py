@@ -10,7 +10,10 @@ from ciaoalgorithms_jl_amd import _lib as L
 from ciaoalgorithms_jl_amd.device import Context, PackedF, ProxG
 torch.cuda.set_device(0)
 ctx = Context(0)
-for dt, d in ((torch.float64, 50), (torch.float64, 120), (torch.float32, 50), (torch.float32, 200)):
+for kv in os.environ.get("CIAO_OPTS", "").split(","):
+    if "=" in kv:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+for dt, d in ((torch.float64, 50), (torch.float64, 120), (torch.float32, 50), (torch.float32, 100), (torch.float32, 200), (torch.float32, 255)):
     N = 4_000_000
     es = 8 if dt == torch.float64 else 4
     A = torch.empty((N, d), dtype=dt, device="cuda"); b = torch.empty((N,), dtype=dt, device="cuda")
