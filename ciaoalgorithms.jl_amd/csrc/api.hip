@@ -542,43 +542,6 @@ static int32_t finito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_p
                 e.g = make_prox<T>(g);
                 return launch_rows<T>(ctx, RM_FINITO_BATCH, a, e);
             };
-#ifdef CIAO_EXP_GRAPH_BATCHES   // experiment builds only (tools/exp_build.sh NAME -DCIAO_EXP_GRAPH_BATCHES): profiles/r02_batches_eager_vs_graph.txt
-            if (ctx->graph_batches && !ctx->hook && t1 - t > 4) {
-                // EXPERIMENT (option "graph_batches"): the run of batches as one captured graph, timed by events around its
-                // launch -- what the batches cost when the host's launch rate is out of the picture
-                CIAO_TRY(one(t));   // eager: sizes the workspace (no allocation may happen while capturing)
-                const bool tsave = ctx->timing;
-                ctx->timing = false;
-                hipGraph_t graph = nullptr;
-                hipGraphExec_t exec = nullptr;
-                CIAO_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-                int32_t st = CIAO_OK;
-                for (int64_t tt = t + 1; tt < t1 && st == CIAO_OK; ++tt) st = one(tt);
-                hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
-                ctx->timing = tsave;
-                if (st != CIAO_OK || ce != hipSuccess) {
-                    if (graph) (void)hipGraphDestroy(graph);
-                    return st != CIAO_OK ? st : hip_fail(ce, "hipStreamEndCapture");
-                }
-                CIAO_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-                hipEvent_t e0, e1;
-                CIAO_HIP(hipEventCreate(&e0));
-                CIAO_HIP(hipEventCreate(&e1));
-                CIAO_HIP(hipEventRecord(e0, ctx->stream));
-                CIAO_HIP(hipGraphLaunch(exec, ctx->stream));
-                CIAO_HIP(hipEventRecord(e1, ctx->stream));
-                CIAO_HIP(hipStreamSynchronize(ctx->stream));
-                float ms = 0.f;
-                CIAO_HIP(hipEventElapsedTime(&ms, e0, e1));
-                char buf[96];
-                snprintf(buf, sizeof buf, " graph_us_per_batch=%.3f batches=%lld", ms * 1e3 / (double)(t1 - t - 1), (long long)(t1 - t - 1));
-                ctx->last_kernel += buf;
-                (void)hipEventDestroy(e0);
-                (void)hipEventDestroy(e1);
-                (void)hipGraphExecDestroy(exec);
-                (void)hipGraphDestroy(graph);
-            } else
-#endif
             {
                 for (int64_t tt = t; tt < t1; ++tt) CIAO_TRY(one(tt));
             }
@@ -1254,10 +1217,6 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "split_max_rows")) {
         CIAO_REQUIRE(value >= -1, "split_max_rows must be >= -1");
         ctx->split_max_rows = value;
-#ifdef CIAO_WS_DBG   // experiment builds only (EXTRA=-DCIAO_WS_DBG=1): device int64[8 waves][8] for chain_ws_kernel's cycle sums
-    } else if (!strcmp(key, "chain_dbg_ptr")) {
-        ctx->chain_dbg = reinterpret_cast<long long *>((uintptr_t)value);
-#endif
     } else if (!strcmp(key, "small_i")) {
         CIAO_REQUIRE(value == 0 || value == 8 || value == 16, "small_i must be 0, 8 or 16");
         ctx->small_i = value;
@@ -1296,10 +1255,6 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "chain_ws_issuers")) {
         CIAO_REQUIRE(value >= 0 && value <= 2, "chain_ws_issuers must be 0 (automatic), 1 or 2");
         ctx->chain_ws_issuers = value;
-#ifdef CIAO_EXP_GRAPH_BATCHES
-    } else if (!strcmp(key, "graph_batches")) {
-        ctx->graph_batches = value != 0;
-#endif
     } else if (!strcmp(key, "force_generic")) {
         ctx->force_generic = value != 0;
     } else {

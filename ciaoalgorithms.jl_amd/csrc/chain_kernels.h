@@ -51,7 +51,6 @@ struct ChainArgs {
     T *av, *z, *zf, *w;
     int64_t N;             // rows the indices may address (index validation): local rows, or N_total with a shard table
     int *errflag;          // device word set to 1 on an out-of-range index
-    long long *dbg;        // CIAO_WS_DBG experiment builds only: [wave][8] cycle sums of chain_ws_kernel (option "chain_dbg_ptr")
     // Row-sharded problem (ciao_ctx_set_shards; SURVEY.md 8e "one chain on one GPU pulling remote rows over xGMI"): the rows
     // live in nshards allocations, shard k = global rows [sh_row0[k], sh_row0[k+1]); the pointers may be peer-mapped memory of
     // other GPUs.  idx then holds GLOBAL rows.  nshards = 0: A / b / table above are the whole problem.
@@ -81,7 +80,7 @@ __device__ __forceinline__ void chain_args_fetch(ChainArgs<T> &a)
         p = (P *)(__attribute__((address_space(1))) P *)(uintptr_t)p;
     };
     glob(a.A), glob(a.b), glob(a.idx), glob(a.gam), glob(a.table), glob(a.g.lo_vec), glob(a.g.hi_vec);
-    glob(a.av), glob(a.z), glob(a.zf), glob(a.w), glob(a.errflag), glob(a.dbg);
+    glob(a.av), glob(a.z), glob(a.zf), glob(a.w), glob(a.errflag);
 }
 
 // Where global row r of a row-sharded problem lives: its data row, its b entry (or nullptr), its table row.
@@ -145,10 +144,6 @@ struct VecOfC<double> {
     typedef double type __attribute__((ext_vector_type(2)));
 };
 
-#ifndef CIAO_CHAIN_DBG
-#define CIAO_CHAIN_DBG 0   // timing experiments only (EXP= builds, tools/exp_build.sh; results are WRONG): 1 = no ring refill, 2 = no cross-wave
-                           // exchange, 4 = no element-wise update
-#endif
 
 constexpr int CHAIN_NT = 256;
 constexpr int CHAIN_NW = CHAIN_NT / WAVE;
@@ -950,13 +945,6 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cplx_reg_kernel(ChainArgs<T> a
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
 {
-#ifdef CIAO_GLDS_SAVE_M0
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-#else
     // m0 (the LDS destination base of the DMA) is declared clobbered instead of saved and restored around every load: hipcc
     // never holds a value in m0 across statements (it sets it next to the few instructions that read it), and two scalar
     // moves per load are on the chain's issue path
@@ -964,7 +952,6 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
 #pragma clang diagnostic ignored "-Winline-asm"
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory", "m0");
 #pragma clang diagnostic pop
-#endif
 }
 
 // The same with the row's (wave-uniform) base address in an SGPR pair and the thread's 32-bit byte offset in a VGPR: the
@@ -1400,21 +1387,12 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                     d1 = readlane(d1, WAVE - 1);
                     if (TWO) d2 = readlane(d2, WAVE - 1);
                 } else {
-#ifdef CIAO_CHAIN_READLANE   // experiment: the all-lanes sum through v_readlane, lane 0 stores
-                d1 = wave_allsum(d1);
-                if (TWO) d2 = wave_allsum(d2);
-                if (lane == 0) {
-                    red[par][wib][0] = d1;
-                    if (TWO) red[par][wib][1] = d2;
-                }
-#else
                 d1 = wave_sum_lane63(d1);   // bitwise the same total, in lane 63 only: no v_readlane / scalar round trip
                 if (TWO) d2 = wave_sum_lane63(d2);
                 if (lane == WAVE - 1) {
                     red[par][wib][0] = d1;
                     if (TWO) red[par][wib][1] = d2;
                 }
-#endif
                 }
                 // work that does not need the dot product goes between the LDS write and the barrier, where it overlaps the
                 // other waves' arrival:  temp = gamma*(a*dc - av) + w  =  (gamma*a)*dc + (w - gamma*av)
@@ -1432,7 +1410,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                 if (ALG == CA_FINITO || ALG == CA_LFINITO) {
                     if constexpr (NW != 1) asm volatile("" : "+v"(pre_rr), "+v"(pre_gn));   // (computed above, complete by here)
                 }
-                if constexpr (NW == 4 && !(CIAO_CHAIN_DBG & 2)) {
+                if constexpr (NW == 4) {
                     // The exchange with its reads in two halves, and in between -- while the partials travel from LDS, about
                     // ninety cycles in which this wave has nothing else to do -- everything of the step that does not need
                     // the dot product: the DMA of the row DEPTH steps ahead (its slot's row is in registers since the last
@@ -1444,7 +1422,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                     constexpr bool SINGLE64 = (sizeof(T) == 8 && !TWO);
                     V rv[SINGLE64 ? 2 : (int)(NW * 2 * sizeof(T) / 16)];
                     if constexpr (SINGLE64) xchg_issue_single64(raddr, rv); else xchg_issue(raddr, rv);
-                    if (SHADOW_REFILL && !(CIAO_CHAIN_DBG & 1)) refill(u, row_n, ptr_n);
+                    if (SHADOW_REFILL) refill(u, row_n, ptr_n);
                     if (SVRG_ANY) {
                         if (u > 0 || s0 > 0 || base > 0) {   // compile-time true except in the first step of a ring revolution
 #pragma unroll
@@ -1469,7 +1447,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                         d1 = lo + hi;
                     }
                     if (TWO) d2 = (val(0, 1) + val(1, 1)) + (val(2, 1) + val(3, 1));
-                } else if constexpr (NW > 1 && !(CIAO_CHAIN_DBG & 2)) {
+                } else if constexpr (NW > 1) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();   // raw barrier: must not drain the DMA queue
                 {
@@ -1496,12 +1474,12 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                         const T gl = a.gamma * plam;
                         const T dc = cz - gp.coef();
     #pragma unroll
-                        for (int j = 0; j < ((CIAO_CHAIN_DBG & 4) ? 0 : J); ++j)
+                        for (int j = 0; j < J; ++j)
     #pragma unroll
                             for (int v = 0; v < VEC; ++v) {
                                 const T t = fmad(q1[j][v], dc, q2[j][v]);
                                 p[j][v] = HB ? prox_bf(t, gl, plo[j][v], phi[j][v]) : prox_l1(t, gl);
-                                if (!(NW == 4 && !(CIAO_CHAIN_DBG & 2))) zs[j][v] += p[j][v];   // four waves: in the next step's exchange shadow
+                                if (NW != 4) zs[j][v] += p[j][v];   // four waves: in the next step's exchange shadow
                             }
                     } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
                         V *sp = reinterpret_cast<V *>(trow_of(row));
@@ -1562,7 +1540,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                 if (++inb == a.batch) inb = 0;
                 // one or eight waves: the refill at the end of the step (four waves: in the exchange's shadow, above -- a table row
                 // it fetches that this step is about to rewrite is flagged stale either way: the flag compares DEPTH steps back)
-                if (!(SHADOW_REFILL && !(CIAO_CHAIN_DBG & 2)) && !(CIAO_CHAIN_DBG & 1)) refill(u, row_n, ptr_n);
+                if (!SHADOW_REFILL) refill(u, row_n, ptr_n);
             }
         };
         // the run-time flags become compile-time tags of the group (SAG only exists for the SAGA chain)
@@ -1591,7 +1569,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
         }
     }
     wait_vmcnt<0>();   // nothing may still be writing LDS when the workgroup retires
-    if (SVRG_ANY && NW == 4 && !(CIAO_CHAIN_DBG & 2) && a.nsteps > 0) {   // the last step's `z += w`
+    if (SVRG_ANY && NW == 4 && a.nsteps > 0) {   // the last step's `z += w`
 #pragma unroll
         for (int j = 0; j < J; ++j) zs[j] += p[j];
     }

@@ -47,10 +47,7 @@ namespace ciao {
 
 constexpr int WS_NCW = 4;          // consumer waves
 constexpr int WS_RR = 256;         // record ring entries (steps staged ahead of the consumers: up to WS_RR - 64)
-#ifndef CIAO_WS_STORE_LAG
-#define CIAO_WS_STORE_LAG 6
-#endif
-constexpr int WS_STORE_LAG = CIAO_WS_STORE_LAG;    // K: a consumer's table stores are known to be written K steps after issue
+constexpr int WS_STORE_LAG = 6;    // K: a consumer's table stores are known to be written K steps after issue
 
 template <typename T>
 struct WsRec {     // per-step scalars, read by every consumer lane from one address
@@ -202,10 +199,6 @@ __device__ __forceinline__ void gstore16s(void *sbase, uint32_t voff, V data)
     asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(data), "s"(sbase) : "memory");
 }
 
-#ifndef CIAO_WS_DBG
-#define CIAO_WS_DBG 0   // timing experiments only: 1 = per-wave cycle sums and spin counts into ChainArgs::dbg [wave][8] (read back through option "chain_dbg_ptr");
-                        // 2 = the issuers issue no DMA (WRONG results: what the consumers alone would do)
-#endif
 
 template <typename T, int J, int ALG, int LOSS, bool MASKED, int NISS>
 __global__ void __launch_bounds__((WS_NCW + 1 + NISS) * WAVE) chain_ws_kernel(ChainArgs<T> a_by_value)
@@ -334,9 +327,6 @@ __global__ void __launch_bounds__((WS_NCW + 1 + NISS) * WAVE) chain_ws_kernel(Ch
             voff[i] = (!MASKED || (int64_t)o < rowb) ? o : 0u;
         }
         int64_t done = 0;   // complete steps, as last seen
-#if (CIAO_WS_DBG & 1)
-        unsigned long long dbg_blocked = 0, dbg_blockspin = 0, dbg_stagespin = 0, dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_issue = 0;
-#endif
         for (int64_t S = 0; S < nsteps; S += WAVE) {
             const int nb = (int)((nsteps - S) < WAVE ? (nsteps - S) : WAVE);
             for (unsigned int spins = 0; (int64_t)lds_peek(&ctl->staged[0]) < S + nb; ws_spin(spins, a.errflag)) __builtin_amdgcn_s_sleep(2);
@@ -354,60 +344,37 @@ __global__ void __launch_bounds__((WS_NCW + 1 + NISS) * WAVE) chain_ws_kernel(Ch
                         wait_vmcnt<0>();
                         if (lane == 0) lds_poke(&ctl->landed[q][0], (unsigned int)s);
                         unsigned int spins = 0;
-#if (CIAO_WS_DBG & 1)
-                        ++dbg_blocked;
-#endif
                         do {
-#if (CIAO_WS_DBG & 1)
-                            ++dbg_blockspin;
-#endif
                             __builtin_amdgcn_s_sleep(1);
                             ws_spin(spins, a.errflag);
                             done = complete();
                         } while (s - R + 1 > done);
                     }
                 }
-#if (CIAO_WS_DBG & 1)
-                const unsigned long long dbg_i0 = __builtin_amdgcn_s_memtime();
-#endif
                 const uint32_t slot = (uint32_t)(s & (R - 1)) * ROW_BYTES;
                 const unsigned char *ap = reinterpret_cast<const unsigned char *>((uintptr_t)(
                     ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)ap_v >> 32), l) << 32) |
                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ap_v, l)));
 #pragma unroll
-                for (int i = 0; i < ((CIAO_WS_DBG & 2) ? 0 : NPIECE / NISS); ++i) glds16s(ap, voff[i], ringA_off + slot + (uint32_t)((q + i * NISS) * 1024));
+                for (int i = 0; i < NPIECE / NISS; ++i) glds16s(ap, voff[i], ringA_off + slot + (uint32_t)((q + i * NISS) * 1024));
                 if (HAS_TABLE) {
                     const unsigned char *tp = reinterpret_cast<const unsigned char *>((uintptr_t)(
                         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)tp_v >> 32), l) << 32) |
                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tp_v, l)));
 #pragma unroll
-                    for (int i = 0; i < ((CIAO_WS_DBG & 2) ? 0 : NPIECE / NISS); ++i) glds16s_sc1(tp, voff[i], ringT_off + slot + (uint32_t)((q + i * NISS) * 1024));
+                    for (int i = 0; i < NPIECE / NISS; ++i) glds16s_sc1(tp, voff[i], ringT_off + slot + (uint32_t)((q + i * NISS) * 1024));
                 }
-#if (CIAO_WS_DBG & 1)
-                dbg_issue += __builtin_amdgcn_s_memtime() - dbg_i0;
-#endif
                 wait_vmcnt<PPW * LAG>();   // the rows of steps <= s - LAG have landed
                 if (s + 1 - LAG > 0 && lane == 0) lds_poke(&ctl->landed[q][0], (unsigned int)(s + 1 - LAG));
             }
         }
         wait_vmcnt<0>();
         if (lane == 0) lds_poke(&ctl->landed[q][0], (unsigned int)nsteps);
-#if (CIAO_WS_DBG & 1)
-        if (a.dbg && lane == 0) {
-            a.dbg[(WS_NCW + 1 + q) * 8 + 0] = (long long)dbg_blocked;
-            a.dbg[(WS_NCW + 1 + q) * 8 + 1] = (long long)dbg_blockspin;
-            a.dbg[(WS_NCW + 1 + q) * 8 + 2] = (long long)(__builtin_amdgcn_s_memtime() - dbg_t0);
-            a.dbg[(WS_NCW + 1 + q) * 8 + 3] = (long long)dbg_issue;
-        }
-#endif
         return;
     }
 
     // ====================================================== CONSUMERS ======================================================
     const int wib = wave;
-#if (CIAO_WS_DBG & 1)
-    unsigned long long dbg_x = 0, dbg_c = 0, dbg_retry = 0, dbg_land = 0, dbg_steps = 0, dbg_prev = 0;
-#endif
     constexpr int CNT_OFF = (int)(LY::ctl - LY::red);                       // cnt[0] relative to red; cnt[1] 64 bytes on
     uint32_t red0 = (uint32_t)(uintptr_t)red;                                // LDS byte addresses of the exchange area,
     uint32_t red_w = red0 + (uint32_t)wib * (TWO ? 2 : 1) * (uint32_t)sizeof(T);   // held in two VGPRs for the whole chain
@@ -494,9 +461,6 @@ __global__ void __launch_bounds__((WS_NCW + 1 + NISS) * WAVE) chain_ws_kernel(Ch
                 l = l1 < l ? l1 : l;
             }
             if ((int64_t)l >= need) break;
-#if (CIAO_WS_DBG & 1)
-            ++dbg_land;
-#endif
             __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");   // nothing that reads the ring or the records moves above the spin
@@ -588,14 +552,6 @@ __global__ void __launch_bounds__((WS_NCW + 1 + NISS) * WAVE) chain_ws_kernel(Ch
                     for (; nq < J * VEC; ++nq) q1[nq / VEC][nq % VEC] = a.gamma * x.ar[nq / VEC][nq % VEC];
                 }
             }
-#if (CIAO_WS_DBG & 1)
-            {
-                asm volatile("" : "+v"(d1));
-                const unsigned long long now = __builtin_amdgcn_s_memtime();
-                if (dbg_prev) dbg_c += now - dbg_prev;
-                dbg_prev = now;
-            }
-#endif
             // ---- ARRIVE.  lane 63: the wave's partial(s), then one arrival on the parity's counter (performed in this order)
             if (lane == WAVE - 1) {
                 if (par == 0) {
@@ -648,20 +604,9 @@ __global__ void __launch_bounds__((WS_NCW + 1 + NISS) * WAVE) chain_ws_kernel(Ch
 #pragma clang loop unroll(disable)
                 do {
                     ws_spin(spins, a.errflag);
-#if (CIAO_WS_DBG & 1)
-                    ++dbg_retry;
-#endif
                     if (par == 0) ws_poll_issue<0, CNT_OFF>(red0, cv, rv); else ws_poll_issue<128, CNT_OFF + 64>(red0, cv, rv);
                 } while (ws_poll_wait(cv, rv) != expect);
             }
-#if (CIAO_WS_DBG & 1)
-            {
-                const unsigned long long now = __builtin_amdgcn_s_memtime();
-                dbg_x += now - dbg_prev;
-                dbg_prev = now;
-                ++dbg_steps;
-            }
-#endif
             auto val = [&](int k) -> T { return rv[k / VEC][k % VEC]; };
             constexpr int ST = TWO ? 2 : 1;
             const T r0 = val(0), r1 = val(ST), r2 = val(2 * ST), r3 = val(3 * ST);
@@ -740,15 +685,6 @@ __global__ void __launch_bounds__((WS_NCW + 1 + NISS) * WAVE) chain_ws_kernel(Ch
         store_prev();
     }
     wait_vmcnt<0>();
-#if (CIAO_WS_DBG & 1)
-    if (a.dbg && lane == 0) {
-        a.dbg[wib * 8 + 0] = (long long)dbg_x;
-        a.dbg[wib * 8 + 1] = (long long)dbg_c;
-        a.dbg[wib * 8 + 2] = (long long)dbg_retry;
-        a.dbg[wib * 8 + 3] = (long long)dbg_land;
-        a.dbg[wib * 8 + 4] = (long long)dbg_steps;
-    }
-#endif
 
 #pragma unroll
     for (int j = 0; j < J; ++j) {

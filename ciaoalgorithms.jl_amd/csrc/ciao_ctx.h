@@ -96,10 +96,6 @@ struct ciao_ctx {
     int chain_last_one_wave = 0;    // E of the single-wave register-ring chain the last launch took, 0 = four waves
     int chain_last_dma = 0;
     bool chain_last_masked = false;
-    long long *chain_dbg = nullptr;   // experiment builds only (CIAO_WS_DBG): device buffer for chain_ws_kernel's cycle sums
-#ifdef CIAO_EXP_GRAPH_BATCHES
-    int64_t graph_batches = 0;      // experiment builds only: capture runs of batch-parallel Finito batches as one graph (api.hip)
-#endif
     int64_t force_generic = 0;      // testing: route every rows launch through the generic kernel
 
     std::string last_kernel;

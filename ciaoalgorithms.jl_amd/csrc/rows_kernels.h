@@ -86,15 +86,10 @@ struct RowsWaves {
 };
 
 // Store flavours (16-byte chunks).  Table rows are written once per visit and not re-read by this kernel; the per-block
-// partials are read by the NEXT kernel (finalize), on other XCDs.  CIAO_TSTORE / CIAO_PSTORE pick the cache policy of the two
-// (experiment builds, tools/exp_build.sh): 0 = non-temporal, 1 = default policy, 2 = sc1 (write-through: the bytes leave the
-// XCD's L2 during the kernel instead of at its end-of-kernel release, MI355X_MICROARCH.md "publish-large").
-#ifndef CIAO_TSTORE
-#define CIAO_TSTORE 0
-#endif
-#ifndef CIAO_PSTORE
-#define CIAO_PSTORE 1
-#endif
+// partials are read by the NEXT kernel (finalize), on other XCDs.  Flavours: 0 = non-temporal, 1 = default policy, 2 = sc1
+// (write-through: the bytes leave the XCD's L2 during the kernel instead of at its end-of-kernel release, MI355X_MICROARCH.md
+// "publish-large").  Measured neutral within 3 % for both uses (profiles/r02_batch_store_policy_ab.txt); table rows go out
+// non-temporal, partials with the default policy.
 template <int FLAVOUR, typename V>
 __device__ __forceinline__ void store16(V val, V *ptr)
 {
@@ -113,8 +108,8 @@ __device__ __forceinline__ void store16(V val, V *ptr)
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(val) : "memory");
     }
 }
-#define TSTORE(val, ptr) store16<CIAO_TSTORE>((val), (ptr))
-#define PSTORE(val, ptr) store16<CIAO_PSTORE>((val), (ptr))
+#define TSTORE(val, ptr) store16<0>((val), (ptr))   // table rows: non-temporal
+#define PSTORE(val, ptr) store16<1>((val), (ptr))   // partials: default policy
 
 template <typename T, int K, int MODE, int PF>
 __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>::value)) rows_fast_kernel(RowsArgs<T> a)
@@ -159,13 +154,9 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
             const V *ap = reinterpret_cast<const V *>(a.A + row * a.ld);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-#ifdef CIAO_PLAIN_LOADS   // timing experiment (EXP= build): default-policy loads instead of non-temporal ones
-                r[k] = ap[k * WAVE + lane];
-#else
                 // every row is read exactly once per sweep: non-temporal loads keep the stream out of L2/MALL and run
                 // ~12 % faster than default-policy loads here (7.1 vs 6.3 TB/s at N=10M, d=1024, fp64)
                 r[k] = __builtin_nontemporal_load(&ap[k * WAVE + lane]);
-#endif
             }
         } else {   // F = fill(Zero(), N): there is no data matrix at all
 #pragma unroll
@@ -605,11 +596,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
         for (int i = 0; i < SMALL_I; ++i) {
             const bool on = live[i] && rrow[i] < nrg;
             const int ec = on ? (PADDED ? aoff[i] : lane + WAVE * i) : 0;
-#ifdef CIAO_SMALL_PLAIN
-            const T val = gp ? gp[ec] : T(0);
-#else
             const T val = gp ? __builtin_nontemporal_load(&gp[ec]) : T(0);
-#endif
             v[i] = on ? val : T(0);
         }
         // volatile: hipcc otherwise sinks these two loads down to their use, behind the prefetch.  Through GLOBAL-address-space
@@ -1569,9 +1556,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_csplit_kernel(RowsArgs<T> a)
 //     sums pairwise), so results are bitwise reproducible run to run.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int FIN_THREADS = 256;
-#ifndef CIAO_FIN_BYTES
-#define CIAO_FIN_BYTES 128   // bytes of one partial row that a finalize block covers (one L2 line)
-#endif
+constexpr int FIN_BYTES = 128;   // bytes of one partial row that a finalize block covers (one L2 line)
 
 template <typename T>
 __global__ void __launch_bounds__(FIN_THREADS)
@@ -1580,9 +1565,9 @@ __global__ void __launch_bounds__(FIN_THREADS)
 {
     constexpr int VEC = 16 / sizeof(T);
     using V = typename ChunkOf<T, VEC>::type;
-    constexpr int LANES = CIAO_FIN_BYTES / 16;         // 16-byte chunks of the line
+    constexpr int LANES = FIN_BYTES / 16;         // 16-byte chunks of the line
     constexpr int SLICES = FIN_THREADS / LANES;        // 32
-    constexpr int COLS = CIAO_FIN_BYTES / sizeof(T);
+    constexpr int COLS = FIN_BYTES / sizeof(T);
     constexpr int U = 8;                               // loads in flight per thread and round
     __shared__ V lds[SLICES][LANES];
     __shared__ V lds2[4][LANES];

@@ -1,10 +1,10 @@
 #!/bin/bash
 # The round's record runs, ON the GPU box (gpurun -- tools/record_runs.sh [a|b|c ...]); everything lands in gpurun_out/final/
 # and the summaries to be judged are copied from there into profiles/rNN_*.
-#   a  the bench line (chains + extras) and the fp32 line
+#   a  the bench line (update figures; the extras go to gpurun_out/bench_extras.json) and the fp32 line
 #   b  rocprofv3 --kernel-trace --stats of the same bench command; the separate --pmc FETCH_SIZE / WRITE_SIZE passes
-#   c  rocprofv3 --kernel-trace --stats of the chain figures at the metric's own size (one SVRG outer iteration m = N = 10M,
-#      SAGA at BASELINE config #3) and of the extras
+#   c  rocprofv3 --kernel-trace --stats of the update figures at their own sizes (one SVRG outer iteration m = N = 10M, SAGA at
+#      BASELINE config #3 and in fp64, Finito batches at config #5's per-rank shape) and of the extras
 set -o pipefail
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 O="$R/gpurun_out/final"
@@ -15,7 +15,7 @@ for part in "${@:-a}"; do
 case "$part" in
 a)
   echo "== bench (default)"; timeout -k 10 1000 python bench.py > "$O/bench_f64.json" 2> "$O/bench_f64.err"; echo "rc=$?"; python -c "
-import json;j=json.load(open('$O/bench_f64.json'));print(j['value'], j['ms_per_step'], j['roofline']['frac'], j['roofline']['kernel_avg_ms']); print(j['svrg_updates_per_sec'], j['saga_updates_per_sec']); print(j['cpu_baseline'], list(j['extra'].keys())[:3])"
+import json;j=json.load(open('$O/bench_f64.json'));print(j['value'], j['ms_per_step'], j['roofline']['frac'], j['roofline']['kernel_avg_ms']); print(j['svrg_updates_per_sec']['value'], j['saga_updates_per_sec']['value'], j['finito_samples_per_sec']['value']); print(j['cpu_baseline']['value'], j.get('extras_file'))"; cp -f "$R/gpurun_out/bench_extras.json" "$O/bench_extras.json" 2>/dev/null
   echo "== bench f32"; timeout -k 10 600 python bench.py --dtype f32 --no-extras --no-chains > "$O/bench_f32.json" 2> "$O/bench_f32.err"; echo "rc=$?"; python -c "
 import json;j=json.load(open('$O/bench_f32.json'));print(j['value'], j['ms_per_step'], j['roofline']['frac'])"
   ;;
