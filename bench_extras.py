@@ -367,6 +367,32 @@ def run(ctx, dev, quick=False):
                                                  "frac_of_8TBps_read_peak": out[key]["alg_GBps"] / 8000.0,
                                                  "source": "profiles/r02_stream_ceilings.txt (plain streaming kernels, same pool)"}
 
+    # ---- the full passes of K solves as ONE pass over A with K right-hand sides on the matrix cores (ciao_full_gradient_multi,
+    # csrc/mrhs_kernels.h) against K single sweeps: what the epoch tails of solvers.solve_together(one_pass=True) cost.  fp64 peak:
+    # 78.6 TFLOP/s (AMD's MI355X figure: matrix = vector rate in fp64); fp32 157.3 (MI355X_MICROARCH.md)
+    try:
+        Nm, dm = 1_000_000 // scale, 1024
+        for tdt, tag, peak in ((torch.float64, "f64", 78.6), (torch.float32, "f32", 157.3)):
+            Fm = _problem(ctx, dev, Nm, dm, tdt, False)
+            x1 = torch.zeros(dm, dtype=tdt, device=dev)
+            a1 = torch.empty_like(x1)
+            ctx.full_gradient(Fm, x1, a1)
+            t1 = _timed(ctx, lambda: ctx.full_gradient(Fm, x1, a1), reps=5)
+            for K in (16, 256):
+                xs = [torch.randn(dm, dtype=tdt, device=dev) * 0.1 for _ in range(K)]
+                avs = [torch.empty_like(x) for x in xs]
+                ctx.full_gradient_multi(Fm, xs, avs)
+                kern = ctx.last_kernel()
+                t = _timed(ctx, lambda: ctx.full_gradient_multi(Fm, xs, avs), reps=3)
+                out[f"multi_rhs_full_pass_{tag}_K{K}_d1024"] = {
+                    "seconds": t, "N": Nm, "TFLOPs": 4.0 * Nm * dm * K / t / 1e12, "K_single_sweeps_seconds": K * t1, "speedup": K * t1 / t,
+                    "roofline": {"bound": "mfma", "achieved": 4.0 * Nm * dm * K / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                 "frac": 4.0 * Nm * dm * K / t / 1e12 / peak}, "kernel": kern}
+            del Fm
+            torch.cuda.empty_cache()
+    except Exception as e:   # noqa: BLE001
+        out["multi_rhs_full_pass"] = {"error": repr(e)}
+
     # ---- K independent SVRG chains over the same A on K streams (a regularisation path): what the idle 255 CUs give through the
     # existing API.  The HIP runtime's hardware queues bound the concurrency (4 by default; tools/lambda_path.py with
     # GPU_MAX_HW_QUEUES=64 reaches 16x one chain: profiles/r03_lambda_path_streams.txt)

@@ -85,6 +85,8 @@ SIGNATURES = {
     "ciao_svrg_inner": (_i32, [_vp, _PP, _GP, _f64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ciao_svrg_iterate": (_i32, [_vp, _PP, _GP, _f64, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ciao_svrg_epoch_tail": (_i32, [_vp, _PP, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ciao_svrg_epoch_tail_multi": (_i32, [_vp, _PP, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ciao_full_gradient_multi": (_i32, [_vp, _PP, _i32, _vp, _vp]),
     "ciao_ctx_set_shards": (_i32, [_vp, C.POINTER(ShardTable)]),
     "ciao_ipc_export": (_i32, [_vp, _vp, C.POINTER(_i64)]),
     "ciao_ipc_open": (_i32, [_vp, _i64, C.POINTER(_vp)]),

@@ -362,6 +362,31 @@ static int32_t svrg_epoch_tail_t(ciao_ctx *ctx, const ciao_problem *p, int64_t m
     return full_gradient_t<T>(ctx, p, z_full, av, true);
 }
 
+// K full passes at K iterates: ONE pass over A on the matrix cores where the shape allows (mrhs_kernels.h), K single sweeps otherwise
+template <typename T>
+static int32_t full_gradient_multi_t(ciao_ctx *ctx, const ciao_problem *p, int32_t K, const void *const *x, void *const *av)
+{
+    ctx->rowdot_A = nullptr;   // whatever was cached belongs to an older pass
+    if (mrhs_supported<T>(ctx, p, K, x, av)) return launch_mrhs<T>(ctx, p, K, x, av);
+    for (int k = 0; k < K; ++k) CIAO_TRY(full_gradient_t<T>(ctx, p, x[k], av[k]));
+    return CIAO_OK;
+}
+
+// SVRG_basic.jl:84-92 for K solves over the same rows: every solve's tail (z_full = z / m; w = z_full; z = 0), then the K full
+// passes at the K new z_full as one multi-right-hand-side pass
+template <typename T>
+static int32_t svrg_epoch_tail_multi_t(ciao_ctx *ctx, const ciao_problem *p, int32_t K, int64_t m, int32_t plus, void *const *av,
+                                       void *const *z, void *const *z_full, void *const *w)
+{
+    ctx->rowdot_A = nullptr;
+    for (int k = 0; k < K; ++k) {
+        hipLaunchKernelGGL((svrg_tail_kernel<T>), dim3((unsigned)((p->d + 255) / 256)), dim3(256), 0, ctx->stream, p->d, (T)m, (int)plus,
+                           (T *)z[k], (T *)z_full[k], (T *)w[k]);
+    }
+    CIAO_HIP(hipGetLastError());
+    return full_gradient_multi_t<T>(ctx, p, K, const_cast<const void *const *>(z_full), av);
+}
+
 template <typename T>
 static int32_t svrg_iterate_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, int64_t m,
                               const int64_t *idx, int32_t plus, int32_t reuse_rowdots, void *av, void *z, void *z_full, void *w)
@@ -896,6 +921,7 @@ int32_t ciao_ctx_destroy(ciao_ctx *ctx)
     DeviceGuard dg(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->partial) (void)hipFree(ctx->partial);
+    if (ctx->mrhs_ptrs) (void)hipFree(ctx->mrhs_ptrs);
     if (ctx->pextra) (void)hipFree(ctx->pextra);
     if (ctx->sumbuf) (void)hipFree(ctx->sumbuf);
     if (ctx->rowdot) (void)hipFree(ctx->rowdot);
@@ -1249,6 +1275,8 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
         ctx->chain_no_dma = value != 0;
     } else if (!strcmp(key, "chain_no_ws")) {
         ctx->chain_no_ws = value != 0;
+    } else if (!strcmp(key, "multi_rhs_off")) {
+        ctx->mrhs_off = value != 0;
     } else if (!strcmp(key, "peer_timeout_s")) {
         CIAO_REQUIRE(value >= 1 && value <= 86400, "peer_timeout_s must be in 1..86400");
         ctx->peer_timeout_s = value;
@@ -1396,6 +1424,16 @@ int32_t ciao_full_gradient(ciao_ctx *ctx, const ciao_problem *p, const void *x, 
     return DISPATCH(p->dtype, full_gradient_t, ctx, p, x, av);
 }
 
+int32_t ciao_full_gradient_multi(ciao_ctx *ctx, const ciao_problem *p, int32_t K, const void *const *x, void *const *av)
+{
+    CIAO_ENTER(ctx);
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_REQUIRE(K >= 1 && K <= 4096 && x && av, "K must be in 1..4096 and the pointer tables non-NULL");
+    for (int k = 0; k < K; ++k) CIAO_REQUIRE(x[k] && av[k], "x[%d] or av[%d] is NULL", k, k);
+    CIAO_REQUIRE(p->loss != CIAO_LOSS_LS_COMPLEX, "complex problems: one ciao_full_gradient per iterate");
+    return DISPATCH(p->dtype, full_gradient_multi_t, ctx, p, K, x, av);
+}
+
 int32_t ciao_proxgrad_step(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, const void *x,
                            void *av, void *y)
 {
@@ -1480,6 +1518,18 @@ int32_t ciao_svrg_epoch_tail(ciao_ctx *ctx, const ciao_problem *p, int64_t m, in
     CIAO_REQUIRE(m >= 1, "m < 1");
     CIAO_REQUIRE(av && z && z_full && w, "NULL state vector");
     return DISPATCH(p->dtype, svrg_epoch_tail_t, ctx, p, m, plus, av, z, z_full, w);
+}
+
+int32_t ciao_svrg_epoch_tail_multi(ciao_ctx *ctx, const ciao_problem *p, int32_t K, int64_t m, int32_t plus, void *const *av,
+                                   void *const *z, void *const *z_full, void *const *w)
+{
+    CIAO_ENTER(ctx);
+    CIAO_TRY(check_problem(ctx, p));
+    CIAO_REQUIRE(m >= 1, "m < 1");
+    CIAO_REQUIRE(K >= 1 && K <= 4096 && av && z && z_full && w, "K must be in 1..4096 and the pointer tables non-NULL");
+    for (int k = 0; k < K; ++k) CIAO_REQUIRE(av[k] && z[k] && z_full[k] && w[k], "NULL state vector of solve %d", k);
+    CIAO_REQUIRE(p->loss != CIAO_LOSS_LS_COMPLEX, "complex problems: one ciao_svrg_epoch_tail per solve");
+    return DISPATCH(p->dtype, svrg_epoch_tail_multi_t, ctx, p, K, m, plus, av, z, z_full, w);
 }
 
 int32_t ciao_saga_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_desc *g, double gamma, const void *x0,

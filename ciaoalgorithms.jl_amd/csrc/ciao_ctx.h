@@ -35,6 +35,10 @@ struct ciao_ctx {
 
     // private workspace (grown on demand, never inside a timed region after the first call of a given shape)
     void *partial = nullptr;   // per-block partial d-vectors
+    void *mrhs_ptrs = nullptr;  // multi-right-hand-side pass: device tables of iterate / output pointers
+    size_t mrhs_ptrs_bytes = 0;
+    std::vector<void *> mrhs_host;   // their host staging copy
+    int64_t mrhs_off = 0;       // option multi_rhs_off: K iterates as K single sweeps (testing)
     size_t partial_bytes = 0;
     void *pextra = nullptr;    // per-block extra scalars
     size_t pextra_bytes = 0;

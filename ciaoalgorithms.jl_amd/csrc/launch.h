@@ -82,6 +82,12 @@ int32_t launch_ws(ciao_ctx *ctx, int J256, bool masked, ChainArgs<T> &a);
 template <typename T>
 int32_t launch_cdma(ciao_ctx *ctx, int alg, int J, bool masked, ChainArgs<T> &a);
 
+// the full-gradient pass for K iterates in one pass over A (mrhs_kernels.h: MFMA).  Specialised in mrhs_f32.hip / mrhs_f64.hip.
+template <typename T>
+bool mrhs_supported(const ciao_ctx *ctx, const ciao_problem *p, int K, const void *const *x, void *const *av);
+template <typename T>
+int32_t launch_mrhs(ciao_ctx *ctx, const ciao_problem *p, int K, const void *const *x, void *const *av);
+
 // ProShI agent rows (init or one batch) + finalize + epilogue.  Specialised in rows_f32.hip / rows_f64.hip.
 template <typename T>
 int32_t launch_proshi(ciao_ctx *ctx, bool init, ProshiArgs<T> &a, const Epilogue<T> &ep);

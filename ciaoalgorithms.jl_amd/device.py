@@ -395,6 +395,24 @@ class Context:
         L.check(self.lib.ciao_svrg_epoch_tail(self._h, p.ref, int(m), 1 if plus else 0, self._vec(av, p, "av"), self._vec(z, p, "z"),
                                               self._vec(z_full, p, "z_full"), self._vec(w, p, "w")))
 
+    def _ptr_table(self, vecs, p, name):
+        arr = (C.c_void_p * len(vecs))(*[self._vec(v, p, f"{name}[{k}]") for k, v in enumerate(vecs)])
+        return arr
+
+    def full_gradient_multi(self, p, xs, avs):
+        """av_k = (1/N) sum_i grad f_i(x_k) for K iterates in ONE pass over A (ciao_full_gradient_multi: matrix cores where the shape
+        allows, K single sweeps otherwise).  xs, avs: lists of K device d-vectors."""
+        assert len(xs) == len(avs) and len(xs) >= 1
+        L.check(self.lib.ciao_full_gradient_multi(self._h, p.ref, len(xs), self._ptr_table(xs, p, "x"), self._ptr_table(avs, p, "av")))
+
+    def svrg_epoch_tail_multi(self, p, m, plus, avs, zs, z_fulls, ws):
+        """SVRG_basic.jl:84-92 for K solves over the same rows: every solve's tail, then the K full passes as one pass over A."""
+        K = len(avs)
+        assert K >= 1 and len(zs) == K and len(z_fulls) == K and len(ws) == K
+        L.check(self.lib.ciao_svrg_epoch_tail_multi(self._h, p.ref, K, int(m), 1 if plus else 0, self._ptr_table(avs, p, "av"),
+                                                    self._ptr_table(zs, p, "z"), self._ptr_table(z_fulls, p, "z_full"),
+                                                    self._ptr_table(ws, p, "w")))
+
     # -- SAGA / SAG ----------------------------------------------------------------------------------------------------
     def saga_init(self, p, g, gamma, x0, table, av, z):
         L.check(self.lib.ciao_saga_init(self._h, p.ref, g.ref, float(gamma), self._vec(x0, p, "x0"),

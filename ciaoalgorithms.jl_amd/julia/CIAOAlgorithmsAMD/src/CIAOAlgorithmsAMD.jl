@@ -349,10 +349,23 @@ function Base.iterate(iter::SVRG_basic_iterable{R}, state::SVRG_basic_state{R}) 
 end
 solution(state::SVRG_basic_state) = state.z_full                                            # SVRG_basic.jl:99
 
+# av[k] = (1/N) sum_i grad f_i(x[k]) for K iterates in ONE pass over the rows (ciao_full_gradient_multi: matrix cores for
+# d = 256 / 512 / 1024, K single sweeps otherwise).  Not in the reference (one problem per call): for hosts that advance several solves.
+function full_gradient_multi!(avs::Vector{<:ROCArray{R}}, F::PackedF{R}, xs::Vector{<:ROCArray{R}}) where {R}
+    length(avs) == length(xs) || throw(ArgumentError("as many outputs as iterates"))
+    xt, at = Ptr{Cvoid}[dptr(x) for x in xs], Ptr{Cvoid}[dptr(a) for a in avs]
+    p = Ref(cproblem(F))
+    GC.@preserve xt at check(ccall((:ciao_full_gradient_multi, libciao), Int32, (Ptr{Cvoid}, Ref{CiaoProblem}, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
+                                   context().h, p, Int32(length(xs)), pointer(xt), pointer(at)))
+    return avs
+end
+
 # K SVRG solves over the same rows (a regularisation path: iterables that differ in g) advanced by ONE reference iteration each:
 # the K inner cycles (:73-82) recorded and launched as one chain batch -- one workgroup, one compute unit, per solve -- then every
 # solve's epoch tail (:84-93).  Each state ends bitwise as Base.iterate(iter, state) leaves it with TRUST_SVRG_STATE[] = false.
-function iterate_together!(iters::Vector{SVRG_basic_iterable{R}}, states::Vector{SVRG_basic_state{R}}) where {R}
+# `one_pass = true` (all iterables over the same packed F, the same m): the K full passes of the epoch tails run as ONE pass over
+# the rows with K right-hand sides on the matrix cores (ciao_svrg_epoch_tail_multi) -- to rounding, not bitwise, K Base.iterate's.
+function iterate_together!(iters::Vector{SVRG_basic_iterable{R}}, states::Vector{SVRG_basic_state{R}}; one_pass::Bool = false) where {R}
     chain_batch() do
         for (iter, state) in zip(iters, states)
             idx = to_dev_idx(rand(1:iter.N, state.m))                                       # :73
@@ -363,6 +376,19 @@ function iterate_together!(iters::Vector{SVRG_basic_iterable{R}}, states::Vector
                         context().h, p, g, Float64(state.γ), state.m, dptr(idx),
                         dptr(state.av), dptr(state.z), dptr(state.z_full), dptr(state.w)))
         end
+    end
+    if one_pass && all(it -> it.F === iters[1].F && it.plus == iters[1].plus, iters) && all(st -> st.m == states[1].m, states)
+        K = length(iters)
+        table(f) = Ptr{Cvoid}[dptr(f(st)) for st in states]                                 # host arrays of K device pointers
+        avs, zs, zfs, ws = table(st -> st.av), table(st -> st.z), table(st -> st.z_full), table(st -> st.w)
+        p = Ref(cproblem(iters[1].F))
+        GC.@preserve avs zs zfs ws check(ccall((:ciao_svrg_epoch_tail_multi, libciao), Int32,
+                    (Ptr{Cvoid}, Ref{CiaoProblem}, Int32, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    context().h, p, Int32(K), states[1].m, Int32(iters[1].plus), pointer(avs), pointer(zs), pointer(zfs), pointer(ws)))
+        for (iter, state) in zip(iters, states)
+            iter.plus && (state.m *= 2)                                                     # :93
+        end
+        return states
     end
     for (iter, state) in zip(iters, states)
         p = Ref(cproblem(iter.F))

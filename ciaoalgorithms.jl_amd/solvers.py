@@ -848,7 +848,7 @@ class Proshi(_Solver):
 Proshi_basic_iterable._chunkable = True
 
 
-def solve_together(iterables, maxit):
+def solve_together(iterables, maxit, one_pass=False):
     """K independent SVRG, SAGA / SAG or small-batch Finito solves over device-resident rows, advanced in LOCKSTEP: `iterables` are what
     `iterator(solver, x0, F=..., g=..., N=..., ctx=ctx)` returns, all on the same ctx (typically the same packed F with a g -- a
     lambda of the regularisation path -- and a sampling stream each).  The reference solves one problem per call and a chain is
@@ -859,7 +859,12 @@ def solve_together(iterables, maxit):
     Each solve ends bitwise as its own `solver(maxit=maxit)(x0, ...)` would -- for SVRG with the row-dot cache off
     (`ctx.set_option("svrg_cache_rowdots", 0)`: a batch's inner cycles recompute a_i'z_full, include/ciao_hip.h:
     ciao_svrg_epoch_tail), for SAGA / SAG and Finito as is (Finito: batches small enough to run as a chain, i.e. the default
-    minibatch of one sample up to option chain_max_batch; larger batches are batch-parallel kernels that fill the GPU alone)."""
+    minibatch of one sample up to option chain_max_batch; larger batches are batch-parallel kernels that fill the GPU alone).
+
+    `one_pass=True` (SVRG over ONE packed F): the K full passes of every outer step (SVRG_basic.jl:87-92 per solve) run as ONE pass
+    over the rows with K right-hand sides on the matrix cores (ciao_svrg_epoch_tail_multi; d = 256 / 512 / 1024) instead of K
+    sweeps -- at N = 10M, K = 256 that is most of what an outer step costs beside the batched inner cycles.  The pass sums in another
+    order, so each solve then follows its own functor call to ROUNDING, not bitwise."""
     its = list(iterables)
     if not its:
         return [], 0
@@ -887,8 +892,14 @@ def solve_together(iterables, maxit):
             with ctx.chain_batch():
                 for it, st, idx in zip(its, states, drawn):
                     ctx.svrg_inner(it.F, it.g, st.γ, idx, st.av, st.z, st.z_full, st.w)            # :74-82
+            same = (one_pass and all(it.F is its[0].F for it in its) and len({st.m for st in states}) == 1
+                    and len({bool(it.plus) for it in its}) == 1)
+            if same:                                                                               # :84-92 of all K solves, one pass over A
+                ctx.svrg_epoch_tail_multi(its[0].F, states[0].m, its[0].plus, [st.av for st in states], [st.z for st in states],
+                                          [st.z_full for st in states], [st.w for st in states])
             for it, st in zip(its, states):
-                ctx.svrg_epoch_tail(it.F, st.m, it.plus, st.av, st.z, st.z_full, st.w)             # :84-92
+                if not same:
+                    ctx.svrg_epoch_tail(it.F, st.m, it.plus, st.av, st.z, st.z_full, st.w)         # :84-92
                 st._tok = None
                 if it.plus:
                     st.m *= 2                                                                      # :93

@@ -168,6 +168,15 @@ CIAO_API int32_t ciao_prox(ciao_ctx *ctx, int32_t dtype, int64_t d, const ciao_p
 /* av = (1/N_total) sum_i grad f_i(x)       SVRG_basic.jl:58-63 (init) and :87-92 (epoch tail).
  * Reads every row of A exactly once. */
 CIAO_API int32_t ciao_full_gradient(ciao_ctx *ctx, const ciao_problem *p, const void *x, void *av);
+/* The same pass for K iterates over the same rows -- av[k] = (1/N_total) sum_i grad f_i(x[k]), k < K -- in ONE pass over A: with
+ * K right-hand sides the contraction is GEMM-shaped (A Z, the link function, A' C) and runs on the matrix cores
+ * (csrc/mrhs_kernels.h; north_star: "MFMA ... if the f_i gradients are expressed as a dense A.x contraction").  x and av are HOST
+ * arrays of K device pointers (16-byte aligned d-vectors).  Not in the reference, which solves one problem per call
+ * (SVRG_basic.jl:87-92 is the single pass): an extension for hosts that advance several solves together (a regularisation path,
+ * folds: ciao_ctx_chain_batch_begin).  Shapes the kernel does not take (d other than 256 / 512 / 1024, unaligned rows, a
+ * row-sharded problem, the objective monitor) run as K single passes inside the call.  Each av[k] agrees with its own
+ * ciao_full_gradient to rounding (another summation order), not bitwise. */
+CIAO_API int32_t ciao_full_gradient_multi(ciao_ctx *ctx, const ciao_problem *p, int32_t K, const void *const *x, void *const *av);
 /* Fused proximal-gradient step on the full gradient (the "full-gradient + prox sweep" of the north star; it is also
  * LFinito's `prox!` + full pass, Finito_LFinito.jl:83-88, in x-coordinates):
  *     av = (1/N_total) sum_i grad f_i(x);   y = prox_{gamma g}(x - gamma * av)          (y may alias x) */
@@ -205,6 +214,10 @@ CIAO_API int32_t ciao_svrg_iterate(ciao_ctx *ctx, const ciao_problem *p, const c
  * finish each solve's outer iteration afterwards. */
 CIAO_API int32_t ciao_svrg_epoch_tail(ciao_ctx *ctx, const ciao_problem *p, int64_t m, int32_t plus, void *av, void *z,
                              void *z_full, void *w);
+/* ... for K solves over the same rows at once (host arrays of K device pointers): every solve's tail, then the K full passes as
+ * ONE pass over A (ciao_full_gradient_multi).  K calls of ciao_svrg_epoch_tail to rounding. */
+CIAO_API int32_t ciao_svrg_epoch_tail_multi(ciao_ctx *ctx, const ciao_problem *p, int32_t K, int64_t m, int32_t plus, void *const *av,
+                                   void *const *z, void *const *z_full, void *const *w);
 
 /* ---- the sequential chains on a row-sharded problem ("one chain on one GPU pulling remote rows over xGMI") --
  * The inner loops of SVRG and SAGA are one dependent chain and do not shard: on a problem whose rows do not fit one GPU
