@@ -388,6 +388,32 @@ def run(ctx, dev, quick=False):
                     "seconds": t, "N": Nm, "TFLOPs": 4.0 * Nm * dm * K / t / 1e12, "K_single_sweeps_seconds": K * t1, "speedup": K * t1 / t,
                     "roofline": {"bound": "mfma", "achieved": 4.0 * Nm * dm * K / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                                  "frac": 4.0 * Nm * dm * K / t / 1e12 / peak}, "kernel": kern}
+            if tdt == torch.float64 and not quick:
+                # one whole outer step of K = 256 lockstep SVRG solves (a regularisation path) over these rows, m = N: the batched inner
+                # cycles (one launch, a workgroup per solve) + the 256 epoch tails as K sweeps / as ONE pass (solve_together(one_pass=))
+                K = 256
+                sts = [tuple(torch.zeros(dm, dtype=tdt, device=dev) for _ in range(4)) for _ in range(K)]
+                gs = [ProxG(L.PROX_L1, lam=1e-3 * (1.0 + k / K)) for k in range(K)]
+                ixs = [ctx._idx(IndexStream(500 + k).rand_indices(Nm, Nm)) for k in range(K)]
+                for k in range(K):
+                    ctx.svrg_init(Fm, x1, *sts[k])
+                ctx.set_option("svrg_cache_rowdots", 0)
+                try:
+                    def chains():
+                        with ctx.chain_batch():
+                            for k in range(K):
+                                ctx.svrg_inner(Fm, gs[k], 1.0 / (7 * 1.3 * Nm), ixs[k], *sts[k])
+                    t_ch = _timed(ctx, chains, reps=1)
+                finally:
+                    ctx.set_option("svrg_cache_rowdots", 1)
+                cols = [[s[i] for s in sts] for i in range(4)]
+                t_k = _timed(ctx, lambda: [ctx.svrg_epoch_tail(Fm, Nm, False, *s) for s in sts], reps=1)
+                t_1 = _timed(ctx, lambda: ctx.svrg_epoch_tail_multi(Fm, Nm, False, *cols), reps=1)
+                out["lambda_path_outer_step_K256_f64_d1024"] = {
+                    "N": Nm, "m": Nm, "K": K, "inner_cycles_s": t_ch, "tails_as_K_sweeps_s": t_k, "tails_as_one_pass_s": t_1,
+                    "outer_step_s": {"K_sweeps": t_ch + t_k, "one_pass": t_ch + t_1}, "updates_per_s_one_pass": K * Nm / (t_ch + t_1),
+                    "note": "an extension beyond the reference's one-problem-per-call API (ciao_ctx_chain_batch_begin, ciao_svrg_epoch_tail_multi)"}
+                del sts, ixs
             del Fm
             torch.cuda.empty_cache()
     except Exception as e:   # noqa: BLE001

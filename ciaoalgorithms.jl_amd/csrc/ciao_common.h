@@ -369,4 +369,24 @@ __device__ __forceinline__ void epilogue_apply2(const Epilogue<T> &e, int64_t k,
     }
 }
 
+// ---- the matrix cores: v_mfma_{f64,f32}_16x16x4 (16 x 16 output, four k-slots, one element of each operand per lane: A lane (row l & 15,
+// slot l >> 4), B lane (column l & 15, slot l >> 4); accumulator lane (column l & 15, l >> 4) holds four rows, row(h, reg))
+template <typename T>
+struct MfmaOf;
+template <>
+struct MfmaOf<double> {
+    typedef double acc __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc mma(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    // C/D: col = lane & 15, row = (lane >> 4) + 4 reg
+    static __device__ __forceinline__ int row(int h, int reg) { return h + 4 * reg; }
+};
+template <>
+struct MfmaOf<float> {
+    typedef float acc __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc mma(float a, float b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    // C/D: col = lane & 15, row = 4 (lane >> 4) + reg
+    static __device__ __forceinline__ int row(int h, int reg) { return 4 * h + reg; }
+};
+
+
 }  // namespace ciao

@@ -88,6 +88,12 @@ bool mrhs_supported(const ciao_ctx *ctx, const ciao_problem *p, int K, const voi
 template <typename T>
 int32_t launch_mrhs(ciao_ctx *ctx, const ciao_problem *p, int K, const void *const *x, void *const *av);
 
+// full-gradient sweeps over rows of 17 .. 256 elements on the matrix cores (rowsm_kernels.h).  Specialised in rowsm_f32.hip / rowsm_f64.hip.
+template <typename T>
+size_t smallm_lds(int64_t d, int nb);
+template <typename T>
+int32_t launch_smallm(ciao_ctx *ctx, int grid, size_t lds, RowsArgs<T> &a);
+
 // ProShI agent rows (init or one batch) + finalize + epilogue.  Specialised in rows_f32.hip / rows_f64.hip.
 template <typename T>
 int32_t launch_proshi(ciao_ctx *ctx, bool init, ProshiArgs<T> &a, const Epilogue<T> &ep);

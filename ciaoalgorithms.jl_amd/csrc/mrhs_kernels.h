@@ -54,23 +54,6 @@ struct MrhsArgs {
     int P;                        // row partitions
 };
 
-template <typename T>
-struct MfmaOf;
-template <>
-struct MfmaOf<double> {
-    typedef double acc __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ acc mma(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-    // C/D: col = lane & 15, row = (lane >> 4) + 4 reg
-    static __device__ __forceinline__ int row(int h, int reg) { return h + 4 * reg; }
-};
-template <>
-struct MfmaOf<float> {
-    typedef float acc __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ acc mma(float a, float b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-    // C/D: col = lane & 15, row = 4 (lane >> 4) + reg
-    static __device__ __forceinline__ int row(int h, int reg) { return 4 * h + reg; }
-};
-
 constexpr int MRHS_TILE = 16;    // rows per tile = MFMA rows
 constexpr int MRHS_KB = 16;      // solves per workgroup = MFMA columns
 

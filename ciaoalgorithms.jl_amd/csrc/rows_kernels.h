@@ -51,6 +51,7 @@ struct RowsArgs {
     T *pextra;             // [gridDim.x]
     int64_t N;             // local rows (index validation)
     int *errflag;          // device word set to 1 on an out-of-range index
+    int small_nb;          // rows_smallm_kernel: tile buffers per wave
 };
 
 template <typename T>

@@ -1,0 +1,262 @@
+// rowsm_kernels.h -- full-gradient sweeps over rows of tabular size (17 .. 256 elements) with the row dots and the rank-1
+// accumulation on the matrix cores (rows_smallm_kernel; VERDICT r3 item 5: "the one formulation north_star allows MFMA for").
+//
+// Why.  rows_small_kernel (rows_kernels.h) is instruction-bound: a dozen vector / LDS instructions per 64 elements for the
+// segmented sums of several short rows sharing a wave (fp32 3.8-4.5 TB/s, fp64 5.2-5.5).  A tile of 16 consecutive rows of a
+// dense matrix (ld == d) is ONE contiguous, 16-byte aligned stretch of 16 d elements; with the tile in LDS
+//      D = A x          16 rows x d  times  d x 16 (the iterate in every column)       d/4 MFMAs of 16x16x4
+//      c = link(D, b)   per row                                                        (SVRG_basic.jl:58-63, :87-92)
+//      G += A' C        (16 columns x 4 rows)(4 rows x 16) per chunk of 16 columns     d/4 MFMAs
+// costs two LDS reads and one MFMA per 64 elements and no other vector instruction; fifteen of the sixteen MFMA columns compute
+// the same thing again -- the matrix pipe is idle otherwise, and d/2 MFMAs per tile stay under the tile's HBM time
+// (4 bytes per cycle and SIMD in either precision = 9.8 TB/s chip-wide).
+//
+// Structure.  A wave owns tiles g, g + #waves, ...; a ring of nb LDS buffers per wave.  The next nb - 1 tiles travel by LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wave-instruction straight into LDS, no registers, no LDS stores) while this one is
+// multiplied; every vector-memory instruction of the loop is such a load, so the wait for the current tile is a counted vmcnt
+// (a wave needs 2-3 tiles in flight: with one, 13 MB chip-wide, the sweep was latency-bound at 4.5 TB/s).  The iterate is
+// operand B of GEMM 1, in registers: lane (column c, slot h) step j = x[4 j + h].
+// Operand A of GEMM 1, lane (row r, slot h) step j = tile[r][4 j + h]; of GEMM 2, lane (column i, slot h) step t =
+// tile[row(h, t)][16 c + i] -- the accumulator layout of D IS operand B of GEMM 2, as in mrhs_kernels.h.  Indexes beyond the row
+// (the last step, the last chunk) are clamped to the row's last element and meet a zero of the iterate / a column that is dropped.
+// The matrix's last tile may hold fewer than 16 rows: it is brought in dword-wise (no 16-byte access may cross the end of A),
+// missing rows are zero.  The b_i of a tile travel the same way (16 values into a 128-byte buffer beside the tile's).  Fixed order everywhere: bitwise reproducible.  Objective monitor (sum of f_i) and the cached row dots
+// of the SVRG chain (rowdot_out) as in the other sweeps.
+#pragma once
+
+#include "chain_kernels.h"   // glds16s: the LDS-DMA load
+#include "rows_kernels.h"
+
+namespace ciao {
+
+// LDS bytes of a workgroup: the iterate (zero-padded, a whole KiB), then per wave `nb` tile buffers (16 d elements each, back to
+// back) and `nb` 128-byte buffers for the tiles' b_i; the per-wave column sums reuse the tile buffers at the end
+template <typename T>
+inline size_t smallm_x_bytes(int64_t d) { return (size_t)(((d + 3) / 4 * 4 * sizeof(T)) + 1023) / 1024 * 1024; }
+template <typename T>
+inline size_t smallm_wave_bytes(int64_t d, int nb) { return (size_t)nb * ((size_t)16 * d * sizeof(T) + 128); }
+template <typename T>
+inline size_t smallm_lds_bytes(int64_t d, int nb) { return smallm_x_bytes<T>(d) + (size_t)ROWS_WAVES * smallm_wave_bytes<T>(d, nb); }
+
+// s_waitcnt vmcnt(k) for a wave-uniform k known only at run time (the instruction takes an immediate): 0 .. 63
+__device__ __forceinline__ void wait_vmcnt_uniform(int k)
+{
+#define CIAO_W1(n) case n: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory"); break;
+#define CIAO_W4(n) CIAO_W1(n) CIAO_W1(n + 1) CIAO_W1(n + 2) CIAO_W1(n + 3)
+#define CIAO_W16(n) CIAO_W4(n) CIAO_W4(n + 4) CIAO_W4(n + 8) CIAO_W4(n + 12)
+    switch (k) {
+        CIAO_W16(0) CIAO_W16(16) CIAO_W16(32) CIAO_W16(48)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef CIAO_W16
+#undef CIAO_W4
+#undef CIAO_W1
+}
+
+// NC2: the row length class, d in (32 (NC2 - 1), 32 NC2]: 2 NC2 chunks of 16 columns, 8 NC2 MFMA steps per product, all unrolled -- the
+// steps and chunks that a shorter row of the class does not have multiply clamped elements by zeros of the iterate / land in
+// columns that are dropped.  Only the last 8 steps and 2 chunks can be such: the others address LDS with immediates.
+template <typename T, int NC2>
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
+{
+    constexpr int NCHMAX = 2 * NC2, SLMAX = 8 * NC2, SAFE = 8 * (NC2 - 1), CSAFE = 2 * (NC2 - 1);
+    using M = MfmaOf<T>;
+    using Acc = typename M::acc;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smm_raw[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 15, h = lane >> 4;
+    const int d = (int)a.d;
+    const int xp = (d + 3) & ~3;
+    const uint32_t tb = 16u * (uint32_t)d * (uint32_t)sizeof(T);   // bytes of a whole tile = the buffer pitch
+    const uint32_t pitch = tb;
+    const int nb = a.small_nb;                                      // tile buffers per wave: nb - 1 tiles in flight behind the current one
+    const uint32_t xbytes = ((uint32_t)(xp * sizeof(T)) + 1023u) & ~1023u;
+    T *xl = reinterpret_cast<T *>(smm_raw);
+    unsigned char *wbuf = smm_raw + xbytes + (size_t)wib * ((size_t)nb * (pitch + 128));
+    const uint32_t wbuf_off = (uint32_t)(uintptr_t)wbuf;
+    const T *bl = reinterpret_cast<const T *>(wbuf + (size_t)nb * pitch);   // [nb][16]
+
+    for (int c = threadIdx.x; c < xp; c += ROWS_BLOCK) xl[c] = c < d ? a.x1[c] : T(0);
+    __syncthreads();
+    // operand B of GEMM 1 stays in registers for the whole sweep: lane (column c, slot h), step j: x[4 j + h], zero beyond the row
+    T xr[SLMAX];
+#pragma unroll
+    for (int j = 0; j < SLMAX; ++j) xr[j] = 4 * j + h < xp ? xl[4 * j + h] : T(0);
+
+    const int64_t ntiles = (a.nrows + 15) >> 4;
+    const int64_t nwaves = (int64_t)gridDim.x * ROWS_WAVES;
+    const T s2 = (a.loss == CIAO_LOSS_LS) ? a.lam : (a.loss == CIAO_LOSS_LOGISTIC ? T(1) : T(0));
+
+    // tile g -> LDS buffer `buf`, with the b_i of its rows.  Everything by LDS-DMA: a load the compiler counts would have it wait,
+    // before the value's first use, with a vmcnt that knows nothing of the DMA in flight behind it -- i.e. for the NEXT tile too
+    // (the first version of this kernel read b_i through volatile loads: every tile waited out the latency of the one after)
+    auto fetch = [&](int64_t g, int buf) {
+        const int64_t row_b = g << 4;
+        const int64_t left = a.nrows - row_b;
+        const int nr = left < 16 ? (int)left : 16;
+        const T *gp = a.A + (a.row0 + row_b) * (int64_t)d;
+        const uint32_t dst = wbuf_off + (uint32_t)buf * pitch;
+        if (nr == 16) {
+            for (uint32_t off = 0; off < tb; off += 1024u) {
+                const uint32_t vo = off + (uint32_t)lane * 16u;
+                if (vo < tb) glds16s(gp, vo, dst + off);
+            }
+        } else {
+            // the matrix's last, short tile: dword by dword (no 16-byte access may cross the end of A); the rows beyond it are zeroed
+            // (their coefficient is zero, but whatever the buffer held -- possibly nothing yet -- times zero need not be)
+            const uint32_t have = (uint32_t)nr * (uint32_t)d * (uint32_t)sizeof(T);
+            for (uint32_t off = 0; off < have; off += 256u) {
+                const uint32_t vo = off + (uint32_t)lane * 4u;
+                if (vo < have) glds4(reinterpret_cast<const unsigned char *>(gp) + vo, dst + off);
+            }
+            uint32_t *zb = reinterpret_cast<uint32_t *>(wbuf + (size_t)buf * pitch);
+            for (uint32_t e = have / 4u + (uint32_t)lane; e < tb / 4u; e += WAVE) zb[e] = 0u;
+        }
+        if (a.b) {
+            const uint32_t vo = (uint32_t)lane * 4u;
+            if (vo < (uint32_t)nr * (uint32_t)sizeof(T))
+                glds4(reinterpret_cast<const unsigned char *>(a.b + a.row0 + row_b) + vo, wbuf_off + (uint32_t)nb * pitch + (uint32_t)buf * 128u);
+        }
+    };
+
+    Acc G[NCHMAX];
+#pragma unroll
+    for (int c = 0; c < NCHMAX; ++c) G[c] = Acc(T(0));
+    T ex = T(0);
+    const bool extras = a.want_fval || a.rowdot_out != nullptr;
+    // LDS-DMA instructions of one whole tile (what stays in flight behind the tile being waited for is a multiple of it)
+    const int per_tile = (int)((tb + 1023u) >> 10) + (a.b ? 1 : 0);
+    int64_t g = (int64_t)blockIdx.x * ROWS_WAVES + wib;
+    int buf = 0;
+    for (int k = 0; k < nb - 1; ++k)
+        if (g + k * nwaves < ntiles) fetch(g + k * nwaves, k);
+    for (; g < ntiles; g += nwaves) {
+        const int64_t row_b = g << 4;
+        const int64_t left = a.nrows - row_b;
+        const int nr = left < 16 ? (int)left : 16;
+        // this tile has landed when no more than the nb - 2 tiles requested after it are outstanding -- counted only while all of
+        // those exist and are whole tiles (the matrix's short last tile issues another number of instructions): else everything
+        const int64_t g_last = g + (int64_t)(nb - 2) * nwaves;      // the youngest tile in flight
+        if (nb > 2 && ((g_last + 1) << 4) <= a.nrows)
+            wait_vmcnt_uniform((nb - 2) * per_tile);
+        else
+            wait_vmcnt_uniform(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) (the short last tile's zero fill), vmcnt / expcnt at their maximum
+        asm volatile("" ::: "memory");
+        {
+            const int64_t gn = g + (int64_t)(nb - 1) * nwaves;       // into the buffer the previous tile has just left
+            int bn = buf + nb - 1;
+            bn = bn >= nb ? bn - nb : bn;
+            if (gn < ntiles) fetch(gn, bn);
+        }
+        const T *tl = reinterpret_cast<const T *>(wbuf + (size_t)buf * pitch);
+        T bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rq = M::row(h, q);
+            bq[q] = (a.b && rq < nr) ? bl[buf * (128 / (int)sizeof(T)) + rq] : T(0);
+        }
+        // ---- GEMM 1: the 16 row dots (every column of D the same), two accumulators in turn
+        Acc D = Acc(T(0)), D1 = Acc(T(0));
+        {
+            const T *ta = tl + r * d + h;
+            const int last = d - 1 - h;                     // (index of the row's last element relative to ta)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < SLMAX; ++j) {
+                const T av = j < SAFE ? ta[4 * j] : ta[4 * j < last ? 4 * j : last];
+                if (j & 1)
+                    D1 = M::mma(av, xr[j], D1);
+                else
+                    D = M::mma(av, xr[j], D);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int j = 0; j < SLMAX - 4; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        D += D1;
+        // ---- the link function: lane (c, h) holds rows row(h, q); rows beyond the matrix get coefficient zero.  One uniform branch
+        // on the loss around the four rows (a switch per row, with the monitor's and the row-dot cache's tests inside it, was
+        // several hundred instructions of branching per tile)
+        Acc C;
+        if (a.loss == CIAO_LOSS_LS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) C[q] = grad_coef(CIAO_LOSS_LS, D[q], bq[q], a.lam).s1 * s2;
+        } else if (a.loss == CIAO_LOSS_LOGISTIC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) C[q] = grad_coef(CIAO_LOSS_LOGISTIC, D[q], bq[q], a.lam).s1 * s2;
+        } else {
+            C = Acc(T(0));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[q] = M::row(h, q) < nr ? C[q] : T(0);
+        if (extras && r == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rq = M::row(h, q);
+                if (rq < nr) {
+                    if (a.want_fval) ex += loss_value(a.loss, D[q], bq[q], a.lam);
+                    if (a.rowdot_out) a.rowdot_out[a.row0 + row_b + rq] = D[q];
+                }
+            }
+        }
+        // ---- GEMM 2: G[chunk] += A'(16 columns x 4 rows) C(4 rows x 16); t outside, chunks inside: consecutive MFMAs are independent
+        {
+            const int cl = d - 1 - r;                       // (the row's last column relative to column r)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const T *tr = tl + M::row(h, t) * d + r;
+#pragma unroll
+                for (int c = 0; c < NCHMAX; ++c) {
+                    const T av = c < CSAFE ? tr[16 * c] : tr[16 * c < cl ? 16 * c : cl];
+                    G[c] = M::mma(av, C[t], G[c]);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int j = 0; j < 4 * NCHMAX - 4; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        buf = buf + 1 == nb ? 0 : buf + 1;
+    }
+
+    // ---- per-wave column sums (lanes of column c = 0 hold them: chunk c, register q -> column 16 c + row(h, q)) -> the block's partial
+    wait_vmcnt_uniform(0);
+    __syncthreads();   // every wave is done with its buffers and with the iterate
+    T *cs = reinterpret_cast<T *>(smm_raw + xbytes) + (size_t)wib * (16 * NCHMAX);   // [wave][column] (over the tile buffers)
+    if (r == 0) {
+#pragma unroll
+        for (int c = 0; c < NCHMAX; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cs[16 * c + M::row(h, q)] = G[c][q];
+    }
+    ex = wave_allsum(ex);
+    __shared__ T red_extra_smallm[ROWS_WAVES];
+    if (lane == 0) red_extra_smallm[wib] = ex;
+    __syncthreads();
+    const T *cs0 = reinterpret_cast<const T *>(smm_raw + xbytes);
+    T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
+    for (int c = threadIdx.x; c < d; c += ROWS_BLOCK) {
+        T sacc = cs0[c];
+        for (int w = 1; w < ROWS_WAVES; ++w) sacc += cs0[w * (16 * NCHMAX) + c];
+        pout[c] = sacc;
+    }
+    if (threadIdx.x == 0) {
+        T e2 = T(0);
+        for (int w = 0; w < ROWS_WAVES; ++w) e2 += red_extra_smallm[w];
+        a.pextra[blockIdx.x] = e2;
+    }
+}
+
+}  // namespace ciao

@@ -131,6 +131,31 @@ def _worker(rank, world, port, q):
         row0, n = shard_rows(N, rank, world)
         ok["sharded_saga_table_shard"] = bool(np.abs(ss.s.cpu().numpy() - sr.s[row0:row0 + n]).max() <= 1e-11 * np.abs(sr.s).max())
         grp2.close()
+        # ---- ProShI on row-sharded agents (ProShI_basic.jl:76-87, :109-121): every rank owns a block (or every world-th) of the agents and
+        # their table rows -- the table IS the solution, so it stays sharded; a batch updates the members a rank owns and one
+        # all-reduce of d + 1 scalars gives every rank the same av / z (hat_gamma = sum_i gamma_i is all-reduced in the init)
+        from ciaoalgorithms_jl_amd.device import PackedSepQuad
+        Na, da = 203, 256
+        rng = np.random.default_rng(77)
+        Qa = rng.uniform(0.5, 3.0, (Na, da))
+        qa = rng.standard_normal((Na, da))
+        eta, lo, hi = 10.0, -2.0, 2.0
+        La = Qa.max(axis=1) + eta
+        osq, obox = O.SepQuad(Qa, qa, eta, lo, hi), O.Prox("box", lo=-np.inf, hi=1.0)
+        gbox = ProxG(L.PROX_BOX, lo=-float("inf"), hi=1.0)
+        row0, n = shard_rows(Na, rank, world)
+        for name, sl, kw in (("block", slice(row0, row0 + n), dict(row0=row0)), ("cyclic", slice(rank, None, world), {})):
+            Fs = PackedSepQuad(torch.from_numpy(np.ascontiguousarray(Qa[sl])).to(dev), torch.from_numpy(np.ascontiguousarray(qa[sl])).to(dev),
+                               eta, lo, hi, N_total=Na, **kw)
+            if name == "cyclic":
+                Fs.cyclic = (rank, world)
+            for sweeping, batch in ((1, 24), (2, 32), (3, 40)):
+                xs, it = S.Proshi(np.float64, maxit=9, sweeping=sweeping, minibatch=(True, batch))(np.zeros(da), F=Fs, g=gbox, L=La, N=Na,
+                                                                                                    ctx=ctx, stream=IndexStream(20 + sweeping))
+                xr, _ = RS.proshi(osq, obox, np.zeros(da), maxit=9, sweeping=sweeping, batch=batch, L=La, stream=IndexStream(20 + sweeping))
+                mine = np.stack([np.asarray(v) for v in xs]) if not isinstance(xs, np.ndarray) else xs
+                ok[f"proshi_{name}_sw{sweeping}"] = bool(mine.shape == xr[sl].shape and
+                                                          np.abs(mine - xr[sl]).max() <= 1e-10 * max(np.abs(xr).max(), 1e-30))
         ctx.synchronize()
         ctx.close()
         q.put((rank, ok))

@@ -883,7 +883,8 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         # ---- modes 0, 2, 3: full gradient, SAGA init, Finito init
         av = torch.empty(d, dtype=tdt, device="cuda")
         ctx.full_gradient(dp, dev(x0), av)
-        assert "rows_small_kernel" in ctx.last_kernel(), ctx.last_kernel()
+        # (dense fp32 rows of 17 .. 256 elements: the sweep runs on the matrix cores, tests/test_gpu_small_mfma.py)
+        assert ("rows_smallm_kernel" if (d >= 17 and pad == 0 and dtype == np.float32) else "rows_small_kernel") in ctx.last_kernel(), ctx.last_kernel()
         close(av, O.full_pass(op, x0), dtype, scale=200, what=f"small rows full gradient d={d}")
         table = torch.empty((N, d), dtype=tdt, device="cuda")
         sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
@@ -1736,6 +1737,7 @@ def test_small_row_kernel_group_sizes(ctx, ciao, dtype, small_i, shape):
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
     table = torch.empty((N, d), dtype=tdt, device="cuda")
     ctx.set_option("small_i", small_i)
+    ctx.set_option("small_mfma", 0)   # (the sweep of dense rows of 17 .. 256 elements otherwise runs on the matrix cores)
     try:
         ctx.full_gradient(dp, dev(x0), av)
         rowb = d * np.dtype(dtype).itemsize
@@ -1760,6 +1762,7 @@ def test_small_row_kernel_group_sizes(ctx, ciao, dtype, small_i, shape):
         close(z, rz, dtype, scale=50, what="finito_init z")
     finally:
         ctx.set_option("small_i", 0)
+        ctx.set_option("small_mfma", -1)
     ctx.synchronize()
 
 

@@ -1,0 +1,129 @@
+"""Full-gradient sweeps over rows of tabular size on the matrix cores (rows_smallm_kernel, csrc/rowsm_kernels.h):
+tiles of 16 dense rows staged by LDS-DMA, the row dots (A x) and the rank-1 accumulation (A' c) as v_mfma_*_16x16x4.
+
+Held against the oracle's full pass (SVRG_basic.jl:58-63 / :87-92 restated) to a stated multiple of eps(R), and against the
+several-rows-per-wave kernel it replaces on these shapes (option small_mfma = 0) to rounding; the objective monitor and the cached
+row dots of the SVRG chain ride on it as on the other sweeps."""
+import numpy as np
+import pytest
+
+import problems as P
+from test_gpu_parity import close, dev, make, make_g
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("loss", ["ls", "logistic"])
+@pytest.mark.parametrize("d", [17, 50, 64, 100, 130, 200, 255])   # (64, 200: multiples of 8, taken on request only)
+def test_sweep_on_the_matrix_cores(ctx, ciao, dtype, loss, d):
+    """Row counts around the 16-row tile (1, 15, 16, 17), a few tiles, and enough for every wave of the grid to take several;
+    d with every remainder modulo 4 (the last MFMA step) and modulo 16 (the last chunk of columns)."""
+    import torch
+    from oracle import oracle as O
+    ctx.set_option("small_mfma", 1)   # (by default only fp32 takes this kernel: in fp64 the several-rows-per-wave kernel is the faster one)
+    for N in (1, 15, 16, 17, 100, 5000, 70001):
+        A, b, x0 = P.synthetic(loss, N, d, dtype, seed=N + d)
+        lam_f = float(N) if loss == "ls" else 1.0
+        op, dp = make(loss, A, b, lam_f, dtype)
+        av = torch.full((d,), float("nan"), dtype=dev(x0).dtype, device="cuda")
+        ctx.full_gradient(dp, dev(x0), av)
+        kern = ctx.last_kernel()
+        rowb = d * np.dtype(dtype).itemsize
+        if rowb % 16 == 0 and rowb >= 1024:
+            assert "rows_split_kernel" in kern or "rows_fast_kernel" in kern, kern     # those shapes keep their kernels
+            continue
+        if dtype == np.float64 and d > 144:   # two 16-row tile buffers per wave no longer fit LDS: the several-rows-per-wave kernel
+            assert "rows_small_kernel" in kern, kern
+            continue
+        assert "rows_smallm_kernel" in kern, kern
+        close(av, O.full_pass(op, x0), dtype, scale=200, what=f"matrix-core sweep d={d} N={N}")
+        av0 = torch.empty_like(av)
+        ctx.set_option("small_mfma", 0)
+        try:
+            ctx.full_gradient(dp, dev(x0), av0)
+            assert "rows_small_kernel" in ctx.last_kernel(), ctx.last_kernel()
+        finally:
+            ctx.set_option("small_mfma", 1)
+        close(av, av0.cpu().numpy(), dtype, scale=200, what=f"matrix-core sweep vs the several-rows-per-wave kernel d={d} N={N}")
+        av2 = torch.empty_like(av)
+        ctx.full_gradient(dp, dev(x0), av2)
+        assert torch.equal(av, av2), "not reproducible"
+    ctx.set_option("small_mfma", -1)
+    ctx.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_row_dots_and_objective_ride_on_the_matrix_core_sweep(ctx, ciao, dtype):
+    """SVRG epochs whose full passes run on rows_smallm_kernel: the inner cycle reuses the row dots the pass cached
+    (reuse_rowdots), so a wrong dot of any row shows in the next epoch; and the objective monitor's sum of f_i."""
+    import torch
+    from oracle import oracle as O
+    N, d = 3001, 50
+    for loss in ("ls", "logistic"):
+        A, b, x0 = P.synthetic(loss, N, d, dtype, seed=11)
+        lam_f = float(N) if loss == "ls" else 1.0
+        op, dp = make(loss, A, b, lam_f, dtype)
+        og, dg = make_g("l1", dtype, d, lam=0.01)
+        Lmax = (lam_f if loss == "ls" else 0.25) * np.max(np.sum(A.astype(np.float64) ** 2, axis=1))
+        gamma = 1.0 / (7 * Lmax)
+        tdt = dev(x0).dtype
+        eps = np.finfo(dtype).eps
+
+        def epochs(mfma):
+            st = ciao.IndexStream(5)
+            av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+            ctx.set_option("small_mfma", 1 if mfma else 0)
+            try:
+                ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+                assert ("rows_smallm_kernel" if mfma else "rows_small_kernel") in ctx.last_kernel(), ctx.last_kernel()
+                for _ in range(3):
+                    ctx.svrg_iterate(dp, dg, gamma, st.rand_indices(N, N), False, av, z, zf, w, reuse_rowdots=True)
+            finally:
+                ctx.set_option("small_mfma", -1)
+            return av, zf
+
+        av, zf = epochs(True)
+        av0, zf0 = epochs(False)
+        rav, rz, rzf, rw = O.svrg_init(op, x0)
+        scale_av = float(np.abs(rav).max())       # av shrinks as the solve converges: its error is held against the first pass's size
+        st = ciao.IndexStream(5)
+        for _ in range(3):
+            O.svrg_iterate(op, og, dtype(gamma), st.rand_indices(N, N), False, rav, rz, rzf, rw)
+        # (a dependent chain's error grows about linearly in its steps: 3 x 3001 here)
+        close(zf, rzf, dtype, scale=5000, what=f"3 svrg epochs over matrix-core passes, z_full vs the oracle ({loss})")
+        close(zf, zf0.cpu().numpy(), dtype, scale=5000, what=f"3 svrg epochs, z_full: matrix-core passes vs the several-rows-per-wave kernel ({loss})")
+        assert np.abs(av.cpu().numpy() - rav).max() <= 5000 * eps * scale_av
+        assert np.abs(av.cpu().numpy() - av0.cpu().numpy()).max() <= 5000 * eps * scale_av
+        obj = ctx.objective(dp, dg, zf)
+        ref = O.objective(op, og, zf.cpu().numpy())
+        assert abs(obj - ref) <= (1e-11 if dtype == np.float64 else 2e-5) * abs(ref), (obj, ref)
+    ctx.synchronize()
+
+
+def test_shapes_the_matrix_core_sweep_leaves_alone(ctx, ciao):
+    """Padded rows and rows shorter than 17 elements stay on the several-rows-per-wave kernel; so does fp64 unless asked; the ring
+    depth option gives the same sums bit for bit."""
+    import torch
+    for (N, d, pad, dtype, want) in ((500, 50, 3, np.float32, "rows_small_kernel"), (500, 16, 0, np.float32, "rows_small_kernel"),
+                                     (500, 5, 0, np.float32, "rows_small_kernel"), (500, 50, 0, np.float64, "rows_small_kernel"),
+                                     (500, 50, 0, np.float32, "rows_smallm_kernel")):
+        A, b, x0 = P.synthetic("ls", N, d, dtype, seed=N)
+        op, dp = make("ls", A, b, float(N), dtype, pad=pad)
+        av = torch.empty(d, dtype=dev(x0).dtype, device="cuda")
+        ctx.full_gradient(dp, dev(x0), av)
+        assert want in ctx.last_kernel(), ctx.last_kernel()
+    A, b, x0 = P.synthetic("logistic", 9001, 77, np.float32, seed=1)
+    op, dp = make("logistic", A, b, 1.0, np.float32)
+    ref = None
+    for nb in (0, 2, 3, 4):
+        ctx.set_option("small_nb", nb)
+        try:
+            av = torch.empty(77, dtype=torch.float32, device="cuda")
+            ctx.full_gradient(dp, dev(x0), av)
+            assert f"ring{nb if nb else 2}" in ctx.last_kernel(), ctx.last_kernel()
+        finally:
+            ctx.set_option("small_nb", 0)
+        ref = av if ref is None else ref
+        assert torch.equal(av, ref), nb
+    ctx.synchronize()
