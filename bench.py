@@ -695,6 +695,28 @@ def chain_figures(ctx, dev, F, g, gamma, A, b, N, d, args, L, np, torch):
         res[ekey]["cpu_baseline"] = {"value": 1.0 / t_cpu_epoch, "unit": "epochs/s", "cores": 1, "kind": "port",
                                      "sample": f"extrapolated from the two oracle rates of this run: {t_cpu_epoch:.0f} s per epoch on one core"}
     del idx
+    # ---- the full passes of K lockstep solves over these rows as ONE pass on the matrix cores (ciao_full_gradient_multi; an EXTENSION
+    # beyond the reference's one-problem-per-call API, labelled so): 4 N d K flops against the dense MFMA peak of the dtype
+    try:
+        if d in (256, 512, 1024):
+            Km = 64
+            xs = [torch.randn(d, dtype=tdt, device=dev) * 0.1 for _ in range(Km)]
+            avs = [torch.empty_like(x) for x in xs]
+            ctx.full_gradient_multi(F, xs, avs)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            ctx.full_gradient_multi(F, xs, avs)
+            ctx.synchronize()
+            tm = time.perf_counter() - t0
+            peak = 78.6 if es == 8 else 157.3
+            tf = 4.0 * N * d * Km / tm / 1e12
+            res["full_pass_K_solves"] = {"K": Km, "seconds": tm, "single_sweep_s": t_sweep, "speedup_vs_K_sweeps": Km * t_sweep / tm,
+                                         "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                                                      "traffic": None},
+                                         "what": "EXTENSION (not in the reference): K iterates' full passes as one pass over A, mrhs_kernel"}
+            del xs, avs
+    except Exception as e:   # noqa: BLE001
+        res["full_pass_K_solves"] = {"error": repr(e)[:200]}
     Ns = args.chain_rows or N
 
     def saga_figure(Fs, gs, gam, x1, tag, kern_note):
