@@ -83,7 +83,7 @@ struct ciao_ctx {
     int64_t sweep_multi = 1;           // short rows (<= 4 KiB): several rows per wave per iteration (rows_multi_kernel)
     int64_t split_max_rows = -1;       // batches up to this many rows run one workgroup per row (rows_split_kernel); -1 = automatic
     int64_t small_nb = 0;              // rows_smallm_kernel: tile buffers per wave, 2 .. 4 (0 = automatic)
-    int64_t small_mfma = -1;           // rows_smallm_kernel (GRAD sweeps on rows of 17 .. 256 elements on the matrix cores): -1 = fp32 only, 0 = off, 1 = both types
+    int64_t small_mfma = -1;           // rows_smallm_kernel (GRAD sweeps on dense rows of 17 .. 256 elements on the matrix cores): 0 = off
     int64_t small_i = 0;               // rows_small_kernel: elements per lane and iteration, 8 or 16 (0 = automatic)
     int64_t split_all = 0;             // tuning experiment: workgroup-per-row kernel for every mode and size
     int64_t split_blocks_per_cu = 0;   // its grid cap in blocks per CU (0 = automatic)

@@ -4,21 +4,20 @@
 // Why.  rows_small_kernel (rows_kernels.h) is instruction-bound: a dozen vector / LDS instructions per 64 elements for the
 // segmented sums of several short rows sharing a wave (fp32 3.8-4.5 TB/s, fp64 5.2-5.5).  A tile of 16 consecutive rows of a
 // dense matrix (ld == d) is ONE contiguous, 16-byte aligned stretch of 16 d elements; with the tile in LDS
-//      D = A x          16 rows x d  times  d x 16 (the iterate in every column)       d/4 MFMAs of 16x16x4
+//      D = A x          16 rows x d  times  d x 16 (the iterate in every column)       d/4 MFMAs of 16x16x4: the segmented sums for free
 //      c = link(D, b)   per row                                                        (SVRG_basic.jl:58-63, :87-92)
-//      G += A' C        (16 columns x 4 rows)(4 rows x 16) per chunk of 16 columns     d/4 MFMAs
-// costs two LDS reads and one MFMA per 64 elements and no other vector instruction; fifteen of the sixteen MFMA columns compute
-// the same thing again -- the matrix pipe is idle otherwise, and d/2 MFMAs per tile stay under the tile's HBM time
-// (4 bytes per cycle and SIMD in either precision = 9.8 TB/s chip-wide).
+//      acc += c_r a_r   lane (row r, slot h) keeps A[r][4 j + h] of step j in its register: one FMA per step, no second read
+// costs one LDS read, one MFMA and one FMA per 64 elements; the sum over the 16 rows of a column waits for the end of the sweep
+// (a butterfly over the 16 lanes of a slot).  Fifteen of the sixteen MFMA columns compute the same dot again -- the matrix pipe is
+// idle otherwise: d/4 MFMAs per tile are 8 bytes per cycle and SIMD in either precision, twice the HBM rate.
 //
 // Structure.  A wave owns tiles g, g + #waves, ...; a ring of nb LDS buffers per wave.  The next nb - 1 tiles travel by LDS-DMA
 // (global_load_lds_dwordx4: 1 KiB per wave-instruction straight into LDS, no registers, no LDS stores) while this one is
 // multiplied; every vector-memory instruction of the loop is such a load, so the wait for the current tile is a counted vmcnt
 // (a wave needs 2-3 tiles in flight: with one, 13 MB chip-wide, the sweep was latency-bound at 4.5 TB/s).  The iterate is
 // operand B of GEMM 1, in registers: lane (column c, slot h) step j = x[4 j + h].
-// Operand A of GEMM 1, lane (row r, slot h) step j = tile[r][4 j + h]; of GEMM 2, lane (column i, slot h) step t =
-// tile[row(h, t)][16 c + i] -- the accumulator layout of D IS operand B of GEMM 2, as in mrhs_kernels.h.  Indexes beyond the row
-// (the last step, the last chunk) are clamped to the row's last element and meet a zero of the iterate / a column that is dropped.
+// Operand A, lane (row r, slot h) step j = tile[r][4 j + h].  Indexes beyond the row (the last steps of a row-length class) are
+// clamped to the row's last element and meet a zero of the iterate / a column that is dropped.
 // The matrix's last tile may hold fewer than 16 rows: it is brought in dword-wise (no 16-byte access may cross the end of A),
 // missing rows are zero.  The b_i of a tile travel the same way (16 values into a 128-byte buffer beside the tile's).  Fixed order everywhere: bitwise reproducible.  Objective monitor (sum of f_i) and the cached row dots
 // of the SVRG chain (rowdot_out) as in the other sweeps.
@@ -34,7 +33,7 @@ namespace ciao {
 template <typename T>
 inline size_t smallm_x_bytes(int64_t d) { return (size_t)(((d + 3) / 4 * 4 * sizeof(T)) + 1023) / 1024 * 1024; }
 template <typename T>
-inline size_t smallm_wave_bytes(int64_t d, int nb) { return (size_t)nb * ((size_t)16 * d * sizeof(T) + 128); }
+inline size_t smallm_wave_bytes(int64_t d, int nb) { return (size_t)nb * ((size_t)16 * d * sizeof(T) + 128) + 128; }
 template <typename T>
 inline size_t smallm_lds_bytes(int64_t d, int nb) { return smallm_x_bytes<T>(d) + (size_t)ROWS_WAVES * smallm_wave_bytes<T>(d, nb); }
 
@@ -53,13 +52,13 @@ __device__ __forceinline__ void wait_vmcnt_uniform(int k)
 #undef CIAO_W1
 }
 
-// NC2: the row length class, d in (32 (NC2 - 1), 32 NC2]: 2 NC2 chunks of 16 columns, 8 NC2 MFMA steps per product, all unrolled -- the
-// steps and chunks that a shorter row of the class does not have multiply clamped elements by zeros of the iterate / land in
-// columns that are dropped.  Only the last 8 steps and 2 chunks can be such: the others address LDS with immediates.
+// NC2: the row length class, d in (32 (NC2 - 1), 32 NC2]: 8 NC2 MFMA steps, all unrolled -- the steps that a shorter row of the class
+// does not have multiply clamped elements by zeros of the iterate and land in columns that are dropped.  Only the last 8 steps can
+// be such: the others address LDS with immediates.
 template <typename T, int NC2>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
 {
-    constexpr int NCHMAX = 2 * NC2, SLMAX = 8 * NC2, SAFE = 8 * (NC2 - 1), CSAFE = 2 * (NC2 - 1);
+    constexpr int SLMAX = 8 * NC2, SAFE = 8 * (NC2 - 1);
     using M = MfmaOf<T>;
     using Acc = typename M::acc;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smm_raw[];
@@ -73,9 +72,10 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
     const int nb = a.small_nb;                                      // tile buffers per wave: nb - 1 tiles in flight behind the current one
     const uint32_t xbytes = ((uint32_t)(xp * sizeof(T)) + 1023u) & ~1023u;
     T *xl = reinterpret_cast<T *>(smm_raw);
-    unsigned char *wbuf = smm_raw + xbytes + (size_t)wib * ((size_t)nb * (pitch + 128));
+    unsigned char *wbuf = smm_raw + xbytes + (size_t)wib * ((size_t)nb * (pitch + 128) + 128);
     const uint32_t wbuf_off = (uint32_t)(uintptr_t)wbuf;
     const T *bl = reinterpret_cast<const T *>(wbuf + (size_t)nb * pitch);   // [nb][16]
+    T *dl = reinterpret_cast<T *>(wbuf + (size_t)nb * (pitch + 128));       // [16]: a tile's row dots, from the accumulator layout to the lanes of each row
 
     for (int c = threadIdx.x; c < xp; c += ROWS_BLOCK) xl[c] = c < d ? a.x1[c] : T(0);
     __syncthreads();
@@ -120,9 +120,9 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
         }
     };
 
-    Acc G[NCHMAX];
+    T acc[SLMAX];
 #pragma unroll
-    for (int c = 0; c < NCHMAX; ++c) G[c] = Acc(T(0));
+    for (int j = 0; j < SLMAX; ++j) acc[j] = T(0);
     T ex = T(0);
     const bool extras = a.want_fval || a.rowdot_out != nullptr;
     // LDS-DMA instructions of one whole tile (what stays in flight behind the tile being waited for is a multiple of it)
@@ -151,25 +151,21 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
             if (gn < ntiles) fetch(gn, bn);
         }
         const T *tl = reinterpret_cast<const T *>(wbuf + (size_t)buf * pitch);
-        T bq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rq = M::row(h, q);
-            bq[q] = (a.b && rq < nr) ? bl[buf * (128 / (int)sizeof(T)) + rq] : T(0);
-        }
-        // ---- GEMM 1: the 16 row dots (every column of D the same), two accumulators in turn
+        // ---- the 16 row dots on the matrix cores (every column of D the same), two accumulators in turn.  The A operand of step j --
+        // lane (row r, slot h): tile[r][4 j + h] -- STAYS in its register: it is this lane's share of the rank-1 accumulation below
         Acc D = Acc(T(0)), D1 = Acc(T(0));
+        T av[SLMAX];
         {
             const T *ta = tl + r * d + h;
             const int last = d - 1 - h;                     // (index of the row's last element relative to ta)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < SLMAX; ++j) {
-                const T av = j < SAFE ? ta[4 * j] : ta[4 * j < last ? 4 * j : last];
+                av[j] = j < SAFE ? ta[4 * j] : ta[4 * j < last ? 4 * j : last];
                 if (j & 1)
-                    D1 = M::mma(av, xr[j], D1);
+                    D1 = M::mma(av[j], xr[j], D1);
                 else
-                    D = M::mma(av, xr[j], D);
+                    D = M::mma(av[j], xr[j], D);
             }
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
@@ -181,65 +177,48 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
             __builtin_amdgcn_sched_barrier(0);
         }
         D += D1;
-        // ---- the link function: lane (c, h) holds rows row(h, q); rows beyond the matrix get coefficient zero.  One uniform branch
-        // on the loss around the four rows (a switch per row, with the monitor's and the row-dot cache's tests inside it, was
-        // several hundred instructions of branching per tile)
-        Acc C;
-        if (a.loss == CIAO_LOSS_LS) {
+        // ---- row r's dot to the lanes of row r: the accumulator holds rows row(h, q) in lane (c, h); through the wave's LDS words
+        if (r == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) C[q] = grad_coef(CIAO_LOSS_LS, D[q], bq[q], a.lam).s1 * s2;
-        } else if (a.loss == CIAO_LOSS_LOGISTIC) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) C[q] = grad_coef(CIAO_LOSS_LOGISTIC, D[q], bq[q], a.lam).s1 * s2;
-        } else {
-            C = Acc(T(0));
+            for (int q = 0; q < 4; ++q) dl[M::row(h, q)] = D[q];
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) C[q] = M::row(h, q) < nr ? C[q] : T(0);
-        if (extras && r == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rq = M::row(h, q);
-                if (rq < nr) {
-                    if (a.want_fval) ex += loss_value(a.loss, D[q], bq[q], a.lam);
-                    if (a.rowdot_out) a.rowdot_out[a.row0 + row_b + rq] = D[q];
-                }
-            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const T dot = dl[r];
+        const T bi = (a.b && r < nr) ? bl[buf * (128 / (int)sizeof(T)) + r] : T(0);
+        // ---- the link function, once per lane: its row's coefficient; rows beyond the matrix get zero
+        T coef;
+        if (a.loss == CIAO_LOSS_LS)
+            coef = grad_coef(CIAO_LOSS_LS, dot, bi, a.lam).s1 * s2;
+        else if (a.loss == CIAO_LOSS_LOGISTIC)
+            coef = grad_coef(CIAO_LOSS_LOGISTIC, dot, bi, a.lam).s1 * s2;
+        else
+            coef = T(0);
+        coef = r < nr ? coef : T(0);
+        if (extras && h == 0 && r < nr) {
+            if (a.want_fval) ex += loss_value(a.loss, dot, bi, a.lam);
+            if (a.rowdot_out) a.rowdot_out[a.row0 + row_b + r] = dot;
         }
-        // ---- GEMM 2: G[chunk] += A'(16 columns x 4 rows) C(4 rows x 16); t outside, chunks inside: consecutive MFMAs are independent
-        {
-            const int cl = d - 1 - r;                       // (the row's last column relative to column r)
-            __builtin_amdgcn_sched_barrier(0);
+        // ---- the rank-1 accumulation: acc[j] += c_r tile[r][4 j + h], from the registers GEMM 1 read (the first form of this kernel
+        // ran it as a second MFMA product: fifteen sixteenths of twice the matrix work for nothing, the matrix pipe 63 % busy and
+        // the bound).  The sum over the 16 rows of a column is taken once, at the end of the sweep.
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const T *tr = tl + M::row(h, t) * d + r;
-#pragma unroll
-                for (int c = 0; c < NCHMAX; ++c) {
-                    const T av = c < CSAFE ? tr[16 * c] : tr[16 * c < cl ? 16 * c : cl];
-                    G[c] = M::mma(av, C[t], G[c]);
-                }
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-            for (int j = 0; j < 4 * NCHMAX - 4; ++j) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int j = 0; j < SLMAX; ++j) acc[j] = __builtin_fma(coef, av[j], acc[j]);
         buf = buf + 1 == nb ? 0 : buf + 1;
     }
 
-    // ---- per-wave column sums (lanes of column c = 0 hold them: chunk c, register q -> column 16 c + row(h, q)) -> the block's partial
+    // ---- per-wave column sums: column 4 j + h is spread over the 16 lanes (rows) of slot h -> summed in a fixed butterfly, written by
+    // the lane of row 0 -> the block's partial
     wait_vmcnt_uniform(0);
     __syncthreads();   // every wave is done with its buffers and with the iterate
-    T *cs = reinterpret_cast<T *>(smm_raw + xbytes) + (size_t)wib * (16 * NCHMAX);   // [wave][column] (over the tile buffers)
-    if (r == 0) {
+    T *cs = reinterpret_cast<T *>(smm_raw + xbytes) + (size_t)wib * (4 * SLMAX);   // [wave][column] (over the tile buffers)
 #pragma unroll
-        for (int c = 0; c < NCHMAX; ++c)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cs[16 * c + M::row(h, q)] = G[c][q];
+    for (int j = 0; j < SLMAX; ++j) {
+        T v = acc[j];
+        v += __shfl_xor(v, 1, WAVE);
+        v += __shfl_xor(v, 2, WAVE);
+        v += __shfl_xor(v, 4, WAVE);
+        v += __shfl_xor(v, 8, WAVE);
+        if (r == 0 && 4 * j + h < d) cs[4 * j + h] = v;
     }
     ex = wave_allsum(ex);
     __shared__ T red_extra_smallm[ROWS_WAVES];
@@ -249,7 +228,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
     T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
     for (int c = threadIdx.x; c < d; c += ROWS_BLOCK) {
         T sacc = cs0[c];
-        for (int w = 1; w < ROWS_WAVES; ++w) sacc += cs0[w * (16 * NCHMAX) + c];
+        for (int w = 1; w < ROWS_WAVES; ++w) sacc += cs0[w * (4 * SLMAX) + c];
         pout[c] = sacc;
     }
     if (threadIdx.x == 0) {

@@ -237,10 +237,11 @@ def test_zero_loss(ctx):
     """F = fill(Zero(), N) (SVRG.jl:58): every gradient is zero, SVRG reduces to repeated prox."""
     import torch
     from ciaoalgorithms_jl_amd.device import PackedF
-    dp = PackedF.zero(10, 33, torch.float64)
-    av = torch.full((33,), 7.0, dtype=torch.float64, device="cuda")
-    ctx.full_gradient(dp, torch.ones(33, dtype=torch.float64, device="cuda"), av)
-    assert torch.count_nonzero(av).item() == 0
+    for tdt in (torch.float64, torch.float32):   # (rows of 17 .. 255 elements WITH data run the LDS-DMA kernel: not these, there is no A)
+        dp = PackedF.zero(10, 33, tdt)
+        av = torch.full((33,), 7.0, dtype=tdt, device="cuda")
+        ctx.full_gradient(dp, torch.ones(33, dtype=tdt, device="cuda"), av)
+        assert torch.count_nonzero(av).item() == 0 and "rows_smallm" not in ctx.last_kernel(), ctx.last_kernel()
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -883,8 +884,9 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         # ---- modes 0, 2, 3: full gradient, SAGA init, Finito init
         av = torch.empty(d, dtype=tdt, device="cuda")
         ctx.full_gradient(dp, dev(x0), av)
-        # (dense fp32 rows of 17 .. 256 elements: the sweep runs on the matrix cores, tests/test_gpu_small_mfma.py)
-        assert ("rows_smallm_kernel" if (d >= 17 and pad == 0 and dtype == np.float32) else "rows_small_kernel") in ctx.last_kernel(), ctx.last_kernel()
+        # (dense rows of 17 .. 256 elements -- fp64: .. 144: the sweep runs on the matrix cores, tests/test_gpu_small_mfma.py)
+        mfma = d >= 17 and pad == 0 and (dtype == np.float32 or d <= 144)
+        assert ("rows_smallm_kernel" if mfma else "rows_small_kernel") in ctx.last_kernel(), ctx.last_kernel()
         close(av, O.full_pass(op, x0), dtype, scale=200, what=f"small rows full gradient d={d}")
         table = torch.empty((N, d), dtype=tdt, device="cuda")
         sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")

@@ -15,13 +15,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("loss", ["ls", "logistic"])
-@pytest.mark.parametrize("d", [17, 50, 64, 100, 130, 200, 255])   # (64, 200: multiples of 8, taken on request only)
+@pytest.mark.parametrize("d", [17, 50, 64, 100, 130, 200, 255])
 def test_sweep_on_the_matrix_cores(ctx, ciao, dtype, loss, d):
     """Row counts around the 16-row tile (1, 15, 16, 17), a few tiles, and enough for every wave of the grid to take several;
     d with every remainder modulo 4 (the last MFMA step) and modulo 16 (the last chunk of columns)."""
     import torch
     from oracle import oracle as O
-    ctx.set_option("small_mfma", 1)   # (by default only fp32 takes this kernel: in fp64 the several-rows-per-wave kernel is the faster one)
     for N in (1, 15, 16, 17, 100, 5000, 70001):
         A, b, x0 = P.synthetic(loss, N, d, dtype, seed=N + d)
         lam_f = float(N) if loss == "ls" else 1.0
@@ -44,12 +43,11 @@ def test_sweep_on_the_matrix_cores(ctx, ciao, dtype, loss, d):
             ctx.full_gradient(dp, dev(x0), av0)
             assert "rows_small_kernel" in ctx.last_kernel(), ctx.last_kernel()
         finally:
-            ctx.set_option("small_mfma", 1)
+            ctx.set_option("small_mfma", -1)
         close(av, av0.cpu().numpy(), dtype, scale=200, what=f"matrix-core sweep vs the several-rows-per-wave kernel d={d} N={N}")
         av2 = torch.empty_like(av)
         ctx.full_gradient(dp, dev(x0), av2)
         assert torch.equal(av, av2), "not reproducible"
-    ctx.set_option("small_mfma", -1)
     ctx.synchronize()
 
 
@@ -73,7 +71,7 @@ def test_row_dots_and_objective_ride_on_the_matrix_core_sweep(ctx, ciao, dtype):
         def epochs(mfma):
             st = ciao.IndexStream(5)
             av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
-            ctx.set_option("small_mfma", 1 if mfma else 0)
+            ctx.set_option("small_mfma", -1 if mfma else 0)
             try:
                 ctx.svrg_init(dp, dev(x0), av, z, zf, w)
                 assert ("rows_smallm_kernel" if mfma else "rows_small_kernel") in ctx.last_kernel(), ctx.last_kernel()
@@ -102,12 +100,12 @@ def test_row_dots_and_objective_ride_on_the_matrix_core_sweep(ctx, ciao, dtype):
 
 
 def test_shapes_the_matrix_core_sweep_leaves_alone(ctx, ciao):
-    """Padded rows and rows shorter than 17 elements stay on the several-rows-per-wave kernel; so does fp64 unless asked; the ring
-    depth option gives the same sums bit for bit."""
+    """Padded rows, rows shorter than 17 elements and fp64 rows beyond 144 elements (two tile buffers per wave no longer fit LDS)
+    stay on the several-rows-per-wave kernel; the ring depth option gives the same sums bit for bit."""
     import torch
     for (N, d, pad, dtype, want) in ((500, 50, 3, np.float32, "rows_small_kernel"), (500, 16, 0, np.float32, "rows_small_kernel"),
-                                     (500, 5, 0, np.float32, "rows_small_kernel"), (500, 50, 0, np.float64, "rows_small_kernel"),
-                                     (500, 50, 0, np.float32, "rows_smallm_kernel")):
+                                     (500, 5, 0, np.float32, "rows_small_kernel"), (500, 149, 0, np.float64, "rows_small_kernel"),
+                                     (500, 50, 0, np.float64, "rows_smallm_kernel"), (500, 50, 0, np.float32, "rows_smallm_kernel")):
         A, b, x0 = P.synthetic("ls", N, d, dtype, seed=N)
         op, dp = make("ls", A, b, float(N), dtype, pad=pad)
         av = torch.empty(d, dtype=dev(x0).dtype, device="cuda")
