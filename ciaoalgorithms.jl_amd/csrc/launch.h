@@ -92,7 +92,7 @@ int32_t launch_mrhs(ciao_ctx *ctx, const ciao_problem *p, int K, const void *con
 template <typename T>
 size_t smallm_lds(int64_t d, int nb);
 template <typename T>
-int32_t launch_smallm(ciao_ctx *ctx, int grid, size_t lds, RowsArgs<T> &a);
+int32_t launch_smallm(ciao_ctx *ctx, bool two, int grid, size_t lds, RowsArgs<T> &a);   // two: RM_GRAD2 (both iterates in one MFMA pass)
 
 // ProShI agent rows (init or one batch) + finalize + epilogue.  Specialised in rows_f32.hip / rows_f64.hip.
 template <typename T>

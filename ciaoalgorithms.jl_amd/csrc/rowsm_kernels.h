@@ -31,11 +31,11 @@ namespace ciao {
 // LDS bytes of a workgroup: the iterate (zero-padded, a whole KiB), then per wave `nb` tile buffers (16 d elements each, back to
 // back) and `nb` 128-byte buffers for the tiles' b_i; the per-wave column sums reuse the tile buffers at the end
 template <typename T>
-inline size_t smallm_x_bytes(int64_t d) { return (size_t)(((d + 3) / 4 * 4 * sizeof(T)) + 1023) / 1024 * 1024; }
+inline size_t smallm_x_bytes(int64_t d) { return (size_t)(((d + 3) / 4 * 4 * sizeof(T)) + 1023) / 1024 * 1024; }   // one iterate; GRAD2 keeps two
 template <typename T>
-inline size_t smallm_wave_bytes(int64_t d, int nb) { return (size_t)nb * ((size_t)16 * d * sizeof(T) + 128) + 128; }
+inline size_t smallm_wave_bytes(int64_t d, int nb) { return (size_t)nb * ((size_t)16 * d * sizeof(T) + 256) + 256; }
 template <typename T>
-inline size_t smallm_lds_bytes(int64_t d, int nb) { return smallm_x_bytes<T>(d) + (size_t)ROWS_WAVES * smallm_wave_bytes<T>(d, nb); }
+inline size_t smallm_lds_bytes(int64_t d, int nb) { return 2 * smallm_x_bytes<T>(d) + (size_t)ROWS_WAVES * smallm_wave_bytes<T>(d, nb); }
 
 // s_waitcnt vmcnt(k) for a wave-uniform k known only at run time (the instruction takes an immediate): 0 .. 63
 __device__ __forceinline__ void wait_vmcnt_uniform(int k)
@@ -55,7 +55,9 @@ __device__ __forceinline__ void wait_vmcnt_uniform(int k)
 // NC2: the row length class, d in (32 (NC2 - 1), 32 NC2]: 8 NC2 MFMA steps, all unrolled -- the steps that a shorter row of the class
 // does not have multiply clamped elements by zeros of the iterate and land in columns that are dropped.  Only the last 8 steps can
 // be such: the others address LDS with immediates.
-template <typename T, int NC2>
+// TWO (RM_GRAD2, LFinito's batch sweep over a row block, Finito_LFinito.jl:93-98): both dots of a row come out of the ONE MFMA pass --
+// the iterate x1 is operand B in output columns 0..7, x2 in columns 8..15 -- and the row's coefficient is c(a'x1) - c(a'x2).
+template <typename T, int NC2, bool TWO>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
 {
     constexpr int SLMAX = 8 * NC2, SAFE = 8 * (NC2 - 1);
@@ -70,19 +72,27 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
     const uint32_t tb = 16u * (uint32_t)d * (uint32_t)sizeof(T);   // bytes of a whole tile = the buffer pitch
     const uint32_t pitch = tb;
     const int nb = a.small_nb;                                      // tile buffers per wave: nb - 1 tiles in flight behind the current one
-    const uint32_t xbytes = ((uint32_t)(xp * sizeof(T)) + 1023u) & ~1023u;
+    const uint32_t xbytes = 2u * (((uint32_t)(xp * sizeof(T)) + 1023u) & ~1023u);
     T *xl = reinterpret_cast<T *>(smm_raw);
-    unsigned char *wbuf = smm_raw + xbytes + (size_t)wib * ((size_t)nb * (pitch + 128) + 128);
+    T *xl2 = reinterpret_cast<T *>(smm_raw + xbytes / 2);
+    unsigned char *wbuf = smm_raw + xbytes + (size_t)wib * ((size_t)nb * (pitch + 256) + 256);
     const uint32_t wbuf_off = (uint32_t)(uintptr_t)wbuf;
-    const T *bl = reinterpret_cast<const T *>(wbuf + (size_t)nb * pitch);   // [nb][16]
-    T *dl = reinterpret_cast<T *>(wbuf + (size_t)nb * (pitch + 128));       // [16]: a tile's row dots, from the accumulator layout to the lanes of each row
+    const T *bl = reinterpret_cast<const T *>(wbuf + (size_t)nb * pitch);              // [nb][16]  b_i
+    const T *gl = reinterpret_cast<const T *>(wbuf + (size_t)nb * (pitch + 128));      // [nb][16]  gamma_i (TWO)
+    T *dl = reinterpret_cast<T *>(wbuf + (size_t)nb * (pitch + 256));                  // [2][16]: a tile's row dots, from the accumulator layout to the lanes of each row
 
-    for (int c = threadIdx.x; c < xp; c += ROWS_BLOCK) xl[c] = c < d ? a.x1[c] : T(0);
+    for (int c = threadIdx.x; c < xp; c += ROWS_BLOCK) {
+        xl[c] = c < d ? a.x1[c] : T(0);
+        if (TWO) xl2[c] = c < d ? a.x2[c] : T(0);
+    }
     __syncthreads();
     // operand B of GEMM 1 stays in registers for the whole sweep: lane (column c, slot h), step j: x[4 j + h], zero beyond the row
     T xr[SLMAX];
+    {
+        const T *xs = (TWO && r >= 8) ? xl2 : xl;
 #pragma unroll
-    for (int j = 0; j < SLMAX; ++j) xr[j] = 4 * j + h < xp ? xl[4 * j + h] : T(0);
+        for (int j = 0; j < SLMAX; ++j) xr[j] = 4 * j + h < xp ? xs[4 * j + h] : T(0);
+    }
 
     const int64_t ntiles = (a.nrows + 15) >> 4;
     const int64_t nwaves = (int64_t)gridDim.x * ROWS_WAVES;
@@ -118,15 +128,20 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
             if (vo < (uint32_t)nr * (uint32_t)sizeof(T))
                 glds4(reinterpret_cast<const unsigned char *>(a.b + a.row0 + row_b) + vo, wbuf_off + (uint32_t)nb * pitch + (uint32_t)buf * 128u);
         }
+        if (TWO && a.gam) {
+            const uint32_t vo = (uint32_t)lane * 4u;
+            if (vo < (uint32_t)nr * (uint32_t)sizeof(T))
+                glds4(reinterpret_cast<const unsigned char *>(a.gam + a.row0 + row_b) + vo, wbuf_off + (uint32_t)nb * (pitch + 128u) + (uint32_t)buf * 128u);
+        }
     };
 
     T acc[SLMAX];
 #pragma unroll
     for (int j = 0; j < SLMAX; ++j) acc[j] = T(0);
     T ex = T(0);
-    const bool extras = a.want_fval || a.rowdot_out != nullptr;
+    const bool extras = TWO || a.want_fval || a.rowdot_out != nullptr;
     // LDS-DMA instructions of one whole tile (what stays in flight behind the tile being waited for is a multiple of it)
-    const int per_tile = (int)((tb + 1023u) >> 10) + (a.b ? 1 : 0);
+    const int per_tile = (int)((tb + 1023u) >> 10) + (a.b ? 1 : 0) + (TWO && a.gam ? 1 : 0);
     int64_t g = (int64_t)blockIdx.x * ROWS_WAVES + wib;
     int buf = 0;
     for (int k = 0; k < nb - 1; ++k)
@@ -178,9 +193,9 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
         }
         D += D1;
         // ---- row r's dot to the lanes of row r: the accumulator holds rows row(h, q) in lane (c, h); through the wave's LDS words
-        if (r == 0) {
+        if (r == 0 || (TWO && r == 8)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dl[M::row(h, q)] = D[q];
+            for (int q = 0; q < 4; ++q) dl[(r >> 3) * 16 + M::row(h, q)] = D[q];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const T dot = dl[r];
@@ -193,10 +208,26 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
             coef = grad_coef(CIAO_LOSS_LOGISTIC, dot, bi, a.lam).s1 * s2;
         else
             coef = T(0);
+        if (TWO) {
+            const T dot2 = dl[16 + r];
+            T c2;
+            if (a.loss == CIAO_LOSS_LS)
+                c2 = grad_coef(CIAO_LOSS_LS, dot2, bi, a.lam).s1 * s2;
+            else if (a.loss == CIAO_LOSS_LOGISTIC)
+                c2 = grad_coef(CIAO_LOSS_LOGISTIC, dot2, bi, a.lam).s1 * s2;
+            else
+                c2 = T(0);
+            coef = coef - c2;
+        }
         coef = r < nr ? coef : T(0);
         if (extras && h == 0 && r < nr) {
-            if (a.want_fval) ex += loss_value(a.loss, dot, bi, a.lam);
-            if (a.rowdot_out) a.rowdot_out[a.row0 + row_b + r] = dot;
+            if (TWO) {
+                const T gi = a.gam ? gl[buf * (128 / (int)sizeof(T)) + r] : a.gam_uniform;
+                ex += a.hat_gamma / gi;
+            } else {
+                if (a.want_fval) ex += loss_value(a.loss, dot, bi, a.lam);
+                if (a.rowdot_out) a.rowdot_out[a.row0 + row_b + r] = dot;
+            }
         }
         // ---- the rank-1 accumulation: acc[j] += c_r tile[r][4 j + h], from the registers GEMM 1 read (the first form of this kernel
         // ran it as a second MFMA product: fifteen sixteenths of twice the matrix work for nothing, the matrix pipe 63 % busy and

@@ -938,7 +938,15 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
             assert "rows_smallb_kernel" in ctx.last_kernel() and "mode1" in ctx.last_kernel(), ctx.last_kernel()
             ctx.lfinito_iterate_blocks(dp, dg, dgam, hg, np.array([x[0] for x in blocks]), np.array([len(x) for x in blocks]), lav2, lz2, lzf2)
             O.lfinito_iterate(op, og, gam, rhg, blocks, rav, rz, rzf)
-            assert torch.equal(lz, lz2) and torch.equal(lav, lav2) and torch.equal(lzf, lzf2)
+            if mfma and (r * d * np.dtype(dtype).itemsize) % 16 == 0:
+                # dense row blocks of such rows run the batch sweep on the matrix cores (both dots from one MFMA pass): another order of
+                # summation than the index-list form, so equal to rounding; each is held against the oracle below
+                assert "rows_smallm_kernel" in ctx.last_kernel() and "mode1" in ctx.last_kernel(), ctx.last_kernel()
+                close(lz2, rz, dtype, scale=20000, what=f"small rows lfinito z it {it}, row blocks ({ctx.last_kernel()})")
+                close(lav2, rav, dtype, scale=20000, what=f"small rows lfinito av it {it}, row blocks")
+                lz2.copy_(lz), lav2.copy_(lav), lzf2.copy_(lzf)       # (so that the two forms start the next iteration from the same state)
+            else:
+                assert torch.equal(lz, lz2) and torch.equal(lav, lav2) and torch.equal(lzf, lzf2)
             close(lz, rz, dtype, scale=20000, what=f"small rows lfinito z it {it} ({ctx.last_kernel()})")
             close(lav, rav, dtype, scale=20000, what=f"small rows lfinito av it {it}")
     finally:

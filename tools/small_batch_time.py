@@ -33,7 +33,7 @@ for d in (50, 100, 255):
         table = torch.empty((N, d), dtype=dt, device="cuda")
         av, z, zf = (torch.empty_like(x0) for _ in range(3))
         ctx.finito_init(F, g, gam, hg, x0, table, av, z)
-        for r in (4096, 65536):
+        for r in (() if os.environ.get("CIAO_LFINITO_ONLY") else (4096, 65536)):
             nit = 16
             idx = ctx._idx(np.concatenate([st.sample_without_replacement(N, r) for _ in range(nit)]))
             bptr = np.arange(nit + 1, dtype=np.int64) * r
@@ -57,13 +57,14 @@ for d in (50, 100, 255):
         first = np.arange(nb, dtype=np.int64) * r
         ln = np.full(nb, r, np.int64)
         ctx.lfinito_init(F, hg, x0, av, z, zf)
-        for generic in (0, 1):
-            ctx.set_option("force_generic", generic)
+        for tag, opt, val in (("matrix cores", "small_mfma", -1), ("smallb      ", "small_mfma", 0), ("generic     ", "force_generic", 1)):
+            ctx.set_option(opt, val)
             ctx.lfinito_iterate_blocks(F, g, gam, hg, first, ln, av, z, zf); ctx.synchronize()
             t0 = time.perf_counter(); ctx.lfinito_iterate_blocks(F, g, gam, hg, first, ln, av, z, zf); ctx.synchronize()
             t = time.perf_counter() - t0
-            print(f"d={d:3d} {'f64' if es == 8 else 'f32'} lfinito iteration (full pass + {nb} batches of {r}) {'generic' if generic else 'smallb '}: "
+            print(f"d={d:3d} {'f64' if es == 8 else 'f32'} lfinito iteration (full pass + {nb} batches of {r}) {tag}: "
                   f"{t * 1e3:7.2f} ms = {2 * nb * r * (d * es + 2 * es) / t / 1e12:5.2f} TB/s  [{ctx.last_kernel().split(' grid')[0]}]", flush=True)
-        ctx.set_option("force_generic", 0)
+            ctx.set_option("small_mfma", -1)
+            ctx.set_option("force_generic", 0)
         del A, b, table, F
         torch.cuda.empty_cache()
