@@ -1277,6 +1277,8 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
         ctx->chain_no_ws = value != 0;
     } else if (!strcmp(key, "small_mfma")) {
         ctx->small_mfma = value;
+    } else if (!strcmp(key, "small_mfma_table")) {
+        ctx->small_mfma_table = value;
     } else if (!strcmp(key, "small_nb")) {
         CIAO_REQUIRE(value == 0 || (value >= 2 && value <= 4), "small_nb must be 0 or 2..4");
         ctx->small_nb = value;

@@ -90,9 +90,9 @@ int32_t launch_mrhs(ciao_ctx *ctx, const ciao_problem *p, int K, const void *con
 
 // full-gradient sweeps over rows of 17 .. 256 elements on the matrix cores (rowsm_kernels.h).  Specialised in rowsm_f32.hip / rowsm_f64.hip.
 template <typename T>
-size_t smallm_lds(int64_t d, int nb);
+size_t smallm_lds(int64_t d, int nb, bool table_in);   // table_in: RM_FINITO_BATCH (a third tile stream: the old table rows)
 template <typename T>
-int32_t launch_smallm(ciao_ctx *ctx, bool two, int grid, size_t lds, RowsArgs<T> &a);   // two: RM_GRAD2 (both iterates in one MFMA pass)
+int32_t launch_smallm(ciao_ctx *ctx, int mode, int grid, size_t lds, RowsArgs<T> &a);
 
 // ProShI agent rows (init or one batch) + finalize + epilogue.  Specialised in rows_f32.hip / rows_f64.hip.
 template <typename T>

@@ -33,9 +33,12 @@ namespace ciao {
 template <typename T>
 inline size_t smallm_x_bytes(int64_t d) { return (size_t)(((d + 3) / 4 * 4 * sizeof(T)) + 1023) / 1024 * 1024; }   // one iterate; GRAD2 keeps two
 template <typename T>
-inline size_t smallm_wave_bytes(int64_t d, int nb) { return (size_t)nb * ((size_t)16 * d * sizeof(T) + 256) + 256; }
+inline size_t smallm_wave_bytes(int64_t d, int nb, bool table_in) { return (size_t)(nb + (table_in ? 1 : 0)) * ((size_t)16 * d * sizeof(T)) + (size_t)nb * 256 + 256; }
 template <typename T>
-inline size_t smallm_lds_bytes(int64_t d, int nb) { return 2 * smallm_x_bytes<T>(d) + (size_t)ROWS_WAVES * smallm_wave_bytes<T>(d, nb); }
+inline size_t smallm_lds_bytes(int64_t d, int nb, bool table_in)
+{
+    return 2 * smallm_x_bytes<T>(d) + (size_t)ROWS_WAVES * smallm_wave_bytes<T>(d, nb, table_in);
+}
 
 // s_waitcnt vmcnt(k) for a wave-uniform k known only at run time (the instruction takes an immediate): 0 .. 63
 __device__ __forceinline__ void wait_vmcnt_uniform(int k)
@@ -55,11 +58,21 @@ __device__ __forceinline__ void wait_vmcnt_uniform(int k)
 // NC2: the row length class, d in (32 (NC2 - 1), 32 NC2]: 8 NC2 MFMA steps, all unrolled -- the steps that a shorter row of the class
 // does not have multiply clamped elements by zeros of the iterate and land in columns that are dropped.  Only the last 8 steps can
 // be such: the others address LDS with immediates.
-// TWO (RM_GRAD2, LFinito's batch sweep over a row block, Finito_LFinito.jl:93-98): both dots of a row come out of the ONE MFMA pass --
-// the iterate x1 is operand B in output columns 0..7, x2 in columns 8..15 -- and the row's coefficient is c(a'x1) - c(a'x2).
-template <typename T, int NC2, bool TWO>
+// MODE (rows_kernels.h): RM_GRAD; RM_GRAD2 (LFinito's batch sweep over a row block, Finito_LFinito.jl:93-98): both dots of a row come
+// out of the ONE MFMA pass -- x1 is operand B in output columns 0..7, x2 in columns 8..15 -- and the row's coefficient is
+// c(a'x1) - c(a'x2); and the TABLE modes over a dense block of rows and table rows: RM_SAGA_INIT (SAGA_basic.jl:42-47), RM_FINITO_INIT
+// (Finito_basic.jl:77-83), RM_FINITO_BATCH (:110-117).  There the lane that holds A[r][4 j + h] forms the new table element
+// t = x - (gamma_r / N) c_r a (or c_r a) on the spot, adds its share to the aggregate, and parks t in LDS -- over the row tile itself, or,
+// when the old table row is needed (FINITO_BATCH), over the table tile that came by a third LDS-DMA stream -- from where the tile
+// leaves as it came: 16 bytes per lane, 1 KiB per wave-instruction.
+template <typename T, int NC2, int MODE>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
 {
+    constexpr bool TWO = (MODE == RM_GRAD2);
+    constexpr bool TABLE = (MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH);
+    constexpr bool SIN = (MODE == RM_FINITO_BATCH);                       // the old table tile comes in
+    constexpr bool GAM = TWO || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH;   // per-row stepsizes are used
+    static_assert(MODE == RM_GRAD || TWO || TABLE, "mode");
     constexpr int SLMAX = 8 * NC2, SAFE = 8 * (NC2 - 1);
     using M = MfmaOf<T>;
     using Acc = typename M::acc;
@@ -75,11 +88,12 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
     const uint32_t xbytes = 2u * (((uint32_t)(xp * sizeof(T)) + 1023u) & ~1023u);
     T *xl = reinterpret_cast<T *>(smm_raw);
     T *xl2 = reinterpret_cast<T *>(smm_raw + xbytes / 2);
-    unsigned char *wbuf = smm_raw + xbytes + (size_t)wib * ((size_t)nb * (pitch + 256) + 256);
+    unsigned char *wbuf = smm_raw + xbytes + (size_t)wib * ((size_t)(nb + (SIN ? 1 : 0)) * pitch + (size_t)nb * 256 + 256);
     const uint32_t wbuf_off = (uint32_t)(uintptr_t)wbuf;
     const T *bl = reinterpret_cast<const T *>(wbuf + (size_t)nb * pitch);              // [nb][16]  b_i
     const T *gl = reinterpret_cast<const T *>(wbuf + (size_t)nb * (pitch + 128));      // [nb][16]  gamma_i (TWO)
     T *dl = reinterpret_cast<T *>(wbuf + (size_t)nb * (pitch + 256));                  // [2][16]: a tile's row dots, from the accumulator layout to the lanes of each row
+    unsigned char *stb = wbuf + (size_t)nb * (pitch + 256) + 256;                      // SIN: the table tile (old rows in, new rows out)
 
     for (int c = threadIdx.x; c < xp; c += ROWS_BLOCK) {
         xl[c] = c < d ? a.x1[c] : T(0);
@@ -128,10 +142,51 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
             if (vo < (uint32_t)nr * (uint32_t)sizeof(T))
                 glds4(reinterpret_cast<const unsigned char *>(a.b + a.row0 + row_b) + vo, wbuf_off + (uint32_t)nb * pitch + (uint32_t)buf * 128u);
         }
-        if (TWO && a.gam) {
+        if (GAM && a.gam) {
             const uint32_t vo = (uint32_t)lane * 4u;
             if (vo < (uint32_t)nr * (uint32_t)sizeof(T))
                 glds4(reinterpret_cast<const unsigned char *>(a.gam + a.row0 + row_b) + vo, wbuf_off + (uint32_t)nb * (pitch + 128u) + (uint32_t)buf * 128u);
+        }
+    };
+
+    // FINITO_BATCH: the table rows of tile g -> the wave's table buffer (the same two forms; the short last tile zero-filled)
+    auto fetch_table = [&](int64_t g) {
+        const int64_t row_b = g << 4;
+        const int64_t left = a.nrows - row_b;
+        const int nr = left < 16 ? (int)left : 16;
+        const T *gp = a.table + (a.row0 + row_b) * (int64_t)d;
+        const uint32_t dst = (uint32_t)(uintptr_t)stb;
+        if (nr == 16) {
+            for (uint32_t off = 0; off < tb; off += 1024u) {
+                const uint32_t vo = off + (uint32_t)lane * 16u;
+                if (vo < tb) glds16s(gp, vo, dst + off);
+            }
+        } else {
+            const uint32_t have = (uint32_t)nr * (uint32_t)d * (uint32_t)sizeof(T);
+            for (uint32_t off = 0; off < have; off += 256u) {
+                const uint32_t vo = off + (uint32_t)lane * 4u;
+                if (vo < have) glds4(reinterpret_cast<const unsigned char *>(gp) + vo, dst + off);
+            }
+            uint32_t *zb = reinterpret_cast<uint32_t *>(stb);
+            for (uint32_t e = have / 4u + (uint32_t)lane; e < tb / 4u; e += WAVE) zb[e] = 0u;
+        }
+    };
+    // the new table rows of tile g leave LDS (from `src`) as the tile came: 16 bytes per lane; the short last tile dword by dword
+    auto store_table = [&](int64_t g, const unsigned char *src) {
+        typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+        const int64_t row_b = g << 4;
+        const int64_t left = a.nrows - row_b;
+        const int nr = left < 16 ? (int)left : 16;
+        unsigned char *gp = reinterpret_cast<unsigned char *>(a.table + (a.row0 + row_b) * (int64_t)d);
+        if (nr == 16) {
+            for (uint32_t off = 0; off < tb; off += 1024u) {
+                const uint32_t vo = off + (uint32_t)lane * 16u;
+                if (vo < tb) __builtin_nontemporal_store(*reinterpret_cast<const V4 *>(src + vo), reinterpret_cast<V4 *>(gp + vo));
+            }
+        } else {
+            const uint32_t have = (uint32_t)nr * (uint32_t)d * (uint32_t)sizeof(T);
+            for (uint32_t vo = (uint32_t)lane * 4u; vo < have; vo += 256u)
+                *reinterpret_cast<uint32_t *>(gp + vo) = *reinterpret_cast<const uint32_t *>(src + vo);
         }
     };
 
@@ -141,11 +196,14 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
     T ex = T(0);
     const bool extras = TWO || a.want_fval || a.rowdot_out != nullptr;
     // LDS-DMA instructions of one whole tile (what stays in flight behind the tile being waited for is a multiple of it)
-    const int per_tile = (int)((tb + 1023u) >> 10) + (a.b ? 1 : 0) + (TWO && a.gam ? 1 : 0);
+    const int per_tile = (int)((tb + 1023u) >> 10) + (a.b ? 1 : 0) + (GAM && a.gam ? 1 : 0);
     int64_t g = (int64_t)blockIdx.x * ROWS_WAVES + wib;
     int buf = 0;
     for (int k = 0; k < nb - 1; ++k)
         if (g + k * nwaves < ntiles) fetch(g + k * nwaves, k);
+    if (SIN && g < ntiles) fetch_table(g);
+    const int n_kib = (int)((tb + 1023u) >> 10);
+    bool first_tile = true;
     for (; g < ntiles; g += nwaves) {
         const int64_t row_b = g << 4;
         const int64_t left = a.nrows - row_b;
@@ -153,8 +211,12 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
         // this tile has landed when no more than the nb - 2 tiles requested after it are outstanding -- counted only while all of
         // those exist and are whole tiles (the matrix's short last tile issues another number of instructions): else everything
         const int64_t g_last = g + (int64_t)(nb - 2) * nwaves;      // the youngest tile in flight
-        if (nb > 2 && ((g_last + 1) << 4) <= a.nrows)
+        if (!TABLE && nb > 2 && ((g_last + 1) << 4) <= a.nrows)
             wait_vmcnt_uniform((nb - 2) * per_tile);
+        else if (SIN && nb == 2 && nr == 16)
+            // FINITO_BATCH: behind this tile's rows, in issue order, are the previous tile's table stores (none before the first tile)
+            // and this tile's table rows -- one instruction per KiB each, this tile being whole; only the rows are needed for the dots
+            wait_vmcnt_uniform((first_tile ? 1 : 2) * n_kib);
         else
             wait_vmcnt_uniform(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) (the short last tile's zero fill), vmcnt / expcnt at their maximum
@@ -201,13 +263,14 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
         const T dot = dl[r];
         const T bi = (a.b && r < nr) ? bl[buf * (128 / (int)sizeof(T)) + r] : T(0);
         // ---- the link function, once per lane: its row's coefficient; rows beyond the matrix get zero
-        T coef;
+        T coef, coef1;
         if (a.loss == CIAO_LOSS_LS)
-            coef = grad_coef(CIAO_LOSS_LS, dot, bi, a.lam).s1 * s2;
+            coef1 = grad_coef(CIAO_LOSS_LS, dot, bi, a.lam).s1;
         else if (a.loss == CIAO_LOSS_LOGISTIC)
-            coef = grad_coef(CIAO_LOSS_LOGISTIC, dot, bi, a.lam).s1 * s2;
+            coef1 = grad_coef(CIAO_LOSS_LOGISTIC, dot, bi, a.lam).s1;
         else
-            coef = T(0);
+            coef1 = T(0);
+        coef = coef1 * s2;
         if (TWO) {
             const T dot2 = dl[16 + r];
             T c2;
@@ -229,12 +292,56 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
                 if (a.rowdot_out) a.rowdot_out[a.row0 + row_b + r] = dot;
             }
         }
-        // ---- the rank-1 accumulation: acc[j] += c_r tile[r][4 j + h], from the registers GEMM 1 read (the first form of this kernel
-        // ran it as a second MFMA product: fifteen sixteenths of twice the matrix work for nothing, the matrix pipe 63 % busy and
-        // the bound).  The sum over the 16 rows of a column is taken once, at the end of the sweep.
+        if (!TABLE) {
+            // ---- the rank-1 accumulation: acc[j] += c_r tile[r][4 j + h], from the registers GEMM 1 read (the first form of this kernel
+            // ran it as a second MFMA product: fifteen sixteenths of twice the matrix work for nothing, the matrix pipe 63 % busy and
+            // the bound).  The sum over the 16 rows of a column is taken once, at the end of the sweep.
 #pragma unroll
-        for (int j = 0; j < SLMAX; ++j) acc[j] = __builtin_fma(coef, av[j], acc[j]);
+            for (int j = 0; j < SLMAX; ++j) acc[j] = __builtin_fma(coef, av[j], acc[j]);
+        } else {
+            // ---- the new table element of (row r, column 4 j + h), its share of the aggregate, and the element parked in LDS.
+            // s1 / s2 as GradCoef::elem applies them: grad f_i = (a s1) s2
+            const T s1 = r < nr ? coef1 : T(0);
+            const T gi = (GAM && a.gam && r < nr) ? gl[buf * (128 / (int)sizeof(T)) + r] : a.gam_uniform;
+            const T cg = gi * a.invN;
+            const T rr = (MODE == RM_FINITO_INIT) ? T(1) / gi : a.hat_gamma / gi;
+            if (SIN) {
+                // the old table rows: everything up to them has landed when only the NEXT tile's rows (requested at the top of this
+                // iteration: per_tile instructions if that tile is whole) are still outstanding
+                const int64_t gn = g + nwaves;
+                wait_vmcnt_uniform((nb == 2 && gn < ntiles && ((gn + 1) << 4) <= a.nrows) ? per_tile : 0);
+                asm volatile("" ::: "memory");
+            }
+            T *tout = SIN ? reinterpret_cast<T *>(stb) : const_cast<T *>(tl);
+            T *to = tout + r * d + h;
+            const bool rowlive = r < nr;
+#pragma unroll
+            for (int j = 0; j < SLMAX; ++j) {
+                const bool live = rowlive && (j < SAFE || 4 * j + h < d);
+                const T gv = (av[j] * s1) * s2;
+                if (MODE == RM_SAGA_INIT) {
+                    acc[j] += gv;
+                    if (live) to[4 * j] = gv;
+                } else {
+                    const T tv = xr[j] - cg * gv;
+                    if (MODE == RM_FINITO_INIT) {
+                        acc[j] += rowlive ? tv * rr : T(0);
+                    } else {
+                        const T sv = to[j < SAFE ? 4 * j : (4 * j + h < d ? 4 * j : d - 1 - h)];
+                        acc[j] += rowlive ? (tv - sv) * rr : T(0);
+                    }
+                    if (live) to[4 * j] = tv;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            store_table(g, reinterpret_cast<const unsigned char *>(tout));
+            if (SIN && g + nwaves < ntiles) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile has left the buffer
+                fetch_table(g + nwaves);
+            }
+        }
         buf = buf + 1 == nb ? 0 : buf + 1;
+        first_tile = false;
     }
 
     // ---- per-wave column sums: column 4 j + h is spread over the 16 lanes (rows) of slot h -> summed in a fixed butterfly, written by

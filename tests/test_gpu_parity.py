@@ -880,25 +880,27 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
     dgam = dev(gam)
     hg = ctx.hat_gamma(dgam)
     ctx.set_option("chain_max_batch", 0)
+    es = np.dtype(dtype).itemsize
+    mfma = d >= 17 and pad == 0 and 2 * 16 * d * es * 4 + 12000 <= 150 * 1024        # two tile buffers per wave fit LDS: the matrix-core kernel
+    mfma_tab = d >= 17 and pad == 0 and 3 * 16 * d * es * 4 + 12000 <= 150 * 1024    # ... three (Finito batches: the table tile comes in too)
     try:
         # ---- modes 0, 2, 3: full gradient, SAGA init, Finito init
         av = torch.empty(d, dtype=tdt, device="cuda")
         ctx.full_gradient(dp, dev(x0), av)
         # (dense rows of 17 .. 256 elements -- fp64: .. 144: the sweep runs on the matrix cores, tests/test_gpu_small_mfma.py)
-        mfma = d >= 17 and pad == 0 and (dtype == np.float32 or d <= 144)
         assert ("rows_smallm_kernel" if mfma else "rows_small_kernel") in ctx.last_kernel(), ctx.last_kernel()
         close(av, O.full_pass(op, x0), dtype, scale=200, what=f"small rows full gradient d={d}")
         table = torch.empty((N, d), dtype=tdt, device="cuda")
         sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
         ctx.saga_init(dp, dg, 0.1 / max(Li.max(), 1.0), dev(x0), table, sav, sz)
-        assert "rows_small_kernel" in ctx.last_kernel() or "prox" in ctx.last_kernel(), ctx.last_kernel()
+        assert ("rows_smallm_kernel" if mfma else "rows_small_kernel") in ctx.last_kernel() or "prox" in ctx.last_kernel(), ctx.last_kernel()
         rt, rav, rz = O.saga_init(op, og, dtype(0.1 / max(Li.max(), 1.0)), x0)
         close(table, rt, dtype, scale=50, what="small rows saga_init table")
         close(sav, rav, dtype, scale=200, what="small rows saga_init av")
         z = torch.empty(d, dtype=tdt, device="cuda")
         rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
         ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
-        assert "rows_small_kernel" in ctx.last_kernel(), ctx.last_kernel()
+        assert ("rows_smallm_kernel" if mfma else "rows_small_kernel") in ctx.last_kernel(), ctx.last_kernel()
         close(table, rt, dtype, scale=50, what="small rows finito_init table")
         close(av, rav, dtype, scale=200, what="small rows finito_init av")
         # ---- mode 4: Finito batches -- random index lists, then static blocks given BOTH as index lists and as row blocks
@@ -918,9 +920,16 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         np.cumsum([len(x) for x in static], out=bp[1:])
         ctx.finito_steps(dp, dg, dgam, hg, bp, np.concatenate(static), table, av, z)
         ctx.finito_steps_blocks(dp, dg, dgam, hg, np.array([x[0] for x in static]), np.array([len(x) for x in static]), t2, av2, z2)
-        assert "rows_smallb_kernel" in ctx.last_kernel(), ctx.last_kernel()
-        assert torch.equal(z, z2) and torch.equal(av, av2) and torch.equal(table, t2), "row blocks and the same batches as index lists differ"
         O.finito_steps(op, og, gam, rhg, static, rt, rav, rz)
+        if mfma_tab and (r * d * np.dtype(dtype).itemsize) % 16 == 0:
+            # dense row blocks of such rows: the batch on the matrix-core kernel (row tile and table tile by LDS-DMA) -- another order
+            # of summation than the index-list form: each against the oracle
+            assert "rows_smallm_kernel" in ctx.last_kernel() and "mode4" in ctx.last_kernel(), ctx.last_kernel()
+            close(z2, rz, dtype, scale=20000, what=f"small rows finito z, row blocks on the matrix-core kernel ({ctx.last_kernel()})")
+            close(t2, rt, dtype, scale=2000, what="small rows finito table, row blocks on the matrix-core kernel")
+        else:
+            assert "rows_smallb_kernel" in ctx.last_kernel(), ctx.last_kernel()
+            assert torch.equal(z, z2) and torch.equal(av, av2) and torch.equal(table, t2), "row blocks and the same batches as index lists differ"
         close(z, rz, dtype, scale=20000, what="small rows finito z, row blocks")
         close(table, rt, dtype, scale=2000, what="small rows finito table, row blocks")
         inv = (table.double() / dgam.double()[:, None]).sum(dim=0).cpu().numpy() * hg

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Finito batches and LFinito's batch sweep on rows of tabular size (d = 50, 100, 255; fp64 and fp32): rows_smallb_kernel
-(round 4) against the scalar generic kernel they used to run (option force_generic=1), index lists and row blocks.
+"""Finito batches and LFinito's batch sweep on rows of tabular size (d = 50, 100, 255; fp64 and fp32): the default kernels (round 4:
+rows_smallm_kernel for dense row blocks where its tiles fit LDS, rows_smallb_kernel for index lists and the rest) against the scalar
+generic kernel they used to run (option force_generic=1), index lists and row blocks.
 TB/s of algorithmic bytes: Finito batch 3*d*s + 2*s + 8 per sample, LFinito batch sweep d*s + 2*s + 8."""
 import os, sys, time
 import numpy as np, torch
@@ -47,7 +48,8 @@ for d in (50, 100, 255):
                     fn(); ctx.synchronize()
                     t0 = time.perf_counter(); fn(); ctx.synchronize()
                     t = time.perf_counter() - t0
-                    row.append(f"{'generic' if generic else 'smallb '} finito {what:6s} {nit * r * (3 * d * es + 2 * es + 8) / t / 1e12:5.2f} TB/s ({t / nit * 1e6:7.1f} us/batch)")
+                    kname = ctx.last_kernel().split("<")[0].replace("rows_", "").replace("_kernel", "")
+                    row.append(f"{kname:7s} finito {what:6s} {nit * r * (3 * d * es + 2 * es + 8) / t / 1e12:5.2f} TB/s ({t / nit * 1e6:7.1f} us/batch)")
                 kern = ctx.last_kernel().split(" grid")[0]
             ctx.set_option("force_generic", 0)
             print(" | ".join(row) + f"  [{kern}]", flush=True)
