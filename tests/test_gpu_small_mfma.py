@@ -125,3 +125,58 @@ def test_shapes_the_matrix_core_sweep_leaves_alone(ctx, ciao):
         ref = av if ref is None else ref
         assert torch.equal(av, ref), nb
     ctx.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("loss", ["ls", "logistic"])
+def test_table_modes_on_the_matrix_core_kernel(ctx, ciao, dtype, loss):
+    """SAGA init, Finito init and Finito batches over row blocks on rows_smallm_kernel with row counts that end in a short tile (1, 17,
+    1003 rows; blocks of 333): every table row written, nothing written past the table's end (a sentinel region behind it), and
+    each result against the oracle."""
+    import torch
+    from oracle import oracle as O
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    for d in (17, 50, 92):
+        for N in (1, 17, 1003):
+            A, b, x0 = P.synthetic(loss, N, d, dtype, seed=N + d)
+            lam_f = float(N) if loss == "ls" else 1.0
+            op, dp = make(loss, A, b, lam_f, dtype)
+            og, dg = make_g("l1", dtype, d, lam=0.02)
+            Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1)
+            gam = (0.999 * N / np.maximum(Li, 1e-3 * Li.max())).astype(dtype)
+            dgam = dev(gam)
+            hg = ctx.hat_gamma(dgam)
+            guard = 64
+            big = torch.full((N + guard, d), float("nan"), dtype=tdt, device="cuda")
+            table = big[:N]
+            av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+            gamma = 0.1 / max(Li.max(), 1.0)
+            ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
+            rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
+            assert torch.isnan(big[N:]).all() and not torch.isnan(table).any(), (d, N)
+            close(table, rt, dtype, scale=50, what=f"saga_init table d={d} N={N}")
+            close(av, rav, dtype, scale=200, what=f"saga_init av d={d} N={N}")
+            big.fill_(float("nan"))
+            ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
+            assert "rows_smallm_kernel" in ctx.last_kernel() and "mode3" in ctx.last_kernel(), ctx.last_kernel()
+            rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
+            assert torch.isnan(big[N:]).all() and not torch.isnan(table).any(), (d, N)
+            close(table, rt, dtype, scale=50, what=f"finito_init table d={d} N={N}")
+            close(av, rav, dtype, scale=200, what=f"finito_init av d={d} N={N}")
+            if N < 1003:
+                continue
+            # static blocks of 333 rows (the last one shorter), cyclic order, every block starting where 16-byte alignment allows or not
+            r = 336 if (336 * d * np.dtype(dtype).itemsize) % 16 == 0 else 333
+            nbk = -(-N // r)
+            order = [(t + 1) % nbk for t in range(nbk + 1)]
+            static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in order]
+            ctx.set_option("chain_max_batch", 0)
+            try:
+                ctx.finito_steps_blocks(dp, dg, dgam, hg, np.array([x[0] for x in static]), np.array([len(x) for x in static]), table, av, z)
+            finally:
+                ctx.set_option("chain_max_batch", -1)
+            O.finito_steps(op, og, gam, rhg, static, rt, rav, rz)
+            assert torch.isnan(big[N:]).all() and not torch.isnan(table).any(), (d, N)
+            close(z, rz, dtype, scale=20000, what=f"finito blocks z d={d} ({ctx.last_kernel()})")
+            close(table, rt, dtype, scale=2000, what=f"finito blocks table d={d}")
+    ctx.synchronize()
