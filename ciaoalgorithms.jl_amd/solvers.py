@@ -862,7 +862,7 @@ def solve_together(iterables, maxit, one_pass=False):
     minibatch of one sample up to option chain_max_batch; larger batches are batch-parallel kernels that fill the GPU alone).
 
     `one_pass=True` (SVRG over ONE packed F): the K full passes of every outer step (SVRG_basic.jl:87-92 per solve) run as ONE pass
-    over the rows with K right-hand sides on the matrix cores (ciao_svrg_epoch_tail_multi; d = 256 / 512 / 1024) instead of K
+    over the rows with K right-hand sides on the matrix cores (ciao_svrg_epoch_tail_multi; d = 256 / 512 / 768 / 1024, fp64 also 128) instead of K
     sweeps -- at N = 10M, K = 256 that is most of what an outer step costs beside the batched inner cycles.  The pass sums in another
     order, so each solve then follows its own functor call to ROUNDING, not bitwise."""
     its = list(iterables)

@@ -173,7 +173,7 @@ CIAO_API int32_t ciao_full_gradient(ciao_ctx *ctx, const ciao_problem *p, const 
  * (csrc/mrhs_kernels.h; north_star: "MFMA ... if the f_i gradients are expressed as a dense A.x contraction").  x and av are HOST
  * arrays of K device pointers (16-byte aligned d-vectors).  Not in the reference, which solves one problem per call
  * (SVRG_basic.jl:87-92 is the single pass): an extension for hosts that advance several solves together (a regularisation path,
- * folds: ciao_ctx_chain_batch_begin).  Shapes the kernel does not take (d other than 256 / 512 / 1024, unaligned rows, a
+ * folds: ciao_ctx_chain_batch_begin).  Shapes the kernel does not take (d other than 256 / 512 / 768 / 1024 -- and 128 in fp64 --, unaligned rows, a
  * row-sharded problem, the objective monitor) run as K single passes inside the call.  Each av[k] agrees with its own
  * ciao_full_gradient to rounding (another summation order), not bitwise. */
 CIAO_API int32_t ciao_full_gradient_multi(ciao_ctx *ctx, const ciao_problem *p, int32_t K, const void *const *x, void *const *av);

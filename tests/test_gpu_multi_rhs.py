@@ -20,7 +20,7 @@ def _iterates(d, K, dtype, seed):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("loss", ["ls", "logistic"])
-@pytest.mark.parametrize("d,K,N", [(256, 2, 37), (256, 16, 1000), (512, 21, 3001), (1024, 48, 2050), (1024, 5, 16), (1024, 33, 40000)])
+@pytest.mark.parametrize("d,K,N", [(256, 2, 37), (256, 16, 1000), (512, 21, 3001), (1024, 48, 2050), (1024, 5, 16), (1024, 33, 40000), (768, 19, 5000), (128, 17, 3000)])
 def test_one_pass_over_the_rows_for_K_iterates(ctx, ciao, dtype, loss, d, K, N):
     """K iterates (asymmetric: every solve its own scale), K not a multiple of the 16-solve column block, N not a multiple of the
     16-row tile and smaller than the partition count; against the oracle and against K single sweeps."""
@@ -33,7 +33,10 @@ def test_one_pass_over_the_rows_for_K_iterates(ctx, ciao, dtype, loss, d, K, N):
     xs = [dev(x) for x in xs_h]
     avs = [torch.full_like(x, float("nan")) for x in xs]
     ctx.full_gradient_multi(dp, xs, avs)
-    assert f"mrhs_kernel<{'f64' if dtype == np.float64 else 'f32'},SL{d // 16}>" in ctx.last_kernel() and f"K={K}" in ctx.last_kernel(), ctx.last_kernel()
+    if d == 128 and dtype == np.float32:   # (a wave's share of a 128-column fp32 tile is under one 256-byte strip: K single sweeps)
+        assert "mrhs_kernel" not in ctx.last_kernel(), ctx.last_kernel()
+    else:
+        assert f"mrhs_kernel<{'f64' if dtype == np.float64 else 'f32'},SL{d // 16}>" in ctx.last_kernel() and f"K={K}" in ctx.last_kernel(), ctx.last_kernel()
     solo = torch.empty_like(xs[0])
     for k in range(K):
         ref = O.full_pass(op, xs_h[k])
