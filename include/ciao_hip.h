@@ -140,6 +140,11 @@ CIAO_API int32_t ciao_ctx_set_monitor(ciao_ctx *ctx, const ciao_prox_desc *g, do
  *   "split_blocks_per_cu"  grid cap of that kernel (0 = automatic)
  *   "split_all"            experiment: that kernel for every mode and size (tools/tune_split.py)
  *   "small_i"              rows_small_kernel (rows under 1 KiB): elements per lane and iteration, 8 or 16 (0 = automatic)
+ *   "small_mfma"           0: dense rows of 17 .. 256 elements do not take the matrix-core tile kernel (rows_smallm_kernel)
+ *   "small_mfma_table"     0: ... its table modes (SAGA / Finito init, Finito batches over row blocks) are off, the sweeps stay
+ *   "small_nb"             ... tile buffers per wave, 2 .. 4 (0 = automatic: 2)
+ *   "multi_rhs_off"        1: ciao_full_gradient_multi / ciao_svrg_epoch_tail_multi run K single sweeps (testing)
+ *   "peer_timeout_s"       wall-clock bound of a peer-mailbox wait, seconds (default 30)
  *   "chain_no_dma"         the register-ring chain instead of the LDS-DMA one;  "chain_big": the any-length kernels at any d
  *   "chain_four_waves"     rows of up to 2 KiB (fp64: 4 KiB) on the four-wave chain instead of the single-wave one
  *   "proshi_chain_max_batch"  ProShI batches up to this size run as one coordinate-parallel chain launch (-1 = measured crossover)
