@@ -922,6 +922,7 @@ int32_t ciao_ctx_destroy(ciao_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->partial) (void)hipFree(ctx->partial);
     if (ctx->mrhs_ptrs) (void)hipFree(ctx->mrhs_ptrs);
+    if (ctx->wide_box) (void)hipFree(ctx->wide_box);
     if (ctx->pextra) (void)hipFree(ctx->pextra);
     if (ctx->sumbuf) (void)hipFree(ctx->sumbuf);
     if (ctx->rowdot) (void)hipFree(ctx->rowdot);
@@ -970,6 +971,12 @@ int32_t ciao_ctx_synchronize(ciao_ctx *ctx)
             set_error("peer all-reduce: a rank's flag never arrived (ciao_ctx_set_peers: every rank must make the same reductions in "
                       "the same order); results since the last synchronize are invalid");
             return CIAO_ERR_HOOK;
+        }
+        if (flag == 5) {
+            set_error("internal: a workgroup of the several-workgroup chain (chain_wide_kernel, rows beyond 8192 elements) never saw "
+                      "another's partial dot product within 4 s -- the chain's workgroups were not all resident (a GPU shared with other "
+                      "work?); results since the last synchronize are invalid -- option chain_no_wide=1 selects the one-workgroup kernel");
+            return CIAO_ERR_HIP;
         }
         set_error("a sample index was outside [0, N): results since the last synchronize are invalid");
         return CIAO_ERR_ARG;
@@ -1273,6 +1280,8 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
         ctx->chain_big = value != 0;
     } else if (!strcmp(key, "chain_no_dma")) {
         ctx->chain_no_dma = value != 0;
+    } else if (!strcmp(key, "chain_no_wide")) {
+        ctx->chain_no_wide = value != 0;
     } else if (!strcmp(key, "chain_no_ws")) {
         ctx->chain_no_ws = value != 0;
     } else if (!strcmp(key, "small_mfma")) {

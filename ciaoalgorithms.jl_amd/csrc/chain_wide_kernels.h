@@ -1,0 +1,290 @@
+// chain_wide_kernels.h -- the sequential SVRG / SAGA chains on rows LONGER than one workgroup's registers hold (more than 8192
+// elements): several workgroups share ONE chain.
+//
+// Why.  chain_big_kernel (chain_kernels.h) keeps the whole state in the caller's vectors and streams row and state through one CU:
+// 12-40 us per update at d = 9000 ... 32 768, a 10-30x cliff behind the register-resident chains (0.25-1.9 us).  A chain step is a
+// dot product over the row and an element-wise update: both split by COLUMNS.  Workgroup g of G owns columns [g S, (g + 1) S) of
+// every vector -- its slice of the state lives in registers for the whole launch, its slices of the next two rows are in flight while
+// this one is used -- and the only thing the workgroups exchange per step is their partial dot products (SVRG: two, a'w and a'z_full;
+// SAGA: one), through a mailbox in global memory.
+//
+// The exchange.  No grid-wide barrier exists inside a kernel; the G workgroups (at most 32: always co-resident on an idle chip)
+// synchronise through the data itself.  Every 64-bit mailbox word carries 32 bits of payload and the 32-bit step number, written
+// and read with relaxed SYSTEM-scope atomics (a plain store / load that bypasses the non-coherent caches: correct wherever the
+// workgroups were placed): a reader spins until the word it reads carries the step it is in -- no fence, no flag to order against
+// the payload, nothing but the words themselves (a fence at system scope would write the L2 back, SAGA's table stores included).
+// An fp64 dot is two such words, an fp32 dot one.  Two parities: a workgroup can be at most one step ahead of the slowest (it needs
+// that one's word of the step before to get there).  Every workgroup adds the G partials in workgroup order: the same sum everywhere,
+// bitwise reproducible.  Spins are bounded in wall-clock time (s_memrealtime); a timeout sets the error word and ends the chain in
+// every workgroup (the others run into the same bound).
+//
+// Results: the chain's arithmetic is chain_big_kernel's, element for element; only the dot products are added in another order
+// (slices, then workgroups).
+#pragma once
+
+#include "chain_kernels.h"
+
+namespace ciao {
+
+constexpr int WIDE_NT = 256;
+constexpr int WIDE_GMAX = 32;
+constexpr unsigned long long WIDE_TIMEOUT_TICKS = 400000000ull;   // 4 s of the 100 MHz constant clock
+
+// mailbox: [2 parities][WIDE_GMAX workgroups][4 words]  (SVRG fp64: a'w hi/lo, a'z_full hi/lo)
+struct WideArgs {
+    unsigned long long *box;
+    int G;
+    int64_t slice;   // columns per workgroup (a multiple of WIDE_NT)
+};
+
+__device__ __forceinline__ void wide_put(unsigned long long *w, unsigned int payload, unsigned int seq)
+{
+    __hip_atomic_store(w, ((unsigned long long)payload << 32) | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// spins until the word carries `seq`; false on timeout
+__device__ __forceinline__ bool wide_get(const unsigned long long *w, unsigned int seq, unsigned int &payload)
+{
+    unsigned long long t0 = 0;
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned int)v == seq) {
+            payload = (unsigned int)(v >> 32);
+            return true;
+        }
+        if ((spins & 1023u) == 1023u) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0)
+                t0 = now;
+            else if (now - t0 > WIDE_TIMEOUT_TICKS)
+                return false;
+        }
+    }
+}
+template <typename T>
+struct WideWord;
+template <>
+struct WideWord<float> {
+    static constexpr int N = 1;
+    static __device__ __forceinline__ void put(unsigned long long *w, float v, unsigned int seq) { wide_put(w, __float_as_uint(v), seq); }
+    static __device__ __forceinline__ bool get(const unsigned long long *w, unsigned int seq, float &v)
+    {
+        unsigned int p;
+        if (!wide_get(w, seq, p)) return false;
+        v = __uint_as_float(p);
+        return true;
+    }
+};
+template <>
+struct WideWord<double> {
+    static constexpr int N = 2;
+    static __device__ __forceinline__ void put(unsigned long long *w, double v, unsigned int seq)
+    {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        wide_put(w, (unsigned int)(b >> 32), seq);
+        wide_put(w + 1, (unsigned int)b, seq);
+    }
+    static __device__ __forceinline__ bool get(const unsigned long long *w, unsigned int seq, double &v)
+    {
+        unsigned int hi, lo;
+        if (!wide_get(w, seq, hi) || !wide_get(w + 1, seq, lo)) return false;
+        v = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        return true;
+    }
+};
+
+// E elements per thread: the workgroup's slice is WIDE_NT E columns
+template <typename T, int E, int ALG, int LOSS>
+__global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, WideArgs wa)
+{
+    static_assert(ALG == CA_SVRG || ALG == CA_SAGA, "SVRG and SAGA chains");
+    constexpr bool TWO = (ALG == CA_SVRG);
+    constexpr int NW = WIDE_NT / WAVE;
+    using W = WideWord<T>;
+    __shared__ T red[2][NW][2];
+    __shared__ T gath[WIDE_GMAX][2];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x, G = wa.G;
+    const int64_t d = a.d;
+    const int64_t base = (int64_t)g * wa.slice;
+    if (tid == 0) s_fail = 0;
+
+    bool valid[E];
+    int64_t col[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        col[e] = base + tid + (int64_t)e * WIDE_NT;
+        valid[e] = col[e] < d && col[e] < base + wa.slice;
+        if (!valid[e]) col[e] = d - 1;   // (a finite, in-bounds element; never written)
+    }
+    T *pp = (ALG == CA_SVRG) ? a.w : a.z;      // the point the moving gradient is taken at
+    const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
+    const T gl = a.gamma * plam;
+    T p[E], av[E], zf[E], zacc[E], plo[E], phi[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        p[e] = valid[e] ? pp[col[e]] : T(0);
+        av[e] = valid[e] ? a.av[col[e]] : T(0);
+        zf[e] = (TWO && valid[e]) ? a.zf[col[e]] : T(0);
+        zacc[e] = (TWO && valid[e]) ? a.z[col[e]] : T(0);
+        plo[e] = -INFINITY;
+        phi[e] = INFINITY;
+        if (a.g.kind == CIAO_PROX_BOX) {
+            plo[e] = a.g.lo_vec ? a.g.lo_vec[col[e]] : a.g.lo;
+            phi[e] = a.g.hi_vec ? a.g.hi_vec[col[e]] : a.g.hi;
+        }
+    }
+    auto row_of = [&](int64_t s) {
+        int64_t row = a.idx[s];
+        if ((uint64_t)row >= (uint64_t)a.N) {   // memory-safe: flag it, use row 0 (results are void once flagged)
+            if (tid == 0 && g == 0) *a.errflag = 1;
+            row = 0;
+        }
+        return row;
+    };
+    auto load_row = [&](T(&o)[E], int64_t row) {
+        const T *ap = a.A + row * a.ld;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = __builtin_nontemporal_load(ap + col[e]);
+    };
+    auto load_tab = [&](T(&o)[E], int64_t row) {
+        const T *sp = a.table + row * d;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = sp[col[e]];
+    };
+
+    // The rows (and, SAGA, the table rows) of the next TWO steps are in flight while this one is worked on: a row is one dependent
+    // HBM access away, and with one step of lookahead the step could not be shorter than that latency (3.1 us at d = 9000 fp64).
+    T cur[E], n1[E], n2[E], scur[E], sn1[E], sn2[E];
+    int64_t r0 = row_of(0), r1 = a.nsteps > 1 ? row_of(1) : r0, r2 = r0;
+    T b0 = a.b ? a.b[r0] : T(0), b1 = a.b ? a.b[r1] : T(0), b2 = T(0);
+    load_row(cur, r0);
+    if (ALG == CA_SAGA) load_tab(scur, r0);
+    if (a.nsteps > 1) {
+        load_row(n1, r1);
+        if (ALG == CA_SAGA) load_tab(sn1, r1);
+    }
+    int par = 0;
+    __syncthreads();
+    for (int64_t s = 0; s < a.nsteps; ++s) {
+        const unsigned int seq = (unsigned int)(s + 1);
+        const bool more1 = s + 1 < a.nsteps, more2 = s + 2 < a.nsteps;
+        if (more2) {
+            r2 = row_of(s + 2);
+            b2 = a.b ? a.b[r2] : T(0);
+            load_row(n2, r2);
+            if (ALG == CA_SAGA) load_tab(sn2, r2);
+        }
+        const int64_t row = r0;
+        const T bi = b0;
+        // ---- this workgroup's share of the dot product(s)
+        T d1 = T(0), d2 = T(0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const T ak = valid[e] ? cur[e] : T(0);
+            d1 += ak * p[e];
+            if (TWO) d2 += ak * zf[e];
+        }
+        d1 = wave_sum_lane63(d1);
+        if (TWO) d2 = wave_sum_lane63(d2);
+        if (lane == WAVE - 1) {
+            red[par][wib][0] = d1;
+            if (TWO) red[par][wib][1] = d2;
+        }
+        __syncthreads();
+        // ---- published by one thread, gathered by one thread per workgroup of the chain, added in workgroup order by everyone
+        unsigned long long *mine = wa.box + ((size_t)(s & 1) * WIDE_GMAX + g) * 4;
+        if (tid == 0) {
+            const T v1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+            W::put(mine, v1, seq);
+            if (TWO) {
+                const T v2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
+                W::put(mine + 2, v2, seq);
+            }
+        }
+        if (tid < G) {
+            const unsigned long long *theirs = wa.box + ((size_t)(s & 1) * WIDE_GMAX + tid) * 4;
+            T v1 = T(0), v2 = T(0);
+            bool ok = W::get(theirs, seq, v1);
+            if (TWO) ok = W::get(theirs + 2, seq, v2) && ok;
+            if (!ok) s_fail = 1;
+            gath[tid][0] = v1;
+            gath[tid][1] = v2;
+        }
+        __syncthreads();
+        if (s_fail) {   // a workgroup of the chain never arrived: give up everywhere (the others run into the same bound)
+            if (tid == 0) *a.errflag = 5;
+            break;
+        }
+        d1 = T(0);
+        d2 = T(0);
+        for (int q = 0; q < G; ++q) {
+            d1 += gath[q][0];
+            if (TWO) d2 += gath[q][1];
+        }
+        par ^= 1;
+        // ---- the element-wise update of this workgroup's columns (chain_big_kernel's arithmetic)
+        const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
+        const GradCoef<T> gz = grad_coef_t<T, LOSS>(d2, bi, a.lam);
+        T *sp = (ALG == CA_SAGA) ? a.table + row * d : nullptr;
+        // SAGA: the table rows of the next two steps were requested BEFORE this step's store (the one for step s + 1 a step ago, the
+        // one for step s + 2 at the top of this step): where they are this very sample's, they are stale -- the row is what this step writes
+        const bool fix1 = (ALG == CA_SAGA) && more1 && r1 == row, fix2 = (ALG == CA_SAGA) && more2 && r2 == row;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const T ak = cur[e];
+            if (ALG == CA_SVRG) {                                            // SVRG_basic.jl:74-81
+                T t = gz.elem(ak) - gp.elem(ak);
+                t -= av[e];
+                t *= a.gamma;
+                t += p[e];
+                const T wn = prox_bf(t, gl, plo[e], phi[e]);
+                p[e] = wn;
+                zacc[e] += wn;
+            } else {                                                         // SAGA_basic.jl:56-65
+                const T gn = gp.elem(ak);
+                const T sk = scur[e];
+                const T del = (gn - sk) * a.invN;
+                T wv;
+                if (a.sag) {
+                    av[e] += del;
+                    wv = p[e] - a.gamma * av[e];
+                } else {
+                    wv = p[e] - a.gamma * (gn - sk + av[e]);
+                    av[e] += del;
+                }
+                p[e] = prox_bf(wv, gl, plo[e], phi[e]);
+                if (valid[e]) sp[col[e]] = gn;
+                if (fix1) sn1[e] = gn;
+                if (fix2) sn2[e] = gn;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            cur[e] = n1[e];
+            n1[e] = n2[e];
+            if (ALG == CA_SAGA) {
+                scur[e] = sn1[e];
+                sn1[e] = sn2[e];
+            }
+        }
+        r0 = r1;
+        r1 = r2;
+        b0 = b1;
+        b1 = b2;
+    }
+    // ---- the slice of the state back to the caller's vectors
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (!valid[e]) continue;
+        pp[col[e]] = p[e];
+        if (ALG == CA_SVRG)
+            a.z[col[e]] = zacc[e];
+        else
+            a.av[col[e]] = av[e];
+    }
+}
+
+}  // namespace ciao

@@ -95,6 +95,9 @@ struct ciao_ctx {
     int64_t proshi_chain_max_batch = -1;   // ProShI batches up to this size run as one coordinate-parallel chain launch (-1 = automatic)
     int64_t chain_four_waves = 0;   // testing: short rows (<= 2 KiB) on the four-wave chain instead of the single-wave one
     int64_t chain_one_wave = 0;     // experiment: 4 KiB rows on a single-wave chain (no cross-wave exchange)
+    int64_t chain_no_wide = 0;      // testing: rows beyond 8192 elements on chain_big_kernel instead of the several-workgroup chain_wide_kernel
+    void *wide_box = nullptr;       // chain_wide_kernel: the workgroups' mailbox
+    size_t wide_box_bytes = 0;
     int64_t chain_big = 0;          // testing: route chains through chain_big_kernel (the any-d kernel) whatever d
     int64_t chain_no_dma = 0;       // testing: route chains through the register-ring kernel instead of the LDS-DMA one
     int64_t chain_no_ws = 0;        // testing: SVRG / SAGA chains on chain_dma_kernel instead of the wave-specialised chain_ws_kernel

@@ -149,6 +149,7 @@ CIAO_API int32_t ciao_ctx_set_monitor(ciao_ctx *ctx, const ciao_prox_desc *g, do
  *   "chain_four_waves"     rows of up to 2 KiB (fp64: 4 KiB) on the four-wave chain instead of the single-wave one
  *   "proshi_chain_max_batch"  ProShI batches up to this size run as one coordinate-parallel chain launch (-1 = measured crossover)
  *   "chain_no_ws"          SAGA / SAG chains on chain_dma_kernel instead of the wave-specialised chain_ws_kernel
+ *   "chain_no_wide"        SVRG / SAGA chains on rows beyond 8192 elements on the one-workgroup kernel instead of chain_wide_kernel
  *   "chain_ws_issuers"     issuer waves of chain_ws_kernel, 1 or 2 (0 = automatic)
  *   "svrg_cache_rowdots"   0: the SVRG full pass does not store a_i'z_full at all (see ciao_svrg_iterate) */
 CIAO_API int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value);

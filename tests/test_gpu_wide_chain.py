@@ -1,0 +1,90 @@
+"""The sequential SVRG / SAGA chains on rows beyond 8192 elements as ONE chain shared by several workgroups
+(chain_wide_kernel, csrc/chain_wide_kernels.h): each workgroup keeps its columns of the state in registers, the partial dot
+products travel through a mailbox of self-validating words.  Against the oracle (SVRG_basic.jl:73-82, SAGA_basic.jl:53-68
+restated), against the one-workgroup kernel it replaces on these shapes (option chain_no_wide) to rounding, and bitwise
+against itself."""
+import numpy as np
+import pytest
+
+import problems as P
+from test_gpu_parity import close, dev, make, make_g
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d", [8193, 9000, 20480, 33000, 70001])
+def test_wide_chains_against_the_oracle(ctx, ciao, dtype, d):
+    """2 .. 32 workgroups (slices of 2048 columns up to 65 536 elements, of 4096 beyond), a last slice that is short or a
+    single column, both losses, l1 and per-coordinate box prox, SAG, a sample repeated inside the one-step prefetch window."""
+    import torch
+    from oracle import oracle as O
+    N = 24
+    loss = "logistic" if d % 2 else "ls"
+    A, b, x0 = P.synthetic(loss, N, d, dtype, seed=d)
+    op, dp = make(loss, A, b, 1.0 if loss == "logistic" else float(N), dtype)
+    tdt = dev(x0).dtype
+    gamma = 0.3 if loss == "logistic" else 1.0 / (7 * N * float(np.max(np.sum(A.astype(np.float64) ** 2, axis=1))))
+    idx = ciao.IndexStream(d).rand_indices(N, 200)
+    idx[4:8] = idx[4]
+    idx[50] = idx[48]
+    G = -(-d // (2048 if d <= 65536 else 4096))
+    for gk in ("l1", "boxvec"):
+        og, dg = make_g(gk, dtype, d, lam=0.01)
+        av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+        ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+        ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
+        assert "chain_wide_kernel" in ctx.last_kernel() and f"grid={G} " in ctx.last_kernel(), ctx.last_kernel()
+        rav, rz, rzf, rw = O.svrg_init(op, x0)
+        O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
+        close(w, rw, dtype, scale=200, what=f"svrg_inner w, {G} workgroups, g={gk}")
+        close(z, rz, dtype, scale=200, what=f"svrg_inner z, {G} workgroups, g={gk}")
+        # the one-workgroup kernel on the same chain: to rounding; itself again: bitwise
+        av1, z1, zf1, w1 = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+        ctx.svrg_init(dp, dev(x0), av1, z1, zf1, w1)
+        ctx.set_option("chain_no_wide", 1)
+        try:
+            ctx.svrg_inner(dp, dg, gamma, idx, av1, z1, zf1, w1)
+            assert "chain_big_kernel" in ctx.last_kernel(), ctx.last_kernel()
+        finally:
+            ctx.set_option("chain_no_wide", 0)
+        close(w, w1.cpu().numpy(), dtype, scale=200, what="several workgroups vs one")
+        av2, z2, zf2, w2 = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
+        ctx.svrg_init(dp, dev(x0), av2, z2, zf2, w2)
+        ctx.svrg_inner(dp, dg, gamma, idx, av2, z2, zf2, w2)
+        assert torch.equal(w, w2) and torch.equal(z, z2), "not reproducible"
+        for sag in (False, True):
+            table = torch.empty((N, d), dtype=tdt, device="cuda")
+            sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+            ctx.saga_init(dp, dg, gamma, dev(x0), table, sav, sz)
+            ctx.saga_steps(dp, dg, gamma, sag, idx, table, sav, sz)
+            assert "chain_wide_kernel" in ctx.last_kernel() and "alg1" in ctx.last_kernel(), ctx.last_kernel()
+            rt, rsav, rsz = O.saga_init(op, og, dtype(gamma), x0)
+            O.saga_steps(op, og, dtype(gamma), sag, idx, rt, rsav, rsz)
+            close(sz, rsz, dtype, scale=200, what=f"saga z sag={sag}, {G} workgroups, g={gk}")
+            close(sav, rsav, dtype, scale=200, what=f"saga av sag={sag}")
+            close(table, rt, dtype, scale=500, what="saga table")
+            close(sav, table.double().mean(dim=0).cpu().numpy(), dtype, scale=500, what="av invariant")
+    ctx.synchronize()
+
+
+def test_wide_chain_epochs_through_the_solver(ctx, ciao):
+    """SVRG epochs on d = 10 000 through svrg_iterate (inner cycle on chain_wide_kernel, full passes in between) against the oracle;
+    the step numbers of consecutive launches start over (the mailbox is cleared per launch)."""
+    import torch
+    from oracle import oracle as O
+    dtype, N, d = np.float64, 60, 10000
+    A, b, x0 = P.synthetic("ls", N, d, dtype, seed=5)
+    op, dp = make("ls", A, b, float(N), dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.01)
+    gamma = 1.0 / (7 * N * float(np.max(np.sum(A ** 2, axis=1))))
+    av, z, zf, w = (torch.empty(d, dtype=torch.float64, device="cuda") for _ in range(4))
+    ctx.svrg_init(dp, dev(x0), av, z, zf, w)
+    rav, rz, rzf, rw = O.svrg_init(op, x0)
+    st = ciao.IndexStream(3)
+    for ep in range(4):
+        idx = st.rand_indices(N, 2 * N)
+        ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w)
+        O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
+        close(zf, rzf, dtype, scale=2000, what=f"svrg epoch {ep} z_full on the several-workgroup chain")
+    ctx.synchronize()
