@@ -334,6 +334,28 @@ def run(ctx, dev, quick=False):
     del Fc, A, b
     torch.cuda.empty_cache()
 
+    # ---- SVRG / SAGA chains on rows beyond 8192 elements: one chain shared by several workgroups (chain_wide_kernel), d = 32768 fp64 ---
+    try:
+        N, d = 4096 // scale, 32768
+        F = _problem(ctx, dev, N, d, torch.float64, False)
+        g = ProxG(L.PROX_L1, lam=1e-3)
+        x0 = torch.zeros(d, dtype=torch.float64, device=dev)
+        av, z, zf, w = (torch.empty_like(x0) for _ in range(4))
+        ctx.svrg_init(F, x0, av, z, zf, w)
+        m = 20_000 // scale
+        idx = ctx._idx(st.rand_indices(N, m))
+        for tag, opt in (("several_workgroups", 0), ("one_workgroup", 1)):
+            ctx.set_option("chain_no_wide", opt)
+            mm = m if not opt else m // 10
+            ctx.svrg_inner(F, g, 1e-7, idx[:100], av, z, zf, w)
+            t = _timed(ctx, lambda: ctx.svrg_inner(F, g, 1e-7, idx[:mm], av, z, zf, w), reps=1)
+            out[f"svrg_inner_f64_d32768_{tag}"] = {"us_per_update": t / mm * 1e6, "m": mm, "N": N, "kernel": ctx.last_kernel()}
+        ctx.set_option("chain_no_wide", 0)
+        del F, idx
+        torch.cuda.empty_cache()
+    except Exception as e:   # noqa: BLE001
+        out["svrg_inner_f64_d32768"] = {"error": repr(e)}
+
     # ---- adaptive Finito on rows beyond the register-resident shapes (afinito_big_kernel), d = 8192 fp64 --------------------
     N, d = 20_000 // scale, 8192
     F = _problem(ctx, dev, N, d, torch.float64, False)
