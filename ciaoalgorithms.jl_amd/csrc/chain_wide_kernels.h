@@ -8,10 +8,11 @@
 // this one is used -- and the only thing the workgroups exchange per step is their partial dot products (SVRG: two, a'w and a'z_full;
 // SAGA: one), through a mailbox in global memory.
 //
-// The exchange.  No grid-wide barrier exists inside a kernel; the G workgroups (at most 32: always co-resident on an idle chip)
+// The exchange.  No grid-wide barrier exists inside a kernel; the G workgroups (at most 64 of 2048 columns each: always co-resident on
+// an idle chip)
 // synchronise through the data itself.  Every 64-bit mailbox word carries 32 bits of payload and the 32-bit step number, written
-// and read with relaxed SYSTEM-scope atomics (a plain store / load that bypasses the non-coherent caches: correct wherever the
-// workgroups were placed): a reader spins until the word it reads carries the step it is in -- no fence, no flag to order against
+// and read with relaxed device-scope atomics (a plain store / load that bypasses the non-coherent caches: correct wherever the
+// workgroups were placed; system scope times the same): a reader spins until the word it reads carries the step it is in -- no fence, no flag to order against
 // the payload, nothing but the words themselves (a fence at system scope would write the L2 back, SAGA's table stores included).
 // An fp64 dot is two such words, an fp32 dot one.  Two parities: a workgroup can be at most one step ahead of the slowest (it needs
 // that one's word of the step before to get there).  Every workgroup adds the G partials in workgroup order: the same sum everywhere,
@@ -27,7 +28,7 @@
 namespace ciao {
 
 constexpr int WIDE_NT = 256;
-constexpr int WIDE_GMAX = 32;
+constexpr int WIDE_GMAX = 64;
 constexpr unsigned long long WIDE_TIMEOUT_TICKS = 400000000ull;   // 4 s of the 100 MHz constant clock
 
 // mailbox: [2 parities][WIDE_GMAX workgroups][4 words]  (SVRG fp64: a'w hi/lo, a'z_full hi/lo)
@@ -107,6 +108,10 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
     const int lane = tid & (WAVE - 1);
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x, G = wa.G;
+    // (A fifth wave that does nothing but publish and poll -- so that the polls do not queue behind the rows in flight of a wave
+    // that also holds state: a wave's memory operations complete in order -- was built and was SLOWER, 3.4 against 2.9 us at d = 9000
+    // fp64: the step is the sum of its serial pieces -- dots, two barriers, the mailbox round trip of ~1.2 us, the update.)
+    constexpr bool poller = false;
     const int64_t d = a.d;
     const int64_t base = (int64_t)g * wa.slice;
     if (tid == 0) s_fail = 0;
@@ -115,27 +120,28 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
     int64_t col[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        col[e] = base + tid + (int64_t)e * WIDE_NT;
-        valid[e] = col[e] < d && col[e] < base + wa.slice;
+        col[e] = base + (tid & (WIDE_NT - 1)) + (int64_t)e * WIDE_NT;
+        valid[e] = !poller && col[e] < d && col[e] < base + wa.slice;
         if (!valid[e]) col[e] = d - 1;   // (a finite, in-bounds element; never written)
     }
     T *pp = (ALG == CA_SVRG) ? a.w : a.z;      // the point the moving gradient is taken at
     const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
     const T gl = a.gamma * plam;
-    T p[E], av[E], zf[E], zacc[E], plo[E], phi[E];
+    const bool boxed = (a.g.kind == CIAO_PROX_BOX);   // (its bounds are read per step where they are vectors: 4 E registers otherwise)
+    T p[E], av[E], zf[E], zacc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         p[e] = valid[e] ? pp[col[e]] : T(0);
         av[e] = valid[e] ? a.av[col[e]] : T(0);
         zf[e] = (TWO && valid[e]) ? a.zf[col[e]] : T(0);
         zacc[e] = (TWO && valid[e]) ? a.z[col[e]] : T(0);
-        plo[e] = -INFINITY;
-        phi[e] = INFINITY;
-        if (a.g.kind == CIAO_PROX_BOX) {
-            plo[e] = a.g.lo_vec ? a.g.lo_vec[col[e]] : a.g.lo;
-            phi[e] = a.g.hi_vec ? a.g.hi_vec[col[e]] : a.g.hi;
-        }
     }
+    auto prox_at = [&](T v, int e) {
+        if (!boxed) return prox_l1(v, gl);
+        const T lo = a.g.lo_vec ? a.g.lo_vec[col[e]] : a.g.lo;
+        const T hi = a.g.hi_vec ? a.g.hi_vec[col[e]] : a.g.hi;
+        return prox_bf(v, gl, lo, hi);
+    };
     auto row_of = [&](int64_t s) {
         int64_t row = a.idx[s];
         if ((uint64_t)row >= (uint64_t)a.N) {   // memory-safe: flag it, use row 0 (results are void once flagged)
@@ -156,45 +162,65 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
     };
 
     // The rows (and, SAGA, the table rows) of the next TWO steps are in flight while this one is worked on: a row is one dependent
-    // HBM access away, and with one step of lookahead the step could not be shorter than that latency (3.1 us at d = 9000 fp64).
-    T cur[E], n1[E], n2[E], scur[E], sn1[E], sn2[E];
-    int64_t r0 = row_of(0), r1 = a.nsteps > 1 ? row_of(1) : r0, r2 = r0;
-    T b0 = a.b ? a.b[r0] : T(0), b1 = a.b ? a.b[r1] : T(0), b2 = T(0);
-    load_row(cur, r0);
-    if (ALG == CA_SAGA) load_tab(scur, r0);
-    if (a.nsteps > 1) {
-        load_row(n1, r1);
-        if (ALG == CA_SAGA) load_tab(sn1, r1);
+    // HBM access away, and a step that has to see its successor's row land cannot be shorter than that latency (1.9 of the 3.1 us
+    // of the first version at d = 9000 fp64).  Three register sets in rotation -- the loop is unrolled by three so that none is ever
+    // copied (a copy waits for the load it copies).
+    T B0[E], B1[E], B2[E], S0[E], S1[E], S2[E];
+    int64_t q0 = 0, q1 = 0, q2 = 0, inext = 0;
+    T c0 = T(0), c1 = T(0), c2 = T(0);
+    if (!poller) {
+        q0 = row_of(0);
+        q1 = a.nsteps > 1 ? row_of(1) : q0;
+        q2 = q0;
+        inext = a.nsteps > 2 ? row_of(2) : q0;            // the row of the step after next
+        c0 = a.b ? a.b[q0] : T(0);
+        c1 = a.b ? a.b[q1] : T(0);
+        load_row(B0, q0);
+        if (ALG == CA_SAGA) load_tab(S0, q0);
+        if (a.nsteps > 1) {
+            load_row(B1, q1);
+            if (ALG == CA_SAGA) load_tab(S1, q1);
+        }
     }
     int par = 0;
     __syncthreads();
-    for (int64_t s = 0; s < a.nsteps; ++s) {
+    // one step: works on (cur, scur, r0, b0); (n1, sn1, r1, b1) is the next step's, requested a step ago; (n2, sn2, r2, b2) is
+    // requested now for the step after next.  false: a workgroup of the chain never arrived
+    auto step = [&](int64_t s, T(&cur)[E], T(&n1)[E], T(&n2)[E], T(&scur)[E], T(&sn1)[E], T(&sn2)[E], int64_t &r0, int64_t &r1, int64_t &r2,
+                    T &b0, T &b1, T &b2) -> bool {
+        (void)n1, (void)b1;
         const unsigned int seq = (unsigned int)(s + 1);
         const bool more1 = s + 1 < a.nsteps, more2 = s + 2 < a.nsteps;
-        if (more2) {
-            r2 = row_of(s + 2);
-            b2 = a.b ? a.b[r2] : T(0);
-            load_row(n2, r2);
-            if (ALG == CA_SAGA) load_tab(sn2, r2);
-        }
+        T d1 = T(0), d2 = T(0);
         const int64_t row = r0;
         const T bi = b0;
-        // ---- this workgroup's share of the dot product(s)
-        T d1 = T(0), d2 = T(0);
+        if (!poller) {
+            if (more2) {
+                // (the index was read a step ago, BEFORE that step's row loads: loads return in order, so waiting for it here does not
+                // wait for them; the next index and b_i are requested before this step's row loads for the same reason)
+                r2 = inext;
+                if (s + 3 < a.nsteps) inext = row_of(s + 3);
+                b2 = a.b ? a.b[r2] : T(0);
+                asm volatile("" ::: "memory");
+                load_row(n2, r2);
+                if (ALG == CA_SAGA) load_tab(sn2, r2);
+            }
+            // ---- this workgroup's share of the dot product(s)
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const T ak = valid[e] ? cur[e] : T(0);
-            d1 += ak * p[e];
-            if (TWO) d2 += ak * zf[e];
-        }
-        d1 = wave_sum_lane63(d1);
-        if (TWO) d2 = wave_sum_lane63(d2);
-        if (lane == WAVE - 1) {
-            red[par][wib][0] = d1;
-            if (TWO) red[par][wib][1] = d2;
+            for (int e = 0; e < E; ++e) {
+                const T ak = valid[e] ? cur[e] : T(0);
+                d1 += ak * p[e];
+                if (TWO) d2 += ak * zf[e];
+            }
+            d1 = wave_sum_lane63(d1);
+            if (TWO) d2 = wave_sum_lane63(d2);
+            if (lane == WAVE - 1) {
+                red[par][wib][0] = d1;
+                if (TWO) red[par][wib][1] = d2;
+            }
         }
         __syncthreads();
-        // ---- published by one thread, gathered by one thread per workgroup of the chain, added in workgroup order by everyone
+        // ---- published by one thread, gathered by one thread per workgroup of the chain (G <= 64: the first wave)
         unsigned long long *mine = wa.box + ((size_t)(s & 1) * WIDE_GMAX + g) * 4;
         if (tid == 0) {
             const T v1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
@@ -205,26 +231,31 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
             }
         }
         if (tid < G) {
-            const unsigned long long *theirs = wa.box + ((size_t)(s & 1) * WIDE_GMAX + tid) * 4;
+            const unsigned long long *theirs = wa.box + ((size_t)(s & 1) * WIDE_GMAX + lane) * 4;
             T v1 = T(0), v2 = T(0);
             bool ok = W::get(theirs, seq, v1);
             if (TWO) ok = W::get(theirs + 2, seq, v2) && ok;
             if (!ok) s_fail = 1;
-            gath[tid][0] = v1;
-            gath[tid][1] = v2;
+            gath[lane][0] = v1;
+            gath[lane][1] = v2;
         }
         __syncthreads();
         if (s_fail) {   // a workgroup of the chain never arrived: give up everywhere (the others run into the same bound)
             if (tid == 0) *a.errflag = 5;
-            break;
-        }
-        d1 = T(0);
-        d2 = T(0);
-        for (int q = 0; q < G; ++q) {
-            d1 += gath[q][0];
-            if (TWO) d2 += gath[q][1];
+            return false;
         }
         par ^= 1;
+        if (poller) return true;
+        // the G partials added by every wave in the same fixed tree (lane q holds workgroup q's; a serial loop over G LDS reads was
+        // 0.7 us of the step at G = 16)
+        d1 = lane < G ? gath[lane][0] : T(0);
+        d1 = readlane(wave_sum_lane63(d1), WAVE - 1);
+        if (TWO) {
+            d2 = lane < G ? gath[lane][1] : T(0);
+            d2 = readlane(wave_sum_lane63(d2), WAVE - 1);
+        } else {
+            d2 = T(0);
+        }
         // ---- the element-wise update of this workgroup's columns (chain_big_kernel's arithmetic)
         const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
         const GradCoef<T> gz = grad_coef_t<T, LOSS>(d2, bi, a.lam);
@@ -240,7 +271,7 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
                 t -= av[e];
                 t *= a.gamma;
                 t += p[e];
-                const T wn = prox_bf(t, gl, plo[e], phi[e]);
+                const T wn = prox_at(t, e);
                 p[e] = wn;
                 zacc[e] += wn;
             } else {                                                         // SAGA_basic.jl:56-65
@@ -255,25 +286,20 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
                     wv = p[e] - a.gamma * (gn - sk + av[e]);
                     av[e] += del;
                 }
-                p[e] = prox_bf(wv, gl, plo[e], phi[e]);
+                p[e] = prox_at(wv, e);
                 if (valid[e]) sp[col[e]] = gn;
                 if (fix1) sn1[e] = gn;
                 if (fix2) sn2[e] = gn;
             }
         }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            cur[e] = n1[e];
-            n1[e] = n2[e];
-            if (ALG == CA_SAGA) {
-                scur[e] = sn1[e];
-                sn1[e] = sn2[e];
-            }
-        }
-        r0 = r1;
-        r1 = r2;
-        b0 = b1;
-        b1 = b2;
+        return true;
+    };
+    for (int64_t s = 0; s < a.nsteps; s += 3) {
+        if (!step(s, B0, B1, B2, S0, S1, S2, q0, q1, q2, c0, c1, c2)) break;
+        if (s + 1 >= a.nsteps) break;
+        if (!step(s + 1, B1, B2, B0, S1, S2, S0, q1, q2, q0, c1, c2, c0)) break;
+        if (s + 2 >= a.nsteps) break;
+        if (!step(s + 2, B2, B0, B1, S2, S0, S1, q2, q0, q1, c2, c0, c1)) break;
     }
     // ---- the slice of the state back to the caller's vectors
 #pragma unroll

@@ -15,8 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("d", [8193, 9000, 20480, 33000, 70001])
 def test_wide_chains_against_the_oracle(ctx, ciao, dtype, d):
-    """2 .. 32 workgroups (slices of 2048 columns up to 65 536 elements, of 4096 beyond), a last slice that is short or a
-    single column, both losses, l1 and per-coordinate box prox, SAG, a sample repeated inside the one-step prefetch window."""
+    """5 .. 35 workgroups (slices of 2048 columns), a last slice that is short or a single column, both losses, l1 and per-coordinate box prox, SAG, a sample repeated inside the one-step prefetch window."""
     import torch
     from oracle import oracle as O
     N = 24
@@ -28,7 +27,7 @@ def test_wide_chains_against_the_oracle(ctx, ciao, dtype, d):
     idx = ciao.IndexStream(d).rand_indices(N, 200)
     idx[4:8] = idx[4]
     idx[50] = idx[48]
-    G = -(-d // (2048 if d <= 65536 else 4096))
+    G = -(-d // 2048)
     for gk in ("l1", "boxvec"):
         og, dg = make_g(gk, dtype, d, lam=0.01)
         av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
