@@ -491,7 +491,9 @@ template <typename T>
 static bool batch_as_chain(const ciao_ctx *ctx, const ciao_problem *p, int64_t r)
 {
     if (ctx->hook) return false;                       // sharded batches need the all-reduce between kernels
-    if (p->d > 32 * CHAIN_NT) return r <= 2;           // beyond 8192 elements the any-d chain runs at launch-pair speed: tiny batches only
+    // beyond 8192 elements: tiny batches only -- the several-workgroup chain (chain_wide_kernel, up to 131 072 elements) takes about 3 us
+    // per sample, the one-workgroup any-d chain 12 us and more, a batch-parallel step of such rows 10 us and more
+    if (p->d > 32 * CHAIN_NT) return r <= ((p->d <= 131072 && !ctx->chain_no_wide) ? 3 : 2);
     int64_t lim = ctx->chain_max_batch;
     if (lim < 0) {
         // measured after the chain work of round 2 (tools/gpu_s34.sh, profiles/r02_batch_chain_crossover.txt; Finito, fp32): a

@@ -1,5 +1,5 @@
-// chain_wide_kernels.h -- the sequential SVRG / SAGA chains on rows LONGER than one workgroup's registers hold (more than 8192
-// elements): several workgroups share ONE chain.
+// chain_wide_kernels.h -- the sequential chains (SVRG, SAGA / SAG, small-batch Finito and LFinito) on rows LONGER than one workgroup's
+// registers hold (more than 8192 elements): several workgroups share ONE chain.
 //
 // Why.  chain_big_kernel (chain_kernels.h) keeps the whole state in the caller's vectors and streams row and state through one CU:
 // 12-40 us per update at d = 9000 ... 32 768, a 10-30x cliff behind the register-resident chains (0.25-1.9 us).  A chain step is a
@@ -97,8 +97,10 @@ struct WideWord<double> {
 template <typename T, int E, int ALG, int LOSS>
 __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, WideArgs wa)
 {
-    static_assert(ALG == CA_SVRG || ALG == CA_SAGA, "SVRG and SAGA chains");
-    constexpr bool TWO = (ALG == CA_SVRG);
+    static_assert(ALG == CA_SVRG || ALG == CA_SAGA || ALG == CA_FINITO || ALG == CA_LFINITO, "the four chains");
+    constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
+    constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
+    constexpr bool HAS_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO);
     constexpr int NW = WIDE_NT / WAVE;
     using W = WideWord<T>;
     __shared__ T red[2][NW][2];
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
     }
     T *pp = (ALG == CA_SVRG) ? a.w : a.z;      // the point the moving gradient is taken at
     const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
-    const T gl = a.gamma * plam;
+    const T gl = (HAS_GAM ? a.hat_gamma : a.gamma) * plam;   // the prox's threshold: gamma lambda (SVRG, SAGA) / hat_gamma lambda (Finito, LFinito)
     const bool boxed = (a.g.kind == CIAO_PROX_BOX);   // (its bounds are read per step where they are vectors: 4 E registers otherwise)
     T p[E], av[E], zf[E], zacc[E];
 #pragma unroll
@@ -134,7 +136,7 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
         p[e] = valid[e] ? pp[col[e]] : T(0);
         av[e] = valid[e] ? a.av[col[e]] : T(0);
         zf[e] = (TWO && valid[e]) ? a.zf[col[e]] : T(0);
-        zacc[e] = (TWO && valid[e]) ? a.z[col[e]] : T(0);
+        zacc[e] = (ALG == CA_SVRG && valid[e]) ? a.z[col[e]] : T(0);
     }
     auto prox_at = [&](T v, int e) {
         if (!boxed) return prox_l1(v, gl);
@@ -168,6 +170,8 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
     T B0[E], B1[E], B2[E], S0[E], S1[E], S2[E];
     int64_t q0 = 0, q1 = 0, q2 = 0, inext = 0;
     T c0 = T(0), c1 = T(0), c2 = T(0);
+    T h0 = a.gam_uniform, h1 = a.gam_uniform, h2 = a.gam_uniform;   // gamma_i of the three steps in flight (Finito, LFinito)
+    int64_t inb = 0;                                                // position in the current batch (Finito, LFinito)
     if (!poller) {
         q0 = row_of(0);
         q1 = a.nsteps > 1 ? row_of(1) : q0;
@@ -175,11 +179,15 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
         inext = a.nsteps > 2 ? row_of(2) : q0;            // the row of the step after next
         c0 = a.b ? a.b[q0] : T(0);
         c1 = a.b ? a.b[q1] : T(0);
+        if (HAS_GAM && a.gam) {
+            h0 = a.gam[q0];
+            h1 = a.gam[q1];
+        }
         load_row(B0, q0);
-        if (ALG == CA_SAGA) load_tab(S0, q0);
+        if (HAS_TABLE) load_tab(S0, q0);
         if (a.nsteps > 1) {
             load_row(B1, q1);
-            if (ALG == CA_SAGA) load_tab(S1, q1);
+            if (HAS_TABLE) load_tab(S1, q1);
         }
     }
     int par = 0;
@@ -187,8 +195,8 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
     // one step: works on (cur, scur, r0, b0); (n1, sn1, r1, b1) is the next step's, requested a step ago; (n2, sn2, r2, b2) is
     // requested now for the step after next.  false: a workgroup of the chain never arrived
     auto step = [&](int64_t s, T(&cur)[E], T(&n1)[E], T(&n2)[E], T(&scur)[E], T(&sn1)[E], T(&sn2)[E], int64_t &r0, int64_t &r1, int64_t &r2,
-                    T &b0, T &b1, T &b2) -> bool {
-        (void)n1, (void)b1;
+                    T &b0, T &b1, T &b2, T &g0, T &g1, T &g2) -> bool {
+        (void)n1, (void)b1, (void)g1;
         const unsigned int seq = (unsigned int)(s + 1);
         const bool more1 = s + 1 < a.nsteps, more2 = s + 2 < a.nsteps;
         T d1 = T(0), d2 = T(0);
@@ -201,9 +209,14 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
                 r2 = inext;
                 if (s + 3 < a.nsteps) inext = row_of(s + 3);
                 b2 = a.b ? a.b[r2] : T(0);
+                if (HAS_GAM && a.gam) g2 = a.gam[r2];
                 asm volatile("" ::: "memory");
                 load_row(n2, r2);
-                if (ALG == CA_SAGA) load_tab(sn2, r2);
+                if (HAS_TABLE) load_tab(sn2, r2);
+            }
+            if (ALG == CA_LFINITO && inb == 0) {     // Finito_LFinito.jl:92  z = prox(av)
+#pragma unroll
+                for (int e = 0; e < E; ++e) p[e] = prox_at(av[e], e);
             }
             // ---- this workgroup's share of the dot product(s)
 #pragma unroll
@@ -259,10 +272,12 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
         // ---- the element-wise update of this workgroup's columns (chain_big_kernel's arithmetic)
         const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
         const GradCoef<T> gz = grad_coef_t<T, LOSS>(d2, bi, a.lam);
-        T *sp = (ALG == CA_SAGA) ? a.table + row * d : nullptr;
+        T *sp = HAS_TABLE ? a.table + row * d : nullptr;
+        const T gi = g0;
+        const bool last_of_batch = (inb + 1 == a.batch) || !more1;
         // SAGA: the table rows of the next two steps were requested BEFORE this step's store (the one for step s + 1 a step ago, the
         // one for step s + 2 at the top of this step): where they are this very sample's, they are stale -- the row is what this step writes
-        const bool fix1 = (ALG == CA_SAGA) && more1 && r1 == row, fix2 = (ALG == CA_SAGA) && more2 && r2 == row;
+        const bool fix1 = HAS_TABLE && more1 && r1 == row, fix2 = HAS_TABLE && more2 && r2 == row;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const T ak = cur[e];
@@ -274,7 +289,7 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
                 const T wn = prox_at(t, e);
                 p[e] = wn;
                 zacc[e] += wn;
-            } else {                                                         // SAGA_basic.jl:56-65
+            } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
                 const T gn = gp.elem(ak);
                 const T sk = scur[e];
                 const T del = (gn - sk) * a.invN;
@@ -290,16 +305,31 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
                 if (valid[e]) sp[col[e]] = gn;
                 if (fix1) sn1[e] = gn;
                 if (fix2) sn2[e] = gn;
+            } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
+                const T t = p[e] - (gi * a.invN) * gp.elem(ak);
+                av[e] += (t - scur[e]) * (a.hat_gamma / gi);
+                if (valid[e]) sp[col[e]] = t;
+                if (fix1) sn1[e] = t;
+                if (fix2) sn2[e] = t;
+                if (last_of_batch) p[e] = prox_at(av[e], e);
+            } else {                                                         // Finito_LFinito.jl:93-98
+                const T c = a.hat_gamma * a.invN;
+                T avk = av[e];
+                avk += c * gz.elem(ak);
+                avk -= c * gp.elem(ak);
+                avk += (a.hat_gamma / gi) * (p[e] - zf[e]);
+                av[e] = avk;
             }
         }
+        if (++inb == a.batch) inb = 0;
         return true;
     };
     for (int64_t s = 0; s < a.nsteps; s += 3) {
-        if (!step(s, B0, B1, B2, S0, S1, S2, q0, q1, q2, c0, c1, c2)) break;
+        if (!step(s, B0, B1, B2, S0, S1, S2, q0, q1, q2, c0, c1, c2, h0, h1, h2)) break;
         if (s + 1 >= a.nsteps) break;
-        if (!step(s + 1, B1, B2, B0, S1, S2, S0, q1, q2, q0, c1, c2, c0)) break;
+        if (!step(s + 1, B1, B2, B0, S1, S2, S0, q1, q2, q0, c1, c2, c0, h1, h2, h0)) break;
         if (s + 2 >= a.nsteps) break;
-        if (!step(s + 2, B2, B0, B1, S2, S0, S1, q2, q0, q1, c2, c0, c1)) break;
+        if (!step(s + 2, B2, B0, B1, S2, S0, S1, q2, q0, q1, c2, c0, c1, h2, h0, h1)) break;
     }
     // ---- the slice of the state back to the caller's vectors
 #pragma unroll
@@ -309,7 +339,7 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
         if (ALG == CA_SVRG)
             a.z[col[e]] = zacc[e];
         else
-            a.av[col[e]] = av[e];
+            a.av[col[e]] = av[e];   // (SAGA, Finito, LFinito: the aggregate moves with the chain)
     }
 }
 

@@ -67,6 +67,54 @@ def test_wide_chains_against_the_oracle(ctx, ciao, dtype, d):
     ctx.synchronize()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d", [8193, 20481])
+def test_wide_finito_and_lfinito_chains(ctx, ciao, dtype, d):
+    """Small-batch Finito (batches of 1, 2 and 3, per-sample stepsizes, a sample again in the next batch: the table row it reads is
+    the one just written) and LFinito iterations on the several-workgroup chain against the oracle and the one-workgroup kernel."""
+    import torch
+    from oracle import oracle as O
+    N = 30
+    loss = "logistic" if d % 2 else "ls"
+    A, b, x0 = P.synthetic(loss, N, d, dtype, seed=d + 1)
+    lam_f = 1.0 if loss == "logistic" else float(N)
+    op, dp = make(loss, A, b, lam_f, dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.01)
+    tdt = dev(x0).dtype
+    Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1)
+    gamh = (0.999 * N / np.maximum(Li, 1e-3 * Li.max())).astype(dtype)
+    gam = dev(gamh)
+    hg = ctx.hat_gamma(gam)
+    for r in (1, 2, 3):
+        table = torch.empty((N, d), dtype=tdt, device="cuda")
+        av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+        ctx.finito_init(dp, dg, gam, hg, dev(x0), table, av, z)
+        rt, rav, rz, rhg = O.finito_init(op, og, gamh, x0)
+        st = ciao.IndexStream(r + d)
+        batches = [st.sample_without_replacement(N, r) for _ in range(40)]
+        batches[5][0] = batches[4][0]
+        batches[6][0] = batches[4][0]
+        bptr = np.arange(len(batches) + 1, dtype=np.int64) * r
+        ctx.finito_steps(dp, dg, gam, hg, bptr, np.concatenate(batches), table, av, z)
+        assert "chain_wide_kernel" in ctx.last_kernel() and "alg2" in ctx.last_kernel(), ctx.last_kernel()
+        O.finito_steps(op, og, gamh, rhg, batches, rt, rav, rz)
+        close(z, rz, dtype, scale=500, what=f"finito z, batches of {r}, several workgroups")
+        close(av, rav, dtype, scale=500, what=f"finito av, batches of {r}")
+        close(table, rt, dtype, scale=500, what=f"finito table, batches of {r}")
+    lav, lz, lzf = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(3))
+    rav, rz, rzf, rhg = O.lfinito_init(op, gamh, x0)
+    ctx.lfinito_init(dp, hg, dev(x0), lav, lz, lzf)
+    blocks = [np.arange(2 * k, 2 * k + 2, dtype=np.int64) for k in range(N // 2)]
+    bp = np.arange(0, N + 1, 2, dtype=np.int64)
+    for it in range(3):
+        ctx.lfinito_iterate(dp, dg, gam, hg, bp, np.concatenate(blocks), lav, lz, lzf)
+        assert "chain_wide_kernel" in ctx.last_kernel() and "alg3" in ctx.last_kernel(), ctx.last_kernel()
+        O.lfinito_iterate(op, og, gamh, rhg, blocks, rav, rz, rzf)
+        close(lz, rz, dtype, scale=2000, what=f"lfinito z it {it}, several workgroups")
+        close(lav, rav, dtype, scale=2000, what=f"lfinito av it {it}")
+    ctx.synchronize()
+
+
 def test_wide_chain_epochs_through_the_solver(ctx, ciao):
     """SVRG epochs on d = 10 000 through svrg_iterate (inner cycle on chain_wide_kernel, full passes in between) against the oracle;
     the step numbers of consecutive launches start over (the mailbox is cleared per launch)."""
