@@ -494,6 +494,7 @@ static bool batch_as_chain(const ciao_ctx *ctx, const ciao_problem *p, int64_t r
     // beyond 8192 elements: tiny batches only -- the several-workgroup chain (chain_wide_kernel, up to 131 072 elements) takes about 3 us
     // per sample, the one-workgroup any-d chain 12 us and more, a batch-parallel step of such rows 10 us and more
     if (p->d > 32 * CHAIN_NT) return r <= ((p->d <= 131072 && !ctx->chain_no_wide) ? 3 : 2);
+    if (sizeof(T) == 8 && p->d > 16 * CHAIN_NT && !ctx->chain_no_wide && ctx->chain_max_batch < 0) return r <= 3;   // (fp64 rows of 4097 .. 8192 elements: the same chain)
     int64_t lim = ctx->chain_max_batch;
     if (lim < 0) {
         // measured after the chain work of round 2 (tools/gpu_s34.sh, profiles/r02_batch_chain_crossover.txt; Finito, fp32): a
