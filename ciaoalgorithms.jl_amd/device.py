@@ -312,7 +312,13 @@ class Context:
     # -- helpers -------------------------------------------------------------------------------------------------------
     def _vec(self, t: torch.Tensor, p: PackedF, name: str, n: int | None = None):
         n = p.d if n is None else n
-        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == p.dtype and t.is_contiguous() and t.numel() == n):
+        # (a length-d view of a longer buffer is taken for the p.d-vector it heads when the problem's rows were padded with fewer than
+        # one 16-byte chunk of zero columns: solvers._Iterable's feature padding -- the kernels read and write all p.d coordinates)
+        ok = isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == p.dtype and t.is_contiguous()
+        if ok and t.numel() != n:
+            es = t.element_size()
+            ok = (0 < n - t.numel() < 16 // es) and t.untyped_storage().nbytes() >= (t.storage_offset() + n) * es
+        if not ok:
             raise ValueError(f"{name}: need a contiguous {p.dtype} device vector of length {n}, got "
                              f"{getattr(t, 'dtype', type(t))} {tuple(getattr(t, 'shape', ()))} on {getattr(t, 'device', '?')}")
         return _ptr(t)

@@ -44,6 +44,9 @@ from . import host_route as HR
 from .operators import UnpackableOperator, pack_F, pack_g, pack_sharing_F, require_packable
 from .sampling import IndexStream
 
+# Problems packed from host operators get their rows padded with zero columns to whole 16-byte chunks (see _Iterable.__init__)
+PAD_FEATURES = True
+
 __all__ = ["SVRG", "SAGA", "SAG", "Finito", "Proshi", "iterator", "solution", "solve_together"]
 
 
@@ -96,12 +99,26 @@ class _Iterable:
         self._x0_dev, self._numpy, self._complex = _x0_to_device(x0, self.R)
         self.d = self._x0_dev.numel()                   # reals: twice the length of a complex x0
         self.ctx = ctx if ctx is not None else default_context()
-        self.F = pack_F(F, self.N, self.d, self.R, self._x0_dev.device, complex_pairs=self._complex)
+        # Feature padding.  The fast chain kernels stream rows of whole 16-byte chunks from 16-byte aligned addresses; a row of, say,
+        # 1001 Float64 is neither, and runs the register-ring chains at 2-3.7x the time per update (d = 51 / 785 / 2049 fp64: 0.28 /
+        # 0.57 / 1.69 us against 0.13-0.17 / 0.27-0.31 / 0.45).  When the problem is PACKED HERE from host operators (not a device
+        # matrix the caller laid out), it is packed with dp - d zero columns, dp = d rounded up to whole chunks: the extra
+        # coordinates multiply nothing and start at zero, so the d real ones evolve as without them (to rounding: another kernel
+        # adds them in another order).  Every state vector is a length-d VIEW of a dp-long buffer -- what the caller sees has the
+        # reference's shapes, identities and aliasing -- and the device calls take the view (device.Context._vec reads on to dp).
+        self.dp = self.d
+        vec = 16 // (8 if self.R == torch.float64 else 4)
+        if PAD_FEATURES and not self._complex and not isinstance(F, PackedF) and self.d >= 1 and self.d % vec != 0 and self._pads_features:
+            self.dp = (self.d + vec - 1) // vec * vec
+            base = torch.zeros(self.dp, dtype=self.R, device=self._x0_dev.device)
+            base[:self.d] = self._x0_dev
+            self._x0_dev = base[:self.d]
+        self.F = pack_F(F, self.N, self.d, self.R, self._x0_dev.device, complex_pairs=self._complex, pad_to=self.dp)
         if self.F.N_total != self.N:
             raise ValueError(f"F holds N_total={self.F.N_total} terms but N={self.N}")
         if self._complex != bool(getattr(self.F, "complex", False)) and self.F.loss != 2:
             raise TypeError("x0 and F must both be complex or both be real (CIAOAlgorithms.jl:3: one type T for the problem)")
-        self.g = pack_g(g, self.d, self.R, self._x0_dev.device, complex_pairs=self._complex)
+        self.g = pack_g(g, self.d, self.R, self._x0_dev.device, complex_pairs=self._complex, pad_to=self.dp)
         self.stream = stream if stream is not None else IndexStream(0)
         self._state = None
         self._started = False
@@ -141,8 +158,17 @@ class _Iterable:
         idx = self.stream.rand_indices(N, m)
         return idx, (int(idx[-1]) if m > 0 else None)
 
+    _pads_features = True    # (the adaptive iterable keeps the caller's d: its per-sample probes and meta are laid out for it)
+
     def _new(self):
-        return torch.empty(self.d, dtype=self.R, device=self._x0_dev.device)
+        """A state d-vector: with feature padding a length-d view of a zeroed dp-long buffer (the padding coordinates start at zero)."""
+        if self.dp == self.d:
+            return torch.empty(self.d, dtype=self.R, device=self._x0_dev.device)
+        return torch.zeros(self.dp, dtype=self.R, device=self._x0_dev.device)[:self.d]
+
+    def _new_table(self):
+        """The N x d table of SAGA / Finito (this rank's rows): dp columns with feature padding (the kernels write them: zeros)."""
+        return torch.empty((self.F.N, self.dp), dtype=self.R, device=self._x0_dev.device)
 
     # Python iteration protocol = Base.iterate(iter) then Base.iterate(iter, state)
     def __iter__(self):
@@ -273,7 +299,7 @@ class SAGA_basic_iterable(_Iterable):
             γ = 1 / (16 * L_M) if self.SAG else 1 / (3 * L_M)
         else:
             γ = self.γ
-        s = torch.empty((self.F.N, self.d), dtype=self.R, device=self._x0_dev.device)   # this rank's rows of the N x d table
+        s = self._new_table()                                              # this rank's rows of the N x d table
         av, z = self._new(), self._new()
         if self.shards is not None:
             self.shards.install(self.F, table=s)
@@ -411,7 +437,7 @@ class FINITO_basic_iterable(_Iterable):
         if gam is None:
             return None
         hat_γ = self.ctx.hat_gamma(gam)                                    # :82
-        s = torch.empty((self.F.N, self.d), dtype=self.R, device=self._x0_dev.device)
+        s = self._new_table()
         av, z = self._new(), self._new()
         self.ctx.finito_init(self.F, self.g, gam, hat_γ, self._x0_dev, s, av, z)   # :76-84
         st = FINITO_basic_state(s, gam, hat_γ, av, z, d_b)
@@ -487,6 +513,8 @@ class FINITO_adaptive_state(_State):
 
 class FINITO_adaptive_iterable(_Iterable):
     """FINITO_adaptive_iterable (Finito_adaptive.jl): per-sample backtracking on γ_i; no minibatch (:162)."""
+
+    _pads_features = False   # its Lipschitz probe (x0 .+ 1, divided by sqrt(d), :86-88) counts the coordinates
 
     def __init__(self, R, F, g, x0, N, L, tol, tol_b, sweeping, α, ctx=None, stream=None):
         super().__init__(R, F, g, x0, N, ctx, stream)
@@ -582,6 +610,7 @@ class Proshi_basic_iterable(_Iterable):
         if self._complex:
             raise TypeError("complex agents are outside the ProShI device path")
         self.d = self._x0_dev.numel()
+        self.dp = self.d
         self.ctx = ctx if ctx is not None else default_context()
         self.F = pack_sharing_F(F, self.N, self.d, self.R, self._x0_dev.device)
         self.g = pack_g(g, self.d, self.R, self._x0_dev.device)
