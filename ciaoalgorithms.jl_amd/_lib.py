@@ -52,7 +52,8 @@ MAX_SHARDS = 8
 class ShardTable(C.Structure):
     """ciao_shard_table"""
     _fields_ = [("nshards", C.c_int32), ("owner", C.c_int32), ("row0", C.c_int64 * (MAX_SHARDS + 1)),
-                ("A", C.c_void_p * MAX_SHARDS), ("b", C.c_void_p * MAX_SHARDS), ("table", C.c_void_p * MAX_SHARDS)]
+                ("A", C.c_void_p * MAX_SHARDS), ("b", C.c_void_p * MAX_SHARDS), ("table", C.c_void_p * MAX_SHARDS),
+                ("meta", C.c_void_p * MAX_SHARDS)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)

@@ -724,10 +724,50 @@ static int32_t afinito_steps_t(ciao_ctx *ctx, const ciao_problem *p, const ciao_
     a.z = (T *)z;
     a.hg = (T *)hat_gamma_dev;
     a.counters = reinterpret_cast<long long *>(ctx->scal);
-    CIAO_TRY(launch_afinito<T>(ctx, p->loss, a));
+    const ciao_shard_table &sh = ctx->shards;
+    const bool sharded = sh.nshards > 0;
+    if (sharded) {   // row-sharded problem: data rows, table rows and scalars of the other shards are peer memory (as the SAGA chain)
+        a.nshards = sh.nshards;
+        a.N = p->N_total;
+        for (int k = 0; k < CIAO_MAX_SHARDS; ++k) {
+            const bool on = k < sh.nshards;
+            a.shA[k] = on ? (const T *)sh.A[k] : nullptr;
+            a.shb[k] = on ? (const T *)sh.b[k] : nullptr;
+            a.shT[k] = on ? (T *)sh.table[k] : nullptr;
+            a.shM[k] = on ? (T *)sh.meta[k] : nullptr;
+        }
+        for (int k = 0; k <= CIAO_MAX_SHARDS; ++k) a.sh_row0[k] = k <= sh.nshards ? sh.row0[k] : sh.row0[sh.nshards];
+    }
     long long c[2] = {0, 0};
-    CIAO_HIP(hipMemcpyAsync(c, ctx->scal, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
-    CIAO_HIP(hipStreamSynchronize(ctx->stream));
+    if (!sharded || sh.owner) {
+        CIAO_TRY(launch_afinito<T>(ctx, p->loss, a));
+        CIAO_HIP(hipMemcpyAsync(c, ctx->scal, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+        CIAO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (sharded && ctx->hook) {
+        // av and z as the chains' hand-over; hat_gamma and the two counters as three Float64 (a Float32 is exact in one, a count
+        // of steps below 2^53 too) behind them, the non-owners contributing zeros
+        CIAO_TRY(broadcast_from_owner<T>(ctx, p->d, av, z, nsteps));
+        double t[3] = {0.0, 0.0, 0.0};
+        if (sh.owner) {
+            T hgv;
+            CIAO_HIP(hipMemcpyAsync(&hgv, hat_gamma_dev, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            CIAO_HIP(hipStreamSynchronize(ctx->stream));
+            t[0] = (double)hgv, t[1] = (double)c[0], t[2] = (double)c[1];
+        }
+        CIAO_HIP(hipMemcpyAsync(ctx->scal, t, sizeof t, hipMemcpyHostToDevice, ctx->stream));
+        const int32_t hs = ctx->hook(ctx->hook_user, ctx->scal, 3, CIAO_F64, (void *)ctx->stream);
+        if (hs != 0) {
+            set_error("all-reduce hook failed with status %d", hs);
+            return CIAO_ERR_HOOK;
+        }
+        CIAO_HIP(hipMemcpyAsync(t, ctx->scal, sizeof t, hipMemcpyDeviceToHost, ctx->stream));
+        CIAO_HIP(hipStreamSynchronize(ctx->stream));
+        const T hgv = (T)t[0];
+        CIAO_HIP(hipMemcpyAsync(hat_gamma_dev, &hgv, sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        CIAO_HIP(hipStreamSynchronize(ctx->stream));
+        c[0] = (long long)t[1], c[1] = (long long)t[2];
+    }
     if (done_host) *done_host = c[0];
     if (trials_host) *trials_host = c[1];
     return CIAO_OK;
@@ -1744,8 +1784,11 @@ int32_t ciao_afinito_init(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox_
     CIAO_REQUIRE(x0 && av && z && hat_gamma_dev && ((table && meta) || p->N == 0), "NULL state vector / table / meta");
     CIAO_REQUIRE(alpha > 0 && alpha < 1, "alpha must be in (0, 1)");
     CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO, "adaptive Finito needs data terms (the Lipschitz probe of Zero() is degenerate)");
-    CIAO_REQUIRE(p->N >= 1, "adaptive Finito needs at least one term");
-    CIAO_REQUIRE(!ctx->hook, "adaptive Finito is a sequential chain: replicas only, not valid on a row-sharded problem");
+    CIAO_REQUIRE(p->N >= 1 || ctx->shards.nshards > 0, "adaptive Finito needs at least one term");
+    CIAO_REQUIRE(!ctx->hook || ctx->shards.nshards > 0,
+                 "adaptive Finito is a sequential chain: on a row-sharded problem it needs a shard table (ciao_ctx_set_shards) with "
+                 "the table and meta shards");
+    CIAO_TRY(check_shards(ctx, p, false));
     return DISPATCH(p->dtype, afinito_init_t, ctx, p, g, alpha, x0, table, meta, av, z, hat_gamma_dev, gam_override);
 }
 
@@ -1758,10 +1801,17 @@ int32_t ciao_afinito_steps(ciao_ctx *ctx, const ciao_problem *p, const ciao_prox
     CIAO_TRY(check_prox(g));
     CIAO_TRY(check_pair(p, g));
     CIAO_REQUIRE(nsteps >= 0 && (nsteps == 0 || idx), "nsteps < 0 or idx is NULL");
-    CIAO_REQUIRE(table && meta && av && z && hat_gamma_dev, "NULL state vector / table / meta");
+    CIAO_REQUIRE(((table && meta) || ctx->shards.nshards > 0) && av && z && hat_gamma_dev, "NULL state vector / table / meta");
     CIAO_REQUIRE(alpha > 0 && alpha < 1 && tol_b > 0, "need 0 < alpha < 1 and tol_b > 0");
-    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO && p->N >= 1, "adaptive Finito needs data terms");
-    CIAO_REQUIRE(!ctx->hook, "adaptive Finito is a sequential chain: replicas only, not valid on a row-sharded problem");
+    CIAO_REQUIRE(p->loss != CIAO_LOSS_ZERO && (p->N >= 1 || ctx->shards.nshards > 0), "adaptive Finito needs data terms");
+    CIAO_REQUIRE(!ctx->hook || ctx->shards.nshards > 0,
+                 "adaptive Finito is a sequential chain: on a row-sharded problem it needs a shard table (ciao_ctx_set_shards) with "
+                 "the table and meta shards");
+    CIAO_TRY(check_shards(ctx, p, true));
+    if (ctx->shards.nshards > 0 && ctx->shards.owner)
+        for (int k = 0; k < ctx->shards.nshards; ++k)
+            CIAO_REQUIRE(ctx->shards.row0[k + 1] == ctx->shards.row0[k] || ctx->shards.meta[k],
+                         "shard %d has no meta pointer on the chain owner (adaptive Finito)", k);
     if (nsteps == 0) {
         if (done_host) *done_host = 0;
         if (trials_host) *trials_host = 0;

@@ -1951,7 +1951,53 @@ struct AFinitoArgs {
     T *hg;                // device scalar: hat_gamma (in/out)
     long long *counters;  // [0] steps completed, [1] backtracking trials (out)
     int *errflag;
+    // Row-sharded problem (ciao_ctx_set_shards, as ChainArgs): shard k = global rows [sh_row0[k], sh_row0[k+1]) with its data rows,
+    // its rows of the s-table and its per-sample scalars in allocations of their own (possibly another GPU's); idx holds GLOBAL rows.
+    int nshards;
+    const T *shA[CIAO_MAX_SHARDS];
+    const T *shb[CIAO_MAX_SHARDS];
+    T *shT[CIAO_MAX_SHARDS];
+    T *shM[CIAO_MAX_SHARDS];
+    int64_t sh_row0[CIAO_MAX_SHARDS + 1];
 };
+
+// The shard table of an adaptive Finito chain (41 qwords: shA | shb | shT | shM | sh_row0), to LDS and searched there exactly as the
+// chains' (shard_table_to_lds / shard_resolve above, and why).
+constexpr int AF_SHARD_QW = 5 * CIAO_MAX_SHARDS + 1;
+template <typename T>
+struct AFShardRow {
+    const T *arow;
+    const T *bp;
+    T *trow;
+    T *mrow;   // the sample's 4 x 4 scalars
+};
+template <typename T>
+__device__ __forceinline__ void af_shard_table_to_lds(int64_t *s_sh, int tid)
+{
+    static_assert(offsetof(AFinitoArgs<T>, shb) == offsetof(AFinitoArgs<T>, shA) + 8 * CIAO_MAX_SHARDS &&
+                  offsetof(AFinitoArgs<T>, shT) == offsetof(AFinitoArgs<T>, shA) + 16 * CIAO_MAX_SHARDS &&
+                  offsetof(AFinitoArgs<T>, shM) == offsetof(AFinitoArgs<T>, shA) + 24 * CIAO_MAX_SHARDS &&
+                  offsetof(AFinitoArgs<T>, sh_row0) == offsetof(AFinitoArgs<T>, shA) + 32 * CIAO_MAX_SHARDS, "the table is 41 contiguous qwords");
+    const unsigned char __attribute__((address_space(4))) *ka =
+        (const unsigned char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    if (tid < AF_SHARD_QW) s_sh[tid] = reinterpret_cast<const int64_t __attribute__((address_space(4))) *>(ka + offsetof(AFinitoArgs<T>, shA))[tid];
+}
+template <typename T>
+__device__ __forceinline__ AFShardRow<T> af_shard_resolve(const int64_t *s_sh, int nshards, int64_t r, int64_t ld, int64_t d)
+{
+    const int64_t *row0 = s_sh + 4 * CIAO_MAX_SHARDS;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < CIAO_MAX_SHARDS; ++j) k += (j < nshards && r >= row0[j]) ? 1 : 0;
+    const int64_t local = r - row0[k];
+    auto glob = [](int64_t q) { return (T *)(__attribute__((address_space(1))) T *)(uintptr_t)q; };
+    AFShardRow<T> o;
+    o.arow = glob(s_sh[k]) + local * ld;
+    o.bp = s_sh[CIAO_MAX_SHARDS + k] ? glob(s_sh[CIAO_MAX_SHARDS + k]) + local : nullptr;
+    o.trow = glob(s_sh[2 * CIAO_MAX_SHARDS + k]) + local * d;
+    o.mrow = glob(s_sh[3 * CIAO_MAX_SHARDS + k]) + local * (CHAIN_NW * 4);
+    return o;
+}
 
 template <typename T, int E, int LOSS>
 __global__ void __launch_bounds__(CHAIN_NT) afinito_chain_kernel(AFinitoArgs<T> a)
@@ -2348,22 +2394,27 @@ __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst)
 
 constexpr int AF_CHUNK = 512;
 
-template <typename T, int J, int NT = CHAIN_NT>
+template <typename T, int J, int NT = CHAIN_NT, bool SHARDED = false>
 constexpr size_t afinito_dma_lds_bytes()
 {
     constexpr int NW = NT / WAVE;
     constexpr int DEPTH = DmaDepth<(J * NT + 255) / 256, true>::value;
     return (size_t)2 * DEPTH * J * NT * 16 + (size_t)DEPTH * NW * 256 + (AF_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
-           AF_CHUNK * sizeof(T) + AF_CHUNK * sizeof(int) + 16 + 2 * NW * 2 * sizeof(T);
+           AF_CHUNK * sizeof(T) + AF_CHUNK * sizeof(int) + 16 + 2 * NW * 2 * sizeof(T) +
+           (SHARDED ? (2 * (AF_CHUNK + 2 * DEPTH) + AF_SHARD_QW) * sizeof(int64_t) : 0);
 }
 
 // NT = 256, or 64: rows of up to 2 KiB on ONE wave (J = 1 / 2), where the exchange of every trial disappears (as in
 // chain_dma_kernel).  The per-sample scalars keep their N x 4 x 4 layout: the single wave reads copy 0 and writes all four.
-template <typename T, int J, int LOSS, bool MASKED, int NT = CHAIN_NT>
+// SHARDED: the rows live in several allocations (AFinitoArgs::sh*): where a step's data row, table row and scalars are is
+// resolved when its index is staged, 512 steps at a time (the table row's ADDRESS is then what the steps and the hazard flags know
+// the sample by, the other two addresses ride beside it in LDS); the step itself is the same instruction for instruction.
+template <typename T, int J, int LOSS, bool MASKED, int NT = CHAIN_NT, bool SHARDED = false>
 __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
 {
     constexpr int NW = NT / WAVE;
     static_assert(NW == 1 || NW == CHAIN_NW, "one wave or four");
+    static_assert(!SHARDED || NW == CHAIN_NW, "the sharded chain runs on four waves");
     using V = typename VecOfC<T>::type;
     constexpr int VEC = 16 / sizeof(T);
     constexpr int DEPTH = DmaDepth<(J * NT + 255) / 256, true>::value;
@@ -2393,6 +2444,11 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
     cur += CH * sizeof(int);
     cur += (16 - (reinterpret_cast<uintptr_t>(cur) & 15)) & 15;
     T(*red)[NW][2] = reinterpret_cast<T(*)[NW][2]>(cur);
+    cur += 2 * NW * 2 * sizeof(T);
+    cur += (8 - (reinterpret_cast<uintptr_t>(cur) & 7)) & 7;
+    int64_t *s_pa = reinterpret_cast<int64_t *>(cur);                    // SHARDED: the steps' data-row addresses ...
+    int64_t *s_pm = s_pa + (SHARDED ? CH + 2 * DEPTH : 0);              // ... the addresses of their scalars ...
+    int64_t *s_sh = s_pm + (SHARDED ? CH + 2 * DEPTH : 0);              // ... and the shard table
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -2401,6 +2457,7 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
     const uint32_t ringA_off = (uint32_t)(uintptr_t)ringA;
     const uint32_t ringT_off = (uint32_t)(uintptr_t)ringT;
     const uint32_t ringM_off = (uint32_t)(uintptr_t)ringM;
+    if constexpr (SHARDED) af_shard_table_to_lds<T>(s_sh, tid);   // (the staging's first __syncthreads orders it before its readers)
 
     // chunk ownership and dead chunks exactly as in chain_dma_kernel
     const int64_t nchunks = d / VEC;
@@ -2446,9 +2503,15 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
         }
     };
 
-    auto refill = [&](int u, int64_t r) {
-        const unsigned char *ap = reinterpret_cast<const unsigned char *>(a.A + r * a.ld);
-        const unsigned char *sp = reinterpret_cast<const unsigned char *>(a.table + r * d);
+    // where a sample's table row and scalars are: unsharded from its row number, SHARDED the staged addresses themselves
+    auto table_row = [&](int64_t row) { return SHARDED ? (T *)(__attribute__((address_space(1))) T *)(uintptr_t)row : a.table + row * d; };
+    auto meta_row = [&](int64_t row, int64_t pm) {
+        return SHARDED ? (T *)(__attribute__((address_space(1))) T *)(uintptr_t)pm : a.meta + row * (CHAIN_NW * 4);
+    };
+    auto refill = [&](int u, int64_t r, int64_t pa, int64_t pm) {
+        const unsigned char *ap = SHARDED ? (const unsigned char *)(__attribute__((address_space(1))) const unsigned char *)(uintptr_t)pa
+                                          : reinterpret_cast<const unsigned char *>(a.A + r * a.ld);
+        const unsigned char *sp = reinterpret_cast<const unsigned char *>(table_row(r));
 #pragma unroll
         for (int j = 0; j < J; ++j)
             glds16(ap + cl[j] * 16, ringA_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
@@ -2456,7 +2519,7 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
         for (int j = 0; j < J; ++j)
             glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
         // this wave's copy of the scalars: lanes l and l + MDW fetch the same dword, only the first MDW LDS dwords are read back
-        const unsigned char *mp = reinterpret_cast<const unsigned char *>(a.meta + (r * CHAIN_NW + wib) * 4);   // CHAIN_NW = the layout's four copies
+        const unsigned char *mp = reinterpret_cast<const unsigned char *>(meta_row(r, pm) + wib * 4);   // the layout's four copies, one per wave
         glds4(mp + (lane & (MDW - 1)) * 4, ringM_off + (uint32_t)((u * NW + wib) * 256));
     };
 
@@ -2464,6 +2527,7 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
         V ar[J], sr[J];
         T m[4];
         int64_t row, row_n;
+        int64_t pm, pa_n, pm_n;   // SHARDED only
         T bi;
         int stale;
     };
@@ -2480,6 +2544,13 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
         for (int q = 0; q < 4; ++q) x.m[q] = mp[q];
         x.row = s_row[DEPTH + s];
         x.row_n = s_row[DEPTH + s + DEPTH];
+        if constexpr (SHARDED) {
+            x.pm = s_pm[DEPTH + s];
+            x.pa_n = s_pa[DEPTH + s + DEPTH];
+            x.pm_n = s_pm[DEPTH + s + DEPTH];
+        } else {
+            x.pm = x.pa_n = x.pm_n = 0;
+        }
         x.bi = s_b[s];
         x.stale = s_stale[s];
     };
@@ -2503,8 +2574,16 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
                 *a.errflag = 1;
                 r = 0;
             }
-            s_row[DEPTH + e] = r;
-            if (e < nch) s_b[e] = a.b ? a.b[r] : T(0);
+            if constexpr (SHARDED) {   // global row -> its shard's memory (which may be another GPU's)
+                const AFShardRow<T> sr = af_shard_resolve<T>(s_sh, a.nshards, r, a.ld, d);
+                s_row[DEPTH + e] = (int64_t)(uintptr_t)sr.trow;
+                s_pa[DEPTH + e] = (int64_t)(uintptr_t)sr.arow;
+                s_pm[DEPTH + e] = (int64_t)(uintptr_t)sr.mrow;
+                if (e < nch) s_b[e] = sr.bp ? *sr.bp : T(0);
+            } else {
+                s_row[DEPTH + e] = r;
+                if (e < nch) s_b[e] = a.b ? a.b[r] : T(0);
+            }
         }
         __syncthreads();
         for (int e = tid; e < nch; e += NT) {
@@ -2517,7 +2596,8 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
         __syncthreads();
         if (base == 0) {
 #pragma unroll
-            for (int u = 0; u < DEPTH; ++u) refill(u, uniform64(s_row[DEPTH + u]));
+            for (int u = 0; u < DEPTH; ++u)
+                refill(u, uniform64(s_row[DEPTH + u]), SHARDED ? uniform64(s_pa[DEPTH + u]) : 0, SHARDED ? uniform64(s_pm[DEPTH + u]) : 0);
         }
         wait_vmcnt<0>();
         drain_vmcnt_visible();
@@ -2549,13 +2629,16 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
                 }
                 const int64_t row = uniform64(x.row);
                 const int64_t row_n = uniform64(x.row_n);
+                const int64_t pm = SHARDED ? uniform64(x.pm) : 0;
+                const int64_t pa_n = SHARDED ? uniform64(x.pa_n) : 0;
+                const int64_t pm_n = SHARDED ? uniform64(x.pm_n) : 0;
                 const T bi = x.bi;
                 if (__builtin_amdgcn_readfirstlane(x.stale)) {
-                    const V *sp = reinterpret_cast<const V *>(a.table + row * d);
+                    const V *sp = reinterpret_cast<const V *>(table_row(row));
 #pragma unroll
                     for (int j = 0; j < J; ++j) x.sr[j] = ok[j] ? sp[cl[j]] : V(T(0));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) x.m[q] = a.meta[(row * CHAIN_NW + wib) * 4 + q];
+                    for (int q = 0; q < 4; ++q) x.m[q] = meta_row(row, pm)[wib * 4 + q];
                     drain_vmcnt_visible();
                 }
                 const T c_old = x.m[0], fi_x = x.m[1], as_i = x.m[3];
@@ -2632,7 +2715,7 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
                 const T c_new = gn.coef();
                 const T r1 = r1_acc;
                 const T r2 = (hg * a.invN) * (c_old - c_new);   // + (hg/N) grad_old - (hg/N) grad_new, both multiples of a_i
-                V *sp = reinterpret_cast<V *>(a.table + row * d);
+                V *sp = reinterpret_cast<V *>(table_row(row));
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
                     if (ok[j]) sp[cl[j]] = p[j];                                                // :146  s_i = z
@@ -2644,14 +2727,14 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
                 }
                 prox_all(hg * plam);                                                            // :150
                 if (NW == 1 ? lane < CHAIN_NW : lane == 0) {   // one wave keeps all four copies of the layout identical
-                    T *mp = a.meta + (row * CHAIN_NW + (NW == 1 ? lane : wib)) * 4;
+                    T *mp = meta_row(row, pm) + (NW == 1 ? lane : wib) * 4;
                     mp[0] = c_new;
                     mp[1] = fi_z;                                                               // :148 fi_x[i] = f_i(z)
                     mp[2] = gi;
                     mp[3] = dz;
                 }
                 ++done;
-                refill(u, row_n);   // after this step's stores (program order); the look-ahead entry always exists
+                refill(u, row_n, pa_n, pm_n);   // after this step's stores (program order); the look-ahead entry always exists
             }
         }
     }

@@ -39,7 +39,7 @@ const CIAO_MAX_SHARDS = 8
 struct CiaoShardTable                       # ciao_shard_table: fixed-size C arrays are NTuples
     nshards::Int32; owner::Int32
     row0::NTuple{9,Int64}
-    A::NTuple{8,Ptr{Cvoid}}; b::NTuple{8,Ptr{Cvoid}}; table::NTuple{8,Ptr{Cvoid}}
+    A::NTuple{8,Ptr{Cvoid}}; b::NTuple{8,Ptr{Cvoid}}; table::NTuple{8,Ptr{Cvoid}}; meta::NTuple{8,Ptr{Cvoid}}
 end
 const CIAO_ABI_VERSION = Int32(2)
 const CIAO_F32, CIAO_F64 = Int32(0), Int32(1)

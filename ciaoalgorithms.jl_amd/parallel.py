@@ -105,7 +105,7 @@ class ShardGroup:
     """The sequential chains (SVRG inner cycle, SAGA steps) on a row-sharded problem: ONE rank -- the owner -- runs the chain
     and reads the other ranks' rows through peer-mapped pointers over xGMI (include/ciao_hip.h:
     ciao_ctx_set_shards).  `install` exchanges HIP IPC handles of every rank's A, b (and SAGA table shard) through the process
-    group, opens them on the owner and hands the library the shard table; the other ranks install the same partition
+    group (adaptive Finito: also of its s-table and per-sample scalars), opens them on the owner and hands the library the shard table; the other ranks install the same partition
     without pointers.  Contiguous block partition only (parallel.shard_rows); an all-reduce hook must be installed too."""
 
     def __init__(self, ctx, owner: int = 0, group=None):
@@ -131,7 +131,7 @@ class ShardGroup:
         self._opened.append((out.value, off))
         return out.value
 
-    def install(self, F, table=None):
+    def install(self, F, table=None, meta=None):
         import torch.distributed as dist
         rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
         if world > L.MAX_SHARDS:
@@ -140,7 +140,8 @@ class ShardGroup:
             raise ValueError("sharded chains need the contiguous block partition (parallel.shard_rows)")
         self.close()
         mine = {"n": F.N, "row0": F.row0, "ld": F.ld, "A": self._export(F.A) if F.N else None,
-                "b": self._export(F.b) if F.N else None, "table": self._export(table) if (table is not None and F.N) else None}
+                "b": self._export(F.b) if F.N else None, "table": self._export(table) if (table is not None and F.N) else None,
+                "meta": self._export(meta) if (meta is not None and F.N) else None}
         every = [None] * world
         dist.all_gather_object(every, mine, group=self.group)
         row0 = 0
@@ -161,10 +162,13 @@ class ShardGroup:
             if k == rank:   # the owner's own shard: its local pointers
                 tbl.A[k], tbl.b[k] = F.A.data_ptr(), F.b.data_ptr()
                 tbl.table[k] = table.data_ptr() if table is not None else None
+                tbl.meta[k] = meta.data_ptr() if meta is not None else None
             else:
                 tbl.A[k], tbl.b[k], tbl.table[k] = self._open(e["A"]), self._open(e["b"]), self._open(e["table"])
+                tbl.meta[k] = self._open(e["meta"])
         tbl.row0[world] = acc
-        self._keep = (F, table)
+        self._keep = (F, table, meta)
+        self.row0 = [int(tbl.row0[k]) for k in range(world + 1)]
         self.ctx.set_shards(tbl)
         dist.barrier(group=self.group)   # nobody may free / reuse an exported allocation before the owner has opened it
         return tbl

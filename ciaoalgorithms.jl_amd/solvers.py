@@ -516,18 +516,21 @@ class FINITO_adaptive_iterable(_Iterable):
 
     _pads_features = False   # its Lipschitz probe (x0 .+ 1, divided by sqrt(d), :86-88) counts the coordinates
 
-    def __init__(self, R, F, g, x0, N, L, tol, tol_b, sweeping, α, ctx=None, stream=None):
+    def __init__(self, R, F, g, x0, N, L, tol, tol_b, sweeping, α, ctx=None, stream=None, shards=None):
         super().__init__(R, F, g, x0, N, ctx, stream)
         self.L, self.tol, self.tol_b, self.sweeping, self.α = L, tol, tol_b, int(sweeping), α
-        if self.F.row0 != 0 or self.F.N != self.N:
-            raise ValueError("adaptive Finito is a sequential chain: it needs the whole problem on one device")
+        self.shards = shards   # parallel.ShardGroup: the owner's chain reads and writes the other shards' rows, table rows and scalars
+        if (self.F.row0 != 0 or self.F.N != self.N) and shards is None:
+            raise ValueError("adaptive Finito is a sequential chain: on a row-sharded problem it needs a parallel.ShardGroup (shards=...)")
 
     def _init(self):                                                       # Finito_adaptive.jl:59-98
         dev = self._x0_dev.device
-        s = torch.empty((self.N, self.d), dtype=self.R, device=dev)
-        meta = torch.empty((self.N, 4, 4), dtype=self.R, device=dev)
+        s = torch.empty((self.F.N, self.d), dtype=self.R, device=dev)      # (a rank's own rows on a row-sharded problem)
+        meta = torch.empty((self.F.N, 4, 4), dtype=self.R, device=dev)
         hg = torch.empty(1, dtype=self.R, device=dev)
         av, z = self._new(), self._new()
+        if self.shards is not None:
+            return self._init_sharded(s, meta, hg, av, z)
         self.ctx.afinito_init(self.F, self.g, self.α, self._x0_dev, s, meta, av, z, hg)
         try:
             self.ctx.synchronize()
@@ -554,6 +557,53 @@ class FINITO_adaptive_iterable(_Iterable):
                 L_int = np.float64(np_R(nmg)) / (np.float64(t) * np.sqrt(np.float64(n_x0)))        # :86 (Float64 whatever R, :73)
                 L_int /= np.float64(self.N)                                                         # :87
                 gam[i] = float(np_R(np.float64(np_R(self.α)) / L_int))                              # :88
+            self.ctx.afinito_init(self.F, self.g, self.α, self._x0_dev, s, meta, av, z, hg, gam_override=gam.contiguous())
+            self.ctx.synchronize()
+        st = FINITO_adaptive_state(s, meta, hg, av, z, self.N)
+        st._it = self
+        return st
+
+    def _init_sharded(self, s, meta, hg, av, z):
+        """The same init on a row-sharded problem: every rank sweeps its own rows (table rows, scalars; sum and hat_gamma all-reduced),
+        the re-probes of :78-85 go through the ranks' replicated streams in increasing GLOBAL i -- every rank draws, the rank that
+        holds the sample probes, its result decides for all how many draws the sample takes."""
+        import torch.distributed as dist
+        grp = self.shards.group
+        rank = dist.get_rank(grp)
+        self.shards.install(self.F, table=s, meta=meta)
+        self.ctx.afinito_init(self.F, self.g, self.α, self._x0_dev, s, meta, av, z, hg)
+        try:
+            self.ctx.synchronize()
+        except CiaoError as e:
+            if e.status != ERR_UNSUPPORTED:
+                raise
+        gam = meta[:, 0, 2].clone()
+        mine = [self.F.row0 + i for i in torch.nonzero(gam < 0).flatten().tolist()]
+        every = [None] * dist.get_world_size(grp)
+        dist.all_gather_object(every, mine, group=grp)
+        todo = sorted((gi, r) for r, rows in enumerate(every) for gi in rows)
+        if todo:
+            np_R = np.float64 if self.R == torch.float64 else np.float32
+            eps = float(np.finfo(np_R).eps)
+            dev = self._x0_dev.device
+            for gi, holder in todo:
+                t = 1
+                while True:
+                    if rank == 0:
+                        print("initial upper bound for L too small")                                # :79
+                    signs = self.stream.rand_signs(self.d).astype(np_R)                             # :80 (every rank: the streams stay in step)
+                    box = [None]
+                    if rank == holder:
+                        box[0] = self.ctx.afinito_probe(self.F, gi - self.F.row0, self._x0_dev, torch.from_numpy(signs).to(dev), float(t))
+                    dist.broadcast_object_list(box, src=dist.get_global_rank(grp, holder) if grp is not None else holder, group=grp)
+                    nmg = box[0]
+                    t *= 2                                                                          # :83
+                    if not nmg < eps:
+                        break
+                if rank == holder:
+                    L_int = np.float64(np_R(nmg)) / (np.float64(t) * np.sqrt(np.float64(self.d)))   # :86
+                    L_int /= np.float64(self.N)                                                     # :87
+                    gam[gi - self.F.row0] = float(np_R(np.float64(np_R(self.α)) / L_int))           # :88
             self.ctx.afinito_init(self.F, self.g, self.α, self._x0_dev, s, meta, av, z, hg, gam_override=gam.contiguous())
             self.ctx.synchronize()
         st = FINITO_adaptive_state(s, meta, hg, av, z, self.N)
@@ -830,7 +880,9 @@ class Finito(_Solver):
         self.minibatch, self.maxit, self.verbose, self.freq, self.α, self.tol, self.tol_b = (
             tuple(minibatch), int(maxit), verbose, int(freq), α, tol, tol_b)
 
-    def _iterable(self, x0, F=None, g=None, L=None, N=None, ctx=None, stream=None, fallback=None, backend=None):   # Finito.jl:80-116
+    def _iterable(self, x0, F=None, g=None, L=None, N=None, ctx=None, stream=None, fallback=None, backend=None, shards=None):   # Finito.jl:80-116
+        if shards is not None and not self.adaptive:
+            raise ValueError("shards= is for the sequential chains (adaptive Finito here); Finito / LFinito batches shard by rows alone")
         if self.LFinito:
             return _route(lambda: FINITO_LFinito_iterable(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α,
                                                           ctx=ctx, stream=stream),
@@ -840,7 +892,7 @@ class Finito(_Solver):
             if backend == "host":
                 raise NotImplementedError("the host route has no adaptive Finito")
             return FINITO_adaptive_iterable(self.R, F, g, x0, N, L, self.tol, self.tol_b, self.sweeping, self.α,
-                                            ctx=ctx, stream=stream)
+                                            ctx=ctx, stream=stream, shards=shards)
         return _route(lambda: FINITO_basic_iterable(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α,
                                                     ctx=ctx, stream=stream),
                       lambda: HR.HostFinito(self.R, F, g, x0, N, L, self.γ, self.sweeping, self.minibatch[1], self.α, stream=stream),

@@ -242,10 +242,14 @@ typedef struct {
     int64_t row0[CIAO_MAX_SHARDS + 1];
     const void *A[CIAO_MAX_SHARDS];
     const void *b[CIAO_MAX_SHARDS];
-    void *table[CIAO_MAX_SHARDS];           /* SAGA gradient table shards (NULL when only SVRG is run) */
+    void *table[CIAO_MAX_SHARDS];           /* SAGA gradient table / adaptive Finito s-table shards (NULL when only SVRG is run) */
+    void *meta[CIAO_MAX_SHARDS];            /* adaptive Finito: the per-sample scalars of the shard's rows (n x 4 x 4; NULL otherwise) */
 } ciao_shard_table;
 /* Installs (copies) the shard table; NULL removes it.  While one is set AND an all-reduce hook is installed,
- * ciao_svrg_inner / ciao_svrg_iterate / ciao_saga_steps are valid on the row-sharded problem: `idx` then holds GLOBAL rows,
+ * ciao_svrg_inner / ciao_svrg_iterate / ciao_saga_steps / ciao_afinito_init / ciao_afinito_steps are valid on the row-sharded
+ * problem (adaptive Finito: every rank initialises its own rows' table and scalars in one all-reduced sweep; the owner's chain
+ * then reads and writes the other shards' table rows and scalars, and av, z, hat_gamma and the two counters reach every rank;
+ * rows must be whole 16-byte chunks of at most 32 KiB): `idx` then holds GLOBAL rows,
  * the owner runs the chain, every other rank skips it, and the iterates the chain produced (z, w; for SAGA z, av) reach all
  * ranks through one all-reduce of 2d scalars in which the non-owners contribute zeros; the tail and the full pass of
  * ciao_svrg_iterate then run sharded as usual.  (The a_i'z_full cache is not used across shards.) */

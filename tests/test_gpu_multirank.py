@@ -131,6 +131,49 @@ def _worker(rank, world, port, q):
         row0, n = shard_rows(N, rank, world)
         ok["sharded_saga_table_shard"] = bool(np.abs(ss.s.cpu().numpy() - sr.s[row0:row0 + n]).max() <= 1e-11 * np.abs(sr.s).max())
         grp2.close()
+        # ---- adaptive Finito (Finito_adaptive.jl:59-155) on the row-sharded problem: every rank initialises its own rows' table rows and
+        # scalars (one all-reduced sweep), rank 0's chain then reads and writes rank 1's table rows and scalars through IPC-mapped pointers
+        for sweeping in (1, 3):
+            grp3 = ShardGroup(ctx, owner=0)
+            xs, nit = S.Finito(np.float64, maxit=3 * N, sweeping=sweeping, adaptive=True)(np.zeros(d), F=F, g=g, L=Li, N=N, ctx=ctx,
+                                                                                       stream=IndexStream(30 + sweeping), shards=grp3)
+            ok[f"sharded_afinito_kernel_sw{sweeping}"] = (rank != 0) or ("afinito_dma_kernel" in ctx.last_kernel() and "sharded" in ctx.last_kernel())
+            xr, rit_n = RS.finito(op, og, np.zeros(d), maxit=3 * N, sweeping=sweeping, adaptive=True, L=Li, stream=IndexStream(30 + sweeping))
+            ok[f"sharded_afinito_sw{sweeping}"] = bool(nit == rit_n and np.abs(xs - xr).max() <= 1e-9 * max(np.abs(xr).max(), 1e-30))
+            gathered = [torch.zeros(d, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(gathered, torch.from_numpy(np.ascontiguousarray(xs)))
+            ok[f"sharded_afinito_replicas_bitwise_sw{sweeping}"] = all(torch.equal(gathered[0], t) for t in gathered)
+            grp3.close()
+        # ... with samples whose Lipschitz probe at x0 .+ 1 is degenerate on BOTH ranks (:78-85): every rank draws the +-1 vectors from
+        # its replicated stream in increasing global i, the rank that holds the sample probes and its result decides for all
+        Ad = A.copy()
+        for i in (3, 57, 250, 402):
+            Ad[i] = 0
+            Ad[i, 5], Ad[i, 6] = 0.7, -0.7
+        opd = O.Problem("ls", Ad, b, float(N))
+        row0, n = shard_rows(N, rank, world)
+        Fd = PackedF(L.LOSS_LS, torch.from_numpy(Ad[row0:row0 + n]).to(dev), torch.from_numpy(b[row0:row0 + n]).to(dev), float(N),
+                     N_total=N, row0=row0)
+        draws = IndexStream(123)
+        signs = np.stack([draws.rand_signs(d).astype(np.float64) for _ in range(64)])
+        rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(opd, og, np.float64(0.999), np.zeros(d), retry_signs=signs)
+        grp4 = ShardGroup(ctx, owner=0)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            sd = next(iter(S.iterator(S.Finito(np.float64, adaptive=True), np.zeros(d), F=Fd, g=g, N=N, ctx=ctx, stream=IndexStream(123), shards=grp4)))
+        ok["sharded_afinito_reprobe_gamma"] = bool(np.abs(sd.γ.cpu().numpy() - rgam[row0:row0 + n]).max() <= 1e-10 * np.abs(rgam).max()
+                                                   and float(sd.γ.min()) > 0)
+        ok["sharded_afinito_reprobe_av"] = bool(np.abs(sd.av.cpu().numpy() - rav).max() <= 1e-11 * np.abs(rav).max() + 1e-14)
+        ok["sharded_afinito_reprobe_hg"] = bool(abs(sd.hat_γ - float(rhg)) <= 1e-12 * float(rhg))
+        idxa = IndexStream(5).rand_indices(N, 500)
+        done, trials = ctx.afinito_steps(Fd, g, 0.999, 1e-9, idxa, sd.s, sd.meta, sd.av, sd.z, sd.hat_γ_dev)
+        rdone, rhg2, rtrials = O.afinito_steps(opd, og, np.float64(0.999), np.float64(1e-9), idxa, rt, rg, rgam, rfi, rhg, rav, rz)
+        ok["sharded_afinito_steps_counts"] = bool(done == rdone == 500 and trials == rtrials)
+        ok["sharded_afinito_steps_z"] = bool(np.abs(sd.z.cpu().numpy() - rz).max() <= 1e-10 * max(np.abs(rz).max(), 1e-30))
+        ok["sharded_afinito_steps_table_shard"] = bool(np.abs(sd.s.cpu().numpy() - rt[row0:row0 + n]).max() <= 1e-10 * max(np.abs(rt).max(), 1e-30))
+        ok["sharded_afinito_steps_hg"] = bool(abs(sd.hat_γ - float(rhg2)) <= 1e-11 * float(rhg2))
+        grp4.close()
         # ---- ProShI on row-sharded agents (ProShI_basic.jl:76-87, :109-121): every rank owns a block (or every world-th) of the agents and
         # their table rows -- the table IS the solution, so it stays sharded; a batch updates the members a rank owns and one
         # all-reduce of d + 1 scalars gives every rank the same av / z (hat_gamma = sum_i gamma_i is all-reduced in the init)

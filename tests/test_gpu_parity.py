@@ -600,6 +600,93 @@ def test_chain_over_a_shard_table_is_bitwise_the_unsharded_chain(ctx, ciao, dtyp
     close(outs[1][0], rw, dtype, scale=10, what="sharded svrg_inner w vs oracle")
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("loss", ["ls", "logistic"])
+@pytest.mark.parametrize("d", [256, 1000, 2048, 4096])
+def test_adaptive_finito_over_a_shard_table_is_bitwise_the_unsharded_chain(ctx, ciao, dtype, loss, d):
+    """Finito_adaptive.jl:118-150 with the rows, the rows of the s-table and the per-sample scalars in several allocations (three
+    uneven shards, one of them empty): the owner's chain finds each step's three addresses through the shard table.  Same arithmetic,
+    same order: iterates, table rows, scalars and the backtracking counts bitwise those of the unsharded chain (itself held against
+    the oracle in test_adaptive_finito_steps), hazards inside the look-ahead window and across a staging boundary included."""
+    import torch
+    import ciaoalgorithms_jl_amd._lib as L
+    N = 300
+    A, b, x0 = P.synthetic(loss, N, d, dtype, seed=43)
+    op, dp = make(loss, A, b, float(N) if loss == "ls" else 1.0, dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.02)
+    tdt = dev(x0).dtype
+    cuts = [0, 117, 117, 230, N]
+    idx = ciao.IndexStream(8).rand_indices(N, 1300)
+    idx[5:8] = idx[5]
+    idx[10] = idx[8]
+    idx[510:514] = idx[509]                             # a hazard across the staging boundary (512 steps)
+    outs = []
+    for sharded in (False, True):
+        table = torch.empty((N, d), dtype=tdt, device="cuda")
+        meta = torch.empty((N, 4, 4), dtype=tdt, device="cuda")
+        hg = torch.empty(1, dtype=tdt, device="cuda")
+        av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+        ctx.afinito_init(dp, dg, 0.999, dev(x0), table, meta, av, z, hg)
+        ctx.synchronize()
+        if sharded:   # the shards as allocations of their own: nothing may be reached through the problem's base pointers
+            parts = [(dp.A[c0:c1].clone(), dp.b[c0:c1].clone(), table[c0:c1].clone(), meta[c0:c1].clone()) for c0, c1 in zip(cuts, cuts[1:])]
+            table.fill_(float("nan")), meta.fill_(float("nan"))
+            t = L.ShardTable()
+            t.nshards, t.owner = len(cuts) - 1, 1
+            for k, (pa, pb, pt, pm) in enumerate(parts):
+                t.row0[k] = cuts[k]
+                if pa.shape[0]:
+                    t.A[k], t.b[k], t.table[k], t.meta[k] = pa.data_ptr(), pb.data_ptr(), pt.data_ptr(), pm.data_ptr()
+            t.row0[len(cuts) - 1] = N
+            ctx.set_shards(t)
+        ctx.set_option("chain_four_waves", 1)   # the sharded chain runs on four waves whatever the row length: the same for its twin
+        try:
+            done, trials = ctx.afinito_steps(dp, dg, 0.999, 1e-9, idx, table, meta, av, z, hg)
+            kern = ctx.last_kernel()
+            ctx.synchronize()
+        finally:
+            ctx.set_shards(None)
+            ctx.set_option("chain_four_waves", 0)
+        assert "afinito_dma_kernel" in kern and ("sharded" in kern) == sharded and "block=256" in kern, kern
+        if sharded:
+            assert torch.isnan(table).all() and torch.isnan(meta).all(), "the chain wrote through the unsharded pointers"
+            table = torch.cat([p_[2] for p_ in parts])
+            meta = torch.cat([p_[3] for p_ in parts])
+        outs.append([done, trials] + [t_.cpu().numpy() for t_ in (z, av, hg, table, meta)])
+    assert outs[0][0] == outs[1][0] == len(idx) and outs[0][1] == outs[1][1]
+    for u, v in zip(outs[0][2:], outs[1][2:]):
+        assert np.array_equal(u, v)
+
+
+def test_adaptive_finito_shard_table_refusals(ctx, ciao):
+    """Rows that are not whole 16-byte chunks cannot take the LDS-DMA kernel: refused over a shard table, never silently unsharded;
+    a shard with rows but no meta pointer on the owner is named."""
+    import torch
+    import ciaoalgorithms_jl_amd._lib as L
+    for d, msg in ((1001, "whole 16-byte chunks"), (1024, "no meta pointer")):
+        A, b, x0 = P.synthetic("ls", 40, d, np.float64)
+        _, dp = make("ls", A, b, 40.0, np.float64)
+        _, dg = make_g("zero", np.float64, d)
+        table = torch.empty((40, d), dtype=torch.float64, device="cuda")
+        meta = torch.empty((40, 4, 4), dtype=torch.float64, device="cuda")
+        hg = torch.empty(1, dtype=torch.float64, device="cuda")
+        av, z = torch.empty(d, dtype=torch.float64, device="cuda"), torch.empty(d, dtype=torch.float64, device="cuda")
+        ctx.afinito_init(dp, dg, 0.999, dev(x0), table, meta, av, z, hg)
+        t = L.ShardTable()
+        t.nshards, t.owner = 1, 1
+        t.row0[0], t.row0[1] = 0, 40
+        t.A[0], t.b[0], t.table[0] = dp.A.data_ptr(), dp.b.data_ptr(), table.data_ptr()
+        if d == 1001:
+            t.meta[0] = meta.data_ptr()
+        ctx.set_shards(t)
+        try:
+            with pytest.raises(ciao._lib.CiaoError, match=msg):
+                ctx.afinito_steps(dp, dg, 0.999, 1e-9, np.zeros(3, np.int64), table, meta, av, z, hg)
+        finally:
+            ctx.set_shards(None)
+    ctx.synchronize()
+
+
 def O_svrg_state(op, x0):
     from oracle import oracle as O
     return O.svrg_init(op, x0)
