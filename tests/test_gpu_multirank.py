@@ -406,6 +406,18 @@ def _peer_worker(rank, world, port, q):
         ok["sharded_saga_over_peers_vs_oracle"] = bool(np.abs(ss.z.cpu().numpy() - sr.z).max() <= 1e-11 * max(np.abs(sr.z).max(), 1e-30))
         ok["sharded_saga_over_peers_table_shard"] = bool(np.abs(ss.s.cpu().numpy() - sr.s[row0:row0 + n]).max() <= 1e-11 * np.abs(sr.s).max())
         grp2.close()
+        # adaptive Finito's chain through the mailboxes: av and z as the chains' hand-over, hat_gamma and the two counters as a second,
+        # 3-element Float64 reduction (rank 1 owns the chain, rank 0 waits)
+        grp2b = ShardGroup(ctx, owner=1)
+        xs, nit = S.Finito(np.float64, maxit=2 * N, sweeping=1, adaptive=True)(np.zeros(d), F=F, g=g, L=Li, N=N, ctx=ctx,
+                                                                                 stream=IndexStream(41), shards=grp2b)
+        ctx.synchronize()
+        xr, rit_n = RS.finito(op, og, np.zeros(d), maxit=2 * N, sweeping=1, adaptive=True, L=Li, stream=IndexStream(41))
+        ok["sharded_afinito_over_peers_vs_oracle"] = bool(nit == rit_n and np.abs(xs - xr).max() <= 1e-9 * max(np.abs(xr).max(), 1e-30))
+        gathered = [torch.zeros(d, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.from_numpy(np.ascontiguousarray(xs)))
+        ok["sharded_afinito_over_peers_replicas_bitwise"] = all(torch.equal(gathered[0], t) for t in gathered)
+        grp2b.close()
         # a long chain (1.5M steps: about half a second of kernel) that the waiting rank has to sit out
         idxl = IndexStream(11).rand_indices(N, 1_500_000)
         grp3 = ShardGroup(ctx, owner=0)
