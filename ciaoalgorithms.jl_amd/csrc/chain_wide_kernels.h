@@ -61,6 +61,33 @@ __device__ __forceinline__ bool wide_get(const unsigned long long *w, unsigned i
         }
     }
 }
+// N consecutive words of one slot at once: all the loads of a poll are in flight together (one after the other they cost a memory
+// round trip each -- an fp64 pair of sums is four words), the poll is repeated until every word carries `seq`
+template <int N>
+__device__ __forceinline__ bool wide_get_run(const unsigned long long *w, unsigned int seq, unsigned int (&payload)[N])
+{
+    unsigned long long t0 = 0;
+    for (unsigned spins = 0;; ++spins) {
+        unsigned long long v[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) all = all && ((unsigned int)v[i] == seq);
+        if (all) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) payload[i] = (unsigned int)(v[i] >> 32);
+            return true;
+        }
+        if ((spins & 1023u) == 1023u) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0)
+                t0 = now;
+            else if (now - t0 > WIDE_TIMEOUT_TICKS)
+                return false;
+        }
+    }
+}
 template <typename T>
 struct WideWord;
 template <>
@@ -74,6 +101,7 @@ struct WideWord<float> {
         v = __uint_as_float(p);
         return true;
     }
+    static __device__ __forceinline__ float decode(const unsigned int *p) { return __uint_as_float(p[0]); }
 };
 template <>
 struct WideWord<double> {
@@ -90,6 +118,10 @@ struct WideWord<double> {
         if (!wide_get(w, seq, hi) || !wide_get(w + 1, seq, lo)) return false;
         v = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
         return true;
+    }
+    static __device__ __forceinline__ double decode(const unsigned int *p)
+    {
+        return __longlong_as_double((long long)(((unsigned long long)p[0] << 32) | p[1]));
     }
 };
 
@@ -240,17 +272,19 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
             W::put(mine, v1, seq);
             if (TWO) {
                 const T v2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
-                W::put(mine + 2, v2, seq);
+                W::put(mine + W::N, v2, seq);
             }
         }
         if (tid < G) {
             const unsigned long long *theirs = wa.box + ((size_t)(s & 1) * WIDE_GMAX + lane) * 4;
-            T v1 = T(0), v2 = T(0);
-            bool ok = W::get(theirs, seq, v1);
-            if (TWO) ok = W::get(theirs + 2, seq, v2) && ok;
-            if (!ok) s_fail = 1;
-            gath[lane][0] = v1;
-            gath[lane][1] = v2;
+            unsigned int pw[(TWO ? 2 : 1) * W::N];
+            if (!wide_get_run(theirs, seq, pw)) {
+                s_fail = 1;
+#pragma unroll
+                for (int i = 0; i < (TWO ? 2 : 1) * W::N; ++i) pw[i] = 0;
+            }
+            gath[lane][0] = W::decode(pw);
+            gath[lane][1] = TWO ? W::decode(pw + (TWO ? W::N : 0)) : T(0);
         }
         __syncthreads();
         if (s_fail) {   // a workgroup of the chain never arrived: give up everywhere (the others run into the same bound)
@@ -340,6 +374,292 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
             a.z[col[e]] = zacc[e];
         else
             a.av[col[e]] = av[e];   // (SAGA, Finito, LFinito: the aggregate moves with the chain)
+    }
+}
+
+}  // namespace ciao
+
+namespace ciao {
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Adaptive Finito (Finito_adaptive.jl:118-150) on rows beyond one workgroup's registers: the same column split and the same mailbox.
+// One exchange per backtracking TRIAL -- both sums of the trial (a_i'z and |z - s_i|^2) travel in one mailbox slot -- and every
+// workgroup takes the same decisions from the same totals (added in the same order everywhere), so the number of exchanges is the
+// same in all of them; the exchange counter, not the step, numbers the mailbox words.  The sample's four scalars (c_i, f_i(x_i),
+// gamma_i, a_i's_i) have ONE reader and writer, workgroup 0 (its own stores and loads: program order), which hands them to the others
+// with the first exchange of every step in its slot's upper words.  hat_gamma lives in every workgroup and moves identically.
+// The arithmetic is afinito_dma_kernel's, element for element; the dot products are added slices first, then workgroups.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int AFW_WORDS = 16;   // mailbox words per workgroup and parity: two sums + workgroup 0's four scalars (fp64: two words each)
+
+template <typename T, int E, int LOSS>
+__global__ void __launch_bounds__(WIDE_NT) afinito_wide_kernel(AFinitoArgs<T> a, WideArgs wa)
+{
+    constexpr int NW = WIDE_NT / WAVE;
+    using W = WideWord<T>;
+    constexpr int WN = W::N;
+    __shared__ T red[2][NW][2];
+    __shared__ T gath[WIDE_GMAX][2];
+    __shared__ T s_meta[4];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x, G = wa.G;
+    const int64_t d = a.d;
+    const int64_t base = (int64_t)g * wa.slice;
+    if (tid == 0) s_fail = 0;
+
+    bool valid[E];
+    int64_t col[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        col[e] = base + tid + (int64_t)e * WIDE_NT;
+        valid[e] = col[e] < d && col[e] < base + wa.slice;
+        if (!valid[e]) col[e] = d - 1;
+    }
+    const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
+    const bool boxed = (a.g.kind == CIAO_PROX_BOX);
+    T p[E], av[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        p[e] = valid[e] ? a.z[col[e]] : T(0);
+        av[e] = valid[e] ? a.av[col[e]] : T(0);
+    }
+    T hg = *a.hg;
+    auto prox_at = [&](T v, T gl, int e) {
+        if (!boxed) return prox_l1(v, gl);
+        const T lo = a.g.lo_vec ? a.g.lo_vec[col[e]] : a.g.lo;
+        const T hi = a.g.hi_vec ? a.g.hi_vec[col[e]] : a.g.hi;
+        return prox_bf(v, gl, lo, hi);
+    };
+    auto row_of = [&](int64_t s) {
+        int64_t row = a.idx[s];
+        if ((uint64_t)row >= (uint64_t)a.N) {
+            if (tid == 0 && g == 0) *a.errflag = 1;
+            row = 0;
+        }
+        return row;
+    };
+    auto load_row = [&](T(&o)[E], int64_t row) {
+        const T *ap = a.A + row * a.ld;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = __builtin_nontemporal_load(ap + col[e]);
+    };
+    auto load_tab = [&](T(&o)[E], int64_t row) {
+        const T *sp = a.table + row * d;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = sp[col[e]];
+    };
+    struct Meta {
+        T c, f, gam, as;
+    };
+    auto load_meta = [&](Meta &m, int64_t row) {   // workgroup 0 only: every wave its own copy of the layout's four (written by its lane 0)
+        const T *mp = a.meta + (row * CHAIN_NW + wib) * 4;
+        m.c = mp[0], m.f = mp[1], m.gam = mp[2], m.as = mp[3];
+    };
+
+    // rows, table rows and (workgroup 0) scalars of the next two steps in flight, three register sets in rotation (chain_wide_kernel)
+    T B0[E], B1[E], B2[E], S0[E], S1[E], S2[E];
+    Meta M0{}, M1{}, M2{};
+    int64_t q0 = row_of(0), q1 = a.nsteps > 1 ? row_of(1) : q0, q2 = q0, inext = a.nsteps > 2 ? row_of(2) : q0;
+    T c0 = a.b ? a.b[q0] : T(0), c1 = a.b ? a.b[q1] : T(0), c2 = T(0);
+    if (g == 0) {
+        load_meta(M0, q0);
+        if (a.nsteps > 1) load_meta(M1, q1);
+    }
+    load_row(B0, q0);
+    load_tab(S0, q0);
+    if (a.nsteps > 1) {
+        load_row(B1, q1);
+        load_tab(S1, q1);
+    }
+    unsigned int xc = 0;   // exchanges made so far: numbers the mailbox words, picks the parity
+    long long done = 0, trials = 0;
+    bool stop = false, fail = false;
+    __syncthreads();
+
+    // one exchange: this workgroup's (v1, v2) out, everybody's in, added in workgroup order; with_meta: workgroup 0's scalars ride along
+    auto exchange = [&](T &v1, T &v2, bool with_meta, Meta &m) -> bool {
+        const unsigned int seq = xc + 1;
+        unsigned long long *mine = wa.box + ((size_t)(xc & 1) * WIDE_GMAX + g) * AFW_WORDS;
+        if (lane == WAVE - 1) {
+            red[xc & 1][wib][0] = v1;
+            red[xc & 1][wib][1] = v2;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int par = xc & 1;
+            W::put(mine, (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]), seq);
+            W::put(mine + WN, (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]), seq);
+            if (with_meta && g == 0) {
+                W::put(mine + 2 * WN, m.c, seq);
+                W::put(mine + 3 * WN, m.f, seq);
+                W::put(mine + 4 * WN, m.gam, seq);
+                W::put(mine + 5 * WN, m.as, seq);
+            }
+        }
+        if (tid < G) {
+            const unsigned long long *theirs = wa.box + ((size_t)(xc & 1) * WIDE_GMAX + lane) * AFW_WORDS;
+            bool ok;
+            if (with_meta && lane == 0 && g != 0) {   // workgroup 0's slot with its four scalars behind the two sums
+                unsigned int pw[6 * WN];
+                ok = wide_get_run(theirs, seq, pw);
+                if (!ok) {
+#pragma unroll
+                    for (int i = 0; i < 6 * WN; ++i) pw[i] = 0;
+                }
+                gath[lane][0] = W::decode(pw);
+                gath[lane][1] = W::decode(pw + WN);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s_meta[q] = W::decode(pw + (2 + q) * WN);
+            } else {
+                unsigned int pw[2 * WN];
+                ok = wide_get_run(theirs, seq, pw);
+                if (!ok) {
+#pragma unroll
+                    for (int i = 0; i < 2 * WN; ++i) pw[i] = 0;
+                }
+                gath[lane][0] = W::decode(pw);
+                gath[lane][1] = W::decode(pw + WN);
+            }
+            if (!ok) s_fail = 1;
+        }
+        __syncthreads();
+        ++xc;
+        if (s_fail) {
+            if (tid == 0) *a.errflag = 5;
+            return false;
+        }
+        T t = lane < G ? gath[lane][0] : T(0);
+        v1 = readlane(wave_sum_lane63(t), WAVE - 1);
+        t = lane < G ? gath[lane][1] : T(0);
+        v2 = readlane(wave_sum_lane63(t), WAVE - 1);
+        if (with_meta && g != 0) m.c = s_meta[0], m.f = s_meta[1], m.gam = s_meta[2], m.as = s_meta[3];
+        return true;
+    };
+
+    auto step = [&](int64_t s, T(&cur)[E], T(&n2)[E], T(&scur)[E], T(&sn1)[E], T(&sn2)[E], int64_t &w0, int64_t &w1, int64_t &w2, T &b0, T &b2,
+                    Meta &m0, Meta &m1, Meta &m2) {
+        const bool more1 = s + 1 < a.nsteps, more2 = s + 2 < a.nsteps;
+        const int64_t row = w0;
+        const T bi = b0;
+        if (more2) {
+            w2 = inext;
+            if (s + 3 < a.nsteps) inext = row_of(s + 3);
+            b2 = a.b ? a.b[w2] : T(0);
+            if (g == 0) load_meta(m2, w2);
+            asm volatile("" ::: "memory");
+            load_row(n2, w2);
+            load_tab(sn2, w2);
+        }
+        T res[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) res[e] = valid[e] ? p[e] - scur[e] : T(0);   // (columns beyond the slice count for nothing in |z - s_i|^2)
+        Meta m = m0;
+        T gi = T(0), dz = T(0), fi_z = T(0), r1_acc = T(0), c_old = T(0), fi_x = T(0), as_i = T(0);
+        bool first = true;
+        while (true) {
+            if (!first && gi < a.tol_b * a.invN) {   // Finito_adaptive.jl:121-124 (checked before the first trial below, once gamma_i is known)
+                stop = true;
+                break;
+            }
+            T p1 = T(0), p2 = T(0);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const T ak = valid[e] ? cur[e] : T(0);
+                p1 = fmad(ak, p[e], p1);
+                p2 = fmad(res[e], res[e], p2);
+            }
+            p1 = wave_sum_lane63(p1);
+            p2 = wave_sum_lane63(p2);
+            if (!exchange(p1, p2, first, m)) {
+                fail = true;
+                break;
+            }
+            if (first) {   // the sample's scalars are here now (workgroup 0: its own; the others: from its slot)
+                c_old = m.c, fi_x = m.f, gi = m.gam, as_i = m.as;
+                first = false;
+                if (gi < a.tol_b * a.invN) {
+                    stop = true;
+                    break;
+                }
+            }
+            ++trials;
+            dz = p1;
+            const T n2v = p2;
+            const double qc = 0.5 * a.Nd * (double)a.alpha / (double)gi;                        // :128
+            const T r1 = hg / gi;                                                               // :145
+            fi_z = loss_value(LOSS, dz, bi, a.lam);                                             // :125
+            const double fi_model = (double)(fi_x + c_old * (dz - as_i)) + qc * (double)n2v;    // :126-129
+            const T tol = T(10) * Eps<T>::value * (T(1) + fabs2(fi_z));                         // :130
+            if ((double)fi_z <= fi_model + (double)tol) {                                       // :131
+                r1_acc = r1;
+                break;
+            }
+            const T gb = gi;                                                                    // :133
+            gi = (T)((double)gi * 0.8);                                                         // :134
+            const T hg_old = hg;
+            hg = T(1) / (T(1) / hg_old + T(1) / gi - T(1) / gb);                                // :139
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                T t = av[e] / hg_old;                                                           // :136
+                t += scur[e] / gi;                                                              // :137
+                t -= scur[e] / gb;                                                              // :138
+                t *= hg;                                                                        // :140
+                av[e] = t;
+                p[e] = prox_at(t, hg * plam, e);                                                // :141
+                res[e] = valid[e] ? p[e] - scur[e] : T(0);                                      // :142
+            }
+        }
+        if (stop || fail) return;
+        // the main step, :145-150
+        const GradCoef<T> gn = grad_coef_t<T, LOSS>(dz, bi, a.lam);
+        const T c_new = gn.coef();
+        const T r1 = r1_acc;
+        const T r2 = (hg * a.invN) * (c_old - c_new);
+        T *sp = a.table + row * d;
+        // the table rows (and, workgroup 0, the scalars) of the next two steps were requested before this step's stores: where they are
+        // this very sample's, what this step writes replaces them
+        const bool fix1 = more1 && w1 == row, fix2 = more2 && w2 == row;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (valid[e]) sp[col[e]] = p[e];                                                    // :146  s_i = z
+            if (fix1) sn1[e] = p[e];
+            if (fix2) sn2[e] = p[e];
+            const T t = fmad(r1, res[e], av[e]);                                                // :145
+            av[e] = fmad(r2, valid[e] ? cur[e] : T(0), t);                                      // :147, :149
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) p[e] = prox_at(av[e], hg * plam, e);                        // :150
+        if (g == 0) {
+            const Meta mn{c_new, fi_z, gi, dz};                                                 // :148 fi_x[i] = f_i(z)
+            if (fix1) m1 = mn;
+            if (fix2) m2 = mn;
+            if (lane == 0) {   // every wave its own copy (it is the one that reads it back: program order)
+                T *mp = a.meta + (row * CHAIN_NW + wib) * 4;
+                mp[0] = c_new, mp[1] = fi_z, mp[2] = gi, mp[3] = dz;
+            }
+        }
+        ++done;
+    };
+    for (int64_t s = 0; s < a.nsteps && !stop && !fail; s += 3) {
+        step(s, B0, B2, S0, S1, S2, q0, q1, q2, c0, c2, M0, M1, M2);
+        if (s + 1 >= a.nsteps || stop || fail) break;
+        step(s + 1, B1, B0, S1, S2, S0, q1, q2, q0, c1, c0, M1, M2, M0);
+        if (s + 2 >= a.nsteps || stop || fail) break;
+        step(s + 2, B2, B1, S2, S0, S1, q2, q0, q1, c2, c1, M2, M0, M1);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (!valid[e]) continue;
+        a.z[col[e]] = p[e];
+        a.av[col[e]] = av[e];
+    }
+    if (g == 0 && tid == 0) {
+        *a.hg = hg;
+        a.counters[0] = done;
+        a.counters[1] = trials;
     }
 }
 

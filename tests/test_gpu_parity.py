@@ -1400,9 +1400,14 @@ def test_adaptive_finito_variants(ctx, ciao, kind, gkind, no_dma):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("kind,N,d,forced", [("ls", 20, 5000, False), ("logistic", 12, 9000, False), ("ls", 6, 20001, False),
                                              ("logistic", 30, 300, True), ("ls", 16, 1024, True)])
-def test_adaptive_finito_on_rows_of_any_length(ctx, ciao, dtype, kind, N, d, forced):
-    """Rows beyond the register-resident shapes (d > 4096; these used to return CIAO_ERR_UNSUPPORTED) run afinito_big_kernel
-    with the state in the caller's vectors; option chain_big forces it at any d, where it must agree with the fast kernels."""
+@pytest.mark.parametrize("route", ["big", "default"])
+def test_adaptive_finito_on_rows_of_any_length(ctx, ciao, dtype, kind, N, d, forced, route):
+    """Rows beyond the register-resident shapes: afinito_big_kernel (one workgroup, the state in the caller's vectors; option chain_big
+    forces it at any d, where it must agree with the fast kernels) and, by default from 32 KiB on, afinito_wide_kernel (the chain shared
+    by several workgroups: one mailbox exchange per backtracking trial, workgroup 0 the keeper of the per-sample scalars); fp32 rows of
+    16-32 KiB keep to the LDS-DMA kernel.  All against the oracle, a sample three times in a row at the end (the look-ahead's fix-ups)."""
+    if route == "default" and forced:
+        pytest.skip("the forced route is the big kernel's")
     import torch
     from oracle import oracle as O
     A, b, x0 = P.synthetic(kind, N, d, dtype, seed=d)
@@ -1419,13 +1424,20 @@ def test_adaptive_finito_on_rows_of_any_length(ctx, ciao, dtype, kind, N, d, for
     rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(alpha), x0)
     close(meta4[:, 0, 2], rgam, dtype, scale=10000, what="adaptive init gamma_i, long rows")   # c(x0 .+ 1) - c(x0) cancels
     close(av, rav, dtype, scale=500, what="adaptive init av, long rows")
-    idx = np.concatenate([ciao.IndexStream(4).rand_indices(N, 3 * N), np.full(3, 2, np.int64)])
+    idx = np.concatenate([ciao.IndexStream(4).rand_indices(N, 3 * N), np.full(3, 2, np.int64), np.array([1, 2, 1, 0, 1], np.int64)])
     ctx.set_option("chain_big", int(forced))
+    if route == "big":
+        ctx.set_option("chain_no_wide", 1)
+        ctx.set_option("chain_no_dma", 1)
     try:
         done, trials = ctx.afinito_steps(dp, dg, alpha, tol_b, idx, table, meta4, av, z, hg)
-        assert "afinito_big_kernel" in ctx.last_kernel(), ctx.last_kernel()
+        rowb = d * np.dtype(dtype).itemsize
+        want = "afinito_big_kernel" if route == "big" else ("afinito_wide_kernel" if rowb > 32768 else "afinito_dma_kernel")
+        assert want in ctx.last_kernel(), ctx.last_kernel()
     finally:
         ctx.set_option("chain_big", 0)
+        ctx.set_option("chain_no_wide", 0)
+        ctx.set_option("chain_no_dma", 0)
     rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(alpha), dtype(tol_b), idx, rt, rg, rgam, rfi, rhg, rav, rz)
     assert done == rdone == len(idx)
     assert abs(trials - rtrials) <= max(2, 0.02 * rtrials), (trials, rtrials)

@@ -135,3 +135,45 @@ def test_wide_chain_epochs_through_the_solver(ctx, ciao):
         O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
         close(zf, rzf, dtype, scale=2000, what=f"svrg epoch {ep} z_full on the several-workgroup chain")
     ctx.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_adaptive_finito_on_several_workgroups_is_repeatable(ctx, ciao, dtype):
+    """afinito_wide_kernel (rows beyond 32 KiB): 3000 steps over 40 samples -- every sample recurs inside the look-ahead window many
+    times, backtracking trials included -- twice from the same state: iterates, table, per-sample scalars (all four copies) and the
+    two counters bitwise equal (every workgroup adds the partials in the same order and takes the same decisions), and the whole run
+    within rounding of the one-workgroup kernel's."""
+    import torch
+    from test_gpu_parity import close, dev, make, make_g
+    import problems as P
+    N, d = 40, 9001
+    A, b, x0 = P.synthetic("ls", N, d, dtype, seed=5)
+    op, dp = make("ls", A, b, float(N), dtype)
+    og, dg = make_g("l1", dtype, d, lam=0.01)
+    tdt = dev(x0).dtype
+    idx = ciao.IndexStream(12).rand_indices(N, 3000)
+    idx[100:104] = idx[100]
+    outs = []
+    for route in ("wide", "wide", "big"):
+        table = torch.empty((N, d), dtype=tdt, device="cuda")
+        meta = torch.empty((N, 4, 4), dtype=tdt, device="cuda")
+        hg = torch.empty(1, dtype=tdt, device="cuda")
+        av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+        ctx.afinito_init(dp, dg, 0.999, dev(x0), table, meta, av, z, hg)
+        ctx.set_option("chain_no_wide", int(route == "big"))
+        try:
+            done, trials = ctx.afinito_steps(dp, dg, 0.999, 1e-9, idx, table, meta, av, z, hg)
+            assert ("afinito_wide_kernel" if route == "wide" else "afinito_big_kernel") in ctx.last_kernel(), ctx.last_kernel()
+            ctx.synchronize()
+        finally:
+            ctx.set_option("chain_no_wide", 0)
+        assert done == len(idx)
+        assert torch.equal(meta[:, 0], meta[:, 1]) and torch.equal(meta[:, 0], meta[:, 2]) and torch.equal(meta[:, 0], meta[:, 3])
+        outs.append((trials, z.clone(), av.clone(), hg.clone(), table.clone(), meta.clone()))
+    assert outs[0][0] == outs[1][0]
+    for u, v in zip(outs[0][1:], outs[1][1:]):
+        assert torch.equal(u, v), "not repeatable"
+    if outs[0][0] == outs[2][0]:   # (a backtracking test on the boundary may fall the other way with another summation order)
+        close(outs[0][1], outs[2][1].cpu().numpy(), dtype, scale=20000, what="several workgroups vs one, z")
+        close(outs[0][2], outs[2][2].cpu().numpy(), dtype, scale=20000, what="several workgroups vs one, av")
+    assert abs(outs[0][0] - outs[2][0]) <= max(2, outs[2][0] // 50)
