@@ -71,28 +71,35 @@ __device__ __forceinline__ void peer_publish(const PeerDev &p)
     }
 }
 
-// Start of the consuming kernel, called by every thread of a workgroup: returns false if a rank never arrived.
+// Start of the consuming kernel, called by every thread of a workgroup (of at least one full wave): returns false if a rank never
+// arrived.  Lane r of the first wave polls rank r's flag, so the world's flags are ONE memory round trip per poll, not one per rank
+// (eight ranks polled one after the other are eight dependent round trips before the first slot is read); the polls are relaxed and
+// the acquire is made once, behind the last of them.
 __device__ __forceinline__ bool peer_wait(const PeerDev &p)
 {
     __shared__ int peer_ok;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < WAVE) {
+        const int r = (int)threadIdx.x;
+        const bool mine = r < p.world;
+        const unsigned int *flag = peer_flag(p, p.rank, mine ? r : 0);
         int ok = 1;
-        for (int r = 0; r < p.world && ok; ++r) {
-            // bounded by WALL-CLOCK time, not by a poll count (a non-owner of a sharded chain waits here for the
-            // owner's whole chain kernel -- seconds at 10^7 steps -- and a count of ~1 us polls gave up on a correct run)
-            unsigned long long t0 = 0;
-            while (__hip_atomic_load(peer_flag(p, p.rank, r), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != p.seq) {
-                __builtin_amdgcn_s_sleep(32);
-                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                if (t0 == 0) t0 = now ? now : 1ull;
-                if (now - t0 > p.wait_ticks) {
-                    *p.errflag = 4;
-                    ok = 0;
-                    break;
-                }
+        // bounded by WALL-CLOCK time, not by a poll count (a non-owner of a sharded chain waits here for the
+        // owner's whole chain kernel -- seconds at 10^7 steps -- and a count of ~1 us polls gave up on a correct run)
+        unsigned long long t0 = 0;
+        while (true) {
+            const unsigned int v = mine ? __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : p.seq;
+            if (__all(v == p.seq)) break;
+            __builtin_amdgcn_s_sleep(32);
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0) t0 = now ? now : 1ull;
+            if (now - t0 > p.wait_ticks) {
+                if (threadIdx.x == 0) *p.errflag = 4;
+                ok = 0;
+                break;
             }
         }
-        peer_ok = ok;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: once, behind the flags
+        if (threadIdx.x == 0) peer_ok = ok;
     }
     __syncthreads();
     return peer_ok != 0;
@@ -108,11 +115,17 @@ __device__ __forceinline__ float peer_load(const float *q)
 {
     return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }
+// (all the world's loads requested before the first addition: a loop over a run-time world waits for each before it asks for the next)
 template <typename T>
 __device__ __forceinline__ T peer_sum(const PeerDev &p, int64_t k)
 {
-    T s = peer_load(peer_slot<T>(p, p.rank, 0) + k);
-    for (int r = 1; r < p.world; ++r) s += peer_load(peer_slot<T>(p, p.rank, r) + k);
+    T v[PEER_MAX];
+#pragma unroll
+    for (int r = 0; r < PEER_MAX; ++r) v[r] = r < p.world ? peer_load(peer_slot<T>(p, p.rank, r) + k) : T(0);
+    T s = v[0];
+#pragma unroll
+    for (int r = 1; r < PEER_MAX; ++r)
+        if (r < p.world) s += v[r];
     return s;
 }
 
