@@ -177,3 +177,35 @@ def test_adaptive_finito_on_several_workgroups_is_repeatable(ctx, ciao, dtype):
         close(outs[0][1], outs[2][1].cpu().numpy(), dtype, scale=20000, what="several workgroups vs one, z")
         close(outs[0][2], outs[2][2].cpu().numpy(), dtype, scale=20000, what="several workgroups vs one, av")
     assert abs(outs[0][0] - outs[2][0]) <= max(2, outs[2][0] // 50)
+
+
+@pytest.mark.parametrize("gk", ["zero", "box", "boxvec"])
+@pytest.mark.parametrize("loss", ["ls", "logistic"])
+def test_adaptive_finito_on_several_workgroups_other_g(ctx, ciao, gk, loss):
+    """The other prox families on afinito_wide_kernel (Zero; IndBox with scalar and with vector bounds, read per step), both losses,
+    against the oracle on the same sample sequence."""
+    import torch
+    from oracle import oracle as O
+    N, d, dtype = 24, 8500, np.float64
+    A, b, x0 = P.synthetic(loss, N, d, dtype, seed=9)
+    lam_f = float(N) if loss == "ls" else 1.0
+    op, dp = make(loss, A, b, lam_f, dtype)
+    og, dg = make_g(gk, dtype, d, lam=0.02)
+    tdt = dev(x0).dtype
+    table = torch.empty((N, d), dtype=tdt, device="cuda")
+    meta = torch.empty((N, 4, 4), dtype=tdt, device="cuda")
+    hg = torch.empty(1, dtype=tdt, device="cuda")
+    av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+    ctx.afinito_init(dp, dg, 0.999, dev(x0), table, meta, av, z, hg)
+    rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(0.999), x0)
+    idx = ciao.IndexStream(3).rand_indices(N, 4 * N)
+    idx[7:10] = idx[7]
+    done, trials = ctx.afinito_steps(dp, dg, 0.999, 1e-9, idx, table, meta, av, z, hg)
+    assert "afinito_wide_kernel" in ctx.last_kernel(), ctx.last_kernel()
+    rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(0.999), dtype(1e-9), idx, rt, rg, rgam, rfi, rhg, rav, rz)
+    assert done == rdone == len(idx) and trials == rtrials
+    close(z, rz, dtype, scale=2000, what=f"adaptive z, g = {gk}")
+    close(av, rav, dtype, scale=2000, what=f"adaptive av, g = {gk}")
+    close(table, rt, dtype, scale=2000, what=f"adaptive table, g = {gk}")
+    close(meta[:, 0, 2], rgam, dtype, scale=5000, what=f"adaptive gamma_i, g = {gk}")
+    ctx.synchronize()
