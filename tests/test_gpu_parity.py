@@ -1999,10 +1999,13 @@ def test_adaptive_finito_random_reprobe(ctx, ciao, dtype, d):
 def _random_chain_cases(n, seed):
     rng = np.random.default_rng(seed)
     out = []
+    dmax = int(os.environ.get("CIAO_FUZZ_DMAX", "0"))   # a one-off hunt on long rows too (the several-workgroup chains): e.g. 20000
     for _ in range(n):
         N = int(rng.choice([2, 3, 7, 33, 100]))
         d = int(rng.choice([rng.integers(1, 70), rng.integers(70, 600), 2 * int(rng.integers(35, 300)), 4 * int(rng.integers(16, 700)),
                             rng.integers(600, 3000)]))
+        if dmax > 4100 and rng.integers(0, 2):
+            d = int(rng.integers(4097, dmax))
         dtype = [np.float64, np.float32][int(rng.integers(0, 2))]
         loss = ["ls", "logistic"][int(rng.integers(0, 2))]
         gk = ["zero", "l1", "box", "boxvec"][int(rng.integers(0, 4))]
