@@ -1019,10 +1019,13 @@ __device__ __forceinline__ void xchg_wait(V (&rv)[N])
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(rv[i]));
 }
 
-template <int J, bool TABLE>   // J = row bytes / 4096
+template <int J, bool TABLE, bool SHARDED = false>   // J = row bytes / 4096
 struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at 0.4-0.9 us per step, within 128 KiB of LDS for the rings:
-                    // with a table ring beside the row ring 64 KiB each, without one the row ring takes it all
-    static constexpr int value = TABLE ? (J <= 2 ? 8 : (J <= 4 ? 4 : 2)) : (J <= 4 ? 8 : 4);
+                    // with a table ring beside the row ring 64 KiB each, without one the row ring takes it all.
+                    // Over a shard table most rows are another GPU's: a load over xGMI is a few us away, eight steps of 0.25 us are
+                    // not -- where LDS allows (rows up to 8 KiB; with a table ring up to 4 KiB) the ring is sixteen deep.  (Not yet
+                    // run across xGMI: the depth is by reasoning, the arithmetic does not depend on it.)
+    static constexpr int value = (SHARDED && (TABLE ? J <= 1 : J <= 2)) ? 16 : (TABLE ? (J <= 2 ? 8 : (J <= 4 ? 4 : 2)) : (J <= 4 ? 8 : 4));
 };
 
 // NT threads (256 or 512): 32 KiB rows are shared by eight waves instead of four (a step costs ~0.38 us + ~0.06 us per
@@ -1041,7 +1044,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
     using V = typename VecOfC<T>::type;
     constexpr int VEC = 16 / sizeof(T);
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
-    constexpr int DEPTH = DmaDepth<J * NT / 256, HAS_TABLE>::value;   // by row bytes (J*NT*16), whatever the thread count
+    constexpr int DEPTH = DmaDepth<J * NT / 256, HAS_TABLE, SHARDED>::value;   // by row bytes (J*NT*16), whatever the thread count
     constexpr int CH = CHAIN_CHUNK;
     constexpr bool SVRG_ANY = (ALG == CA_SVRG || ALG == CA_SVRGC);
     constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
@@ -1917,7 +1920,7 @@ constexpr size_t chain_dma_lds_bytes()
 {
     constexpr int NW = NT / WAVE;
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
-    constexpr int DEPTH = DmaDepth<J * NT / 256, HAS_TABLE>::value;
+    constexpr int DEPTH = DmaDepth<J * NT / 256, HAS_TABLE, SHARDED>::value;
     constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO || ALG == CA_SVRGC);
     constexpr bool STAGE_PTR = SHARDED && HAS_TABLE;
     return (size_t)DEPTH * J * NT * 16 * (HAS_TABLE ? 2 : 1) + (STAGE_PTR ? 2 : 1) * (CHAIN_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
