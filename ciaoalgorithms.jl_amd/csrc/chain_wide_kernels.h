@@ -88,6 +88,45 @@ __device__ __forceinline__ bool wide_get_run(const unsigned long long *w, unsign
         }
     }
 }
+// ... and a slot's first N words for every lane with M more behind them for the lanes that `want_more` -- in the SAME poll (two loops, one per
+// kind of lane, would run one after the other in a wave: two round trips)
+template <int N, int M>
+__device__ __forceinline__ bool wide_get_run2(const unsigned long long *w, unsigned int seq, bool want_more, unsigned int (&payload)[N],
+                                              unsigned int (&more)[M])
+{
+    unsigned long long t0 = 0;
+    for (unsigned spins = 0;; ++spins) {
+        unsigned long long v[N], u[M];
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (want_more) {
+#pragma unroll
+            for (int i = 0; i < M; ++i) u[i] = __hip_atomic_load(w + N + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+#pragma unroll
+            for (int i = 0; i < M; ++i) u[i] = seq;
+        }
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) all = all && ((unsigned int)v[i] == seq);
+#pragma unroll
+        for (int i = 0; i < M; ++i) all = all && ((unsigned int)u[i] == seq);
+        if (all) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) payload[i] = (unsigned int)(v[i] >> 32);
+#pragma unroll
+            for (int i = 0; i < M; ++i) more[i] = (unsigned int)(u[i] >> 32);
+            return true;
+        }
+        if ((spins & 1023u) == 1023u) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t0 == 0)
+                t0 = now;
+            else if (now - t0 > WIDE_TIMEOUT_TICKS)
+                return false;
+        }
+    }
+}
 template <typename T>
 struct WideWord;
 template <>
@@ -501,29 +540,23 @@ __global__ void __launch_bounds__(WIDE_NT) afinito_wide_kernel(AFinitoArgs<T> a,
         }
         if (tid < G) {
             const unsigned long long *theirs = wa.box + ((size_t)(xc & 1) * WIDE_GMAX + lane) * AFW_WORDS;
-            bool ok;
-            if (with_meta && lane == 0 && g != 0) {   // workgroup 0's slot with its four scalars behind the two sums
-                unsigned int pw[6 * WN];
-                ok = wide_get_run(theirs, seq, pw);
-                if (!ok) {
+            // every lane its workgroup's two sums; lane 0 (workgroup 0's slot) also the four scalars behind them, in the same poll
+            const bool want_meta = with_meta && lane == 0 && g != 0;
+            unsigned int pw[2 * WN], pm[4 * WN];
+            const bool ok = wide_get_run2(theirs, seq, want_meta, pw, pm);
+            if (!ok) {
 #pragma unroll
-                    for (int i = 0; i < 6 * WN; ++i) pw[i] = 0;
-                }
-                gath[lane][0] = W::decode(pw);
-                gath[lane][1] = W::decode(pw + WN);
+                for (int i = 0; i < 2 * WN; ++i) pw[i] = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) s_meta[q] = W::decode(pw + (2 + q) * WN);
-            } else {
-                unsigned int pw[2 * WN];
-                ok = wide_get_run(theirs, seq, pw);
-                if (!ok) {
-#pragma unroll
-                    for (int i = 0; i < 2 * WN; ++i) pw[i] = 0;
-                }
-                gath[lane][0] = W::decode(pw);
-                gath[lane][1] = W::decode(pw + WN);
+                for (int i = 0; i < 4 * WN; ++i) pm[i] = 0;
+                s_fail = 1;
             }
-            if (!ok) s_fail = 1;
+            gath[lane][0] = W::decode(pw);
+            gath[lane][1] = W::decode(pw + WN);
+            if (want_meta) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s_meta[q] = W::decode(pm + q * WN);
+            }
         }
         __syncthreads();
         ++xc;
