@@ -1021,6 +1021,12 @@ int32_t ciao_ctx_synchronize(ciao_ctx *ctx)
                       "work?); results since the last synchronize are invalid -- option chain_no_wide=1 selects the one-workgroup kernel");
             return CIAO_ERR_HIP;
         }
+        if (flag == 6) {
+            set_error("internal: a workgroup of the cluster sweep (rows_long_kernel, rows beyond 64 KiB) never saw another's partial dot "
+                      "product within 4 s -- the grid was not all resident (a GPU shared with other work?); results since the last "
+                      "synchronize are invalid -- option long_rows=0 selects the generic kernel");
+            return CIAO_ERR_HIP;
+        }
         set_error("a sample index was outside [0, N): results since the last synchronize are invalid");
         return CIAO_ERR_ARG;
     }
@@ -1301,6 +1307,11 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "split_blocks_per_cu")) {
         CIAO_REQUIRE(value >= 0 && value <= 16, "split_blocks_per_cu must be in 0..16");
         ctx->split_blocks_per_cu = value;
+    } else if (!strcmp(key, "long_rows")) {
+        ctx->long_rows = value != 0;
+    } else if (!strcmp(key, "long_j")) {
+        CIAO_REQUIRE(value == 0 || value == 4 || value == 8, "long_j must be 0, 4 or 8");
+        ctx->long_j = value;
     } else if (!strcmp(key, "sweep_grid")) {
         CIAO_REQUIRE(value >= 0 && value <= 65535, "sweep_grid must be in 0..65535");
         ctx->sweep_grid = value;

@@ -88,6 +88,8 @@ struct ciao_ctx {
     int64_t small_i = 0;               // rows_small_kernel: elements per lane and iteration, 8 or 16 (0 = automatic)
     int64_t split_all = 0;             // tuning experiment: workgroup-per-row kernel for every mode and size
     int64_t split_blocks_per_cu = 0;   // its grid cap in blocks per CU (0 = automatic)
+    int64_t long_rows = 1;             // rows beyond 64 KiB on the cluster kernel (rows_long_kernel); 0 = the generic kernel (testing)
+    int64_t long_j = 0;                // its chunks per thread, 4 or 8 (0 = automatic)
     int64_t sweep_grid = 0;            // testing: absolute grid override for the rows kernels (0 = automatic)
     int64_t sweep_prefetch = -1;    // gradient sweeps: 1 = two-deep register pipeline, 0 = occupancy only, -1 = by row size
     int64_t chain_max_batch = -1;   // Finito/LFinito batches up to this size run as a sequential chain (-1 = automatic)

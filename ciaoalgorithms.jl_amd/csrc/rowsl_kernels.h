@@ -1,0 +1,217 @@
+// rowsl_kernels.h -- the sweeps and batch steps over rows LONGER than one workgroup's registers hold (more than 64 KiB: beyond 8192
+// fp64 / 16 384 fp32 elements): a CLUSTER of S workgroups per row (rows_long_kernel).
+//
+// Why.  rows_split_kernel (rows_kernels.h) ends at 4096 chunks of 16 bytes per row -- sixteen per thread, the row, the iterate and the
+// accumulators in registers.  Beyond that the scalar generic kernel took over with its accumulators in global memory: 0.5-1.6 TB/s,
+// while the chains on such rows (chain_wide_kernels.h) had already moved to several workgroups.  A row's work is a dot product over
+// the row and an element-wise accumulation: both split by COLUMNS.  Workgroup (c, s) -- segment s of cluster c -- owns the chunks
+// [s J 256, (s + 1) J 256) of every vector: its slice of the iterate(s) and of the accumulators lives in registers for the whole
+// launch, the next row's slice is in flight while this one is used, and all the S workgroups of a cluster exchange per row is their
+// partial dot product(s), through the mailbox of chain_wide_kernels.h (64-bit words of payload + sequence number, relaxed device-scope
+// atomics, no fence; two parities; spins bounded in wall-clock time).  Unlike a chain, the rows of a sweep are independent: the
+// clusters run side by side and several workgroups per CU hide the exchange's round trip, so the kernel streams.
+//
+// Results: rows_split_kernel's arithmetic element for element; the dot products are added in another order (slices, then segments in
+// one fixed tree), and a cluster writes ONE partial d-vector (every workgroup its own columns), so finalize sums C partials.
+// Residency: every workgroup of a cluster must be on the chip at once -- the grid never exceeds what the occupancy calculator says is
+// resident (rowsl_launch.inc), and a workgroup that never sees another's word gives up after 4 s (error word 6).
+#pragma once
+
+#include "chain_wide_kernels.h"
+#include "rows_kernels.h"
+
+namespace ciao {
+
+constexpr int LONG_SMAX = 64;   // segments per row (the exchange's fixed tree is one wave wide)
+
+struct LongArgs {
+    unsigned long long *box;   // [2 parities][C][S][words]
+    int S, C;
+};
+
+template <typename T, int J, int MODE>
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a, LongArgs la)
+{
+    using V = typename VecOf<T>::type;
+    using W = WideWord<T>;
+    constexpr int VEC = VecOf<T>::N;
+    constexpr bool TWO = (MODE == RM_GRAD2);
+    constexpr bool TABLE = (MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH);
+    constexpr bool TREAD = (MODE == RM_FINITO_BATCH);
+    constexpr int NWORD = (TWO ? 2 : 1) * W::N;
+    static_assert(MODE != RM_AFINITO_INIT, "the adaptive init keeps to the wave-per-row kernels");
+
+    __shared__ T red[2][ROWS_WAVES][2];
+    __shared__ T tot[2][2];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = la.S, C = la.C;
+    const int c = (int)blockIdx.x / S, s = (int)blockIdx.x - c * S;
+    const int64_t nchunks = a.d / VEC;
+    const int64_t coff = (int64_t)s * J * ROWS_BLOCK + tid;   // this thread's first chunk
+    if (tid == 0) s_fail = 0;
+
+    bool ok[J];
+    V x1[J], x2[J], acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        ok[j] = coff + j * ROWS_BLOCK < nchunks;
+        x1[j] = ok[j] ? reinterpret_cast<const V *>(a.x1)[coff + j * ROWS_BLOCK] : V(T(0));
+        x2[j] = (TWO && ok[j]) ? reinterpret_cast<const V *>(a.x2)[coff + j * ROWS_BLOCK] : V(T(0));
+        acc[j] = V(T(0));
+    }
+    T extra = T(0);
+    int par = 0;
+    unsigned int seq = 0;
+    __syncthreads();
+
+    struct RowIn {
+        V ar[J], sr[J];
+        V *sp;
+        T bi, gi;
+        int64_t row;
+    };
+    // request everything this workgroup needs of row q at once: its slice of the row and of the table row, the row's scalars
+    auto issue = [&](RowIn &x, int64_t q) {
+        int64_t row = a.idx ? a.idx[q] : a.row0 + q;
+        if (a.idx && (uint64_t)row >= (uint64_t)a.N) {
+            if (tid == 0) *a.errflag = 1;
+            row = 0;
+        }
+        x.row = row;
+        x.sp = TABLE ? reinterpret_cast<V *>(a.table + row * a.d) + coff : nullptr;
+        if (a.A) {
+            const V *ap = reinterpret_cast<const V *>(a.A + row * a.ld) + coff;
+#pragma unroll
+            for (int j = 0; j < J; ++j) x.ar[j] = ok[j] ? __builtin_nontemporal_load(&ap[j * ROWS_BLOCK]) : V(T(0));
+        } else {
+#pragma unroll
+            for (int j = 0; j < J; ++j) x.ar[j] = V(T(0));
+        }
+        if (TREAD) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) x.sr[j] = ok[j] ? __builtin_nontemporal_load(&x.sp[j * ROWS_BLOCK]) : V(T(0));
+        }
+        x.bi = a.b ? a.b[row] : T(0);
+        x.gi = (MODE == RM_GRAD || MODE == RM_SAGA_INIT) ? T(1) : (a.gam ? a.gam[row] : a.gam_uniform);
+    };
+    // false: the cluster's exchange timed out
+    auto process = [&](RowIn &x) -> bool {
+        T d1 = T(0), d2 = T(0);
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                d1 += x.ar[j][v] * x1[j][v];
+                if (TWO) d2 += x.ar[j][v] * x2[j][v];
+            }
+        d1 = wave_sum_lane63(d1);
+        if (TWO) d2 = wave_sum_lane63(d2);
+        if (lane == WAVE - 1) {
+            red[par][wib][0] = d1;
+            if (TWO) red[par][wib][1] = d2;
+        }
+        __syncthreads();
+        ++seq;
+        if (wib == 0) {
+            // the workgroup's partial(s) out, the cluster's in: lane q polls segment q's word(s), the S values are added in one fixed
+            // tree (lanes beyond S hold zeros)
+            const T p1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
+            const T p2 = TWO ? (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]) : T(0);
+            unsigned long long *slot = la.box + (((size_t)par * C + c) * S) * NWORD;
+            if (lane == 0) {
+                W::put(slot + (size_t)s * NWORD, p1, seq);
+                if (TWO) W::put(slot + (size_t)s * NWORD + W::N, p2, seq);
+            }
+            T g1 = T(0), g2 = T(0);
+            if (lane < S) {
+                unsigned int pw[NWORD];
+                if (!wide_get_run(slot + (size_t)lane * NWORD, seq, pw)) {
+#pragma unroll
+                    for (int i = 0; i < NWORD; ++i) pw[i] = 0;
+                    s_fail = 1;
+                }
+                g1 = W::decode(pw);
+                if (TWO) g2 = W::decode(pw + (TWO ? W::N : 0));
+            }
+            g1 = wave_sum_lane63(g1);
+            if (TWO) g2 = wave_sum_lane63(g2);
+            if (lane == WAVE - 1) {
+                tot[par][0] = g1;
+                if (TWO) tot[par][1] = g2;
+            }
+        }
+        __syncthreads();
+        if (s_fail) {
+            if (tid == 0) *a.errflag = 6;
+            return false;
+        }
+        d1 = tot[par][0];
+        if (TWO) d2 = tot[par][1];
+        par ^= 1;
+
+        const GradCoef<T> g1 = grad_coef(a.loss, d1, x.bi, a.lam);
+        if (MODE == RM_GRAD) {                        // SVRG_basic.jl:58-63, :87-92
+            const T cf = g1.coef();
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc[j] += cf * x.ar[j];
+            if (a.want_fval) extra += loss_value(a.loss, d1, x.bi, a.lam);
+            if (a.rowdot_out && s == 0 && tid == 0) a.rowdot_out[x.row] = d1;
+        } else if (MODE == RM_GRAD2) {                // Finito_LFinito.jl:93-98
+            const T cf = g1.coef() - grad_coef(a.loss, d2, x.bi, a.lam).coef();
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc[j] += cf * x.ar[j];
+            extra += a.hat_gamma / x.gi;
+        } else if (MODE == RM_SAGA_INIT) {            // SAGA_basic.jl:42-47
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                V gv;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) gv[v] = g1.elem(x.ar[j][v]);
+                acc[j] += gv;
+                if (ok[j]) TSTORE(gv, &x.sp[j * ROWS_BLOCK]);
+            }
+        } else {                                      // Finito_basic.jl:77-83 (init) / :110-117 (batch)
+            const T cg = x.gi * a.invN;
+            const T rr = (MODE == RM_FINITO_INIT) ? T(1) / x.gi : a.hat_gamma / x.gi;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                V tv;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    tv[v] = x1[j][v] - cg * g1.elem(x.ar[j][v]);
+                    if (MODE == RM_FINITO_INIT)
+                        acc[j][v] += tv[v] * rr;
+                    else
+                        acc[j][v] += (tv[v] - x.sr[j][v]) * rr;
+                }
+                if (ok[j]) TSTORE(tv, &x.sp[j * ROWS_BLOCK]);
+            }
+        }
+        return true;
+    };
+
+    // cluster c takes rows c, c + C, ...; the next row's slice is requested before this one is reduced (two register sets)
+    RowIn r0, r1;
+    int64_t q = c;
+    if (q < a.nrows) issue(r0, q);
+    while (q < a.nrows) {
+        if (q + C < a.nrows) issue(r1, q + C);
+        if (!process(r0)) return;
+        q += C;
+        if (q >= a.nrows) break;
+        if (q + C < a.nrows) issue(r0, q + C);
+        if (!process(r1)) return;
+        q += C;
+    }
+
+    V *pout = reinterpret_cast<V *>(a.partial + (int64_t)c * a.pstride) + coff;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+        if (ok[j]) PSTORE(acc[j], &pout[j * ROWS_BLOCK]);
+    if (s == 0 && tid == 0) a.pextra[c] = extra;   // extra is the same in every workgroup of the cluster
+}
+
+}  // namespace ciao
