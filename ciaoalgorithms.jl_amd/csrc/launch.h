@@ -96,8 +96,8 @@ int32_t launch_smallm(ciao_ctx *ctx, int mode, int grid, size_t lds, RowsArgs<T>
 
 // sweeps / batch steps over rows beyond 64 KiB: a cluster of S workgroups per row (rowsl_kernels.h).  Specialised in rowsl_f32.hip /
 // rowsl_f64.hip.  long_plan: CIAO_ERR_UNSUPPORTED (no error text) when the shape is not for this kernel.
-constexpr int LONG_J_DEFAULT = 4;   // 16-byte chunks per thread: a workgroup's segment is J * 4 KiB of the row
-constexpr int LONG_BPC_J4 = 4, LONG_BPC_J8 = 2;   // workgroups per CU
+constexpr int LONG_J_DEFAULT = 8;   // 16-byte chunks per thread: a workgroup's segment is J * 4 KiB of the row (Finito batches: 4)
+constexpr int LONG_BPC_J4 = 4, LONG_BPC_J8 = 2;   // workgroups per CU (never more than the occupancy calculator allows)
 template <typename T>
 int32_t long_plan(ciao_ctx *ctx, int mode, int64_t d, int64_t nrows, int *J, int *S, int *C);
 template <typename T>

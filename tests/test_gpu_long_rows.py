@@ -20,7 +20,7 @@ def _gam(A, lam_f, loss, N, dtype):
 @pytest.mark.parametrize("dtype,d", [(np.float64, 8194), (np.float64, 16384), (np.float64, 40000), (np.float32, 16388), (np.float32, 65536),
                                      (np.float32, 100000)])
 @pytest.mark.parametrize("loss", ["ls", "logistic"])
-@pytest.mark.parametrize("opts", [{}, {"long_j": 8}, {"split_blocks_per_cu": 1}])
+@pytest.mark.parametrize("opts", [{}, {"long_j": 4}, {"long_j": 8}, {"split_blocks_per_cu": 1}])
 def test_long_rows_in_all_five_modes(ctx, ciao, dtype, d, loss, opts):
     import torch
     from oracle import oracle as O
@@ -42,7 +42,7 @@ def test_long_rows_in_all_five_modes(ctx, ciao, dtype, d, loss, opts):
         av, av2, z = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(3))
         ctx.full_gradient(dp, dev(x0), av)
         name = ctx.last_kernel()
-        assert "rows_long_kernel" in name and f"J{opts.get('long_j', 4)}," in name, name
+        assert "rows_long_kernel" in name and f"J{opts.get('long_j', 8)}," in name, name
         ref = O.full_pass(op, x0)
         close(av, ref, dtype, scale=200, what=f"long rows full gradient d={d} ({name})")
         ctx.full_gradient(dp, dev(x0), av2)
@@ -71,7 +71,7 @@ def test_long_rows_in_all_five_modes(ctx, ciao, dtype, d, loss, opts):
         rnd = [st.sample_without_replacement(N, r) for _ in range(3)]
         bptr = np.arange(len(rnd) + 1, dtype=np.int64) * r
         ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(rnd), table, av, z)
-        assert "rows_long_kernel" in ctx.last_kernel() and "mode4" in ctx.last_kernel(), ctx.last_kernel()
+        assert "rows_long_kernel" in ctx.last_kernel() and f"J{opts.get('long_j', 4)},mode4" in ctx.last_kernel(), ctx.last_kernel()
         O.finito_steps(op, og, gam, rhg, rnd, rt, rav, rz)
         close(z, rz, dtype, scale=2000, what=f"long rows finito z, index lists ({ctx.last_kernel()})")
         close(table, rt, dtype, scale=200, what="long rows finito table, index lists")
@@ -146,12 +146,12 @@ def test_long_rows_padded_stride_monitor_and_an_svrg_epoch(ctx, ciao, dtype, d):
 
 
 def test_long_rows_on_few_rows_and_at_the_segment_limit(ctx, ciao):
-    """One row, two rows (fewer rows than clusters), and the longest row the exchange's one-wave tree takes (64 segments of 16 KiB:
-    131 072 fp64 elements); one element more falls back to the generic kernel."""
+    """One row, two rows (fewer rows than clusters), and the longest row the exchange's one-wave tree takes (64 segments of 32 KiB:
+    262 144 fp64 elements); one chunk more falls back to the generic kernel."""
     import torch
     from oracle import oracle as O
     dtype = np.float64
-    for N, d, long in ((1, 20000, True), (2, 131072, True), (3, 131074, False)):
+    for N, d, long in ((1, 20000, True), (2, 262144, True), (3, 262146, False)):
         A, b, x0 = P.synthetic("ls", N, d, dtype, seed=N)
         op, dp = make("ls", A, b, float(N), dtype)
         av = torch.empty(d, dtype=torch.float64, device="cuda")
