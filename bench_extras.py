@@ -351,6 +351,15 @@ def run(ctx, dev, quick=False):
             t = _timed(ctx, lambda: ctx.svrg_inner(F, g, 1e-7, idx[:mm], av, z, zf, w), reps=1)
             out[f"svrg_inner_f64_d32768_{tag}"] = {"us_per_update": t / mm * 1e6, "m": mm, "N": N, "kernel": ctx.last_kernel()}
         ctx.set_option("chain_no_wide", 0)
+        # ... and the full-gradient sweep over the same rows (SVRG_basic.jl:87-92): a cluster of workgroups per row (rows_long_kernel,
+        # csrc/rowsl_kernels.h) against the generic kernel it replaced (1 GB here: part of it comes out of the memory-side cache;
+        # tools/long_rows_time.py measures 8 GB, profiles/r04_long_rows.txt)
+        for tag, opt in (("cluster_per_row", 1), ("generic", 0)):
+            ctx.set_option("long_rows", opt)
+            ctx.full_gradient(F, x0, av)
+            t = _timed(ctx, lambda: ctx.full_gradient(F, x0, av), reps=3)
+            out[f"sweep_f64_d32768_{tag}"] = {"seconds": t, "alg_GBps": N * d * 8 / t / 1e9, "N": N, "kernel": ctx.last_kernel()}
+        ctx.set_option("long_rows", 1)
         del F, idx
         torch.cuda.empty_cache()
     except Exception as e:   # noqa: BLE001

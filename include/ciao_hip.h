@@ -151,6 +151,8 @@ CIAO_API int32_t ciao_ctx_set_monitor(ciao_ctx *ctx, const ciao_prox_desc *g, do
  *   "chain_no_ws"          SAGA / SAG chains on chain_dma_kernel instead of the wave-specialised chain_ws_kernel
  *   "chain_no_wide"        SVRG / SAGA chains on rows beyond 8192 elements on the one-workgroup kernel instead of chain_wide_kernel
  *   "chain_ws_issuers"     issuer waves of chain_ws_kernel, 1 or 2 (0 = automatic)
+ *   "long_rows"            0: sweeps / batches on rows beyond 64 KiB on the generic kernel instead of rows_long_kernel (a cluster of
+ *                          workgroups per row);  "long_j": its 16-byte chunks per thread, 4 or 8 (0 = automatic)
  *   "svrg_cache_rowdots"   0: the SVRG full pass does not store a_i'z_full at all (see ciao_svrg_iterate) */
 CIAO_API int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value);
 /* Kernel timing for bench.py's roofline line: when enabled, every launch of the dominant streaming kernel of an entry

@@ -311,6 +311,9 @@ def _peer_worker(rank, world, port, q):
     try:
         dev = torch.device("cuda", 0)
         ctx = Context(0)
+        # (the ranks do host work of different length between reductions -- the oracle runs beside them -- and on a box whose CPU share is
+        # contended one rank was once 30 s behind: the wall-clock bound of a peer wait is a setting, 30 s by default)
+        ctx.set_option("peer_timeout_s", 150)
         N, d = 403, 1024
         A, b, x = P.synthetic("ls", N, d, np.float64, seed=12)
         row0, n = shard_rows(N, rank, world)
