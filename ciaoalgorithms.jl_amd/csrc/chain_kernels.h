@@ -61,6 +61,50 @@ struct ChainArgs {
     int64_t sh_row0[CIAO_MAX_SHARDS + 1];
 };
 
+// The argument block a chain kernel reads its fields from, in the constant address space (scalar loads, where a field is used):
+// the kernel-argument segment itself, or -- a batch of chains (ChainArgs::multi) -- workgroup k's own block in device memory, which
+// the host wrote before the launch and nothing writes during it.
+template <typename T>
+using ChainArgsK = const __attribute__((address_space(4))) ChainArgs<T>;
+template <typename T>
+__device__ __forceinline__ ChainArgsK<T> *chain_args_block()
+{
+    ChainArgsK<T> *k = (ChainArgsK<T> *)__builtin_amdgcn_kernarg_segment_ptr();
+    const ChainArgs<T> *m = k->multi;
+    if (m) k = (ChainArgsK<T> *)(uintptr_t)(m + blockIdx.x);
+    return k;
+}
+
+// A field of the argument block that the STEP LOOP reads: loaded once, and made opaque in its scalar register(s) so that hipcc
+// neither re-loads it from the block inside the loop (a scalar-cache round trip on the dependent path of every step -- what it did
+// with a.gamma, a.invN, a.lam once the block was read through a pointer) nor keeps it anywhere but in SGPRs.
+template <typename X>
+__device__ __forceinline__ X sgpr_pin(X v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
+// ... a value COMPUTED from such fields (the vector pipeline did the arithmetic): through v_readfirstlane, then pinned
+__device__ __forceinline__ float sgpr_pin_computed(float v)
+{
+    return sgpr_pin(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))));
+}
+__device__ __forceinline__ double sgpr_pin_computed(double v)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return sgpr_pin(__builtin_bit_cast(double, ((uint64_t)hi << 32) | lo));
+}
+// ... a pointer field: the asm hides that it came from the argument block, so say again that it is global memory (generic
+// pointers make FLAT loads / stores, which count on both memory counters and break the hand-counted waits)
+template <typename P>
+__device__ __forceinline__ P *sgpr_pin_global(P *p)
+{
+    asm volatile("" : "+s"(p));
+    return (P *)(__attribute__((address_space(1))) P *)(uintptr_t)p;
+}
+
 // A batch of chains (ChainArgs::multi): workgroup k takes its own argument block.  Word by word through v_readfirstlane, so that
 // every field is in scalar registers exactly as a kernel argument would be (the inline asm of the chain kernels names SGPRs).
 template <typename T>
@@ -964,6 +1008,25 @@ __device__ __forceinline__ void glds16s(const void *sbase, uint32_t voff, uint32
 #pragma clang diagnostic pop
 }
 
+// The LDS destination as (a wave's base in ONE scalar register) + (a byte offset that is a compile-time constant once the ring's
+// loops are unrolled): written as base + offset in C++, hipcc hoists every sum out of the step loop into a scalar register of its
+// own -- 2 * DEPTH * J of them (32-64 for a table chain), the largest single consumer of the chain kernels' scalar registers and
+// why they spilled.  The addition is one scalar instruction either way (s_add_i32 for s_mov_b32).
+__device__ __forceinline__ void glds16_at(const void *gsrc, uint32_t lds_base, int off)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_add_i32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_base), "i"(off) : "memory", "m0", "scc");
+#pragma clang diagnostic pop
+}
+__device__ __forceinline__ void glds16s_at(const void *sbase, uint32_t voff, uint32_t lds_base, int off)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base), "i"(off) : "memory", "m0", "scc");
+#pragma clang diagnostic pop
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
 {
@@ -1036,9 +1099,12 @@ struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at 0.4-0.9 u
 template <typename T, int J, int ALG, int LOSS, bool MASKED, int NT, bool SHARDED = false>
 __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
 {
-    // a batch of chains: this workgroup's own argument block (`a` is a private copy whose fields all end up in scalar registers)
-    ChainArgs<T> a = a_in;
-    chain_args_fetch(a);
+    // The arguments are read THROUGH THE KERNEL-ARGUMENT SEGMENT (or, in a batch of chains, through this workgroup's own block of
+    // ChainArgs::multi), field by field where they are used: hipcc loads every field of a by-value argument into scalar registers in
+    // the entry block, where the fields only the staging or the final stores need stay live through the step loop and push 10-80
+    // of them out to VGPR lanes (chain_ws_kernel: the same cure).  Both blocks are constant for the kernel's lifetime.
+    (void)a_in;
+    const ChainArgsK<T> &a = *chain_args_block<T>();
     constexpr int NW = NT / WAVE;
     static_assert(NW == 1 || NW == 4 || NW == 8, "one, four or eight waves");
     using V = typename VecOfC<T>::type;
@@ -1107,6 +1173,22 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
     if constexpr (SHARDED) shard_table_to_lds<T>(s_sh, tid);   // (the staging's first __syncthreads orders it before its readers)
     const uint32_t ringA_off = (uint32_t)(uintptr_t)ringA;   // LDS byte offsets (low 32 bits of the flat address)
     const uint32_t ringT_off = (uint32_t)(uintptr_t)ringT;
+    // this wave's 1 KiB pieces of the ring slots start here: ONE scalar register per ring (glds16_at)
+    const uint32_t ringA_w = sgpr_pin(ringA_off + (uint32_t)wib * 1024u);
+    const uint32_t ringT_w = sgpr_pin(ringT_off + (uint32_t)wib * 1024u);
+    // what the step loop reads of the argument block (sgpr_pin); everything else is read where it is used
+    const int64_t nsteps = sgpr_pin(a.nsteps);
+    const T gamma = (SVRG_ANY || ALG == CA_SAGA) ? sgpr_pin(a.gamma) : T(0);
+    const T lam = (LOSS == CIAO_LOSS_LOGISTIC) ? T(0) : sgpr_pin(a.lam);
+    const T invN = (ALG == CA_SVRG || ALG == CA_SVRGC) ? T(0) : sgpr_pin(a.invN);
+    const T hat_gamma = (ALG == CA_FINITO || ALG == CA_LFINITO) ? sgpr_pin(a.hat_gamma) : T(0);
+    const int64_t batch = (ALG == CA_FINITO || ALG == CA_LFINITO) ? sgpr_pin(a.batch) : 0;
+    const bool sag = (ALG == CA_SAGA) && sgpr_pin(a.sag) != 0;
+    // rows and table rows by index (chains with a table on ONE allocation): base pointers and strides
+    const T *const Abase = (!PTR_IN_ROW && !STAGE_PTR) ? sgpr_pin_global(a.A) : nullptr;
+    const int64_t ld = (!PTR_IN_ROW && !STAGE_PTR) ? sgpr_pin(a.ld) : 0;
+    T *const tbase = (HAS_TABLE && !STAGE_PTR) ? sgpr_pin_global(a.table) : nullptr;
+    const int64_t dtab = (HAS_TABLE && !STAGE_PTR) ? sgpr_pin(a.d) : 0;
 
     // chunk ownership: thread t owns 16-byte chunks t + 256*j; with MASKED those at or beyond the row's end are dead (their
     // state stays zero, their loads are redirected to chunk 0 and discarded, their stores are predicated off)
@@ -1153,32 +1235,43 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
     // SVRG: av is constant over the inner cycle, so gamma*av is hoisted out of the chain
     V gav[J];
 #pragma unroll
-    for (int j = 0; j < J; ++j) gav[j] = a.gamma * av[j];
+    for (int j = 0; j < J; ++j) gav[j] = gamma * av[j];
 
     // issue the DMA of row r (at address ap; STAGE_PTR: r IS its table row's address) into ring slot u: J (+J) wave-instructions of 1 KiB each
-    auto refill = [&](int u, int64_t r, const unsigned char *ap) {
+    // const_u: the slot number is a compile-time constant where the call is inlined (the unrolled step groups): the LDS destination
+    // is then the wave's base + an immediate (glds16_at); the one-off first filling of the ring runs as a loop over the slots
+    auto refill = [&](auto const_u, int u, int64_t r, const unsigned char *ap) {
+        constexpr bool CU = decltype(const_u)::value;
         // table-free chains: base in SGPRs + 32-bit lane offset (-3 % per SVRG step); with a table ring beside it the plain
         // 64-bit VGPR addresses schedule better (measured: SAGA 0.416 us against 0.422 / 0.430 with the scalar base)
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            if constexpr (HAS_TABLE)
-                glds16(ap + cl[j] * 16, ringA_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
-            else
-                glds16s(ap, (uint32_t)cl[j] * 16u, ringA_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
+            const int off = (u * J + j) * NW * 1024;
+            if constexpr (HAS_TABLE) {
+                if constexpr (CU) glds16_at(ap + cl[j] * 16, ringA_w, off);
+                else glds16(ap + cl[j] * 16, ringA_w + (uint32_t)off);
+            } else {
+                if constexpr (CU) glds16s_at(ap, (uint32_t)cl[j] * 16u, ringA_w, off);
+                else glds16s(ap, (uint32_t)cl[j] * 16u, ringA_w + (uint32_t)off);
+            }
         }
         if (HAS_TABLE) {
             const unsigned char *sp = STAGE_PTR ? reinterpret_cast<const unsigned char *>((uintptr_t)r)
-                                                : reinterpret_cast<const unsigned char *>(a.table + r * a.d);
+                                                : reinterpret_cast<const unsigned char *>(tbase + r * dtab);
 #pragma unroll
-            for (int j = 0; j < J; ++j)
-                glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
+            for (int j = 0; j < J; ++j) {
+                const int off = (u * J + j) * NW * 1024;
+                if constexpr (CU) glds16_at(sp + cl[j] * 16, ringT_w, off);
+                else glds16(sp + cl[j] * 16, ringT_w + (uint32_t)off);
+            }
         }
     };
 
-    // the table row of the sample a step knows as `row`: its index, or (STAGE_PTR) the row's address itself
+    // the table row of the sample a step knows as `row`: its index, or (STAGE_PTR) the row's address itself (global memory, this
+    // GPU's or a peer's: said so, or the stores through it are FLAT ones)
     auto trow_of = [&](int64_t row) -> T * {
-        if constexpr (STAGE_PTR) return reinterpret_cast<T *>((uintptr_t)row);
-        else return a.table + row * a.d;
+        if constexpr (STAGE_PTR) return (T *)(__attribute__((address_space(1))) T *)(uintptr_t)row;
+        else return tbase + row * dtab;
     };
 
     // everything step s needs from LDS: its ring slot and its staged scalars (two register sets, ping-pong by step parity)
@@ -1219,8 +1312,8 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
 
     int par = 0;
     int64_t inb = 0;
-    for (int64_t base = 0; base < a.nsteps; base += CH) {
-        const int nch = (int)((a.nsteps - base) < CH ? (a.nsteps - base) : CH);
+    for (int64_t base = 0; base < nsteps; base += CH) {
+        const int nch = (int)((nsteps - base) < CH ? (nsteps - base) : CH);
 
         // ---- stage this chunk's gathers in LDS (ordinary loads: the compiler drains the queue here, once per chunk) ----
         __syncthreads();
@@ -1230,7 +1323,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
         if (tid < DEPTH) s_row[tid] = hist;
         for (int e = tid; e < nch + DEPTH; e += NT) {
             int64_t st = base + e;
-            if (st > a.nsteps - 1) st = a.nsteps - 1;
+            if (st > nsteps - 1) st = nsteps - 1;
             int64_t r = a.idx[st];
             if ((uint64_t)r >= (uint64_t)a.N) {
                 *a.errflag = 1;
@@ -1256,7 +1349,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                     // SVRG with cached row dots: what the step needs of a_i'z_full is the link-function coefficient at it,
                     // which does not depend on the chain -- evaluated HERE, 256 steps at a time, instead of once per step on
                     // the chain's only wave per SIMD (for the logistic loss that is an exp and a division per step)
-                    s_g[e] = (ALG == CA_SVRGC) ? grad_coef_t<T, LOSS>(gv, bp ? *bp : T(0), a.lam).coef() : gv;
+                    s_g[e] = (ALG == CA_SVRGC) ? grad_coef_t<T, LOSS>(gv, bp ? *bp : T(0), lam).coef() : gv;
                 }
             }
         }
@@ -1272,12 +1365,13 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
             __syncthreads();
         }
         if (base == 0) {
-#pragma unroll
-            for (int u = 0; u < DEPTH; ++u) {
+#pragma unroll 1
+            for (int u = 0; u < DEPTH; ++u) {   // once per launch: a loop (unrolled, its DEPTH sets of LDS addresses cost scalar registers)
                 const int64_t r0 = uniform64(s_row[DEPTH + u]);
-                refill(u, r0, PTR_IN_ROW ? reinterpret_cast<const unsigned char *>((uintptr_t)r0)
-                              : STAGE_PTR ? reinterpret_cast<const unsigned char *>(uniform64((int64_t)(uintptr_t)s_ptr[DEPTH + u]))
-                                          : reinterpret_cast<const unsigned char *>(a.A + r0 * a.ld));
+                refill(std::false_type{}, u, r0,
+                       PTR_IN_ROW ? reinterpret_cast<const unsigned char *>((uintptr_t)r0)
+                       : STAGE_PTR ? reinterpret_cast<const unsigned char *>(uniform64((int64_t)(uintptr_t)s_ptr[DEPTH + u]))
+                                   : reinterpret_cast<const unsigned char *>(Abase + r0 * ld));
             }
         }
         wait_vmcnt<0>();          // ring fully landed: the counted waits below assume the steady-state op sequence
@@ -1313,11 +1407,11 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                 const int64_t row_n = uniform64(x.row_n);
                 const unsigned char *ptr_n = PTR_IN_ROW ? reinterpret_cast<const unsigned char *>((uintptr_t)row_n)
                                              : STAGE_PTR ? reinterpret_cast<const unsigned char *>(uniform64((int64_t)(uintptr_t)x.ptr_n))
-                                                         : reinterpret_cast<const unsigned char *>(a.A + row_n * a.ld);
+                                                         : reinterpret_cast<const unsigned char *>(Abase + row_n * ld);
                 const T bi = x.bi;
 
                 if (ALG == CA_LFINITO && inb == 0) {   // Finito_LFinito.jl:92  z = prox(av)
-                    const T gl = a.hat_gamma * plam;
+                    const T gl = hat_gamma * plam;
 #pragma unroll
                     for (int j = 0; j < J; ++j)
 #pragma unroll
@@ -1337,8 +1431,8 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                 // DPP stages and the exchange's first shadow instead of standing behind the exchange
                 T pre_rr = T(0), pre_gn = T(0);
                 if (ALG == CA_FINITO || ALG == CA_LFINITO) {
-                    pre_rr = a.hat_gamma / x.gi;
-                    pre_gn = x.gi * a.invN;
+                    pre_rr = hat_gamma / x.gi;
+                    pre_gn = x.gi * invN;
                 }
                 T d1 = T(0), d2 = T(0);
 #pragma unroll
@@ -1363,7 +1457,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                         for (int e = 0; e < n && nq < NQ; ++e, ++nq) {
                             const int k = nq >> 1, j = k / VEC, v = k % VEC;
                             if (nq & 1) {
-                                q1[j][v] = a.gamma * x.ar[j][v];
+                                q1[j][v] = gamma * x.ar[j][v];
                                 asm volatile("" : "+v"(q1[j][v]));
                             } else {
                                 q2[j][v] = p[j][v] - gav[j][v];
@@ -1402,7 +1496,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                 if (SVRG_ANY && NW != 1) {
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
-                        q1[j] = a.gamma * x.ar[j];
+                        q1[j] = gamma * x.ar[j];
                         q2[j] = p[j] - gav[j];
                         // four waves: computed HERE, before the barrier (the empty asm is volatile and stays in front of the
                         // volatile wait below; hipcc otherwise sinks half of these eight instructions behind the exchange,
@@ -1425,7 +1519,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                     constexpr bool SINGLE64 = (sizeof(T) == 8 && !TWO);
                     V rv[SINGLE64 ? 2 : (int)(NW * 2 * sizeof(T) / 16)];
                     if constexpr (SINGLE64) xchg_issue_single64(raddr, rv); else xchg_issue(raddr, rv);
-                    if (SHADOW_REFILL) refill(u, row_n, ptr_n);
+                    if (SHADOW_REFILL) refill(std::true_type{}, u, row_n, ptr_n);
                     if (SVRG_ANY) {
                         if (u > 0 || s0 > 0 || base > 0) {   // compile-time true except in the first step of a ring revolution
 #pragma unroll
@@ -1469,12 +1563,12 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                 // everything after the exchange, instantiated twice: with the IndBox clamp and without it (g = Zero / NormL1),
                 // selected by ONE workgroup-uniform branch per step instead of a select per coordinate
                 {
-                    const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
+                    const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, lam);
                     if (SVRG_ANY) {                                                  // SVRG_basic.jl:74-81
                         // a_i'z_full: recomputed (CA_SVRG) or the value the last full pass stored for this row (CA_SVRGC)
                         // the coefficient at a_i'z_full: staged ready-made (CA_SVRGC), or from this step's second dot product
-                        const T cz = (ALG == CA_SVRGC) ? x.gi : grad_coef_t<T, LOSS>(d2, bi, a.lam).coef();
-                        const T gl = a.gamma * plam;
+                        const T cz = (ALG == CA_SVRGC) ? x.gi : grad_coef_t<T, LOSS>(d2, bi, lam).coef();
+                        const T gl = gamma * plam;
                         const T dc = cz - gp.coef();
     #pragma unroll
                         for (int j = 0; j < J; ++j)
@@ -1486,9 +1580,9 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                             }
                     } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
                         V *sp = reinterpret_cast<V *>(trow_of(row));
-                        const T gl = a.gamma * plam;
+                        const T gl = gamma * plam;
                         const T cp = gp.coef();
-                        const T ngam = -a.gamma;
+                        const T ngam = -gamma;
     #pragma unroll
                         for (int j = 0; j < J; ++j) {
                             V gnv;
@@ -1497,7 +1591,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                                 const T gn = x.ar[j][v] * cp;
                                 const T del = gn - x.sr[j][v];
                                 // SAGA steps with (g_new - s_i + av_old), SAG with av_new (SAGA_basic.jl:58-62)
-                                const T avn = fmad(del, a.invN, av[j][v]);
+                                const T avn = fmad(del, invN, av[j][v]);
                                 const T wv = fmad(ngam, SAG ? avn : del + av[j][v], p[j][v]);
                                 av[j][v] = avn;
                                 p[j][v] = HB ? prox_bf(wv, gl, plo[j][v], phi[j][v]) : prox_l1(wv, gl);
@@ -1519,16 +1613,16 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                             }
                             if (ok[j]) sp[cl[j]] = tv;
                         }
-                        if (inb + 1 == a.batch || (base + s + 1) == a.nsteps) {
-                            const T gl = a.hat_gamma * plam;
+                        if (inb + 1 == batch || (base + s + 1) == nsteps) {
+                            const T gl = hat_gamma * plam;
     #pragma unroll
                             for (int j = 0; j < J; ++j)
     #pragma unroll
                                 for (int v = 0; v < VEC; ++v) p[j][v] = HB ? prox_bf(av[j][v], gl, plo[j][v], phi[j][v]) : prox_l1(av[j][v], gl);
                         }
                     } else {                                                         // Finito_LFinito.jl:93-98
-                        const GradCoef<T> gzf = grad_coef_t<T, LOSS>(d2, bi, a.lam);
-                        const T dc = (a.hat_gamma * a.invN) * (gzf.coef() - gp.coef());
+                        const GradCoef<T> gzf = grad_coef_t<T, LOSS>(d2, bi, lam);
+                        const T dc = (hat_gamma * invN) * (gzf.coef() - gp.coef());
                         const T rr = pre_rr;                  // hat_gamma / gamma_i
     #pragma unroll
                         for (int j = 0; j < J; ++j)
@@ -1540,16 +1634,16 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
                     }
                 }
 
-                if (++inb == a.batch) inb = 0;
+                if (++inb == batch) inb = 0;
                 // one or eight waves: the refill at the end of the step (four waves: in the exchange's shadow, above -- a table row
                 // it fetches that this step is about to rewrite is flagged stale either way: the flag compares DEPTH steps back)
-                if (!SHADOW_REFILL) refill(u, row_n, ptr_n);
+                if (!SHADOW_REFILL) refill(std::true_type{}, u, row_n, ptr_n);
             }
         };
         // the run-time flags become compile-time tags of the group (SAG only exists for the SAGA chain)
         auto pick_sag = [&](auto hb_tag, auto chk_tag, const int s0) {
             if constexpr (ALG == CA_SAGA) {
-                if (a.sag)
+                if (sag)
                     group(hb_tag, chk_tag, std::true_type{}, s0);
                 else
                     group(hb_tag, chk_tag, std::false_type{}, s0);
@@ -1572,7 +1666,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
         }
     }
     wait_vmcnt<0>();   // nothing may still be writing LDS when the workgroup retires
-    if (SVRG_ANY && NW == 4 && a.nsteps > 0) {   // the last step's `z += w`
+    if (SVRG_ANY && NW == 4 && nsteps > 0) {   // the last step's `z += w`
 #pragma unroll
         for (int j = 0; j < J; ++j) zs[j] += p[j];
     }
@@ -1603,8 +1697,11 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
 constexpr int CDMA_CHUNK = 512;
 
 template <typename T, int J, int ALG, bool MASKED>
-__global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
+__global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a_by_value)
 {
+    // the arguments through the kernel-argument segment, field by field where they are used (chain_dma_kernel, and why)
+    (void)a_by_value;
+    ChainArgsK<T> &a = *(ChainArgsK<T> *)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int NW = CHAIN_NW, NT = CHAIN_NT;
     using V = typename VecOfC<T>::type;
     constexpr int VEC = 16 / sizeof(T), PC = VEC / 2;          // reals / complex entries per chunk
@@ -1644,6 +1741,19 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t d = a.d;
     const uint32_t ringA_off = (uint32_t)(uintptr_t)ringA, ringT_off = (uint32_t)(uintptr_t)ringT;
+    const uint32_t ringA_w = sgpr_pin(ringA_off + (uint32_t)wib * 1024u), ringT_w = sgpr_pin(ringT_off + (uint32_t)wib * 1024u);
+    // what the step loop reads of the argument block (sgpr_pin); everything else is read where it is used
+    const int64_t nsteps = sgpr_pin(a.nsteps);
+    const T gamma = (ALG == CA_SVRG || ALG == CA_SAGA) ? sgpr_pin(a.gamma) : T(0);
+    const T lam = sgpr_pin(a.lam);
+    const T invN = (ALG == CA_SVRG) ? T(0) : sgpr_pin(a.invN);
+    const T hat_gamma = PER_SAMPLE_GAM ? sgpr_pin(a.hat_gamma) : T(0);
+    const int64_t batch = PER_SAMPLE_GAM ? sgpr_pin(a.batch) : 0;
+    const bool sag = (ALG == CA_SAGA) && sgpr_pin(a.sag) != 0;
+    const T glam = sgpr_pin(a.g.lam);
+    const T *const Abase = sgpr_pin_global(a.A);
+    const int64_t ld = sgpr_pin(a.ld);
+    T *const tbase = HAS_TABLE ? sgpr_pin_global(a.table) : nullptr;
     const int64_t nchunks = d / VEC;
     bool ok[J];
     int64_t cl[J];
@@ -1657,7 +1767,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
     const bool l1 = (a.g.kind == CIAO_PROX_L1_COMPLEX);
     auto proxc = [&](T tau, T vr, T vi, T &yr, T &yi) {
         if (l1) {
-            prox_cpair_chain(tau * a.g.lam, vr, vi, yr, yi);
+            prox_cpair_chain(tau * glam, vr, vi, yr, yi);
         } else {
             yr = vr;
             yi = vi;
@@ -1673,20 +1783,30 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
         zs[j] = (ALG == CA_SVRG) ? reinterpret_cast<const V *>(a.z)[c] : V(T(0));
         if (!ok[j]) av[j] = p[j] = q[j] = zs[j] = V(T(0));
     }
-    auto refill = [&](int u, int64_t r) {
-        const unsigned char *ap = reinterpret_cast<const unsigned char *>(a.A + r * a.ld);
+    // const_u: the slot number is a compile-time constant where the call is inlined (chain_dma_kernel's refill, and why)
+    auto refill = [&](auto const_u, int u, int64_t r) {
+        constexpr bool CU = decltype(const_u)::value;
+        const unsigned char *ap = reinterpret_cast<const unsigned char *>(Abase + r * ld);
 #pragma unroll
-        for (int j = 0; j < J; ++j) glds16(ap + cl[j] * 16, ringA_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
+        for (int j = 0; j < J; ++j) {
+            const int off = (u * J + j) * NW * 1024;
+            if constexpr (CU) glds16_at(ap + cl[j] * 16, ringA_w, off);
+            else glds16(ap + cl[j] * 16, ringA_w + (uint32_t)off);
+        }
         if (HAS_TABLE) {
-            const unsigned char *sp = reinterpret_cast<const unsigned char *>(a.table + r * d);
+            const unsigned char *sp = reinterpret_cast<const unsigned char *>(tbase + r * d);
 #pragma unroll
-            for (int j = 0; j < J; ++j) glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
+            for (int j = 0; j < J; ++j) {
+                const int off = (u * J + j) * NW * 1024;
+                if constexpr (CU) glds16_at(sp + cl[j] * 16, ringT_w, off);
+                else glds16(sp + cl[j] * 16, ringT_w + (uint32_t)off);
+            }
         }
     };
     int par = 0;
     int64_t inb = 0;
-    for (int64_t base = 0; base < a.nsteps; base += CH) {
-        const int nch = (int)((a.nsteps - base) < CH ? (a.nsteps - base) : CH);
+    for (int64_t base = 0; base < nsteps; base += CH) {
+        const int nch = (int)((nsteps - base) < CH ? (nsteps - base) : CH);
         __syncthreads();
         int64_t hist = -1;
         if (tid < DEPTH && base > 0) hist = s_row[CH + tid];
@@ -1694,7 +1814,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
         if (tid < DEPTH) s_row[tid] = hist;
         for (int e = tid; e < nch + DEPTH; e += NT) {
             int64_t st = base + e;
-            if (st > a.nsteps - 1) st = a.nsteps - 1;
+            if (st > nsteps - 1) st = nsteps - 1;
             int64_t r = a.idx[st];
             if ((uint64_t)r >= (uint64_t)a.N) {
                 *a.errflag = 1;
@@ -1719,8 +1839,8 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
             __syncthreads();
         }
         if (base == 0) {
-#pragma unroll
-            for (int u = 0; u < DEPTH; ++u) refill(u, uniform64(s_row[DEPTH + u]));
+#pragma unroll 1
+            for (int u = 0; u < DEPTH; ++u) refill(std::false_type{}, u, uniform64(s_row[DEPTH + u]));   // once per launch: a loop
         }
         wait_vmcnt<0>();
         drain_vmcnt_visible();
@@ -1766,7 +1886,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
                 const T br = s_b[2 * s], bi = s_b[2 * s + 1];
                 const T gi = PER_SAMPLE_GAM ? s_g[s] : T(1);
                 if (HAS_TABLE && __builtin_amdgcn_readfirstlane(s_stale[s])) {
-                    const V *sp = reinterpret_cast<const V *>(a.table + row * d);
+                    const V *sp = reinterpret_cast<const V *>(tbase + row * d);
 #pragma unroll
                     for (int j = 0; j < J; ++j) sr[j] = ok[j] ? sp[cl[j]] : V(T(0));
                     drain_vmcnt_visible();
@@ -1777,7 +1897,7 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
 #pragma unroll
                         for (int c = 0; c < PC; ++c) {
                             T yr, yi;
-                            proxc(a.hat_gamma, av[j][2 * c], av[j][2 * c + 1], yr, yi);
+                            proxc(hat_gamma, av[j][2 * c], av[j][2 * c + 1], yr, yi);
                             p[j][2 * c] = yr;
                             p[j][2 * c + 1] = yi;
                         }
@@ -1821,8 +1941,8 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
                 par ^= 1;
                 const T rpr = t0 - br, rpi = t1 - bi;                   // residual at p
                 const T rzr = t2 - br, rzi = t3 - bi;                   // residual at z_full (TWO)
-                const bool last_of_batch = (inb + 1 == a.batch) || (base + s + 1 == a.nsteps);
-                V *sp = HAS_TABLE ? reinterpret_cast<V *>(a.table + row * d) : nullptr;
+                const bool last_of_batch = (inb + 1 == batch) || (base + s + 1 == nsteps);
+                V *sp = HAS_TABLE ? reinterpret_cast<V *>(tbase + row * d) : nullptr;
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
                     V tv = V(T(0));
@@ -1832,53 +1952,53 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
                         T pr = p[j][2 * c], pi = p[j][2 * c + 1];           // (vector elements cannot be bound by reference:
                         T avr = av[j][2 * c], avi = av[j][2 * c + 1];       //  scalar copies, written back at the end of the entry)
                         T gpr, gpi, gzr, gzi;
-                        cgrad_elem(xr, xi, rpr, rpi, a.lam, gpr, gpi);
-                        cgrad_elem(xr, xi, rzr, rzi, a.lam, gzr, gzi);
+                        cgrad_elem(xr, xi, rpr, rpi, lam, gpr, gpi);
+                        cgrad_elem(xr, xi, rzr, rzi, lam, gzr, gzi);
                         if (ALG == CA_SVRG) {                                            // SVRG_basic.jl:74-81
                             T tr = gzr - gpr, ti = gzi - gpi;
                             tr -= avr;
                             ti -= avi;
-                            tr *= a.gamma;
-                            ti *= a.gamma;
+                            tr *= gamma;
+                            ti *= gamma;
                             tr += pr;
                             ti += pi;
-                            proxc(a.gamma, tr, ti, pr, pi);
+                            proxc(gamma, tr, ti, pr, pi);
                             zs[j][2 * c] += pr;
                             zs[j][2 * c + 1] += pi;
                         } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
                             const T s_r = sr[j][2 * c], s_i = sr[j][2 * c + 1];
-                            const T delr = (gpr - s_r) * a.invN, deli = (gpi - s_i) * a.invN;
+                            const T delr = (gpr - s_r) * invN, deli = (gpi - s_i) * invN;
                             T wr, wi;
-                            if (a.sag) {
+                            if (sag) {
                                 avr += delr;
                                 avi += deli;
-                                wr = pr - a.gamma * avr;
-                                wi = pi - a.gamma * avi;
+                                wr = pr - gamma * avr;
+                                wi = pi - gamma * avi;
                             } else {
-                                wr = pr - a.gamma * (gpr - s_r + avr);
-                                wi = pi - a.gamma * (gpi - s_i + avi);
+                                wr = pr - gamma * (gpr - s_r + avr);
+                                wi = pi - gamma * (gpi - s_i + avi);
                                 avr += delr;
                                 avi += deli;
                             }
-                            proxc(a.gamma, wr, wi, pr, pi);
+                            proxc(gamma, wr, wi, pr, pi);
                             tv[2 * c] = gpr;
                             tv[2 * c + 1] = gpi;
                         } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
                             const T s_r = sr[j][2 * c], s_i = sr[j][2 * c + 1];
-                            const T tr = pr - (gi * a.invN) * gpr, ti = pi - (gi * a.invN) * gpi;
-                            avr += (tr - s_r) * (a.hat_gamma / gi);
-                            avi += (ti - s_i) * (a.hat_gamma / gi);
+                            const T tr = pr - (gi * invN) * gpr, ti = pi - (gi * invN) * gpi;
+                            avr += (tr - s_r) * (hat_gamma / gi);
+                            avi += (ti - s_i) * (hat_gamma / gi);
                             tv[2 * c] = tr;
                             tv[2 * c + 1] = ti;
-                            if (last_of_batch) proxc(a.hat_gamma, avr, avi, pr, pi);
+                            if (last_of_batch) proxc(hat_gamma, avr, avi, pr, pi);
                         } else {                                                         // Finito_LFinito.jl:93-98
-                            const T cc = a.hat_gamma * a.invN;
+                            const T cc = hat_gamma * invN;
                             avr += cc * gzr;
                             avi += cc * gzi;
                             avr -= cc * gpr;
                             avi -= cc * gpi;
-                            avr += (a.hat_gamma / gi) * (pr - q[j][2 * c]);
-                            avi += (a.hat_gamma / gi) * (pi - q[j][2 * c + 1]);
+                            avr += (hat_gamma / gi) * (pr - q[j][2 * c]);
+                            avi += (hat_gamma / gi) * (pi - q[j][2 * c + 1]);
                         }
                         p[j][2 * c] = pr;
                         p[j][2 * c + 1] = pi;
@@ -1888,9 +2008,9 @@ __global__ void __launch_bounds__(CHAIN_NT) chain_cdma_kernel(ChainArgs<T> a)
                     if (HAS_TABLE && ok[j]) sp[cl[j]] = tv;
                     if (MASKED && !ok[j]) av[j] = p[j] = zs[j] = V(T(0));   // (dead chunks: keep the state exactly zero)
                 }
-                if (++inb == a.batch) inb = 0;
+                if (++inb == batch) inb = 0;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this lane's LDS reads of slot u are done before the DMA overwrites it
-                refill(u, row_n);
+                refill(std::true_type{}, u, row_n);
             }
         }
     }
@@ -2395,6 +2515,14 @@ __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst)
 #pragma clang diagnostic pop
 }
 
+__device__ __forceinline__ void glds4_at(const void *gsrc, uint32_t lds_base, int off)   // (scalar base) + (immediate): glds16_at
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_add_i32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lds_base), "i"(off) : "memory", "m0", "scc");
+#pragma clang diagnostic pop
+}
+
 constexpr int AF_CHUNK = 512;
 
 template <typename T, int J, int NT = CHAIN_NT, bool SHARDED = false>
@@ -2413,8 +2541,12 @@ constexpr size_t afinito_dma_lds_bytes()
 // resolved when its index is staged, 512 steps at a time (the table row's ADDRESS is then what the steps and the hazard flags know
 // the sample by, the other two addresses ride beside it in LDS); the step itself is the same instruction for instruction.
 template <typename T, int J, int LOSS, bool MASKED, int NT = CHAIN_NT, bool SHARDED = false>
-__global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
+__global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a_by_value)
 {
+    // the arguments through the kernel-argument segment, field by field where they are used (chain_dma_kernel, and why)
+    (void)a_by_value;
+    typedef const __attribute__((address_space(4))) AFinitoArgs<T> KernArgs;
+    KernArgs &a = *(KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int NW = NT / WAVE;
     static_assert(NW == 1 || NW == CHAIN_NW, "one wave or four");
     static_assert(!SHARDED || NW == CHAIN_NW, "the sharded chain runs on four waves");
@@ -2460,6 +2592,20 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
     const uint32_t ringA_off = (uint32_t)(uintptr_t)ringA;
     const uint32_t ringT_off = (uint32_t)(uintptr_t)ringT;
     const uint32_t ringM_off = (uint32_t)(uintptr_t)ringM;
+    // this wave's pieces of the ring slots: ONE scalar register per ring (glds16_at)
+    const uint32_t ringA_w = sgpr_pin(ringA_off + (uint32_t)wib * 1024u);
+    const uint32_t ringT_w = sgpr_pin(ringT_off + (uint32_t)wib * 1024u);
+    const uint32_t ringM_w = sgpr_pin(ringM_off + (uint32_t)wib * 256u);
+    // what the step loop reads of the argument block (sgpr_pin); everything else is read where it is used
+    const int64_t nsteps = sgpr_pin(a.nsteps);
+    const T lam = (LOSS == CIAO_LOSS_LOGISTIC) ? T(0) : sgpr_pin(a.lam);
+    const T invN = sgpr_pin(a.invN);
+    const T tol_stop = sgpr_pin_computed(a.tol_b * a.invN);                       // Finito_adaptive.jl:121
+    const double half_N_alpha = sgpr_pin_computed(0.5 * a.Nd * (double)a.alpha);   // :128 (left to right: (0.5 N) alpha, then / gamma_i)
+    const T *const Abase = SHARDED ? nullptr : sgpr_pin_global(a.A);
+    const int64_t ld = SHARDED ? 0 : sgpr_pin(a.ld);
+    T *const tbase = SHARDED ? nullptr : sgpr_pin_global(a.table);
+    T *const mbase = SHARDED ? nullptr : sgpr_pin_global(a.meta);
     if constexpr (SHARDED) af_shard_table_to_lds<T>(s_sh, tid);   // (the staging's first __syncthreads orders it before its readers)
 
     // chunk ownership and dead chunks exactly as in chain_dma_kernel
@@ -2507,23 +2653,33 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
     };
 
     // where a sample's table row and scalars are: unsharded from its row number, SHARDED the staged addresses themselves
-    auto table_row = [&](int64_t row) { return SHARDED ? (T *)(__attribute__((address_space(1))) T *)(uintptr_t)row : a.table + row * d; };
+    auto table_row = [&](int64_t row) { return SHARDED ? (T *)(__attribute__((address_space(1))) T *)(uintptr_t)row : tbase + row * d; };
     auto meta_row = [&](int64_t row, int64_t pm) {
-        return SHARDED ? (T *)(__attribute__((address_space(1))) T *)(uintptr_t)pm : a.meta + row * (CHAIN_NW * 4);
+        return SHARDED ? (T *)(__attribute__((address_space(1))) T *)(uintptr_t)pm : mbase + row * (CHAIN_NW * 4);
     };
-    auto refill = [&](int u, int64_t r, int64_t pa, int64_t pm) {
+    // const_u: the slot number is a compile-time constant where the call is inlined (the unrolled steps): LDS destinations as the
+    // wave's base + an immediate; the one-off first filling of the ring runs as a loop over the slots (chain_dma_kernel)
+    auto refill = [&](auto const_u, int u, int64_t r, int64_t pa, int64_t pm) {
+        constexpr bool CU = decltype(const_u)::value;
         const unsigned char *ap = SHARDED ? (const unsigned char *)(__attribute__((address_space(1))) const unsigned char *)(uintptr_t)pa
-                                          : reinterpret_cast<const unsigned char *>(a.A + r * a.ld);
+                                          : reinterpret_cast<const unsigned char *>(Abase + r * ld);
         const unsigned char *sp = reinterpret_cast<const unsigned char *>(table_row(r));
 #pragma unroll
-        for (int j = 0; j < J; ++j)
-            glds16(ap + cl[j] * 16, ringA_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
+        for (int j = 0; j < J; ++j) {
+            const int off = (u * J + j) * NW * 1024;
+            if constexpr (CU) glds16_at(ap + cl[j] * 16, ringA_w, off);
+            else glds16(ap + cl[j] * 16, ringA_w + (uint32_t)off);
+        }
 #pragma unroll
-        for (int j = 0; j < J; ++j)
-            glds16(sp + cl[j] * 16, ringT_off + (uint32_t)(((u * J + j) * NW + wib) * 1024));
+        for (int j = 0; j < J; ++j) {
+            const int off = (u * J + j) * NW * 1024;
+            if constexpr (CU) glds16_at(sp + cl[j] * 16, ringT_w, off);
+            else glds16(sp + cl[j] * 16, ringT_w + (uint32_t)off);
+        }
         // this wave's copy of the scalars: lanes l and l + MDW fetch the same dword, only the first MDW LDS dwords are read back
         const unsigned char *mp = reinterpret_cast<const unsigned char *>(meta_row(r, pm) + wib * 4);   // the layout's four copies, one per wave
-        glds4(mp + (lane & (MDW - 1)) * 4, ringM_off + (uint32_t)((u * NW + wib) * 256));
+        if constexpr (CU) glds4_at(mp + (lane & (MDW - 1)) * 4, ringM_w, u * NW * 256);
+        else glds4(mp + (lane & (MDW - 1)) * 4, ringM_w + (uint32_t)(u * NW * 256));
     };
 
     struct StepIn {
@@ -2561,8 +2717,8 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
     int par = 0;
     long long done = 0, trials = 0;
     bool stop = false;
-    for (int64_t base = 0; base < a.nsteps && !stop; base += CH) {
-        const int nch = (int)((a.nsteps - base) < CH ? (a.nsteps - base) : CH);
+    for (int64_t base = 0; base < nsteps && !stop; base += CH) {
+        const int nch = (int)((nsteps - base) < CH ? (nsteps - base) : CH);
 
         __syncthreads();
         int64_t hist = -1;
@@ -2571,7 +2727,7 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
         if (tid < DEPTH) s_row[tid] = hist;
         for (int e = tid; e < nch + DEPTH; e += NT) {
             int64_t st = base + e;
-            if (st > a.nsteps - 1) st = a.nsteps - 1;
+            if (st > nsteps - 1) st = nsteps - 1;
             int64_t r = a.idx[st];
             if ((uint64_t)r >= (uint64_t)a.N) {
                 *a.errflag = 1;
@@ -2598,9 +2754,10 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
         }
         __syncthreads();
         if (base == 0) {
-#pragma unroll
-            for (int u = 0; u < DEPTH; ++u)
-                refill(u, uniform64(s_row[DEPTH + u]), SHARDED ? uniform64(s_pa[DEPTH + u]) : 0, SHARDED ? uniform64(s_pm[DEPTH + u]) : 0);
+#pragma unroll 1
+            for (int u = 0; u < DEPTH; ++u)   // once per launch: a loop
+                refill(std::false_type{}, u, uniform64(s_row[DEPTH + u]), SHARDED ? uniform64(s_pa[DEPTH + u]) : 0,
+                       SHARDED ? uniform64(s_pm[DEPTH + u]) : 0);
         }
         wait_vmcnt<0>();
         drain_vmcnt_visible();
@@ -2651,7 +2808,7 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
                 for (int j = 0; j < J; ++j) res[j] = p[j] - x.sr[j];
                 T dz = T(0), fi_z = T(0), r1_acc = T(0);
                 while (true) {
-                    if (gi < a.tol_b * a.invN) {          // Finito_adaptive.jl:121-124: the stepsize collapsed
+                    if (gi < tol_stop) {          // Finito_adaptive.jl:121-124: the stepsize collapsed
                         stop = true;
                         break;
                     }
@@ -2674,7 +2831,7 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
                     }
                     // the two divisions of the step depend only on gamma_i and hat_gamma: issued here, they run in the shadow of
                     // the exchange instead of behind it
-                    const double qc = 0.5 * a.Nd * (double)a.alpha / (double)gi;                // :128 (Float64 in the reference whatever R)
+                    const double qc = half_N_alpha / (double)gi;                // :128 (Float64 in the reference whatever R)
                     const T r1 = hg / gi;                                                       // :145
                     T n2;
                     if constexpr (NW == 1) {   // one wave: the sums reach every lane through SGPRs, no LDS exchange
@@ -2687,7 +2844,7 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
                         n2 = (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]);
                         par ^= 1;
                     }
-                    fi_z = loss_value(LOSS, dz, bi, a.lam);                                     // :125
+                    fi_z = loss_value(LOSS, dz, bi, lam);                                     // :125
                     const double fi_model = (double)(fi_x + c_old * (dz - as_i)) + qc * (double)n2;   // :126-129
                     const T tol = T(10) * Eps<T>::value * (T(1) + fabs2(fi_z));                 // :130
                     if ((double)fi_z <= fi_model + (double)tol) {                               // :131
@@ -2714,10 +2871,10 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
                 }
                 if (stop) break;
                 // the main step, :145-150
-                const GradCoef<T> gn = grad_coef_t<T, LOSS>(dz, bi, a.lam);
+                const GradCoef<T> gn = grad_coef_t<T, LOSS>(dz, bi, lam);
                 const T c_new = gn.coef();
                 const T r1 = r1_acc;
-                const T r2 = (hg * a.invN) * (c_old - c_new);   // + (hg/N) grad_old - (hg/N) grad_new, both multiples of a_i
+                const T r2 = (hg * invN) * (c_old - c_new);   // + (hg/N) grad_old - (hg/N) grad_new, both multiples of a_i
                 V *sp = reinterpret_cast<V *>(table_row(row));
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
@@ -2737,7 +2894,7 @@ __global__ void __launch_bounds__(NT) afinito_dma_kernel(AFinitoArgs<T> a)
                     mp[3] = dz;
                 }
                 ++done;
-                refill(u, row_n, pa_n, pm_n);   // after this step's stores (program order); the look-ahead entry always exists
+                refill(std::true_type{}, u, row_n, pa_n, pm_n);   // after this step's stores (program order); the look-ahead entry always exists
             }
         }
     }

@@ -166,8 +166,33 @@ struct WideWord<double> {
 
 // E elements per thread: the workgroup's slice is WIDE_NT E columns
 template <typename T, int E, int ALG, int LOSS>
-__global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, WideArgs wa)
+__global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a_by_value, WideArgs wa)
 {
+    (void)a_by_value;
+    CIAO_KERNARG0(ChainArgs<T>, a);
+    // what the step loop reads of the argument block: loaded once and pinned in scalar registers (sgpr_pin); the rest where it is used
+    struct {
+        int64_t nsteps, ld, batch, N;
+        const int64_t *idx;
+        const T *A, *b, *gam;
+        T *table;
+        T gamma, invN, hat_gamma, lam;
+        int sag;
+    } h;
+    h.nsteps = sgpr_pin(a.nsteps);
+    h.ld = sgpr_pin(a.ld);
+    h.batch = sgpr_pin(a.batch);
+    h.N = sgpr_pin(a.N);
+    h.idx = sgpr_pin_global(a.idx);
+    h.A = sgpr_pin_global(a.A);
+    h.b = sgpr_pin_global(a.b);
+    h.gam = sgpr_pin_global(a.gam);
+    h.table = sgpr_pin_global(a.table);
+    h.gamma = sgpr_pin(a.gamma);
+    h.invN = sgpr_pin(a.invN);
+    h.hat_gamma = sgpr_pin(a.hat_gamma);
+    h.lam = sgpr_pin(a.lam);
+    h.sag = sgpr_pin(a.sag);
     static_assert(ALG == CA_SVRG || ALG == CA_SAGA || ALG == CA_FINITO || ALG == CA_LFINITO, "the four chains");
     constexpr bool TWO = (ALG == CA_SVRG || ALG == CA_LFINITO);
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
@@ -199,7 +224,7 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
     }
     T *pp = (ALG == CA_SVRG) ? a.w : a.z;      // the point the moving gradient is taken at
     const T plam = (a.g.kind == CIAO_PROX_L1) ? a.g.lam : T(0);
-    const T gl = (HAS_GAM ? a.hat_gamma : a.gamma) * plam;   // the prox's threshold: gamma lambda (SVRG, SAGA) / hat_gamma lambda (Finito, LFinito)
+    const T gl = (HAS_GAM ? h.hat_gamma : h.gamma) * plam;   // the prox's threshold: gamma lambda (SVRG, SAGA) / hat_gamma lambda (Finito, LFinito)
     const bool boxed = (a.g.kind == CIAO_PROX_BOX);   // (its bounds are read per step where they are vectors: 4 E registers otherwise)
     T p[E], av[E], zf[E], zacc[E];
 #pragma unroll
@@ -216,20 +241,20 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
         return prox_bf(v, gl, lo, hi);
     };
     auto row_of = [&](int64_t s) {
-        int64_t row = a.idx[s];
-        if ((uint64_t)row >= (uint64_t)a.N) {   // memory-safe: flag it, use row 0 (results are void once flagged)
+        int64_t row = h.idx[s];
+        if ((uint64_t)row >= (uint64_t)h.N) {   // memory-safe: flag it, use row 0 (results are void once flagged)
             if (tid == 0 && g == 0) *a.errflag = 1;
             row = 0;
         }
         return row;
     };
     auto load_row = [&](T(&o)[E], int64_t row) {
-        const T *ap = a.A + row * a.ld;
+        const T *ap = h.A + row * h.ld;
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = __builtin_nontemporal_load(ap + col[e]);
     };
     auto load_tab = [&](T(&o)[E], int64_t row) {
-        const T *sp = a.table + row * d;
+        const T *sp = h.table + row * d;
 #pragma unroll
         for (int e = 0; e < E; ++e) o[e] = sp[col[e]];
     };
@@ -245,18 +270,18 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
     int64_t inb = 0;                                                // position in the current batch (Finito, LFinito)
     if (!poller) {
         q0 = row_of(0);
-        q1 = a.nsteps > 1 ? row_of(1) : q0;
+        q1 = h.nsteps > 1 ? row_of(1) : q0;
         q2 = q0;
-        inext = a.nsteps > 2 ? row_of(2) : q0;            // the row of the step after next
-        c0 = a.b ? a.b[q0] : T(0);
-        c1 = a.b ? a.b[q1] : T(0);
-        if (HAS_GAM && a.gam) {
-            h0 = a.gam[q0];
-            h1 = a.gam[q1];
+        inext = h.nsteps > 2 ? row_of(2) : q0;            // the row of the step after next
+        c0 = h.b ? h.b[q0] : T(0);
+        c1 = h.b ? h.b[q1] : T(0);
+        if (HAS_GAM && h.gam) {
+            h0 = h.gam[q0];
+            h1 = h.gam[q1];
         }
         load_row(B0, q0);
         if (HAS_TABLE) load_tab(S0, q0);
-        if (a.nsteps > 1) {
+        if (h.nsteps > 1) {
             load_row(B1, q1);
             if (HAS_TABLE) load_tab(S1, q1);
         }
@@ -269,7 +294,7 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
                     T &b0, T &b1, T &b2, T &g0, T &g1, T &g2) -> bool {
         (void)n1, (void)b1, (void)g1;
         const unsigned int seq = (unsigned int)(s + 1);
-        const bool more1 = s + 1 < a.nsteps, more2 = s + 2 < a.nsteps;
+        const bool more1 = s + 1 < h.nsteps, more2 = s + 2 < h.nsteps;
         T d1 = T(0), d2 = T(0);
         const int64_t row = r0;
         const T bi = b0;
@@ -278,9 +303,9 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
                 // (the index was read a step ago, BEFORE that step's row loads: loads return in order, so waiting for it here does not
                 // wait for them; the next index and b_i are requested before this step's row loads for the same reason)
                 r2 = inext;
-                if (s + 3 < a.nsteps) inext = row_of(s + 3);
-                b2 = a.b ? a.b[r2] : T(0);
-                if (HAS_GAM && a.gam) g2 = a.gam[r2];
+                if (s + 3 < h.nsteps) inext = row_of(s + 3);
+                b2 = h.b ? h.b[r2] : T(0);
+                if (HAS_GAM && h.gam) g2 = h.gam[r2];
                 asm volatile("" ::: "memory");
                 load_row(n2, r2);
                 if (HAS_TABLE) load_tab(sn2, r2);
@@ -343,11 +368,11 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
             d2 = T(0);
         }
         // ---- the element-wise update of this workgroup's columns (chain_big_kernel's arithmetic)
-        const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, a.lam);
-        const GradCoef<T> gz = grad_coef_t<T, LOSS>(d2, bi, a.lam);
-        T *sp = HAS_TABLE ? a.table + row * d : nullptr;
+        const GradCoef<T> gp = grad_coef_t<T, LOSS>(d1, bi, h.lam);
+        const GradCoef<T> gz = grad_coef_t<T, LOSS>(d2, bi, h.lam);
+        T *sp = HAS_TABLE ? h.table + row * d : nullptr;
         const T gi = g0;
-        const bool last_of_batch = (inb + 1 == a.batch) || !more1;
+        const bool last_of_batch = (inb + 1 == h.batch) || !more1;
         // SAGA: the table rows of the next two steps were requested BEFORE this step's store (the one for step s + 1 a step ago, the
         // one for step s + 2 at the top of this step): where they are this very sample's, they are stale -- the row is what this step writes
         const bool fix1 = HAS_TABLE && more1 && r1 == row, fix2 = HAS_TABLE && more2 && r2 == row;
@@ -357,7 +382,7 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
             if (ALG == CA_SVRG) {                                            // SVRG_basic.jl:74-81
                 T t = gz.elem(ak) - gp.elem(ak);
                 t -= av[e];
-                t *= a.gamma;
+                t *= h.gamma;
                 t += p[e];
                 const T wn = prox_at(t, e);
                 p[e] = wn;
@@ -365,13 +390,13 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
             } else if (ALG == CA_SAGA) {                                     // SAGA_basic.jl:56-65
                 const T gn = gp.elem(ak);
                 const T sk = scur[e];
-                const T del = (gn - sk) * a.invN;
+                const T del = (gn - sk) * h.invN;
                 T wv;
-                if (a.sag) {
+                if (h.sag) {
                     av[e] += del;
-                    wv = p[e] - a.gamma * av[e];
+                    wv = p[e] - h.gamma * av[e];
                 } else {
-                    wv = p[e] - a.gamma * (gn - sk + av[e]);
+                    wv = p[e] - h.gamma * (gn - sk + av[e]);
                     av[e] += del;
                 }
                 p[e] = prox_at(wv, e);
@@ -379,29 +404,29 @@ __global__ void __launch_bounds__(WIDE_NT) chain_wide_kernel(ChainArgs<T> a, Wid
                 if (fix1) sn1[e] = gn;
                 if (fix2) sn2[e] = gn;
             } else if (ALG == CA_FINITO) {                                   // Finito_basic.jl:110-118
-                const T t = p[e] - (gi * a.invN) * gp.elem(ak);
-                av[e] += (t - scur[e]) * (a.hat_gamma / gi);
+                const T t = p[e] - (gi * h.invN) * gp.elem(ak);
+                av[e] += (t - scur[e]) * (h.hat_gamma / gi);
                 if (valid[e]) sp[col[e]] = t;
                 if (fix1) sn1[e] = t;
                 if (fix2) sn2[e] = t;
                 if (last_of_batch) p[e] = prox_at(av[e], e);
             } else {                                                         // Finito_LFinito.jl:93-98
-                const T c = a.hat_gamma * a.invN;
+                const T c = h.hat_gamma * h.invN;
                 T avk = av[e];
                 avk += c * gz.elem(ak);
                 avk -= c * gp.elem(ak);
-                avk += (a.hat_gamma / gi) * (p[e] - zf[e]);
+                avk += (h.hat_gamma / gi) * (p[e] - zf[e]);
                 av[e] = avk;
             }
         }
-        if (++inb == a.batch) inb = 0;
+        if (++inb == h.batch) inb = 0;
         return true;
     };
-    for (int64_t s = 0; s < a.nsteps; s += 3) {
+    for (int64_t s = 0; s < h.nsteps; s += 3) {
         if (!step(s, B0, B1, B2, S0, S1, S2, q0, q1, q2, c0, c1, c2, h0, h1, h2)) break;
-        if (s + 1 >= a.nsteps) break;
+        if (s + 1 >= h.nsteps) break;
         if (!step(s + 1, B1, B2, B0, S1, S2, S0, q1, q2, q0, c1, c2, c0, h1, h2, h0)) break;
-        if (s + 2 >= a.nsteps) break;
+        if (s + 2 >= h.nsteps) break;
         if (!step(s + 2, B2, B0, B1, S2, S0, S1, q2, q0, q1, c2, c0, c1, h2, h0, h1)) break;
     }
     // ---- the slice of the state back to the caller's vectors
@@ -432,8 +457,16 @@ namespace ciao {
 constexpr int AFW_WORDS = 16;   // mailbox words per workgroup and parity: two sums + workgroup 0's four scalars (fp64: two words each)
 
 template <typename T, int E, int LOSS>
-__global__ void __launch_bounds__(WIDE_NT) afinito_wide_kernel(AFinitoArgs<T> a, WideArgs wa)
+__global__ void __launch_bounds__(WIDE_NT) afinito_wide_kernel(AFinitoArgs<T> a_by_value, WideArgs wa)
 {
+    (void)a_by_value;
+    CIAO_KERNARG0(AFinitoArgs<T>, a);
+    // Read where they are used, not pinned: this kernel's scalar registers are taken by its own uniform state (three sets of
+    // per-sample scalars, rows, b_i in flight; eight validity masks), and a step is 4 us of mailbox round trips -- a scalar load
+    // from the argument block is nothing beside them, a pinned field is a register for the whole launch (pinned: 27-34 spilled
+    // scalar registers, read in place: 0-10).  The two products the backtracking loop needs are formed once.
+    const T tol_stop = sgpr_pin_computed(a.tol_b * a.invN);                       // Finito_adaptive.jl:121
+    const double half_N_alpha = sgpr_pin_computed(0.5 * a.Nd * (double)a.alpha);   // :128, left to right
     constexpr int NW = WIDE_NT / WAVE;
     using W = WideWord<T>;
     constexpr int WN = W::N;
@@ -593,7 +626,7 @@ __global__ void __launch_bounds__(WIDE_NT) afinito_wide_kernel(AFinitoArgs<T> a,
         T gi = T(0), dz = T(0), fi_z = T(0), r1_acc = T(0), c_old = T(0), fi_x = T(0), as_i = T(0);
         bool first = true;
         while (true) {
-            if (!first && gi < a.tol_b * a.invN) {   // Finito_adaptive.jl:121-124 (checked before the first trial below, once gamma_i is known)
+            if (!first && gi < tol_stop) {   // Finito_adaptive.jl:121-124 (checked before the first trial below, once gamma_i is known)
                 stop = true;
                 break;
             }
@@ -613,7 +646,7 @@ __global__ void __launch_bounds__(WIDE_NT) afinito_wide_kernel(AFinitoArgs<T> a,
             if (first) {   // the sample's scalars are here now (workgroup 0: its own; the others: from its slot)
                 c_old = m.c, fi_x = m.f, gi = m.gam, as_i = m.as;
                 first = false;
-                if (gi < a.tol_b * a.invN) {
+                if (gi < tol_stop) {
                     stop = true;
                     break;
                 }
@@ -621,7 +654,7 @@ __global__ void __launch_bounds__(WIDE_NT) afinito_wide_kernel(AFinitoArgs<T> a,
             ++trials;
             dz = p1;
             const T n2v = p2;
-            const double qc = 0.5 * a.Nd * (double)a.alpha / (double)gi;                        // :128
+            const double qc = half_N_alpha / (double)gi;                        // :128
             const T r1 = hg / gi;                                                               // :145
             fi_z = loss_value(LOSS, dz, bi, a.lam);                                             // :125
             const double fi_model = (double)(fi_x + c_old * (dz - as_i)) + qc * (double)n2v;    // :126-129

@@ -16,6 +16,15 @@ namespace ciao {
 
 constexpr int WAVE = 64;
 
+// The FIRST kernel argument (a struct passed by value), read through the kernel-argument segment, field by field WHERE IT IS USED:
+// hipcc loads every field of a by-value argument into scalar registers in the entry block, and the fields that only a prologue, a
+// staging phase or the final stores need then stay live through the hot loop -- 10 to 100 scalar registers pushed out to VGPR lanes
+// in the chain / long-row / small-row families (tools/kernel_meta.py).  The block is constant memory: scalar loads.  A field the hot
+// loop reads goes into a local first (chain_kernels.h sgpr_pin where hipcc would otherwise re-load it inside the loop).
+#define CIAO_KERNARG0(Type, name)                                   \
+    typedef const __attribute__((address_space(4))) Type name##_kernarg_t; \
+    name##_kernarg_t &name = *(name##_kernarg_t *)__builtin_amdgcn_kernarg_segment_ptr()
+
 // ------------------------------------------------------------------------------------------------------------------
 // DPP cross-lane moves (32-bit halves; 64-bit values move as two halves).  Controls used:
 //   quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140.

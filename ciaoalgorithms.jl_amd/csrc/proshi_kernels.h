@@ -322,8 +322,10 @@ constexpr size_t proshi_chain_lds_bytes()
 // load queue at the loop's back-edge once per ring revolution (measured at d = 1024: 0.44-0.49 us per visit; here 0.31-0.35 fp64, 0.24-0.26 fp32).  gamma_i is staged
 // in LDS with the indices.  No compiler-visible load is left inside the loop.
 template <typename T>
-__global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a)
+__global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a_by_value)
 {
+    (void)a_by_value;
+    CIAO_KERNARG0(ProshiChainArgs<T>, a);
     constexpr int CH = PROSHI_CH, PD = ProshiDepth<T>::value, NW = 4;
     constexpr int DW = sizeof(T) / 4;                 // dwords per value
     constexpr int OPS = 3 * DW + 1;                   // per visit and wave: 3 DW LDS-DMA loads + the table store (every wave that visits has a live lane)

@@ -535,8 +535,10 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_split_kernel(RowsArgs<T> a)
 // SMALL_I elements per lane and wave-iteration (8 or 16): the smaller group halves the registers and doubles the waves per CU
 
 template <typename T, int MODE, int SMALL_I, bool PADDED>
-__global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a_by_value)
 {
+    (void)a_by_value;
+    CIAO_KERNARG0(RowsArgs<T>, a);
     constexpr int SMALL_GE = WAVE * SMALL_I;   // elements of one wave-iteration
     static_assert(MODE == RM_GRAD || MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT, "contiguous full sweeps only");
     extern __shared__ __attribute__((aligned(16))) unsigned char small_raw[];
@@ -563,17 +565,20 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
     // ld == d that is the element's own number e, the loads are perfectly contiguous and no offset table is kept (its 16
     // registers cost the fp64 variant half its bandwidth: 4.5 -> 2.4 TB/s)
     const int ld = PADDED ? (int)a.ld : d;
-    bool live[SMALL_I];
+    // An element beyond the group's G*d (a dead slot of the wave-iteration) carries the row number WAVE: "its row is one of this
+    // group's nr <= G <= WAVE rows" is then the ONE test that also says the slot is live.  (As an array of booleans the liveness
+    // was 2 * SMALL_I scalar registers of loop-invariant lane masks: with 16 slots per lane the kernel spilled 12-47 of them.)
+    // s1s[WAVE] is ggs[0]: finite, and multiplied by the dead slot's zero.
     int rrow[SMALL_I], aoff[PADDED ? SMALL_I : 1];
     T xcol[SMALL_I], acc[SMALL_I];
 #pragma unroll
     for (int i = 0; i < SMALL_I; ++i) {
         const int e = lane + WAVE * i;
-        live[i] = e < used;
-        rrow[i] = live[i] ? e / d : 0;
-        const int c = live[i] ? e - rrow[i] * d : 0;
-        if (PADDED) aoff[i] = rrow[i] * ld + c;
-        xcol[i] = live[i] ? a.x1[c] : T(0);
+        const bool live = e < used;
+        rrow[i] = live ? e / d : WAVE;
+        const int c = live ? e - rrow[i] * d : 0;
+        if (PADDED) aoff[i] = live ? rrow[i] * ld + c : 0;
+        xcol[i] = live ? a.x1[c] : T(0);
         acc[i] = T(0);
     }
     T ex = T(0);
@@ -595,7 +600,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
         // element costs an exec-mask branch each; the loop was instruction-bound at ~1500 instructions per group)
 #pragma unroll
         for (int i = 0; i < SMALL_I; ++i) {
-            const bool on = live[i] && rrow[i] < nrg;
+            const bool on = rrow[i] < nrg;
             const int ec = on ? (PADDED ? aoff[i] : lane + WAVE * i) : 0;
             const T val = gp ? __builtin_nontemporal_load(&gp[ec]) : T(0);
             v[i] = on ? val : T(0);
@@ -663,7 +668,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
                 acc[i] += (s1s[rrow[i]] * s2) * av[i];               // coef() * a, as the wave-per-row kernels
                 continue;
             }
-            if (!(live[i] && rrow[i] < nr)) continue;
+            if (!(rrow[i] < nr)) continue;
             const T s1 = s1s[rrow[i]];
             if (MODE == RM_SAGA_INIT) {
                 const T gv = (av[i] * s1) * s2;                       // GradCoef::elem
@@ -688,7 +693,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a)
     // columns: element (lane, i) -> prod[e]; lane c then adds rows 0..G-1 of column c in row order
 #pragma unroll
     for (int i = 0; i < SMALL_I; ++i)
-        if (live[i]) prod[lane + WAVE * i] = acc[i];
+        if (rrow[i] < WAVE) prod[lane + WAVE * i] = acc[i];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     T colsum[(256 + WAVE - 1) / WAVE];
 #pragma unroll
@@ -749,8 +754,10 @@ constexpr size_t smallb_wave_bytes()
 // GATHER = false: a dense row block (no index list, ld == d): the group's rows -- and table rows -- are ONE contiguous stretch, an
 // element's address is the group's base plus its own number, and only b_i / gamma_i go through the staging.
 template <typename T, int MODE, int SMALL_I, bool GATHER>
-__global__ void __launch_bounds__(ROWS_BLOCK) rows_smallb_kernel(RowsArgs<T> a)
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_smallb_kernel(RowsArgs<T> a_by_value)
 {
+    (void)a_by_value;
+    CIAO_KERNARG0(RowsArgs<T>, a);
     static_assert(MODE == RM_GRAD2 || MODE == RM_FINITO_BATCH, "the batch modes");
     constexpr bool TWO = (MODE == RM_GRAD2), TABLE = (MODE == RM_FINITO_BATCH);
     constexpr int GE = WAVE * SMALL_I;
@@ -1006,8 +1013,10 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallb_kernel(RowsArgs<T> a)
 // runs their R reductions interleaved, so R*rowbytes = 8 KiB whatever the row size.
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T, int K, int R, int MODE>
-__global__ void __launch_bounds__(ROWS_BLOCK) rows_multi_kernel(RowsArgs<T> a)
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_multi_kernel(RowsArgs<T> a_by_value)
 {
+    (void)a_by_value;
+    CIAO_KERNARG0(RowsArgs<T>, a);
     using V = typename VecOf<T>::type;
     constexpr int VEC = VecOf<T>::N;
     constexpr int D = K * WAVE * VEC;

@@ -30,8 +30,10 @@ struct LongArgs {
 };
 
 template <typename T, int J, int MODE>
-__global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a, LongArgs la)
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_value, LongArgs la)
 {
+    (void)a_by_value;
+    CIAO_KERNARG0(RowsArgs<T>, a);
     using V = typename VecOf<T>::type;
     using W = WideWord<T>;
     constexpr int VEC = VecOf<T>::N;

@@ -66,8 +66,10 @@ __device__ __forceinline__ void wait_vmcnt_uniform(int k)
 // when the old table row is needed (FINITO_BATCH), over the table tile that came by a third LDS-DMA stream -- from where the tile
 // leaves as it came: 16 bytes per lane, 1 KiB per wave-instruction.
 template <typename T, int NC2, int MODE>
-__global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a)
+__global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a_by_value)
 {
+    (void)a_by_value;
+    CIAO_KERNARG0(RowsArgs<T>, a);
     constexpr bool TWO = (MODE == RM_GRAD2);
     constexpr bool TABLE = (MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH);
     constexpr bool SIN = (MODE == RM_FINITO_BATCH);                       // the old table tile comes in

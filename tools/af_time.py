@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the adaptive Finito chain on cuda:0 for a few (dtype, N, d); prints us per step and trials per step."""
-import os, sys, time
+import hashlib, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -36,6 +36,9 @@ for dt, N, d in cases:
     ctx.afinito_steps(F, g, 0.999, 1e-9, idx[:2000], table, meta, av, z, hg)
     t0 = time.perf_counter(); done, trials = ctx.afinito_steps(F, g, 0.999, 1e-9, idx, table, meta, av, z, hg)
     t = time.perf_counter() - t0
-    out.append(f"{'f64' if dt == torch.float64 else 'f32'} N={N} d={d}: {t / max(done, 1) * 1e6:.3f} us/step, {trials / max(done, 1):.3f} trials/step")
+    hh = hashlib.sha1()
+    for tt in (z, av, hg, table[idx[:2048]]):
+        hh.update(tt.detach().cpu().numpy().tobytes())
+    out.append(f"{'f64' if dt == torch.float64 else 'f32'} N={N} d={d}: {t / max(done, 1) * 1e6:.3f} us/step, {trials / max(done, 1):.3f} trials/step [{hh.hexdigest()[:10]}]")
     del A, table
 print(" | ".join(out))

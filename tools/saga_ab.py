@@ -7,7 +7,7 @@ The shard table is made of two slices of the same matrix / table (ciao_ctx_set_s
 sharded run is the unsharded run plus the address resolution through the table), and the results of all four routes of a dtype
 are compared BITWISE.  us per update over CIAO_M steps (default 400k), indices on the device beforehand.
 VERDICT r3 item 3: fp64 SAGA had never been timed; the sharded chain_dma SAGA carried 520 bytes of scratch."""
-import os, sys, time
+import hashlib, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -69,6 +69,9 @@ for tdt in dtypes:
     ctx.set_option("chain_no_ws", 0)
     ref = results[("ws", False)]
     same = all(all(torch.equal(a, b) for a, b in zip(ref, r)) for r in results.values())
-    print(f"{str(tdt).split('.')[-1]}: all four routes bitwise equal (z, av, 4096 table rows): {same}", flush=True)
+    hh = hashlib.sha1()
+    for tt in ref:
+        hh.update(tt.detach().cpu().numpy().tobytes())
+    print(f"{str(tdt).split('.')[-1]}: all four routes bitwise equal (z, av, 4096 table rows): {same} [{hh.hexdigest()[:10]}]", flush=True)
     del A, y, table, F, results
     torch.cuda.empty_cache()
