@@ -1000,11 +1000,24 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
 
 // The same with the row's (wave-uniform) base address in an SGPR pair and the thread's 32-bit byte offset in a VGPR: the
 // 64-bit address addition per load disappears from the vector pipeline.
+//
+// THE SCALAR BASE IS COPIED BY A SCALAR INSTRUCTION INSIDE THE ASM, and the memory instruction reads the copy.  gfx9 rule (CDNA3/4
+// ISA, manually inserted wait states): "VALU writes SGPR -> VMEM reads that SGPR: 5 wait states".  hipcc inserts the s_nops for the
+// memory instructions it emits itself; the operands of an inline asm are opaque to its hazard recognizer.  A base that reaches the asm
+// from a v_readfirstlane_b32 (uniform64 of a pointer read from LDS) or -- the case that faulted in round 4 -- from the v_readlane_b32
+// that RESTORES a spilled scalar register, which hipcc puts directly in front of the use, is read STALE by the memory instruction:
+// on MI355X 76-98 % of the loads of tools/micro/sgpr_hazard_lab.hip go through the old content of the register pair with 0-3 wait
+// states in between, none with 4 or more, none with a scalar instruction in between (profiles/r05_sgpr_hazard_lab.txt).  A scalar
+// instruction reading a VALU-written SGPR is interlocked by the hardware, and a VMEM instruction reading a SALU-written SGPR has no
+// hazard: the copy makes the asm correct wherever the compiler puts the definition of its operand.  It takes the place of the s_nop
+// that the m0 write needs before the LDS-DMA anyway: no instruction more.  tools/sgpr_vmem_hazard.py checks the built library.
 __device__ __forceinline__ void glds16s(const void *sbase, uint32_t voff, uint32_t lds_dst)
 {
+    uint64_t base_copy;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %3\n\ts_mov_b64 %0, %2\n\tglobal_load_lds_dwordx4 %1, %0"
+                 : "=&s"(base_copy) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 #pragma clang diagnostic pop
 }
 
@@ -1021,9 +1034,11 @@ __device__ __forceinline__ void glds16_at(const void *gsrc, uint32_t lds_base, i
 }
 __device__ __forceinline__ void glds16s_at(const void *sbase, uint32_t voff, uint32_t lds_base, int off)
 {
+    uint64_t base_copy;   // (glds16s: the memory instruction reads a scalar COPY of the base)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-    asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base), "i"(off) : "memory", "m0", "scc");
+    asm volatile("s_add_i32 m0, %3, %4\n\ts_mov_b64 %0, %2\n\tglobal_load_lds_dwordx4 %1, %0"
+                 : "=&s"(base_copy) : "v"(voff), "s"(sbase), "s"(lds_base), "i"(off) : "memory", "m0", "scc");
 #pragma clang diagnostic pop
 }
 

@@ -182,21 +182,30 @@ __device__ __forceinline__ unsigned int ws_poll_wait(unsigned int &c, V (&rv)[4]
     return (unsigned int)__builtin_amdgcn_readfirstlane((int)c);
 }
 
-// the table-row DMA with agent scope (sc1): never served from a line the CU's vector L1 cached before a consumer's store
+// the table-row DMA with agent scope (sc1): never served from a line the CU's vector L1 cached before a consumer's store.
+// (The memory instruction reads a scalar COPY of the base made inside the asm: glds16s in chain_kernels.h, and why.)
 __device__ __forceinline__ void glds16s_sc1(const void *sbase, uint32_t voff, uint32_t lds_dst)
 {
+    uint64_t base_copy;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %3\n\ts_mov_b64 %0, %2\n\tglobal_load_lds_dwordx4 %1, %0 sc1"
+                 : "=&s"(base_copy) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 #pragma clang diagnostic pop
 }
 
 // 16-byte store to (uniform base in SGPRs) + (32-bit lane offset): the consumers' only vector-memory instruction, in inline asm
-// so that the hand-counted vmcnt wait is the only wait it ever gets
+// so that the hand-counted vmcnt wait is the only wait it ever gets.  THE BASE IS COPIED BY A SCALAR INSTRUCTION FIRST: the base is
+// the table row's address of the PREVIOUS step (`tprev`), live across a whole step -- the first thing hipcc spills when scalar
+// registers are short -- and a spilled register comes back by v_readlane_b32 directly in front of its use.  "VALU writes SGPR ->
+// VMEM reads that SGPR" needs five wait states that no one inserts for an inline asm: the store then goes to whatever the register
+// pair held before (measured: 92 % of the time with no wait state in between, profiles/r05_sgpr_hazard_lab.txt) -- round 4's
+// "Memory access fault by GPU" in the variant of this kernel that spilled 142 scalar registers (CHANGELOG round 5).
 template <typename V>
 __device__ __forceinline__ void gstore16s(void *sbase, uint32_t voff, V data)
 {
-    asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(data), "s"(sbase) : "memory");
+    uint64_t base_copy;
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, %0" : "=&s"(base_copy) : "v"(voff), "v"(data), "s"(sbase) : "memory");
 }
 
 

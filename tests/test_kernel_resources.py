@@ -123,6 +123,28 @@ def test_no_hot_kernel_parks_vgprs_in_agprs(kernels):
     assert not bad, "hot kernels with VGPRs spilled (to AGPRs or scratch):\n" + "\n".join(f"  {n}: {v}" for n, v in bad)
 
 
+def test_no_vector_memory_instruction_reads_a_scalar_base_a_vector_instruction_just_wrote():
+    """gfx9: "VALU writes SGPR -> VMEM reads that SGPR: 5 wait states" -- and the hardware does NOT interlock it (on MI355X 76-98 % of
+    such loads go through the STALE register pair, tools/micro/sgpr_hazard_lab.hip, profiles/r05_sgpr_hazard_lab.txt).  hipcc pads the
+    memory instructions it emits; the operands of the chain kernels' inline-asm LDS-DMA loads and table-row stores are opaque to it,
+    and a spilled base comes back by v_readlane_b32 directly in front of its use: round 4's GPU fault.  Every such asm now copies its
+    base with a scalar instruction first.  This disassembles the BUILT library and checks every vector-memory instruction with a scalar
+    base (55 000 of them): the round-4 library has 1953 inside the window (all behind an s_mov to m0, which happened to interlock)."""
+    import sgpr_vmem_hazard
+    import kernel_meta
+    import subprocess
+    import tempfile
+    bad, n = [], 0
+    with tempfile.TemporaryDirectory(prefix="ciao_hz_") as wd:
+        for elf in kernel_meta.code_objects(LIB, wd):
+            out = subprocess.run([f"{kernel_meta.LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", "--no-leading-addr", elf],
+                                 capture_output=True, text=True, check=True).stdout.splitlines()
+            n += sum(1 for line in out if sgpr_vmem_hazard.VMEM.match(line) and sgpr_vmem_hazard.SBASE.search(line))
+            bad += sgpr_vmem_hazard.check(out, os.path.basename(elf))
+    assert n > 10000, "the disassembly of the library's code objects could not be read"
+    assert not bad, "\n".join(f"{name}:{ln}: `{t}` <- `{u}` {ws} wait states earlier" for name, ln, t, un, u, ws in bad[:20])
+
+
 def test_hot_list_matches_kernels_that_exist(kernels):
     names = [r["name"] for r in kernels]
     for p in HOT:
