@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CIAO_HIP_LIB selects another build of the same sources: the experiment builds of tools/exp_build.sh (timing macros), which
 # live under build/<name>/ and never replace the product library.  ciao_build_flags() tells the two apart.
 LIB_PATH = os.environ.get("CIAO_HIP_LIB") or os.path.join(_HERE, "libciao_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_ALLOC, ERR_HOOK = 0, -1, -2, -3, -4, -5
 F32, F64 = 0, 1

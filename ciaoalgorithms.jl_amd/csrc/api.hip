@@ -1157,18 +1157,20 @@ int32_t ciao_ctx_set_peers(ciao_ctx *ctx, int32_t rank, int32_t world, void *con
     for (int r = 0; r < PEER_MAX; ++r) ctx->peer_mail[r] = r < world ? static_cast<unsigned char *>(mailboxes[r]) : nullptr;
     ctx->peer_world = world;
     ctx->peer_rank = rank;
-    // The sequence number lives WITH the mailboxes: this rank's own mailbox holds, per parity, the number of the last reduction every
-    // rank published, so a group that is set again (off and on; another ctx) continues after the largest of them instead of
-    // restarting at 1 and meeting flags of an earlier life that happen to equal the new numbers.  Every rank made the
-    // same reductions, so every rank reads the same maximum; fresh mailboxes read 0.
+    // The sequence number lives WITH the mailboxes, so that a group that is set again (off and on; another ctx) continues instead of
+    // restarting at 1 and meeting flags of an earlier life that happen to equal the new numbers.  It is read from THIS
+    // RANK'S OWN flag in its own mailbox -- the two words (one per parity) that only this rank's kernels ever write: every rank made
+    // the same reductions, so every rank reads the same number, and no peer can change what is read.  (Until round 5 the maximum over
+    // ALL ranks' flags was taken: a rank that finished set_peers first and started reduction last+1 wrote its flag into a slower
+    // rank's mailbox before that rank read it, the slow rank started at last+1 and the two stayed one number -- one parity -- apart
+    // until both timed out: ADVICE r4.)  Fresh mailboxes read 0.
     {
         CIAO_HIP(hipStreamSynchronize(ctx->stream));
         unsigned int flags[2 * PEER_MAX * 16];
         static_assert(sizeof flags == PEER_HDR, "the header is two parities of eight 64-byte flag lines");
         CIAO_HIP(hipMemcpy(flags, mailboxes[rank], sizeof flags, hipMemcpyDeviceToHost));
         unsigned int last = 0;
-        for (int par = 0; par < 2; ++par)
-            for (int r = 0; r < world; ++r) last = flags[(par * PEER_MAX + r) * 16] > last ? flags[(par * PEER_MAX + r) * 16] : last;
+        for (int par = 0; par < 2; ++par) last = flags[(par * PEER_MAX + rank) * 16] > last ? flags[(par * PEER_MAX + rank) * 16] : last;
         ctx->peer_seq = last;
     }
     ctx->peer_max_elems = max_elems;

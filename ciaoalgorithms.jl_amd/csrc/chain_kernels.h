@@ -1106,6 +1106,24 @@ struct DmaDepth {   // ring slots: enough lead to cover an HBM miss at 0.4-0.9 u
     static constexpr int value = (SHARDED && (TABLE ? J <= 1 : J <= 2)) ? 16 : (TABLE ? (J <= 2 ? 8 : (J <= 4 ? 4 : 2)) : (J <= 4 ? 8 : 4));
 };
 
+// Chains with a table: are BOTH addresses of a step's sample (data row, table row) resolved while staging and kept in LDS (the step then
+// multiplies nothing: two 64-bit multiplies, eighteen scalar instructions, leave every step), or only the row index?  Always over a
+// shard table (the step must not search it); on one allocation wherever the second address array (8 KiB) still fits the 160 KiB of
+// LDS beside the rings -- everything but the 16 KiB-row Finito chains.  Round 5: the sharded SAGA chain, the same instructions but for
+// this, ran 5-8 % FASTER than the unsharded one (fp64 d = 1024 0.479 against 0.507 us, fp32 d = 2048 0.443 against 0.483).
+template <typename T, int J, int ALG, int NT, bool SHARDED>
+constexpr bool chain_dma_stage_ptr()
+{
+    constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
+    constexpr int NW = NT / WAVE;
+    constexpr int DEPTH = DmaDepth<J * NT / 256, HAS_TABLE, SHARDED>::value;
+    constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO || ALG == CA_SVRGC);
+    constexpr size_t with_ptr = (size_t)DEPTH * J * NT * 16 * 2 + 2 * (CHAIN_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
+                                CHAIN_CHUNK * sizeof(T) * (PER_SAMPLE_GAM ? 2 : 1) + CHAIN_CHUNK * sizeof(int) + 16 + 2 * NW * 2 * sizeof(T) +
+                                (SHARDED ? SHARD_QW * sizeof(int64_t) : 0);
+    return HAS_TABLE && (SHARDED || with_ptr <= 160 * 1024);
+}
+
 // NT threads (256 or 512): 32 KiB rows are shared by eight waves instead of four (a step costs ~0.38 us + ~0.06 us per
 // 16-byte chunk a thread owns, but eight waves also pay more for the exchange: chain_launch.inc has the measurements).
 // SHARDED: the rows live in several allocations (ChainArgs::sh*, ciao_ctx_set_shards): each step's row ADDRESS is resolved
@@ -1150,12 +1168,13 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
     static_assert(!SHARDED || ALG == CA_SVRG || ALG == CA_SAGA, "only the SVRG and SAGA chains run over a shard table");
     // Chains without a table (SVRG, LFinito) need a step's row only as an ADDRESS: the staged entry is the row's address
     // itself (resolved while staging, with full parallelism), which takes the 64-bit multiply -- nine scalar instructions -- out
-    // of every step.  Chains with a table also need the row index (table row, hazard flags): they keep it and compute
-    // the address in the step, or -- over a shard table (STAGE_PTR) -- stage BOTH addresses: s_row holds the TABLE row's address
-    // (which identifies the sample as well as its index does: the hazard flags compare it) and s_ptr the data row's, so that a
-    // step never searches the shard table.
+    // of every step.  Chains with a table need the sample's identity as well (table row, hazard flags): STAGE_PTR (over a shard
+    // table always; on one allocation wherever LDS has room, chain_dma_stage_ptr) stages BOTH addresses -- s_row holds the TABLE
+    // row's address (which identifies the sample as well as its index does: the hazard flags compare it) and s_ptr the data row's, so
+    // that a step neither multiplies nor searches the shard table; the 16 KiB-row Finito chains keep the index and compute both
+    // addresses in the step.
     constexpr bool PTR_IN_ROW = !HAS_TABLE;
-    constexpr bool STAGE_PTR = SHARDED && HAS_TABLE;
+    constexpr bool STAGE_PTR = chain_dma_stage_ptr<T, J, ALG, NT, SHARDED>();
     static_assert(CH % DEPTH == 0 && DEPTH % 2 == 0, "ring slots must line up with chunk starts; ping-pong needs even DEPTH");
 
     // one dynamic LDS block, carved by hand (16-byte aligned pieces):
@@ -1354,6 +1373,7 @@ __global__ void __launch_bounds__(NT) chain_dma_kernel(ChainArgs<T> a_in)
             } else {
                 arow = a.A + r * a.ld;
                 bp = a.b ? a.b + r : nullptr;
+                if (STAGE_PTR) ident = (int64_t)(uintptr_t)(a.table + r * a.d);
             }
             s_row[DEPTH + e] = PTR_IN_ROW ? (int64_t)(uintptr_t)arow : ident;
             if (STAGE_PTR) s_ptr[DEPTH + e] = reinterpret_cast<const unsigned char *>(arow);
@@ -2057,7 +2077,7 @@ constexpr size_t chain_dma_lds_bytes()
     constexpr bool HAS_TABLE = (ALG == CA_SAGA || ALG == CA_FINITO);
     constexpr int DEPTH = DmaDepth<J * NT / 256, HAS_TABLE, SHARDED>::value;
     constexpr bool PER_SAMPLE_GAM = (ALG == CA_FINITO || ALG == CA_LFINITO || ALG == CA_SVRGC);
-    constexpr bool STAGE_PTR = SHARDED && HAS_TABLE;
+    constexpr bool STAGE_PTR = chain_dma_stage_ptr<T, J, ALG, NT, SHARDED>();
     return (size_t)DEPTH * J * NT * 16 * (HAS_TABLE ? 2 : 1) + (STAGE_PTR ? 2 : 1) * (CHAIN_CHUNK + 2 * DEPTH) * sizeof(int64_t) +
            CHAIN_CHUNK * sizeof(T) * (PER_SAMPLE_GAM ? 2 : 1) + (HAS_TABLE ? CHAIN_CHUNK * sizeof(int) : 0) + 16 +
            2 * NW * 2 * sizeof(T) + (SHARDED ? SHARD_QW * sizeof(int64_t) : 0);

@@ -107,6 +107,8 @@ struct ciao_ctx {
     int chain_last_ws = 0;          // issuer waves of the wave-specialised chain the last launch took, 0 = another kernel
     int chain_last_one_wave = 0;    // E of the single-wave register-ring chain the last launch took, 0 = four waves
     int chain_last_dma = 0;
+    int long_occ[2][8] = {};        // rows_long_kernel: workgroups per CU by (J == 8, mode), asked of the runtime once (0 = not yet)
+    int chain_last_block = 0;   // threads of the chain_dma_kernel launch that was made (the launcher records it: the name reports what ran)
     bool chain_last_masked = false;
     int64_t force_generic = 0;      // testing: route every rows launch through the generic kernel
 

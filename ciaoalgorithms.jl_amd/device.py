@@ -64,6 +64,9 @@ class PackedF:
         elif loss != L.LOSS_ZERO:
             raise ValueError("b (targets / labels) is required for LeastSquares and logistic F")
         self.A, self.b, self.lam = A, b, float(lam)
+        # Feature padding (operators.pack_F(pad_to=...)): the rows carry self.d - padded_from zero columns, and the solver's state
+        # vectors are length-padded_from VIEWS of length-self.d buffers.  None: every vector must have exactly self.d elements.
+        self.padded_from: int | None = None
         self.N_total = int(N_total) if N_total is not None else self.N
         self.row0 = int(row0)
         self._c = L.Problem(self.loss, _DT[self.dtype], self.N, self.d, max(self.ld, self.d), self.N_total,
@@ -312,12 +315,15 @@ class Context:
     # -- helpers -------------------------------------------------------------------------------------------------------
     def _vec(self, t: torch.Tensor, p: PackedF, name: str, n: int | None = None):
         n = p.d if n is None else n
-        # (a length-d view of a longer buffer is taken for the p.d-vector it heads when the problem's rows were padded with fewer than
-        # one 16-byte chunk of zero columns: solvers._Iterable's feature padding -- the kernels read and write all p.d coordinates)
+        # A length-padded_from VIEW of a longer buffer is taken for the p.d-vector it heads -- only for a problem whose rows the host
+        # mirror padded itself (PackedF.padded_from, set by operators.pack_F(pad_to=...): solvers._Iterable owns those buffers and
+        # made them p.d long).  For every other problem the length must be exact: the kernels read and write all p.d coordinates,
+        # and a caller's big[:d-1] would be written one element past its end.
         ok = isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == p.dtype and t.is_contiguous()
         if ok and t.numel() != n:
             es = t.element_size()
-            ok = (0 < n - t.numel() < 16 // es) and t.untyped_storage().nbytes() >= (t.storage_offset() + n) * es
+            ok = (n == p.d and getattr(p, "padded_from", None) is not None and t.numel() == p.padded_from and
+                  t.untyped_storage().nbytes() >= (t.storage_offset() + n) * es)
         if not ok:
             raise ValueError(f"{name}: need a contiguous {p.dtype} device vector of length {n}, got "
                              f"{getattr(t, 'dtype', type(t))} {tuple(getattr(t, 'shape', ()))} on {getattr(t, 'device', '?')}")

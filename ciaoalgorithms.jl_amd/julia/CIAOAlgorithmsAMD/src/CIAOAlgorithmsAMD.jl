@@ -41,7 +41,7 @@ struct CiaoShardTable                       # ciao_shard_table: fixed-size C arr
     row0::NTuple{9,Int64}
     A::NTuple{8,Ptr{Cvoid}}; b::NTuple{8,Ptr{Cvoid}}; table::NTuple{8,Ptr{Cvoid}}; meta::NTuple{8,Ptr{Cvoid}}
 end
-const CIAO_ABI_VERSION = Int32(2)
+const CIAO_ABI_VERSION = Int32(3)
 const CIAO_F32, CIAO_F64 = Int32(0), Int32(1)
 const LOSS_LS, LOSS_LOGISTIC, LOSS_ZERO, LOSS_LS_COMPLEX = Int32(0), Int32(1), Int32(2), Int32(3)
 const PROX_ZERO, PROX_L1, PROX_BOX, PROX_L1_COMPLEX = Int32(0), Int32(1), Int32(2), Int32(3)

@@ -122,6 +122,11 @@ def _dev(a: np.ndarray, dtype: torch.dtype, device) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a)).to(dtype=dtype, device=device).contiguous()
 
 
+def _mark_padded(p: PackedF, d: int, dp: int) -> PackedF:
+    p.padded_from = d if dp != d else None
+    return p
+
+
 def pack_F(F, N: int, d: int, R, device=None, complex_pairs: bool = False, pad_to: int | None = None) -> PackedF:
     """Recognise and pack the finite-sum term.  F is None (Zero()), a PackedF, or a sequence of N one-row operators.
     d counts the REAL coordinates of x0; with complex_pairs (complex x0) they are (re, im) pairs and the operators' rows
@@ -146,14 +151,14 @@ def pack_F(F, N: int, d: int, R, device=None, complex_pairs: bool = False, pad_t
             raise ValueError(f"F has d={F.d} but x0 has {d} (real) coordinates")
         return F
     if F is None:
-        return PackedF.zero(N, dp, dtype)
+        return _mark_padded(PackedF.zero(N, dp, dtype), d, dp)
     F = list(F)
     if len(F) != N:
         raise ValueError(f"F has {len(F)} terms but N={N}")
     if N == 0:
-        return PackedF.zero(0, dp, dtype)
+        return _mark_padded(PackedF.zero(0, dp, dtype), d, dp)
     if all(isinstance(f, Zero) for f in F):
-        return PackedF.zero(N, dp, dtype)
+        return _mark_padded(PackedF.zero(N, dp, dtype), d, dp)
     if all(isinstance(f, LeastSquares) for f in F):
         lam = F[0].lam
         if any(f.lam != lam for f in F):
@@ -170,7 +175,9 @@ def pack_F(F, N: int, d: int, R, device=None, complex_pairs: bool = False, pad_t
             Ap = np.ascontiguousarray(A.astype(ct)).view(ct(0).real.dtype)
             bp = np.ascontiguousarray(b.astype(ct)).view(ct(0).real.dtype)
             return PackedF.least_squares_complex(_dev(Ap, dtype, device), _dev(bp, dtype, device), lam)
-        return PackedF.least_squares(_dev(padded(A), dtype, device), _dev(b, dtype, device), lam)
+        out = PackedF.least_squares(_dev(padded(A), dtype, device), _dev(b, dtype, device), lam)
+        out.padded_from = d if dp != d else None
+        return out
     if complex_pairs:
         raise UnpackableOperator("with a complex x0 the device path packs LeastSquares rows and Zero only")
     if all(isinstance(f, Precompose) and isinstance(f.f, LogisticLoss) for f in F):
@@ -179,7 +186,9 @@ def pack_F(F, N: int, d: int, R, device=None, complex_pairs: bool = False, pad_t
                 raise UnpackableOperator("only Precompose(LogisticLoss([y_i], 1.0), a_i' (1 x d), mu) terms are packable")
         A = np.concatenate([f.L for f in F], axis=0)
         y = np.concatenate([f.f.y for f in F], axis=0)
-        return PackedF.logistic(_dev(padded(A), dtype, device), _dev(y, dtype, device))
+        out = PackedF.logistic(_dev(padded(A), dtype, device), _dev(y, dtype, device))
+        out.padded_from = d if dp != d else None
+        return out
     kinds = sorted({type(f).__name__ for f in F})
     raise UnpackableOperator(f"F of kinds {kinds} is not a family the device path can pack (LeastSquares rows, "
                              f"Precompose(LogisticLoss) rows, Zero).  An opaque operator object cannot be called per sample from a GPU "

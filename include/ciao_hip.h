@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CIAO_ABI_VERSION 2
+#define CIAO_ABI_VERSION 3   /* 3: ciao_shard_table grew by meta[8] (round 4 changed the layout under version 2: ADVICE r4) */
 
 #if defined(__GNUC__)
 #define CIAO_API __attribute__((visibility("default")))

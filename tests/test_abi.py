@@ -58,7 +58,7 @@ def test_library_exports_every_declared_symbol(ciao):
     lib = ciao._lib.load()
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} is declared in include/ciao_hip.h but not exported by libciao_hip.so"
-    assert lib.ciao_abi_version() == 2
+    assert lib.ciao_abi_version() == 3
 
 
 def test_ctypes_table_matches_header(ciao):
@@ -93,7 +93,7 @@ def test_struct_layouts_match_the_header(ciao, tmp_path):
 def test_header_is_plain_c(tmp_path):
     """The boundary must be consumable from C (and therefore from Julia's ccall): compile the header as C11, pedantic."""
     src = tmp_path / "inc.c"
-    src.write_text('#define CIAO_BENCH_API 1\n#include "ciao_hip.h"\nint main(void){return CIAO_ABI_VERSION - 2;}\n')
+    src.write_text('#define CIAO_BENCH_API 1\n#include "ciao_hip.h"\nint main(void){return CIAO_ABI_VERSION - 3;}\n')
     subprocess.run(["gcc", "-std=c11", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                     "-o", str(tmp_path / "inc.o")], check=True)
 

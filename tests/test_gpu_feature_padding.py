@@ -82,3 +82,29 @@ def test_padding_is_not_applied_where_it_must_not_be(api, ctx, ciao):
         pass
     z = S.solution(st).cpu().numpy()
     assert z.shape == (d,) and np.all(z <= hi + 1e-12) and np.all(z >= lo - 1e-12)
+
+
+def test_a_short_view_is_refused_unless_the_host_mirror_padded_the_problem(api, ctx, ciao):
+    """the entry points accept a length-d view of a longer buffer for the padded problem's d'-vector ONLY when the host
+    mirror padded the problem itself (PackedF.padded_from); a caller's `big[:d-1]` on a matrix it laid out is an error, not a write past
+    the end of the view."""
+    import torch
+    from ciaoalgorithms_jl_amd.device import PackedF, ProxG
+    T, N, d = np.float64, 24, 34
+    A, b, _ = P.synthetic("ls", N, d, T, seed=2)
+    packed = PackedF.least_squares(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda(), float(N))
+    assert packed.padded_from is None
+    big = torch.zeros(d + 8, dtype=torch.float64, device="cuda")
+    x, av = torch.zeros(d, dtype=torch.float64, device="cuda"), torch.zeros(d, dtype=torch.float64, device="cuda")
+    ctx.full_gradient(packed, x, av)
+    with pytest.raises(ValueError, match="length 34"):
+        ctx.full_gradient(packed, x, big[:d - 1])
+    with pytest.raises(ValueError, match="length 34"):
+        ctx.full_gradient(packed, big[:d - 1], av)
+    assert float(big.abs().max()) == 0.0
+    S, ops = api
+    F = [ops.LeastSquares(A[i:i + 1, :d - 1].copy(), b[i:i + 1], float(N)) for i in range(N)]      # d - 1 = 33 columns: padded to 34
+    it = S.iterator(S.SVRG(T, γ=1e-3), np.zeros(d - 1), F=F, g=ops.NormL1(0.1), N=N, ctx=ctx)
+    assert it.F.padded_from == d - 1 and it.F.d == d
+    state = next(iter(it))
+    assert tuple(state.av.shape) == (d - 1,)

@@ -483,7 +483,14 @@ def _peer_worker(rank, world, port, q):
         ok["c5_replicas_bitwise"] = all(torch.equal(zs5[0], t) for t in zs5)
         # (7) ADVICE r3 (low): the same group turned off and on again continues its sequence numbers (flags of the earlier
         # reductions are still in the mailboxes and would match a restarted count), and what the peers displaced is back after "off"
+        # ... and ONE RANK IS LATE: rank 0 has set the group again and published its first reduction -- its flag, one number
+        # further, is in rank 1's mailbox -- before rank 1 reads where to continue.  Each rank continues from its OWN flag, which no
+        # peer writes (until round 5 it took the largest flag in its mailbox: the late rank then started one number ahead and both
+        # timed out)
         ctx.set_peers(None)
+        if rank == 1:
+            import time
+            time.sleep(1.5)
         ctx.set_peers(pg5)
         t7 = torch.full((d5 + 1,), float(rank + 1), dtype=torch.float32, device=dev)
         for _ in range(3):

@@ -75,11 +75,11 @@ SGPR_EXCEPTIONS = {
     r"ciao::afinito_dma_kernel<double, 8, 1, true, 256, (true|false)>": 11,
 }
 # VGPRs parked in AGPRs (vgpr_spill > 0 with no scratch: v_accvgpr moves).  One class: a thread that owns FOUR or more 16-byte chunks
-# of every state vector (rows of 16 KiB on four waves, fp64 rows of 4 KiB on one wave, adaptive Finito rows of 32 KiB) holds more state
+# of every state vector (rows of 16 KiB on four waves, adaptive Finito rows of 32 KiB) holds more state
 # than the 256 architectural VGPRs a VALU instruction can name; the other 256 registers of a one-wave-per-SIMD kernel are reachable
 # only as AGPRs.  Measured against the alternatives on one box (the parked form is the fastest of what exists):
 #   16 KiB rows: four waves with parking 0.62 us per SVRG update, eight waves with half the chunks per thread 0.68 (chain_dma_launch.inc);
-#   fp64 4 KiB rows on one wave 0.277 us against 0.306 on four waves without parking (chain_dma_launch.inc);
+#   (fp64 4 KiB rows on one wave, four chunks per lane, parked too and lost to four waves in round 5: no longer built);
 #   32 KiB rows on eight waves: scratch, the round-4 exception below (profiles/r04_chain_32k_ab.txt).
 AGPR_PARKING_OK = [
     r"ciao::chain_dma_kernel<(float|double), 4, ",

@@ -20,8 +20,10 @@ for kv in os.environ.get("CIAO_OPTS", "").split(","):
         ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 N = int(os.environ.get("CIAO_N", "4000000"))
 st = IndexStream(0)
-for d in (50, 100, 255):
-    for dt in (torch.float64, torch.float32):
+DS = tuple(int(x) for x in os.environ.get("CIAO_DS", "50,100,255").split(","))           # CIAO_DS=50 CIAO_DT=f64: one shape (profiling)
+DTS = {"f64": (torch.float64,), "f32": (torch.float32,)}.get(os.environ.get("CIAO_DT", ""), (torch.float64, torch.float32))
+for d in DS:
+    for dt in DTS:
         es = 8 if dt == torch.float64 else 4
         A = torch.empty((N, d), dtype=dt, device="cuda"); b = torch.empty((N,), dtype=dt, device="cuda")
         ctx.synth_normal(A, 0, 1, 1 / np.sqrt(d))
@@ -34,8 +36,8 @@ for d in (50, 100, 255):
         table = torch.empty((N, d), dtype=dt, device="cuda")
         av, z, zf = (torch.empty_like(x0) for _ in range(3))
         ctx.finito_init(F, g, gam, hg, x0, table, av, z)
-        for r in (() if os.environ.get("CIAO_LFINITO_ONLY") else (4096, 65536)):
-            nit = 16
+        for r in (() if os.environ.get("CIAO_LFINITO_ONLY") else tuple(int(x) for x in os.environ.get("CIAO_RS", "4096,65536").split(","))):
+            nit = 16 if r <= 65536 else 4
             idx = ctx._idx(np.concatenate([st.sample_without_replacement(N, r) for _ in range(nit)]))
             bptr = np.arange(nit + 1, dtype=np.int64) * r
             first = (np.arange(1, nit + 1, dtype=np.int64) % (N // r)) * r
