@@ -1342,6 +1342,10 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
         ctx->chain_no_ws = value != 0;
     } else if (!strcmp(key, "small_mfma")) {
         ctx->small_mfma = value;
+    } else if (!strcmp(key, "wrow_rows_per_wave")) {
+        ctx->wrow_rows_per_wave = value;
+    } else if (!strcmp(key, "small_wrow")) {
+        ctx->small_wrow = value;
     } else if (!strcmp(key, "small_mfma_table")) {
         ctx->small_mfma_table = value;
     } else if (!strcmp(key, "small_nb")) {

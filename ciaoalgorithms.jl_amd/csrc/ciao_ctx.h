@@ -82,6 +82,8 @@ struct ciao_ctx {
     int64_t sweep_blocks_per_cu = 0;   // 0 = choose from the row size (rows_launch.inc)
     int64_t sweep_multi = 1;           // short rows (<= 4 KiB): several rows per wave per iteration (rows_multi_kernel)
     int64_t split_max_rows = -1;       // batches up to this many rows run one workgroup per row (rows_split_kernel); -1 = automatic
+    int64_t wrow_rows_per_wave = 0;    // ... rows per wave a small batch is cut into (0: four)
+    int64_t small_wrow = -1;           // Finito batches over index lists on rows of tabular size one wave per row (rows_wrow_kernel): 0 = off (rows_smallb_kernel)
     int64_t small_mfma_table = -1;     // ... also the table modes (SAGA / Finito init, Finito batches over row blocks): 0 = off
     int64_t small_nb = 0;              // rows_smallm_kernel: tile buffers per wave, 2 .. 4 (0 = automatic)
     int64_t small_mfma = -1;           // rows_smallm_kernel (GRAD sweeps on dense rows of 17 .. 256 elements on the matrix cores): 0 = off

@@ -94,6 +94,13 @@ size_t smallm_lds(int64_t d, int nb, bool table_in);   // table_in: RM_FINITO_BA
 template <typename T>
 int32_t launch_smallm(ciao_ctx *ctx, int mode, int grid, size_t lds, RowsArgs<T> &a);
 
+// Finito batches over an index list (or a row block) of rows of tabular size, one wave per row (rowsw_kernels.h).  Specialised in
+// rowsw_f32.hip / rowsw_f64.hip.  wrow_plan: false when the shape / mode is not for this kernel.
+template <typename T>
+bool wrow_plan(int mode, const RowsArgs<T> &a, int *vec, int *k);
+template <typename T>
+int32_t launch_wrow(ciao_ctx *ctx, int mode, int vec, int k, int grid, RowsArgs<T> &a);
+
 // sweeps / batch steps over rows beyond 64 KiB: a cluster of S workgroups per row (rowsl_kernels.h).  Specialised in rowsl_f32.hip /
 // rowsl_f64.hip.  long_plan: CIAO_ERR_UNSUPPORTED (no error text) when the shape is not for this kernel.
 constexpr int LONG_J_DEFAULT = 8;   // 16-byte chunks per thread: a workgroup's segment is J * 4 KiB of the row (Finito batches: 4)

@@ -953,9 +953,11 @@ def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, path):
 def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
     """Rows of tabular size (d = 3 ... 255, the shape of the reference's own problems: test/test_lasso.jl:15,
     test/test_logistic_l1.jl:12-26) in all five modes of the batch-parallel kernels, dense and padded row stride, N = 6000 (dozens
-    of row groups per wave, several workgroups): the full gradient, SAGA init and Finito init on rows_small_kernel, Finito
-    batches (index lists AND row blocks) and LFinito's batch sweep (index lists AND row blocks) on rows_smallb_kernel (round 4;
-    they used to run the scalar generic kernel) -- each against the oracle, the two batch forms of the same batches bitwise equal."""
+    of row groups per wave, several workgroups): the full gradient, SAGA init and Finito init on rows_small_kernel (dense rows of
+    17 ... : rows_smallm_kernel), Finito batches over index lists on rows_wrow_kernel (round 5: one wave per row -- the reference's
+    default sweeping = 1 draws lists) and over row blocks on rows_smallm_kernel where its tiles fit, else rows_wrow_kernel too, LFinito's
+    batch sweep (index lists AND row blocks) on rows_smallb_kernel / rows_smallm_kernel -- each against the oracle, the two batch forms
+    of the same batches bitwise equal where they run the same kernel; the lists again on rows_smallb_kernel (option small_wrow=0)."""
     import torch
     from oracle import oracle as O
     N, r = 6000, 700
@@ -997,11 +999,26 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         st = ciao.IndexStream(d)
         rnd = [st.sample_without_replacement(N, r) for _ in range(4)]
         bptr = np.arange(len(rnd) + 1, dtype=np.int64) * r
+        # (the last two lists: the rows of the one before in another order -- every row met again one batch later -- and a short list)
+        rnd.append(rnd[-1][np.argsort(-rnd[-1] % 97, kind="stable")])
+        rnd.append(st.sample_without_replacement(N, 37))
+        bptr = np.zeros(len(rnd) + 1, np.int64)
+        np.cumsum([len(x) for x in rnd], out=bptr[1:])
+        t3, av3, z3 = table.clone(), av.clone(), z.clone()
         ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(rnd), table, av, z)
-        assert "rows_smallb_kernel" in ctx.last_kernel() and "mode4" in ctx.last_kernel(), ctx.last_kernel()
+        assert "rows_wrow_kernel" in ctx.last_kernel() and "mode4" in ctx.last_kernel(), ctx.last_kernel()
+        assert ("chunks" in ctx.last_kernel()) == (pad == 0 and (d * es) % 16 == 0), ctx.last_kernel()   # 16 bytes per lane where rows allow
         O.finito_steps(op, og, gam, rhg, rnd, rt, rav, rz)
         close(z, rz, dtype, scale=20000, what=f"small rows finito z, index lists ({ctx.last_kernel()})")
         close(table, rt, dtype, scale=2000, what="small rows finito table, index lists")
+        ctx.set_option("small_wrow", 0)   # ... and the same lists on the several-rows-per-wave kernel: another order of summation
+        try:
+            ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(rnd), t3, av3, z3)
+            assert "rows_smallb_kernel" in ctx.last_kernel() and "mode4" in ctx.last_kernel(), ctx.last_kernel()
+        finally:
+            ctx.set_option("small_wrow", -1)
+        close(z3, rz, dtype, scale=20000, what="small rows finito z, index lists on rows_smallb_kernel")
+        close(t3, rt, dtype, scale=2000, what="small rows finito table, index lists on rows_smallb_kernel")
         nb = -(-N // r)
         order = [(t + 1) % nb for t in range(nb + 2)]                     # cyclic: the first step uses batch 2 (Finito_basic.jl:99)
         static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in order]   # the last block is short (6000 = 8 * 700 + 400)
@@ -1018,7 +1035,8 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
             close(z2, rz, dtype, scale=20000, what=f"small rows finito z, row blocks on the matrix-core kernel ({ctx.last_kernel()})")
             close(t2, rt, dtype, scale=2000, what="small rows finito table, row blocks on the matrix-core kernel")
         else:
-            assert "rows_smallb_kernel" in ctx.last_kernel(), ctx.last_kernel()
+            # the list IS a block and both forms run the one-wave-per-row kernel (row q on the same wave either way): BITWISE
+            assert "rows_wrow_kernel" in ctx.last_kernel(), ctx.last_kernel()
             assert torch.equal(z, z2) and torch.equal(av, av2) and torch.equal(table, t2), "row blocks and the same batches as index lists differ"
         close(z, rz, dtype, scale=20000, what="small rows finito z, row blocks")
         close(table, rt, dtype, scale=2000, what="small rows finito table, row blocks")
