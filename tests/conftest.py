@@ -23,7 +23,7 @@ def pytest_sessionfinish(session, exitstatus):
     import json
     worst = {}
     for rec in P.PARITY_LOG:
-        key = f"{rec['test']}:{rec['line']}:{rec['dtype']}" + (f":{rec['what']}" if rec["line"] == 0 else "")
+        key = f"{rec.get('file', '')}:{rec['test']}:{rec['line']}:{rec['dtype']}:{rec.get('form', '')}" + (f":{rec['what']}" if rec["line"] == 0 else "")
         if key not in worst or rec["ratio"] > worst[key]["ratio"]:
             worst[key] = rec
     out = os.path.join(ROOT, "gpurun_out")

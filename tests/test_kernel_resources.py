@@ -19,7 +19,7 @@ LIB = os.path.join(ROOT, "ciaoalgorithms.jl_amd", "libciao_hip.so")
 # chain; ProShI.
 HOT = [
     r"ciao::rows_fast_kernel<", r"ciao::rows_multi_kernel<", r"ciao::rows_split_kernel<", r"ciao::rows_csplit_kernel<", r"ciao::rows_long_kernel<",
-    r"ciao::rows_small_kernel<", r"ciao::rows_smallm_kernel<", r"ciao::rows_tile_kernel<", r"ciao::mrhs_kernel<", r"ciao::mrhs_finalize_kernel<",
+    r"ciao::rows_small_kernel<", r"ciao::rows_smallb_kernel<", r"ciao::rows_wrow_kernel<", r"ciao::rows_smallm_kernel<", r"ciao::rows_tile_kernel<", r"ciao::mrhs_kernel<", r"ciao::mrhs_finalize_kernel<",
     r"ciao::chain_dma_kernel<", r"ciao::chain_ws_kernel<", r"ciao::chain_wide_kernel<", r"ciao::chain_cdma_kernel<", r"ciao::afinito_dma_kernel<", r"ciao::afinito_wide_kernel<",
     r"ciao::proshi_\w+_kernel<", r"ciao::finalize_kernel<", r"ciao::epilogue_kernel<", r"ciao::peer_epilogue_kernel<",
     r"ciao::prox_kernel<",
