@@ -71,9 +71,9 @@ def test_padded_problem_looks_and_solves_like_the_unpadded_one(api, ctx, ciao, T
         for name, ref in refs.items():
             for pad in (True, False):
                 if wide_oracle:
-                    close(results[(name, pad)], ref.astype(T), T, scale={32: 190}, what=f"{name} d={d} padded={pad}", ref64=ref, scale64=190)
+                    close(results[(name, pad)], ref.astype(T), T, scale={32: 180}, what=f"{name} d={d} padded={pad}", ref64=ref, scale64=180)
                 else:
-                    close(results[(name, pad)], ref, T, scale={64: 120, 32: 110}, what=f"{name} d={d} padded={pad} vs the oracle's iterable")
+                    close(results[(name, pad)], ref, T, scale={64: 110, 32: 100}, what=f"{name} d={d} padded={pad} vs the oracle's iterable")
 
 
 def test_padding_is_not_applied_where_it_must_not_be(api, ctx, ciao):

@@ -44,28 +44,28 @@ def test_long_rows_in_all_five_modes(ctx, ciao, dtype, d, loss, opts):
         name = ctx.last_kernel()
         assert "rows_long_kernel" in name and f"J{opts.get('long_j', 8)}," in name, name
         ref = O.full_pass(op, x0)
-        close(av, ref, dtype, scale={64: 170, 32: 250}, what=f"long rows full gradient d={d} ({name})", scale64=16)
+        close(av, ref, dtype, scale={64: 160, 32: 240}, what=f"long rows full gradient d={d} ({name})", scale64=15)
         ctx.full_gradient(dp, dev(x0), av2)
         assert torch.equal(av, av2), "the cluster sweep is not reproducible run to run"
         ctx.set_option("long_rows", 0)
         ctx.full_gradient(dp, dev(x0), av2)
         assert "rows_long_kernel" not in ctx.last_kernel()
         ctx.set_option("long_rows", 1)
-        close(av2, ref, dtype, scale={64: 180, 32: 250}, what="the generic kernel on the same rows", scale64=33)
+        close(av2, ref, dtype, scale={64: 170, 32: 240}, what="the generic kernel on the same rows", scale64=32)
         # SAGA init, Finito init
         table = torch.empty((N, d), dtype=tdt, device="cuda")
         sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
         gs = dtype(0.1 / max(float(np.sum(A.astype(np.float64) ** 2, axis=1).max()), 1.0))
         ctx.saga_init(dp, dg, gs, dev(x0), table, sav, sz)
         rt, rav, rz = O.saga_init(op, og, gs, x0)
-        close(table, rt, dtype, scale={64: 280, 32: 380}, what="long rows saga_init table", scale64=13)
-        close(sav, rav, dtype, scale={64: 170, 32: 260}, what="long rows saga_init av", scale64=16)
+        close(table, rt, dtype, scale={64: 270, 32: 370}, what="long rows saga_init table", scale64=12)
+        close(sav, rav, dtype, scale={64: 160, 32: 250}, what="long rows saga_init av", scale64=15)
         close(sz, rz, dtype, scale=8, what="long rows saga_init z", scale64=8)
         rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
         ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
         assert "rows_long_kernel" in ctx.last_kernel() and "mode3" in ctx.last_kernel(), ctx.last_kernel()
-        close(table, rt, dtype, scale={64: 9.3, 32: 8.9}, what="long rows finito_init table", scale64=8)
-        close(av, rav, dtype, scale={64: 93, 32: 68}, what="long rows finito_init av", scale64=14)
+        close(table, rt, dtype, scale={64: 9.200000000000001, 32: 8.8}, what="long rows finito_init table", scale64=8)
+        close(av, rav, dtype, scale={64: 92, 32: 67}, what="long rows finito_init av", scale64=13)
         # Finito batches: random index lists, then static blocks as index lists AND as row blocks (bitwise the same)
         st = ciao.IndexStream(d)
         rnd = [st.sample_without_replacement(N, r) for _ in range(3)]
@@ -73,8 +73,8 @@ def test_long_rows_in_all_five_modes(ctx, ciao, dtype, d, loss, opts):
         ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(rnd), table, av, z)
         assert "rows_long_kernel" in ctx.last_kernel() and f"J{opts.get('long_j', 4)},mode4" in ctx.last_kernel(), ctx.last_kernel()
         O.finito_steps(op, og, gam, rhg, rnd, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 150, 32: 300}, what=f"long rows finito z, index lists ({ctx.last_kernel()})", scale64=35)
-        close(table, rt, dtype, scale={64: 120, 32: 220}, what="long rows finito table, index lists", scale64=29)
+        close(z, rz, dtype, scale={64: 140, 32: 290}, what=f"long rows finito z, index lists ({ctx.last_kernel()})", scale64=34)
+        close(table, rt, dtype, scale={64: 110, 32: 210}, what="long rows finito table, index lists", scale64=28)
         nb = -(-N // r)
         static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in [(t + 1) % nb for t in range(nb + 1)]]
         t2, a2, z2 = table.clone(), av.clone(), z.clone()
@@ -84,10 +84,10 @@ def test_long_rows_in_all_five_modes(ctx, ciao, dtype, d, loss, opts):
         ctx.finito_steps_blocks(dp, dg, dgam, hg, np.array([x[0] for x in static]), np.array([len(x) for x in static]), t2, a2, z2)
         assert torch.equal(z, z2) and torch.equal(av, a2) and torch.equal(table, t2), "row blocks and the same batches as index lists differ"
         O.finito_steps(op, og, gam, rhg, static, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 400, 32: 1500}, what="long rows finito z, row blocks", scale64=70)
-        close(table, rt, dtype, scale={64: 370, 32: 1400}, what="long rows finito table, row blocks", scale64=60)
+        close(z, rz, dtype, scale={64: 390, 32: 1400}, what="long rows finito z, row blocks", scale64=69)
+        close(table, rt, dtype, scale={64: 360, 32: 1300}, what="long rows finito table, row blocks", scale64=59)
         inv = (table.double() / dgam.double()[:, None]).sum(dim=0).cpu().numpy() * hg
-        close(av, inv, dtype, scale=27, what="long rows finito av invariant")
+        close(av, inv, dtype, scale=26, what="long rows finito av invariant")
         # LFinito: the full pass + the batch sweep with two dot products per row
         lav, lz, lzf = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(3))
         rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
@@ -99,8 +99,8 @@ def test_long_rows_in_all_five_modes(ctx, ciao, dtype, d, loss, opts):
             ctx.lfinito_iterate(dp, dg, dgam, hg, bp, np.concatenate(blocks), lav, lz, lzf)
             assert "rows_long_kernel" in ctx.last_kernel() and "mode1" in ctx.last_kernel(), ctx.last_kernel()
             O.lfinito_iterate(op, og, gam, rhg, blocks, rav, rz, rzf)
-            close(lz, rz, dtype, scale={64: 460, 32: 4100}, what=f"long rows lfinito z it {it}", scale64=130)
-            close(lav, rav, dtype, scale={64: 420, 32: 4400}, what=f"long rows lfinito av it {it}", scale64=140)
+            close(lz, rz, dtype, scale={64: 450, 32: 4000}, what=f"long rows lfinito z it {it}", scale64=120)
+            close(lav, rav, dtype, scale={64: 410, 32: 4300}, what=f"long rows lfinito av it {it}", scale64=130)
     finally:
         ctx.set_option("chain_max_batch", -1)
         ctx.set_option("long_rows", 1)
@@ -124,7 +124,7 @@ def test_long_rows_padded_stride_monitor_and_an_svrg_epoch(ctx, ciao, dtype, d):
     av = torch.empty(d, dtype=tdt, device="cuda")
     ctx.full_gradient(dp, dev(x0), av)
     assert "rows_long_kernel" in ctx.last_kernel(), ctx.last_kernel()
-    close(av, O.full_pass(op, x0), dtype, scale={64: 63, 32: 130}, what="long padded rows full gradient", scale64=11)
+    close(av, O.full_pass(op, x0), dtype, scale={64: 62, 32: 120}, what="long padded rows full gradient", scale64=10)
     fv = ctx.objective(dp, dg, dev(x0))
     rf = O.objective(op, og, x0)
     assert abs(fv - rf) <= 200 * np.finfo(dtype).eps * abs(rf), (fv, rf)
@@ -134,14 +134,14 @@ def test_long_rows_padded_stride_monitor_and_an_svrg_epoch(ctx, ciao, dtype, d):
     z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(3))
     ctx.svrg_init(dp, dev(x0), av, z, zf, w)
     rav, rz, rzf, rw = O.svrg_init(op, x0)
-    close(av, rav, dtype, scale={64: 63, 32: 130}, what="svrg_init av on long rows", scale64=11)
+    close(av, rav, dtype, scale={64: 62, 32: 120}, what="svrg_init av on long rows", scale64=10)
     st = ciao.IndexStream(11)
     for ep in range(2):
         idx = st.rand_indices(N, N)
         ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w, reuse_rowdots=True)
         O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
-        close(zf, rzf, dtype, scale={64: 19, 32: 29}, what=f"SVRG epoch {ep} on long rows, z_full", scale64=240)
-        close(av, rav, dtype, scale={64: 76, 32: 110}, what=f"SVRG epoch {ep} on long rows, av", scale64=120)
+        close(zf, rzf, dtype, scale={64: 18, 32: 28}, what=f"SVRG epoch {ep} on long rows, z_full", scale64=230)
+        close(av, rav, dtype, scale={64: 75, 32: 100}, what=f"SVRG epoch {ep} on long rows, av", scale64=110)
     ctx.synchronize()
 
 
@@ -157,5 +157,5 @@ def test_long_rows_on_few_rows_and_at_the_segment_limit(ctx, ciao):
         av = torch.empty(d, dtype=torch.float64, device="cuda")
         ctx.full_gradient(dp, dev(x0), av)
         assert ("rows_long_kernel" in ctx.last_kernel()) == long, ctx.last_kernel()
-        close(av, O.full_pass(op, x0), dtype, scale={64: 340}, what=f"long rows N={N} d={d}")
+        close(av, O.full_pass(op, x0), dtype, scale={64: 330}, what=f"long rows N={N} d={d}")
     ctx.synchronize()

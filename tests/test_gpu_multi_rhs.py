@@ -40,9 +40,9 @@ def test_one_pass_over_the_rows_for_K_iterates(ctx, ciao, dtype, loss, d, K, N):
     solo = torch.empty_like(xs[0])
     for k in range(K):
         ref = O.full_pass(op, xs_h[k])
-        close(avs[k], ref, dtype, scale=200, what=f"multi-rhs pass, solve {k} of {K} vs the oracle (d={d}, N={N})")
+        close(avs[k], ref, dtype, scale={64: 670, 32: 650}, what=f"multi-rhs pass, solve {k} of {K} vs the oracle (d={d}, N={N})")
         ctx.full_gradient(dp, xs[k], solo)
-        close(avs[k], solo.cpu().numpy(), dtype, scale=200, what=f"multi-rhs pass, solve {k} vs its own single sweep")
+        close(avs[k], solo.cpu().numpy(), dtype, scale={64: 44, 32: 48}, what=f"multi-rhs pass, solve {k} vs its own single sweep")
     # deterministic: the same call again is bitwise the same
     avs2 = [torch.empty_like(x) for x in xs]
     ctx.full_gradient_multi(dp, xs, avs2)
@@ -90,7 +90,7 @@ def test_svrg_epoch_tails_of_K_solves_in_one_pass(ctx, ciao):
     for k in range(K):
         ctx.svrg_epoch_tail(dp, 17, False, *st2[k])
         assert torch.equal(st[k][1], st2[k][1]) and torch.equal(st[k][2], st2[k][2]) and torch.equal(st[k][3], st2[k][3])
-        close(st[k][0], st2[k][0].cpu().numpy(), dtype, scale=200, what=f"epoch tail of solve {k}: av")
+        close(st[k][0], st2[k][0].cpu().numpy(), dtype, scale={64: 34}, what=f"epoch tail of solve {k}: av")
     # the lockstep driver, one pass per outer step against K sweeps per outer step
     F = PackedF.least_squares(dp.A, dp.b, float(N))
     Li = float(N) * np.sum(A * A, axis=1)

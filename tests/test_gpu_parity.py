@@ -137,8 +137,8 @@ def test_gradient_single_sample(ctx, dtype, loss):
     for i in (0, 4, 8):
         ctx.gradient(dp, i, dev(x), y, fv)
         gy, f = O.gradient(op.loss, A[i], b[i], 9.0, x)
-        close(y, gy, dtype, scale={64: 510, 32: 250}, what=f"gradient i={i}", scale64=41)
-        close(fv, [f], dtype, scale={64: 1100, 32: 510}, what="f_i value")
+        close(y, gy, dtype, scale={64: 500, 32: 240}, what=f"gradient i={i}", scale64=40)
+        close(fv, [f], dtype, scale={64: 1000, 32: 500}, what="f_i value")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -175,8 +175,8 @@ def test_full_gradient(ctx, dtype, loss, shape):
     ref = O.full_pass(op, x)
     ref64 = O.full_pass(O.Problem(loss, A.astype(np.float64), b.astype(np.float64), float(N)), x.astype(np.float64))
     # judge against the fp64 oracle so that the fp32 oracle's own sequential-sum error does not enter
-    close(av, ref64, dtype, scale={64: 82, 32: 16}, what=f"full_gradient {ctx.last_kernel()}")
-    close(av, ref, dtype, scale={64: 82, 32: 110}, what="full_gradient vs same-precision oracle", scale64=16)
+    close(av, ref64, dtype, scale={64: 81, 32: 15}, what=f"full_gradient {ctx.last_kernel()}")
+    close(av, ref, dtype, scale={64: 81, 32: 100}, what="full_gradient vs same-precision oracle", scale64=15)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -195,7 +195,7 @@ def test_full_gradient_generic_equals_fast(ctx, dtype):
         assert "rows_generic_kernel" in ctx.last_kernel()
     finally:
         ctx.set_option("force_generic", 0)
-    close(av2, av1.cpu().numpy(), dtype, scale={64: 11, 32: 8}, what="generic vs fast")
+    close(av2, av1.cpu().numpy(), dtype, scale={64: 10, 32: 8}, what="generic vs fast")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -212,7 +212,7 @@ def test_full_gradient_padded_rows_and_prefetch_variants(ctx, dtype):
         av = torch.empty(256, dtype=dev(x).dtype, device="cuda")
         ctx.full_gradient(dp, dev(x), av)
         assert "rows_fast_kernel" in ctx.last_kernel() or "rows_multi_kernel" in ctx.last_kernel()
-        close(av, ref, dtype, scale={64: 80, 32: 47}, what=f"padded rows prefetch={pf}", scale64=8)
+        close(av, ref, dtype, scale={64: 79, 32: 46}, what=f"padded rows prefetch={pf}", scale64=8)
         outs.append(av.cpu().numpy())
     ctx.set_option("sweep_prefetch", -1)
     # the two pipelining flavours assign the same rows to the same waves: identical summation order
@@ -221,14 +221,14 @@ def test_full_gradient_padded_rows_and_prefetch_variants(ctx, dtype):
     av = torch.empty(256, dtype=dev(x).dtype, device="cuda")
     ctx.full_gradient(dp2, dev(x), av)
     assert "rows_split_kernel" in ctx.last_kernel() and "scalar" in ctx.last_kernel(), ctx.last_kernel()
-    close(av, ref, dtype, scale={64: 80, 32: 38}, what="unaligned rows", scale64=8)
+    close(av, ref, dtype, scale={64: 79, 32: 37}, what="unaligned rows", scale64=8)
     ctx.set_option("force_generic", 1)
     try:
         ctx.full_gradient(dp2, dev(x), av)
         assert "rows_generic_kernel" in ctx.last_kernel()
     finally:
         ctx.set_option("force_generic", 0)
-    close(av, ref, dtype, scale={64: 85, 32: 43}, what="unaligned rows, generic kernel", scale64=8)
+    close(av, ref, dtype, scale={64: 84, 32: 42}, what="unaligned rows, generic kernel", scale64=8)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -251,8 +251,8 @@ def test_multi_row_sweep_matches_single_row_sweep(ctx, dtype, d):
     if d * np.dtype(dtype).itemsize in (2048, 4096):
         assert "rows_multi_kernel" in outs[1][1] and "rows_fast_kernel" in outs[0][1]
     ref = O.full_pass(op, x)
-    close(outs[1][0], ref, dtype, scale={64: 62, 32: 74}, what="multi-row sweep", scale64=9)
-    close(outs[0][0], ref, dtype, scale={64: 62, 32: 74}, what="single-row sweep", scale64=8)
+    close(outs[1][0], ref, dtype, scale={64: 61, 32: 73}, what="multi-row sweep", scale64=8.9)
+    close(outs[0][0], ref, dtype, scale={64: 61, 32: 73}, what="single-row sweep", scale64=8)
 
 
 def test_full_gradient_empty_problem(ctx):
@@ -294,7 +294,7 @@ def test_proxgrad_step_and_objective(ctx, dtype, gk):
         ctx.proxgrad_step(dp, dg, gamma, dev(x), av, y)
         rav = O.full_pass(op, x)
         ry = O.prox(og, (x - dtype(gamma) * rav).astype(dtype), dtype(gamma))
-        close(av, rav, dtype, scale={64: 37, 32: 51}, what="proxgrad av", scale64=9)
+        close(av, rav, dtype, scale={64: 36, 32: 50}, what="proxgrad av", scale64=8.9)
         close(y, ry, dtype, scale=8, what="proxgrad y", scale64=8)
         obj = ctx.objective(dp, dg, dev(x))
         robj = O.objective(op, og, x)
@@ -327,7 +327,7 @@ def test_objective_monitor_rides_on_the_full_pass(ctx, ciao, dtype, shape):
             assert abs(o[0] - ref) <= rtol * max(1.0, abs(ref)), (o, ref)
             assert abs(o[0] - (o[1] + o[2])) <= 1e-15 * max(1.0, abs(o[0]))
             assert abs(o[2] - 0.02 * np.abs(x.astype(np.float64)).sum()) <= (1e-12 if dtype == np.float64 else 1e-6) * max(1.0, o[2])
-            close(av, O.full_pass(op, x), dtype, scale={64: 66, 32: 40}, what="the gradient is unchanged by the monitor", scale64=9.9)
+            close(av, O.full_pass(op, x), dtype, scale={64: 65, 32: 39}, what="the gradient is unchanged by the monitor", scale64=9.8)
             # prox-gradient step IN PLACE: the monitored point is the x the pass read, not the y it wrote
             xin = dev(x).clone()
             ctx.proxgrad_step(dp, dg, 0.01, xin, av, xin)
@@ -409,16 +409,16 @@ def test_svrg_epochs(ctx, ciao, chain_variant, dtype, loss, shape):
     av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
     ctx.svrg_init(dp, dev(x0), av, z, zf, w)
     rav, rz, rzf, rw = O.svrg_init(op, x0)
-    close(av, rav, dtype, scale={64: 68, 32: 70}, what="svrg_init av", scale64=16)
+    close(av, rav, dtype, scale={64: 67, 32: 69}, what="svrg_init av", scale64=15)
     assert np.array_equal(zf.cpu().numpy(), x0) and np.array_equal(w.cpu().numpy(), x0) and not z.any().item()
     m = 2 * N
     for ep in range(3):
         idx = st.rand_indices(N, m)
         ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w)
         O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
-        close(zf, rzf, dtype, scale={64: 620, 32: 420}, what=f"svrg epoch {ep} z_full ({ctx.last_kernel()})", scale64=840)
-        close(w, rw, dtype, scale={64: 620, 32: 420}, what=f"svrg epoch {ep} w", scale64=840)
-        close(av, rav, dtype, scale={64: 170, 32: 180}, what=f"svrg epoch {ep} av", scale64=300)
+        close(zf, rzf, dtype, scale={64: 610, 32: 410}, what=f"svrg epoch {ep} z_full ({ctx.last_kernel()})", scale64=840)
+        close(w, rw, dtype, scale={64: 610, 32: 410}, what=f"svrg epoch {ep} w", scale64=840)
+        close(av, rav, dtype, scale={64: 160, 32: 170}, what=f"svrg epoch {ep} av", scale64=290)
         assert not z.any().item()
     ctx.synchronize()
 
@@ -450,8 +450,8 @@ def test_chain_path_selection(ctx, ciao, dtype, d, expect):
     name = expect.format(t="f64" if es == 8 else "f32", j=j, jj=j)
     assert name in ctx.last_kernel(), ctx.last_kernel()
     O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
-    close(w, rw, dtype, scale={64: 3800, 32: 3400}, what=f"svrg_inner w ({ctx.last_kernel()})", scale64=840)
-    close(z, rz, dtype, scale={64: 2400, 32: 2000}, what="svrg_inner z (sum of 3000 iterates)", scale64=840)
+    close(w, rw, dtype, scale={64: 3700, 32: 3300}, what=f"svrg_inner w ({ctx.last_kernel()})", scale64=840)
+    close(z, rz, dtype, scale={64: 2300, 32: 1900}, what="svrg_inner z (sum of 3000 iterates)", scale64=840)
     ctx.synchronize()
 
 
@@ -475,14 +475,14 @@ def test_svrg_plus_and_inner_only(ctx, ciao, dtype):
         ctx.svrg_iterate(dp, dg, gamma, idx, True, av, z, zf, w)
         O.svrg_iterate(op, og, dtype(gamma), idx, True, rav, rz, rzf, rw)
         m *= 2
-        close(zf, rzf, dtype, scale={64: 83, 32: 9.700000000000001}, what=f"svrg++ epoch {ep} z_full", scale64=28)
-        close(w, rw, dtype, scale={64: 110, 32: 16}, what=f"svrg++ epoch {ep} w", scale64=39)
+        close(zf, rzf, dtype, scale={64: 82, 32: 9.600000000000001}, what=f"svrg++ epoch {ep} z_full", scale64=27)
+        close(w, rw, dtype, scale={64: 100, 32: 15}, what=f"svrg++ epoch {ep} w", scale64=38)
     # inner cycle alone accumulates into z
     idx = st.rand_indices(N, 17)
     ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
     O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
-    close(z, rz, dtype, scale={64: 96, 32: 15}, what="svrg_inner z", scale64=46)
-    close(w, rw, dtype, scale={64: 110, 32: 16}, what="svrg_inner w", scale64=45)
+    close(z, rz, dtype, scale={64: 95, 32: 14}, what="svrg_inner z", scale64=45)
+    close(w, rw, dtype, scale={64: 100, 32: 15}, what="svrg_inner w", scale64=44)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -511,8 +511,8 @@ def test_svrg_rowdot_cache(ctx, ciao, dtype):
     for ep in range(3):
         O.svrg_iterate(op, og, dtype(gamma), st.rand_indices(N, 2 * N), False, rav, rz, rzf, rw)
     for reuse in (True, False):
-        close(outs[reuse][0], rzf, dtype, scale={64: 720, 32: 1300}, what=f"svrg z_full reuse={reuse}", scale64=840)
-        close(outs[reuse][1], rw, dtype, scale={64: 720, 32: 1300}, what=f"svrg w reuse={reuse}", scale64=840)
+        close(outs[reuse][0], rzf, dtype, scale={64: 710, 32: 1200}, what=f"svrg z_full reuse={reuse}", scale64=840)
+        close(outs[reuse][1], rw, dtype, scale={64: 710, 32: 1200}, what=f"svrg w reuse={reuse}", scale64=840)
     # (b) z_full edited IN PLACE between two iterates (same pointer): without the flag nothing cached is read
     av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
     ctx.svrg_init(dp, dev(x0), av, z, zf, w)
@@ -529,7 +529,7 @@ def test_svrg_rowdot_cache(ctx, ciao, dtype):
     idx = ciao.IndexStream(5).rand_indices(N, N)
     ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w)              # ... and does not vouch for the old row dots
     O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
-    close(zf, rzf, dtype, scale={64: 490, 32: 380}, what="svrg after an in-place z_full edit (reuse_rowdots=0)", scale64=340)
+    close(zf, rzf, dtype, scale={64: 480, 32: 370}, what="svrg after an in-place z_full edit (reuse_rowdots=0)", scale64=330)
     # (c) another entry point in between: the library drops the cache even if the caller (wrongly) vouches
     av, z, zf, w = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
     ctx.svrg_init(dp, dev(x0), av, z, zf, w)
@@ -541,7 +541,7 @@ def test_svrg_rowdot_cache(ctx, ciao, dtype):
     O.assign(rav, O.full_pass(op, x1))
     ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w, reuse_rowdots=True)
     O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
-    close(zf, rzf, dtype, scale={64: 320, 32: 330}, what="svrg after external z_full change", scale64=210)
+    close(zf, rzf, dtype, scale={64: 310, 32: 320}, what="svrg after external z_full change", scale64=200)
     ctx.synchronize()
 
 
@@ -564,7 +564,7 @@ def test_svrg_state_edit_between_epochs_through_the_iterable(ctx, ciao, dtype):
     rav, rz, rzf, rw = O.svrg_init(op, x0)
     ref_stream = ciao.IndexStream(9)
     O.svrg_iterate(op, og, dtype(gamma), ref_stream.rand_indices(N, N), False, rav, rz, rzf, rw)
-    close(st.z_full, rzf, dtype, scale=280, what="epoch 1", scale64=390)
+    close(st.z_full, rzf, dtype, scale=270, what="epoch 1", scale64=380)
     st.z_full.mul_(0.25)                                # user edits the solution tensor in place
     st.w.copy_(st.z_full)
     ctx.full_gradient(dp, st.z_full, st.av)
@@ -573,10 +573,10 @@ def test_svrg_state_edit_between_epochs_through_the_iterable(ctx, ciao, dtype):
     O.assign(rav, O.full_pass(op, rzf))
     st = next(states)
     O.svrg_iterate(op, og, dtype(gamma), ref_stream.rand_indices(N, N), False, rav, rz, rzf, rw)
-    close(st.z_full, rzf, dtype, scale={64: 470, 32: 480}, what="epoch after an in-place edit of state.z_full", scale64=650)
+    close(st.z_full, rzf, dtype, scale={64: 460, 32: 470}, what="epoch after an in-place edit of state.z_full", scale64=640)
     st = next(states)                                   # untouched state again: reuse is back on and still right
     O.svrg_iterate(op, og, dtype(gamma), ref_stream.rand_indices(N, N), False, rav, rz, rzf, rw)
-    close(st.z_full, rzf, dtype, scale={64: 640, 32: 600}, what="epoch after that", scale64=820)
+    close(st.z_full, rzf, dtype, scale={64: 630, 32: 590}, what="epoch after that", scale64=810)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -805,9 +805,9 @@ def test_short_rows_run_the_chains_on_one_wave(ctx, ciao, dtype, d):
                 assert "chain_ws_kernel" in ctx.last_kernel(), ctx.last_kernel()
         finally:
             ctx.set_option("chain_four_waves", 0)
-        close(zf, rzf, dtype, scale={64: 240, 32: 180}, what=f"short rows svrg z_full (four_waves={four})", scale64=260)
-        close(sz, rsz, dtype, scale={64: 53, 32: 71}, what=f"short rows saga z (four_waves={four}; {ctx.last_kernel()})", scale64=420)
-        close(table, rt, dtype, scale={64: 18, 32: 17}, what=f"short rows saga table (four_waves={four})", scale64=22)
+        close(zf, rzf, dtype, scale={64: 230, 32: 170}, what=f"short rows svrg z_full (four_waves={four})", scale64=250)
+        close(sz, rsz, dtype, scale={64: 52, 32: 70}, what=f"short rows saga z (four_waves={four}; {ctx.last_kernel()})", scale64=410)
+        close(table, rt, dtype, scale={64: 17, 32: 16}, what=f"short rows saga table (four_waves={four})", scale64=21)
     ctx.synchronize()
 
 
@@ -872,9 +872,9 @@ def test_wave_specialised_saga_is_bitwise_the_dma_chain(ctx, ciao, dtype, d, sag
         for name in ("ws2", "ws1"):
             for u, v, what in zip(outs["dma"], outs[name], ("z", "av", "table")):
                 assert np.array_equal(u, v), f"{name} differs from the DMA chain in {what} (N={N}, d={d})"
-        close(outs["ws2"][0], rz, dtype, scale={64: 540, 32: 270}, what=f"ws saga z N={N}", scale64=760)
+        close(outs["ws2"][0], rz, dtype, scale={64: 530, 32: 260}, what=f"ws saga z N={N}", scale64=750)
         if loss == "logistic":   # (an interpolating least-squares problem drives its gradients -- the table -- to rounding level)
-            close(outs["ws2"][2], rt, dtype, scale={64: 76, 32: 88}, what=f"ws saga table N={N}", scale64=110)
+            close(outs["ws2"][2], rt, dtype, scale={64: 75, 32: 87}, what=f"ws saga table N={N}", scale64=100)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -898,9 +898,9 @@ def test_saga_steps(ctx, ciao, chain_variant, dtype, sag, shape):
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
     ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
     rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
-    close(table, rt, dtype, scale={64: 29, 32: 33}, what="saga_init table", scale64=9.4)
-    close(av, rav, dtype, scale={64: 30, 32: 29}, what="saga_init av", scale64=14)
-    close(z, rz, dtype, scale=8, what="saga_init z  (= prox((1-gamma) x0))", scale64=12)
+    close(table, rt, dtype, scale={64: 28, 32: 32}, what="saga_init table", scale64=9.3)
+    close(av, rav, dtype, scale={64: 29, 32: 28}, what="saga_init av", scale64=13)
+    close(z, rz, dtype, scale=8, what="saga_init z  (= prox((1-gamma) x0))", scale64=11)
     st = ciao.IndexStream(21)
     for chunk in (1, 2, 4 * N, 7):
         idx = st.rand_indices(N, chunk)
@@ -908,11 +908,11 @@ def test_saga_steps(ctx, ciao, chain_variant, dtype, sag, shape):
             idx[:] = idx[0]   # the same row seven times in a row
         ctx.saga_steps(dp, dg, gamma, sag, idx, table, av, z)
         O.saga_steps(op, og, dtype(gamma), sag, idx, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 140, 32: 110}, what=f"saga z after chunk {chunk} ({ctx.last_kernel()})", scale64=840)
-        close(av, rav, dtype, scale={64: 140, 32: 150}, what=f"saga av after chunk {chunk}", scale64=120)
-        close(table, rt, dtype, scale={64: 230, 32: 210}, what=f"saga table after chunk {chunk}", scale64=120)
+        close(z, rz, dtype, scale={64: 130, 32: 100}, what=f"saga z after chunk {chunk} ({ctx.last_kernel()})", scale64=840)
+        close(av, rav, dtype, scale={64: 130, 32: 140}, what=f"saga av after chunk {chunk}", scale64=110)
+        close(table, rt, dtype, scale={64: 220, 32: 200}, what=f"saga table after chunk {chunk}", scale64=110)
     # invariant av == (1/N) sum_i s_i  
-    close(av, table.double().mean(dim=0).cpu().numpy(), dtype, scale={64: 75, 32: 120}, what="av invariant")
+    close(av, table.double().mean(dim=0).cpu().numpy(), dtype, scale={64: 74, 32: 110}, what="av invariant")
     ctx.synchronize()
 
 
@@ -957,9 +957,9 @@ def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, path):
     rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
     assert abs(hg - float(rhg)) <= (1e-12 if dtype == np.float64 else 1e-5) * abs(float(rhg))
     ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
-    close(table, rt, dtype, scale={64: 9.5, 32: 12}, what="finito_init table", scale64=13)
-    close(av, rav, dtype, scale={64: 68, 32: 42}, what="finito_init av", scale64=13)
-    close(z, rz, dtype, scale={64: 68, 32: 46}, what="finito_init z", scale64=14)
+    close(table, rt, dtype, scale={64: 9.4, 32: 11}, what="finito_init table", scale64=12)
+    close(av, rav, dtype, scale={64: 67, 32: 41}, what="finito_init av", scale64=12)
+    close(z, rz, dtype, scale={64: 67, 32: 45}, what="finito_init z", scale64=13)
     ctx.set_option("chain_max_batch", 64 if path == "chain" else 0)
     ctx.set_option("split_max_rows", 0 if path == "wave_per_row" else -1)
     try:
@@ -970,15 +970,15 @@ def test_finito_steps(ctx, ciao, chain_variant, dtype, shape, r, path):
             np.cumsum([len(x) for x in batches], out=bptr[1:])
             ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(batches), table, av, z)
             O.finito_steps(op, og, gam, rhg, batches, rt, rav, rz)
-            close(z, rz, dtype, scale={64: 1400, 32: 15000}, what=f"finito z {mode} ({ctx.last_kernel()})", scale64=280)
-            close(av, rav, dtype, scale={64: 1400, 32: 15000}, what=f"finito av {mode}", scale64=250)
-            close(table, rt, dtype, scale={64: 1200, 32: 13000}, what=f"finito table {mode}", scale64=210)
+            close(z, rz, dtype, scale={64: 1300, 32: 14000}, what=f"finito z {mode} ({ctx.last_kernel()})", scale64=270)
+            close(av, rav, dtype, scale={64: 1300, 32: 14000}, what=f"finito av {mode}", scale64=240)
+            close(table, rt, dtype, scale={64: 1100, 32: 12000}, what=f"finito table {mode}", scale64=200)
     finally:
         ctx.set_option("chain_max_batch", -1)
         ctx.set_option("split_max_rows", -1)
     # invariant av == hat_gamma * sum_i s_i / gamma_i   (row F3)
     inv = (table.double() / dgam.double()[:, None]).sum(dim=0).cpu().numpy() * hg
-    close(av, inv, dtype, scale={64: 61, 32: 58}, what="finito av invariant")
+    close(av, inv, dtype, scale={64: 60, 32: 57}, what="finito av invariant")
     ctx.synchronize()
 
 
@@ -1016,20 +1016,20 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         ctx.full_gradient(dp, dev(x0), av)
         # (dense rows of 17 .. 256 elements -- fp64: .. 144: the sweep runs on the matrix cores, tests/test_gpu_small_mfma.py)
         assert ("rows_smallm_kernel" if mfma else "rows_small_kernel") in ctx.last_kernel(), ctx.last_kernel()
-        close(av, O.full_pass(op, x0), dtype, scale={64: 190, 32: 210}, what=f"small rows full gradient d={d}", scale64=8.1)
+        close(av, O.full_pass(op, x0), dtype, scale={64: 180, 32: 200}, what=f"small rows full gradient d={d}", scale64=8)
         table = torch.empty((N, d), dtype=tdt, device="cuda")
         sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
         ctx.saga_init(dp, dg, 0.1 / max(Li.max(), 1.0), dev(x0), table, sav, sz)
         assert ("rows_smallm_kernel" if mfma else "rows_small_kernel") in ctx.last_kernel() or "prox" in ctx.last_kernel(), ctx.last_kernel()
         rt, rav, rz = O.saga_init(op, og, dtype(0.1 / max(Li.max(), 1.0)), x0)
-        close(table, rt, dtype, scale={64: 17, 32: 20}, what="small rows saga_init table", scale64=9.5)
-        close(sav, rav, dtype, scale={64: 20, 32: 24}, what="small rows saga_init av", scale64=8.1)
+        close(table, rt, dtype, scale={64: 16, 32: 19}, what="small rows saga_init table", scale64=9.4)
+        close(sav, rav, dtype, scale={64: 19, 32: 23}, what="small rows saga_init av", scale64=8)
         z = torch.empty(d, dtype=tdt, device="cuda")
         rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
         ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
         assert ("rows_smallm_kernel" if mfma else "rows_small_kernel") in ctx.last_kernel(), ctx.last_kernel()
-        close(table, rt, dtype, scale={64: 14, 32: 17}, what="small rows finito_init table", scale64=12)
-        close(av, rav, dtype, scale={64: 42, 32: 26}, what="small rows finito_init av", scale64=9.1)
+        close(table, rt, dtype, scale={64: 13, 32: 16}, what="small rows finito_init table", scale64=11)
+        close(av, rav, dtype, scale={64: 41, 32: 25}, what="small rows finito_init av", scale64=9)
         # ---- mode 4: Finito batches -- random index lists, then static blocks given BOTH as index lists and as row blocks
         st = ciao.IndexStream(d)
         rnd = [st.sample_without_replacement(N, r) for _ in range(4)]
@@ -1044,16 +1044,16 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         assert "rows_wrow_kernel" in ctx.last_kernel() and "mode4" in ctx.last_kernel(), ctx.last_kernel()
         assert ("chunks" in ctx.last_kernel()) == (pad == 0 and (d * es) % 16 == 0), ctx.last_kernel()   # 16 bytes per lane where rows allow
         O.finito_steps(op, og, gam, rhg, rnd, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 210, 32: 1400}, what=f"small rows finito z, index lists ({ctx.last_kernel()})", scale64=18)
-        close(table, rt, dtype, scale={64: 130, 32: 810}, what="small rows finito table, index lists", scale64=14)
+        close(z, rz, dtype, scale={64: 200, 32: 1300}, what=f"small rows finito z, index lists ({ctx.last_kernel()})", scale64=17)
+        close(table, rt, dtype, scale={64: 120, 32: 800}, what="small rows finito table, index lists", scale64=13)
         ctx.set_option("small_wrow", 0)   # ... and the same lists on the several-rows-per-wave kernel: another order of summation
         try:
             ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(rnd), t3, av3, z3)
             assert "rows_smallb_kernel" in ctx.last_kernel() and "mode4" in ctx.last_kernel(), ctx.last_kernel()
         finally:
             ctx.set_option("small_wrow", -1)
-        close(z3, rz, dtype, scale={64: 210, 32: 1400}, what="small rows finito z, index lists on rows_smallb_kernel", scale64=18)
-        close(t3, rt, dtype, scale={64: 140, 32: 810}, what="small rows finito table, index lists on rows_smallb_kernel", scale64=14)
+        close(z3, rz, dtype, scale={64: 200, 32: 1300}, what="small rows finito z, index lists on rows_smallb_kernel", scale64=17)
+        close(t3, rt, dtype, scale={64: 130, 32: 800}, what="small rows finito table, index lists on rows_smallb_kernel", scale64=13)
         nb = -(-N // r)
         order = [(t + 1) % nb for t in range(nb + 2)]                     # cyclic: the first step uses batch 2 (Finito_basic.jl:99)
         static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in order]   # the last block is short (6000 = 8 * 700 + 400)
@@ -1067,16 +1067,16 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
             # dense row blocks of such rows: the batch on the matrix-core kernel (row tile and table tile by LDS-DMA) -- another order
             # of summation than the index-list form: each against the oracle
             assert "rows_smallm_kernel" in ctx.last_kernel() and "mode4" in ctx.last_kernel(), ctx.last_kernel()
-            close(z2, rz, dtype, scale={64: 690, 32: 4000}, what=f"small rows finito z, row blocks on the matrix-core kernel ({ctx.last_kernel()})", scale64=46)
-            close(t2, rt, dtype, scale={64: 430, 32: 2300}, what="small rows finito table, row blocks on the matrix-core kernel", scale64=30)
+            close(z2, rz, dtype, scale={64: 680, 32: 3900}, what=f"small rows finito z, row blocks on the matrix-core kernel ({ctx.last_kernel()})", scale64=45)
+            close(t2, rt, dtype, scale={64: 420, 32: 2200}, what="small rows finito table, row blocks on the matrix-core kernel", scale64=29)
         else:
             # the list IS a block and both forms run the one-wave-per-row kernel (row q on the same wave either way): BITWISE
             assert "rows_wrow_kernel" in ctx.last_kernel(), ctx.last_kernel()
             assert torch.equal(z, z2) and torch.equal(av, av2) and torch.equal(table, t2), "row blocks and the same batches as index lists differ"
-        close(z, rz, dtype, scale={64: 1200, 32: 7000}, what="small rows finito z, row blocks", scale64=190)
-        close(table, rt, dtype, scale={64: 530, 32: 2300}, what="small rows finito table, row blocks", scale64=33)
+        close(z, rz, dtype, scale={64: 1100, 32: 6900}, what="small rows finito z, row blocks", scale64=180)
+        close(table, rt, dtype, scale={64: 520, 32: 2200}, what="small rows finito table, row blocks", scale64=32)
         inv = (table.double() / dgam.double()[:, None]).sum(dim=0).cpu().numpy() * hg
-        close(av, inv, dtype, scale={64: 34, 32: 28}, what="small rows finito av invariant")
+        close(av, inv, dtype, scale={64: 33, 32: 27}, what="small rows finito av invariant")
         # ---- mode 1: LFinito iterations (full pass + the batch sweep with two dot products per row), lists and blocks
         lav, lz, lzf = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(3))
         rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
@@ -1094,13 +1094,13 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
                 # dense row blocks of such rows run the batch sweep on the matrix cores (both dots from one MFMA pass): another order of
                 # summation than the index-list form, so equal to rounding; each is held against the oracle below
                 assert "rows_smallm_kernel" in ctx.last_kernel() and "mode1" in ctx.last_kernel(), ctx.last_kernel()
-                close(lz2, rz, dtype, scale={64: 940, 32: 2200}, what=f"small rows lfinito z it {it}, row blocks ({ctx.last_kernel()})", scale64=74)
-                close(lav2, rav, dtype, scale={64: 970, 32: 1900}, what=f"small rows lfinito av it {it}, row blocks", scale64=68)
+                close(lz2, rz, dtype, scale={64: 930, 32: 2100}, what=f"small rows lfinito z it {it}, row blocks ({ctx.last_kernel()})", scale64=73)
+                close(lav2, rav, dtype, scale={64: 960, 32: 1800}, what=f"small rows lfinito av it {it}, row blocks", scale64=67)
                 lz2.copy_(lz), lav2.copy_(lav), lzf2.copy_(lzf)       # (so that the two forms start the next iteration from the same state)
             else:
                 assert torch.equal(lz, lz2) and torch.equal(lav, lav2) and torch.equal(lzf, lzf2)
-            close(lz, rz, dtype, scale={64: 2500, 32: 2200}, what=f"small rows lfinito z it {it} ({ctx.last_kernel()})", scale64=74)
-            close(lav, rav, dtype, scale={64: 2200, 32: 1900}, what=f"small rows lfinito av it {it}", scale64=59)
+            close(lz, rz, dtype, scale={64: 2400, 32: 2100}, what=f"small rows lfinito z it {it} ({ctx.last_kernel()})", scale64=73)
+            close(lav, rav, dtype, scale={64: 2100, 32: 1800}, what=f"small rows lfinito av it {it}", scale64=58)
     finally:
         ctx.set_option("chain_max_batch", -1)
     ctx.synchronize()
@@ -1127,7 +1127,7 @@ def test_lfinito_iterations(ctx, ciao, chain_variant, dtype, shape, r, path):
     hg = ctx.hat_gamma(dgam)
     rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
     ctx.lfinito_init(dp, hg, dev(x0), av, z, zf)
-    close(av, rav, dtype, scale=140, what="lfinito_init av", scale64=8)
+    close(av, rav, dtype, scale=130, what="lfinito_init av", scale64=8)
     assert torch.equal(z, av) and torch.equal(zf, av)
     nb = -(-N // r)
     static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in range(nb)]
@@ -1142,9 +1142,9 @@ def test_lfinito_iterations(ctx, ciao, chain_variant, dtype, shape, r, path):
             np.cumsum([len(x) for x in batches], out=bptr[1:])
             ctx.lfinito_iterate(dp, dg, dgam, hg, bptr, np.concatenate(batches), av, z, zf)
             O.lfinito_iterate(op, og, gam, rhg, batches, rav, rz, rzf)
-            close(zf, rzf, dtype, scale={64: 570, 32: 4800}, what=f"lfinito z_full it {it}", scale64=170)
-            close(z, rz, dtype, scale={64: 570, 32: 5800}, what=f"lfinito z it {it} ({ctx.last_kernel()})", scale64=190)
-            close(av, rav, dtype, scale={64: 650, 32: 7300}, what=f"lfinito av it {it}", scale64=180)
+            close(zf, rzf, dtype, scale={64: 560, 32: 4700}, what=f"lfinito z_full it {it}", scale64=160)
+            close(z, rz, dtype, scale={64: 560, 32: 5700}, what=f"lfinito z it {it} ({ctx.last_kernel()})", scale64=180)
+            close(av, rav, dtype, scale={64: 640, 32: 7200}, what=f"lfinito av it {it}", scale64=170)
     finally:
         ctx.set_option("chain_max_batch", -1)
         ctx.set_option("split_max_rows", -1)
@@ -1243,30 +1243,30 @@ def test_rows_longer_than_lds(ctx, ciao, dtype, d):
     av, z, zf = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(3))
     ctx.full_gradient(dp, dev(x0), av)
     assert "global_acc" in ctx.last_kernel() or "rows_split" in ctx.last_kernel() or "rows_long" in ctx.last_kernel()
-    close(av, O.full_pass(op, x0), dtype, scale={64: 120, 32: 170}, what=f"sweep d={d} ({ctx.last_kernel()})", scale64=24)
+    close(av, O.full_pass(op, x0), dtype, scale={64: 110, 32: 160}, what=f"sweep d={d} ({ctx.last_kernel()})", scale64=23)
     table = torch.empty((N, d), dtype=tdt, device="cuda")
     ctx.saga_init(dp, dg, 0.1, dev(x0), table, av, z)
     rt, rav, rz = O.saga_init(op, og, dtype(0.1), x0)
-    close(table, rt, dtype, scale={64: 140, 32: 180}, what="saga_init table (long rows)", scale64=18)
-    close(av, rav, dtype, scale={64: 120, 32: 170}, what="saga_init av (long rows)", scale64=26)
+    close(table, rt, dtype, scale={64: 130, 32: 170}, what="saga_init table (long rows)", scale64=17)
+    close(av, rav, dtype, scale={64: 110, 32: 160}, what="saga_init av (long rows)", scale64=25)
     gam = torch.full((N,), 0.4, dtype=tdt, device="cuda")
     hg = ctx.hat_gamma(gam)
     ctx.finito_init(dp, dg, gam, hg, dev(x0), table, av, z)
     rt, rav, rz, rhg = O.finito_init(op, og, gam.cpu().numpy(), x0)
-    close(av, rav, dtype, scale={64: 19, 32: 20}, what="finito_init av (long rows)", scale64=14)
+    close(av, rav, dtype, scale={64: 18, 32: 19}, what="finito_init av (long rows)", scale64=13)
     batch = np.arange(3, 20, dtype=np.int64)
     ctx.set_option("chain_max_batch", 0)
     try:
         ctx.finito_steps(dp, dg, gam, hg, np.array([0, batch.size], np.int64), batch, table, av, z)
         O.finito_steps(op, og, gam.cpu().numpy(), rhg, [batch], rt, rav, rz)
-        close(z, rz, dtype, scale={64: 31, 32: 37}, what=f"finito batch z (long rows, {ctx.last_kernel()})", scale64=25)
-        close(table, rt, dtype, scale={64: 19, 32: 20}, what="finito batch table (long rows)", scale64=17)
+        close(z, rz, dtype, scale={64: 30, 32: 36}, what=f"finito batch z (long rows, {ctx.last_kernel()})", scale64=24)
+        close(table, rt, dtype, scale={64: 18, 32: 19}, what="finito batch table (long rows)", scale64=16)
         ctx.lfinito_init(dp, hg, dev(x0), av, z, zf)
         ctx.lfinito_iterate(dp, dg, gam, hg, np.array([0, 12, N], np.int64), np.arange(N, dtype=np.int64), av, z, zf)
         rav, rz, rzf, rhg = O.lfinito_init(op, gam.cpu().numpy(), x0)
         O.lfinito_iterate(op, og, gam.cpu().numpy(), rhg, [np.arange(12), np.arange(12, N)], rav, rz, rzf)
-        close(av, rav, dtype, scale={64: 91, 32: 100}, what="lfinito av (long rows)", scale64=31)
-        close(z, rz, dtype, scale={64: 77, 32: 55}, what="lfinito z (long rows)", scale64=17)
+        close(av, rav, dtype, scale={64: 90, 32: 99}, what="lfinito av (long rows)", scale64=30)
+        close(z, rz, dtype, scale={64: 76, 32: 54}, what="lfinito z (long rows)", scale64=16)
     finally:
         ctx.set_option("chain_max_batch", -1)
     ctx.synchronize()
@@ -1299,8 +1299,8 @@ def test_chains_on_rows_of_any_length(ctx, ciao, dtype, d, forced):
         assert ("chain_big_kernel" if forced else "chain_wide_kernel") in ctx.last_kernel(), ctx.last_kernel()
         rav, rz, rzf, rw = O.svrg_init(op, x0)
         O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
-        close(w, rw, dtype, scale={64: 29, 32: 24}, what="svrg_inner w (any-d chain)", scale64=470)
-        close(z, rz, dtype, scale={64: 21, 32: 24}, what="svrg_inner z (any-d chain)", scale64=280)
+        close(w, rw, dtype, scale={64: 28, 32: 23}, what="svrg_inner w (any-d chain)", scale64=460)
+        close(z, rz, dtype, scale={64: 20, 32: 23}, what="svrg_inner z (any-d chain)", scale64=270)
         for sag in (False, True):
             table = torch.empty((N, d), dtype=tdt, device="cuda")
             sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
@@ -1309,8 +1309,8 @@ def test_chains_on_rows_of_any_length(ctx, ciao, dtype, d, forced):
             assert ("chain_big_kernel" if forced else "chain_wide_kernel") in ctx.last_kernel(), ctx.last_kernel()
             rt, rsav, rsz = O.saga_init(op, og, dtype(gamma), x0)
             O.saga_steps(op, og, dtype(gamma), sag, idx, rt, rsav, rsz)
-            close(sz, rsz, dtype, scale={64: 27, 32: 25}, what=f"saga z sag={sag} (any-d chain)", scale64=510)
-            close(table, rt, dtype, scale={64: 190, 32: 130}, what="saga table (any-d chain)", scale64=220)
+            close(sz, rsz, dtype, scale={64: 26, 32: 24}, what=f"saga z sag={sag} (any-d chain)", scale64=500)
+            close(table, rt, dtype, scale={64: 180, 32: 120}, what="saga table (any-d chain)", scale64=210)
         gam = torch.full((N,), 0.4, dtype=tdt, device="cuda")
         hg = ctx.hat_gamma(gam)
         table = torch.empty((N, d), dtype=tdt, device="cuda")
@@ -1320,14 +1320,14 @@ def test_chains_on_rows_of_any_length(ctx, ciao, dtype, d, forced):
         assert ("chain_big_kernel" if forced else "chain_wide_kernel") in ctx.last_kernel(), ctx.last_kernel()
         rt, rav, rz, rhg = O.finito_init(op, og, gam.cpu().numpy(), x0)
         O.finito_steps(op, og, gam.cpu().numpy(), rhg, batches, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 91, 32: 110}, what="finito z (any-d chain)", scale64=74)
-        close(table, rt, dtype, scale={64: 87, 32: 110}, what="finito table (any-d chain)", scale64=74)
+        close(z, rz, dtype, scale={64: 90, 32: 100}, what="finito z (any-d chain)", scale64=73)
+        close(table, rt, dtype, scale={64: 86, 32: 100}, what="finito table (any-d chain)", scale64=73)
         ctx.lfinito_init(dp, hg, dev(x0), av, z, zf)
         ctx.lfinito_iterate(dp, dg, gam, hg, np.arange(0, N + 1, 2, dtype=np.int64), np.concatenate(batches), av, z, zf)
         rav, rz, rzf, rhg = O.lfinito_init(op, gam.cpu().numpy(), x0)
         O.lfinito_iterate(op, og, gam.cpu().numpy(), rhg, batches, rav, rz, rzf)
-        close(z, rz, dtype, scale={64: 130, 32: 170}, what="lfinito z (any-d chain)", scale64=140)
-        close(av, rav, dtype, scale={64: 130, 32: 170}, what="lfinito av (any-d chain)", scale64=140)
+        close(z, rz, dtype, scale={64: 120, 32: 160}, what="lfinito z (any-d chain)", scale64=130)
+        close(av, rav, dtype, scale={64: 120, 32: 160}, what="lfinito av (any-d chain)", scale64=130)
         ctx.synchronize()
     finally:
         ctx.set_option("chain_big", 0)
@@ -1362,11 +1362,11 @@ def test_adaptive_finito_steps(ctx, ciao, dtype, shape):
     # DIFFERENCE Lipschitz estimate |c(x0 + 1) - c(x0)| ||a_i||, Finito_adaptive.jl:65-88, whose cancellation is the algorithm's own in
     # Float32 -- the reference's Float32 run is as far from the Float64 value as the device's.)
     S = 50 if dtype == np.float64 else 10
-    close(meta[:, 2], rgam, dtype, scale={64: 5500, 32: 17000}, what="adaptive init gamma_i", ref64=False)   # eps32: the comment above
-    close(meta[:, 1], rfi, dtype, scale={64: 140, 32: 460}, what="adaptive init f_i(x0)", scale64=42)
-    close(hg, [rhg], dtype, scale=36, what="adaptive init hat_gamma")
-    close(av, rav, dtype, scale={64: 82, 32: 72}, what="adaptive init av", scale64=17)
-    close(z, rz, dtype, scale={64: 82, 32: 72}, what="adaptive init z", scale64=18)
+    close(meta[:, 2], rgam, dtype, scale={64: 5400, 32: 16000}, what="adaptive init gamma_i", ref64=False)   # eps32: the comment above
+    close(meta[:, 1], rfi, dtype, scale={64: 130, 32: 450}, what="adaptive init f_i(x0)", scale64=41)
+    close(hg, [rhg], dtype, scale=35, what="adaptive init hat_gamma")
+    close(av, rav, dtype, scale={64: 81, 32: 71}, what="adaptive init av", scale64=16)
+    close(z, rz, dtype, scale={64: 81, 32: 71}, what="adaptive init z", scale64=17)
     assert torch.equal(table, dev(x0).expand(N, d))
     st = ciao.IndexStream(4)
     idx = st.rand_indices(N, 3 * N)
@@ -1398,25 +1398,25 @@ def test_adaptive_finito_steps(ctx, ciao, dtype, shape):
     assert abs(trials - rtrials) <= max(1, rtrials // 50), (trials, rtrials)
     if trials == rtrials:
         # (no Float64-oracle form here: oracle/twin.py runs afinito_steps untwinned, and says why)
-        close(z, rz, dtype, scale={64: 920, 32: 310}, what=f"adaptive z ({ctx.last_kernel()})")
-        close(av, rav, dtype, scale={64: 920, 32: 310}, what="adaptive av")
-        close(hg, [rhg], dtype, scale={64: 59, 32: 49}, what="adaptive hat_gamma")
-        close(meta[:, 2], rgam, dtype, scale={64: 3100, 32: 3900}, what="adaptive gamma_i")   # eps32: see the init's gamma_i
-        close(table, rt, dtype, scale={64: 880, 32: 300}, what="adaptive table")
+        close(z, rz, dtype, scale={64: 910, 32: 300}, what=f"adaptive z ({ctx.last_kernel()})")
+        close(av, rav, dtype, scale={64: 910, 32: 300}, what="adaptive av")
+        close(hg, [rhg], dtype, scale={64: 58, 32: 48}, what="adaptive hat_gamma")
+        close(meta[:, 2], rgam, dtype, scale={64: 3000, 32: 3800}, what="adaptive gamma_i")   # eps32: see the init's gamma_i
+        close(table, rt, dtype, scale={64: 870, 32: 290}, what="adaptive table")
         # grad f_i = c_i a_i: the oracle's full gradient table against the device's N scalars
         gdev = meta[:, 0:1].double().cpu().numpy() * A.astype(np.float64)
-        close(gdev, rg, dtype, scale={64: 260, 32: 200}, what="adaptive gradient table (c_i a_i)")
+        close(gdev, rg, dtype, scale={64: 250, 32: 190}, what="adaptive gradient table (c_i a_i)")
     # invariant of the algorithm (Finito_adaptive.jl:93 and every update after it):
     #   av == hat_gamma * (sum_i x_i/gamma_i - (1/N) sum_i grad f_i),   hat_gamma == 1 / sum_i 1/gamma_i
     md = meta.double()
     hgd = float(hg.item())
     assert abs(hgd - 1.0 / float((1.0 / md[:, 2]).sum())) <= (1e-10 if dtype == np.float64 else 2e-4) * hgd
     inv = hgd * ((table.double() / md[:, 2:3]).sum(dim=0) - (md[:, 0:1] * dev(A).double()).sum(dim=0) / N)
-    close(av, inv.cpu().numpy(), dtype, scale={64: 320, 32: 330}, what="adaptive invariant av")
+    close(av, inv.cpu().numpy(), dtype, scale={64: 310, 32: 320}, what="adaptive invariant av")
     # the stored scalars are consistent with the stored points: a_i'x_i, c_i = coef(a_i'x_i), f_i(x_i)
     dots = (dev(A).double() * table.double()).sum(dim=1)
-    close(md[:, 3], dots.cpu().numpy(), dtype, scale={64: 15, 32: 11}, what="adaptive a_i'x_i")
-    close(md[:, 0], (lam_f * (dots - dev(b).double())).cpu().numpy(), dtype, scale={64: 15, 32: 13}, what="adaptive c_i")
+    close(md[:, 3], dots.cpu().numpy(), dtype, scale={64: 14, 32: 10}, what="adaptive a_i'x_i")
+    close(md[:, 0], (lam_f * (dots - dev(b).double())).cpu().numpy(), dtype, scale={64: 14, 32: 12}, what="adaptive c_i")
     ctx.synchronize()
 
 
@@ -1449,10 +1449,10 @@ def test_adaptive_finito_variants(ctx, ciao, kind, gkind, no_dma):
         ctx.set_option("chain_no_dma", 0)
     rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(alpha), dtype(tol_b), idx, rt, rg, rgam, rfi, rhg, rav, rz)
     assert done == rdone == len(idx) and trials == rtrials
-    close(z, rz, dtype, scale={64: 71000}, what=f"adaptive z ({ctx.last_kernel()})")
-    close(av, rav, dtype, scale={64: 71000}, what="adaptive av")
-    close(hg, [rhg], dtype, scale={64: 71}, what="adaptive hat_gamma")
-    close(table, rt, dtype, scale={64: 71000}, what="adaptive table")
+    close(z, rz, dtype, scale={64: 70000}, what=f"adaptive z ({ctx.last_kernel()})")
+    close(av, rav, dtype, scale={64: 70000}, what="adaptive av")
+    close(hg, [rhg], dtype, scale={64: 70}, what="adaptive hat_gamma")
+    close(table, rt, dtype, scale={64: 70000}, what="adaptive table")
     assert torch.equal(meta4[:, 0], meta4[:, 1]) and torch.equal(meta4[:, 0], meta4[:, 2]) and torch.equal(meta4[:, 0], meta4[:, 3])
     ctx.synchronize()
 
@@ -1482,8 +1482,8 @@ def test_adaptive_finito_on_rows_of_any_length(ctx, ciao, dtype, kind, N, d, for
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
     ctx.afinito_init(dp, dg, alpha, dev(x0), table, meta4, av, z, hg)
     rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(alpha), x0)
-    close(meta4[:, 0, 2], rgam, dtype, scale={64: 5100, 32: 2400}, what="adaptive init gamma_i, long rows", scale64=840)   # c(x0 .+ 1) - c(x0) cancels
-    close(av, rav, dtype, scale={64: 71, 32: 230}, what="adaptive init av, long rows", scale64=17)
+    close(meta4[:, 0, 2], rgam, dtype, scale={64: 5000, 32: 2300}, what="adaptive init gamma_i, long rows", scale64=840)   # c(x0 .+ 1) - c(x0) cancels
+    close(av, rav, dtype, scale={64: 70, 32: 220}, what="adaptive init av, long rows", scale64=16)
     idx = np.concatenate([ciao.IndexStream(4).rand_indices(N, 3 * N), np.full(3, 2, np.int64), np.array([1, 2, 1, 0, 1], np.int64)])
     ctx.set_option("chain_big", int(forced))
     if route == "big":
@@ -1502,11 +1502,11 @@ def test_adaptive_finito_on_rows_of_any_length(ctx, ciao, dtype, kind, N, d, for
     assert done == rdone == len(idx)
     assert abs(trials - rtrials) <= max(2, 0.02 * rtrials), (trials, rtrials)
     if trials == rtrials:
-        close(z, rz, dtype, scale={64: 310, 32: 300}, what=f"adaptive z ({ctx.last_kernel()})")
-        close(av, rav, dtype, scale={64: 310, 32: 300}, what="adaptive av, long rows")
-        close(hg, [rhg], dtype, scale={64: 590, 32: 370}, what="adaptive hat_gamma, long rows")
-        close(table, rt, dtype, scale={64: 320, 32: 290}, what="adaptive table, long rows")
-        close(meta4[:, 0, 2], rgam, dtype, scale={64: 360, 32: 450}, what="adaptive gamma_i, long rows")
+        close(z, rz, dtype, scale={64: 300, 32: 290}, what=f"adaptive z ({ctx.last_kernel()})")
+        close(av, rav, dtype, scale={64: 300, 32: 290}, what="adaptive av, long rows")
+        close(hg, [rhg], dtype, scale={64: 580, 32: 360}, what="adaptive hat_gamma, long rows")
+        close(table, rt, dtype, scale={64: 310, 32: 280}, what="adaptive table, long rows")
+        close(meta4[:, 0, 2], rgam, dtype, scale={64: 350, 32: 440}, what="adaptive gamma_i, long rows")
     assert torch.equal(meta4[:, 0], meta4[:, 1]) and torch.equal(meta4[:, 0], meta4[:, 2]) and torch.equal(meta4[:, 0], meta4[:, 3])
     ctx.synchronize()
 
@@ -1572,9 +1572,9 @@ def test_proshi_steps(ctx, ciao, dtype, shape, r, generic):
         ctx.set_option("force_generic", 0)
     rt, rav, rz, rhg = O.proshi_init(of, og, gam, x0)
     close(table, rt, dtype, scale=8, what="proshi init table", scale64=8)
-    close(hg, [rhg], dtype, scale={64: 17, 32: 530}, what="proshi hat_gamma")
-    close(av, rav, dtype, scale={64: 75, 32: 50}, what="proshi init av", scale64=11)
-    close(z, rz, dtype, scale={64: 68, 32: 490}, what="proshi init z", size=np.abs(rav).max() / abs(float(rhg)), scale64=14)
+    close(hg, [rhg], dtype, scale={64: 16, 32: 520}, what="proshi hat_gamma")
+    close(av, rav, dtype, scale={64: 74, 32: 49}, what="proshi init av", scale64=10)
+    close(z, rz, dtype, scale={64: 67, 32: 480}, what="proshi init z", size=np.abs(rav).max() / abs(float(rhg)), scale64=13)
     st = ciao.IndexStream(2)
     batches = [st.sample_without_replacement(N, r) for _ in range(12)]
     bptr = np.arange(len(batches) + 1, dtype=np.int64) * r
@@ -1584,15 +1584,15 @@ def test_proshi_steps(ctx, ciao, dtype, shape, r, generic):
     finally:
         ctx.set_option("force_generic", 0)
     O.proshi_steps(of, og, gam, rhg, batches, rt, rav, rz)
-    close(table, rt, dtype, scale={64: 110, 32: 540}, what=f"proshi table ({ctx.last_kernel()})", scale64=42)
-    close(av, rav, dtype, scale={64: 150, 32: 180}, what="proshi av", scale64=37)
+    close(table, rt, dtype, scale={64: 100, 32: 530}, what=f"proshi table ({ctx.last_kernel()})", scale64=41)
+    close(av, rav, dtype, scale={64: 140, 32: 170}, what="proshi av", scale64=36)
     # z = (prox(av) - av) / hat_gamma (ProShI_basic.jl:119-121): a difference of quantities |av| large, divided by hat_gamma -- its
     # rounding unit is theirs (at (700, 1100) |z| is a thousandth of |av| / hat_gamma, and the reference's own Float32 z is 100-1500
     # eps32 of |z| from its Float64 value)
-    close(z, rz, dtype, scale={64: 12, 32: 31}, what="proshi z", size=np.abs(rav).max() / abs(float(rhg)), scale64=30)
-    close(av, table.double().sum(dim=0).cpu().numpy(), dtype, scale={64: 46, 32: 84}, what="invariant av == sum_i s_i")
+    close(z, rz, dtype, scale={64: 11, 32: 30}, what="proshi z", size=np.abs(rav).max() / abs(float(rhg)), scale64=29)
+    close(av, table.double().sum(dim=0).cpu().numpy(), dtype, scale={64: 45, 32: 83}, what="invariant av == sum_i s_i")
     ctx.proshi_solution(df, dev(gam), z, table)
-    close(table, O.proshi_solution(of, gam, rz, rt), dtype, scale={64: 110, 32: 540}, what="proshi solution", scale64=40)
+    close(table, O.proshi_solution(of, gam, rz, rt), dtype, scale={64: 100, 32: 530}, what="proshi solution", scale64=39)
     ctx.synchronize()
 
 
@@ -1632,17 +1632,17 @@ def test_proshi_dense_quadratic(ctx, ciao, dtype, shape, r):
         Q.astype(np.float64) @ x0.astype(np.float64) + q + eta * (x0 - np.clip(x0, lo, hi)).astype(np.float64))
     close(table, want, dtype, scale=8, what="dense proshi init table vs numpy")
     close(table, rt, dtype, scale=8, what="dense proshi init table", scale64=8)
-    close(av, rav, dtype, scale={64: 27, 32: 36}, what="dense proshi init av", scale64=8)
-    close(z, rz, dtype, scale={64: 23, 32: 64}, what="dense proshi init z", size=np.abs(rav).max() / abs(float(rhg)), scale64=13)
+    close(av, rav, dtype, scale={64: 26, 32: 35}, what="dense proshi init av", scale64=8)
+    close(z, rz, dtype, scale={64: 22, 32: 63}, what="dense proshi init z", size=np.abs(rav).max() / abs(float(rhg)), scale64=12)
     st = ciao.IndexStream(2)
     batches = [st.sample_without_replacement(N, r) if 2 * r <= N else np.sort(st.randperm(N)[:r]) for _ in range(10)]
     bptr = np.arange(len(batches) + 1, dtype=np.int64) * r
     ctx.proshi_steps(df, dg, dev(gam), float(hg.item()), bptr, np.concatenate(batches), table, av, z)
     O.proshi_steps(of, og, gam, rhg, batches, rt, rav, rz)
-    close(table, rt, dtype, scale={64: 140, 32: 150}, what=f"dense proshi table ({ctx.last_kernel()})", scale64=21)
-    close(av, rav, dtype, scale={64: 280, 32: 96}, what="dense proshi av", scale64=26)
-    close(z, rz, dtype, scale={64: 8, 32: 11}, what="dense proshi z", size=np.abs(rav).max() / abs(float(rhg)), scale64=8)
-    close(av, table.double().sum(dim=0).cpu().numpy(), dtype, scale={64: 21, 32: 26}, what="dense invariant av == sum_i s_i")
+    close(table, rt, dtype, scale={64: 130, 32: 140}, what=f"dense proshi table ({ctx.last_kernel()})", scale64=20)
+    close(av, rav, dtype, scale={64: 270, 32: 95}, what="dense proshi av", scale64=25)
+    close(z, rz, dtype, scale={64: 8, 32: 10}, what="dense proshi z", size=np.abs(rav).max() / abs(float(rhg)), scale64=8)
+    close(av, table.double().sum(dim=0).cpu().numpy(), dtype, scale={64: 20, 32: 25}, what="dense invariant av == sum_i s_i")
     # contiguous blocks of agents (sweeping 2 / 3) are the same batches
     t2, av2, z2 = table.clone(), av.clone(), z.clone()
     first = np.array([0, N // 2], np.int64)
@@ -1694,9 +1694,9 @@ def test_proshi_small_batches_run_as_one_coordinate_parallel_chain(ctx, ciao, dt
             assert ("proshi_chain_kernel" in ctx.last_kernel()) == (lim == -1), ctx.last_kernel()
         finally:
             ctx.set_option("proshi_chain_max_batch", -1)
-        close(table, rt, dtype, scale={64: 200, 32: 170}, what=f"proshi small batches table ({ctx.last_kernel()})", scale64=150)
-        close(av, rav, dtype, scale={64: 95, 32: 90}, what="proshi small batches av", scale64=80)
-        close(z, rz, dtype, scale={64: 21, 32: 17}, what="proshi small batches z", size=np.abs(rav).max() / abs(float(rhg)), scale64=9.600000000000001)
+        close(table, rt, dtype, scale={64: 190, 32: 160}, what=f"proshi small batches table ({ctx.last_kernel()})", scale64=140)
+        close(av, rav, dtype, scale={64: 94, 32: 89}, what="proshi small batches av", scale64=79)
+        close(z, rz, dtype, scale={64: 20, 32: 16}, what="proshi small batches z", size=np.abs(rav).max() / abs(float(rhg)), scale64=9.5)
         res[lim] = (table, av, z)
     # static contiguous blocks (sweeping 2 / 3) through the chain == the same batches as index lists
     if r <= N:
@@ -1759,9 +1759,9 @@ def test_proshi_chain_with_wholly_dead_waves_over_thousands_of_visits(ctx, ciao,
         runs.append((table.clone(), av.clone(), z.clone()))
     for u, v in zip(*runs):
         assert torch.equal(u, v)
-    close(runs[0][0], rt, dtype, scale={64: 110, 32: 79}, what="proshi long chain table", scale64=82)
-    close(runs[0][0][:, d - 1], rt[:, d - 1], dtype, scale={64: 8, 32: 20}, what="proshi long chain table, coordinate d-1")
-    close(runs[0][1], rav, dtype, scale={64: 110, 32: 290}, what="proshi long chain av", scale64=840)
+    close(runs[0][0], rt, dtype, scale={64: 100, 32: 78}, what="proshi long chain table", scale64=81)
+    close(runs[0][0][:, d - 1], rt[:, d - 1], dtype, scale={64: 8, 32: 19}, what="proshi long chain table, coordinate d-1")
+    close(runs[0][1], rav, dtype, scale={64: 100, 32: 280}, what="proshi long chain av", scale64=840)
 
 
 def test_proshi_dense_is_validated(ctx, ciao):
@@ -1841,20 +1841,20 @@ def test_row_length_boundaries(ctx, ciao, dtype, d):
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
     ctx.full_gradient(dp, dev(x0), av)   # every row length has a kernel (beyond LDS: the generic kernel with global accumulators)
     k_sweep = ctx.last_kernel()
-    close(av, O.full_pass(op, x0), dtype, scale={64: 140, 32: 82}, what=f"sweep d={d} ({k_sweep})", scale64=17)
+    close(av, O.full_pass(op, x0), dtype, scale={64: 130, 32: 81}, what=f"sweep d={d} ({k_sweep})", scale64=16)
     table = torch.empty((N, d), dtype=tdt, device="cuda")
     gamma = 0.5 / N
     ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
     rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
-    close(table, rt, dtype, scale={64: 230, 32: 130}, what=f"saga_init table d={d} ({ctx.last_kernel()})", scale64=17)
-    close(av, rav, dtype, scale={64: 140, 32: 83}, what="saga_init av", scale64=17)
+    close(table, rt, dtype, scale={64: 220, 32: 120}, what=f"saga_init table d={d} ({ctx.last_kernel()})", scale64=16)
+    close(av, rav, dtype, scale={64: 130, 32: 82}, what="saga_init av", scale64=16)
     Li = float(N) * np.sum(A.astype(np.float64) ** 2, axis=1)
     gam = (0.999 * N / Li).astype(dtype)
     dgam = dev(gam)
     hg = ctx.hat_gamma(dgam)
     rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
     ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
-    close(table, rt, dtype, scale={64: 9.700000000000001, 32: 9.9}, what=f"finito_init table d={d}", scale64=8)
+    close(table, rt, dtype, scale={64: 9.600000000000001, 32: 9.8}, what=f"finito_init table d={d}", scale64=8)
     ctx.set_option("chain_max_batch", 0)
     try:
         batch = np.array([3, 19, 0, 7, 11, 22, 5], dtype=np.int64)
@@ -1862,8 +1862,8 @@ def test_row_length_boundaries(ctx, ciao, dtype, d):
     finally:
         ctx.set_option("chain_max_batch", -1)
     O.finito_steps(op, og, gam, rhg, [batch], rt, rav, rz)
-    close(table, rt, dtype, scale=28, what=f"finito batch table d={d} ({ctx.last_kernel()})", scale64=15)
-    close(z, rz, dtype, scale={64: 38, 32: 36}, what="finito batch z", scale64=19)
+    close(table, rt, dtype, scale=27, what=f"finito batch table d={d} ({ctx.last_kernel()})", scale64=14)
+    close(z, rz, dtype, scale={64: 37, 32: 35}, what="finito batch z", scale64=18)
     ctx.synchronize()
 
 
@@ -1890,14 +1890,14 @@ def test_chain_row_length_boundaries(ctx, ciao, dtype, d):
     # (beyond one workgroup's registers -- 8192 elements, fp64: 4096 -- several workgroups share the chain)
     assert ("chain_wide_kernel" in ctx.last_kernel()) == (d > (4096 if dtype == np.float64 else 8192)), ctx.last_kernel()
     O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
-    close(w, rw, dtype, scale={64: 350, 32: 250}, what=f"svrg_inner w d={d} ({ctx.last_kernel()})", scale64=470)
+    close(w, rw, dtype, scale={64: 340, 32: 240}, what=f"svrg_inner w d={d} ({ctx.last_kernel()})", scale64=460)
     table = torch.empty((N, d), dtype=tdt, device="cuda")
     ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
     rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
     ctx.saga_steps(dp, dg, gamma, False, idx, table, av, z)
     O.saga_steps(op, og, dtype(gamma), False, idx, rt, rav, rz)
-    close(z, rz, dtype, scale={64: 21, 32: 210}, what=f"saga z d={d} ({ctx.last_kernel()})")   # 20.4 eps observed at d = 2 (a two-element vector, scale64=490)
-    close(table, rt, dtype, scale={64: 92, 32: 130}, what="saga table", scale64=110)
+    close(z, rz, dtype, scale={64: 20, 32: 200}, what=f"saga z d={d} ({ctx.last_kernel()})")   # 20.4 eps observed at d = 2 (a two-element vector, scale64=480)
+    close(table, rt, dtype, scale={64: 91, 32: 120}, what="saga table", scale64=100)
     ctx.synchronize()
 
 
@@ -1927,21 +1927,21 @@ def test_small_row_kernel_group_sizes(ctx, ciao, dtype, small_i, shape):
             assert "rows_split_kernel" in ctx.last_kernel(), ctx.last_kernel()
         else:
             assert "rows_small_kernel" in ctx.last_kernel() and f"I{small_i}" in ctx.last_kernel(), ctx.last_kernel()
-        close(av, O.full_pass(op, x0), dtype, scale={64: 38, 32: 55}, what=f"sweep ({ctx.last_kernel()})", scale64=15)
+        close(av, O.full_pass(op, x0), dtype, scale={64: 37, 32: 54}, what=f"sweep ({ctx.last_kernel()})", scale64=14)
         gamma = 0.5 / N
         ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
         rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
-        close(table, rt, dtype, scale={64: 19, 32: 21}, what="saga_init table", scale64=8.3)
-        close(av, rav, dtype, scale={64: 28, 32: 48}, what="saga_init av", scale64=15)
+        close(table, rt, dtype, scale={64: 18, 32: 20}, what="saga_init table", scale64=8.200000000000001)
+        close(av, rav, dtype, scale={64: 27, 32: 47}, what="saga_init av", scale64=14)
         Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1)
         gam = (0.999 * N / Li).astype(dtype)
         dgam = dev(gam)
         hg = ctx.hat_gamma(dgam)
         rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
         ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
-        close(table, rt, dtype, scale={64: 9.5, 32: 17}, what="finito_init table", scale64=15)
-        close(av, rav, dtype, scale={64: 39, 32: 47}, what="finito_init av", scale64=9.8)
-        close(z, rz, dtype, scale={64: 39, 32: 47}, what="finito_init z", scale64=12)
+        close(table, rt, dtype, scale={64: 9.4, 32: 16}, what="finito_init table", scale64=14)
+        close(av, rav, dtype, scale={64: 38, 32: 46}, what="finito_init av", scale64=9.700000000000001)
+        close(z, rz, dtype, scale={64: 38, 32: 46}, what="finito_init z", scale64=11)
     finally:
         ctx.set_option("small_i", 0)
         ctx.set_option("small_mfma", -1)
@@ -1979,22 +1979,22 @@ def test_random_shapes(ctx, ciao, case):
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
     table = torch.empty((N, d), dtype=tdt, device="cuda")
     ctx.full_gradient(dp, dev(x0), av)
-    close(av, O.full_pass(op, x0), dtype, scale=110, what=f"sweep ({ctx.last_kernel()})", scale64=18)
+    close(av, O.full_pass(op, x0), dtype, scale=100, what=f"sweep ({ctx.last_kernel()})", scale64=17)
     gamma = 0.5 / max(lam_f, 1.0)
     ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
     rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
-    close(table, rt, dtype, scale=110, what=f"saga_init table ({ctx.last_kernel()})", scale64=17)
+    close(table, rt, dtype, scale=100, what=f"saga_init table ({ctx.last_kernel()})", scale64=16)
     idx = ciao.IndexStream(N + d).rand_indices(N, 25)
     ctx.saga_steps(dp, dg, gamma, False, idx, table, av, z)
     O.saga_steps(op, og, dtype(gamma), False, idx, rt, rav, rz)
-    close(z, rz, dtype, scale={64: 50, 32: 87}, what=f"saga z ({ctx.last_kernel()})", scale64=150)
+    close(z, rz, dtype, scale={64: 49, 32: 86}, what=f"saga z ({ctx.last_kernel()})", scale64=140)
     Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1) + 1e-12
     gam = (0.999 * N / Li).astype(dtype)
     dgam = dev(gam)
     hg = ctx.hat_gamma(dgam)
     rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
     ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
-    close(table, rt, dtype, scale={64: 13, 32: 19}, what=f"finito_init table ({ctx.last_kernel()})", scale64=13)
+    close(table, rt, dtype, scale={64: 12, 32: 18}, what=f"finito_init table ({ctx.last_kernel()})", scale64=12)
     r = min(N, 9)
     batch = ciao.IndexStream(d).sample_without_replacement(N, r)
     ctx.set_option("chain_max_batch", 0)
@@ -2003,8 +2003,8 @@ def test_random_shapes(ctx, ciao, case):
     finally:
         ctx.set_option("chain_max_batch", -1)
     O.finito_steps(op, og, gam, rhg, [batch], rt, rav, rz)
-    close(table, rt, dtype, scale={64: 70, 32: 60}, what=f"finito batch table ({ctx.last_kernel()})", scale64=13)
-    close(z, rz, dtype, scale={64: 88, 32: 98}, what="finito batch z", scale64=19)
+    close(table, rt, dtype, scale={64: 69, 32: 59}, what=f"finito batch table ({ctx.last_kernel()})", scale64=12)
+    close(z, rz, dtype, scale={64: 87, 32: 97}, what="finito batch z", scale64=18)
     ctx.synchronize()
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -2034,9 +2034,9 @@ def test_adaptive_finito_random_reprobe(ctx, ciao, dtype, d):
     rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(0.999), x0, retry_signs=signs)
     it = S.iterator(S.Finito(dtype, adaptive=True), dev(x0), F=dp, g=dg, N=N, ctx=ctx, stream=ciao.IndexStream(seed))
     st = next(iter(it))
-    close(st.γ, rgam, dtype, scale={64: 210, 32: 150}, what="gamma_i after the random re-probe", scale64=110)
-    close(st.av, rav, dtype, scale={64: 28, 32: 9.5}, what="av after the random re-probe", scale64=11)
-    close(st.z, rz, dtype, scale={64: 29, 32: 9.600000000000001}, what="z after the random re-probe", scale64=14)
+    close(st.γ, rgam, dtype, scale={64: 200, 32: 140}, what="gamma_i after the random re-probe", scale64=100)
+    close(st.av, rav, dtype, scale={64: 27, 32: 9.4}, what="av after the random re-probe", scale64=10)
+    close(st.z, rz, dtype, scale={64: 28, 32: 9.5}, what="z after the random re-probe", scale64=13)
     assert abs(st.hat_γ - float(rhg)) <= 200 * float(np.finfo(dtype).eps) * float(rhg)
     assert float(st.γ.min()) > 0
     # the low-level contract: without a host the flagged samples carry gamma_i = -1 and the status is CIAO_ERR_UNSUPPORTED
@@ -2055,7 +2055,7 @@ def test_adaptive_finito_random_reprobe(ctx, ciao, dtype, d):
     rdone, rhg2, rtrials = O.afinito_steps(op, og, dtype(0.999), dtype(1e-9), idx, rt, rg, rgam, rfi, rhg, rav, rz)
     assert done == rdone == 60
     if trials == rtrials:
-        close(st.z, rz, dtype, scale={64: 220, 32: 130}, what="z after 60 steps from the re-probed init")
+        close(st.z, rz, dtype, scale={64: 210, 32: 120}, what="z after 60 steps from the re-probed init")
 
 
 def _random_chain_cases(n, seed):
@@ -2105,8 +2105,8 @@ def test_random_chain_configurations(ctx, ciao, case):
             idx = st.rand_indices(N, 3 * N + 5)
             ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w, reuse_rowdots=(alg == "svrg_cached"))
             O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
-        close(zf, rzf, dtype, scale=840, what=f"random chain {alg} z_full ({ctx.last_kernel()})", scale64=820)
-        close(av, rav, dtype, scale={64: 370, 32: 420}, what=f"random chain {alg} av", scale64=430)
+        close(zf, rzf, dtype, scale=830, what=f"random chain {alg} z_full ({ctx.last_kernel()})", scale64=810)
+        close(av, rav, dtype, scale={64: 360, 32: 410}, what=f"random chain {alg} av", scale64=420)
     elif alg in ("saga", "sag"):
         gamma = 1.0 / ((16 if alg == "sag" else 3) * Li.max())
         table = torch.empty((N, d), dtype=tdt, device="cuda")
@@ -2116,8 +2116,8 @@ def test_random_chain_configurations(ctx, ciao, case):
         idx = st.rand_indices(N, 6 * N + 3)
         ctx.saga_steps(dp, dg, gamma, alg == "sag", idx, table, av, z)
         O.saga_steps(op, og, dtype(gamma), alg == "sag", idx, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 440, 32: 90}, what=f"random chain {alg} z ({ctx.last_kernel()})", scale64=840)
-        close(table, rt, dtype, scale={64: 410, 32: 300}, what=f"random chain {alg} table", scale64=810)
+        close(z, rz, dtype, scale={64: 430, 32: 89}, what=f"random chain {alg} z ({ctx.last_kernel()})", scale64=840)
+        close(table, rt, dtype, scale={64: 400, 32: 290}, what=f"random chain {alg} table", scale64=800)
     else:
         gam = (0.999 * N / Li).astype(dtype)
         dgam = dev(gam)
@@ -2136,8 +2136,8 @@ def test_random_chain_configurations(ctx, ciao, case):
                 np.cumsum([len(x) for x in batches], out=bptr[1:])
                 ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(batches), table, av, z)
                 O.finito_steps(op, og, gam, rhg, batches, rt, rav, rz)
-                close(z, rz, dtype, scale={64: 170, 32: 160}, what=f"random chain finito z ({ctx.last_kernel()})", scale64=150)
-                close(table, rt, dtype, scale={64: 66, 32: 120}, what="random chain finito table", scale64=87)
+                close(z, rz, dtype, scale={64: 160, 32: 150}, what=f"random chain finito z ({ctx.last_kernel()})", scale64=140)
+                close(table, rt, dtype, scale={64: 65, 32: 110}, what="random chain finito table", scale64=86)
             else:
                 av, z, zf = new(), new(), new()
                 rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
@@ -2149,8 +2149,8 @@ def test_random_chain_configurations(ctx, ciao, case):
                     np.cumsum([len(x) for x in batches], out=bptr[1:])
                     ctx.lfinito_iterate(dp, dg, dgam, hg, bptr, np.concatenate(batches), av, z, zf)
                     O.lfinito_iterate(op, og, gam, rhg, batches, rav, rz, rzf)
-                close(zf, rzf, dtype, scale={64: 170, 32: 38}, what=f"random chain lfinito z_full ({ctx.last_kernel()})", scale64=26)
-                close(av, rav, dtype, scale={64: 200, 32: 51}, what="random chain lfinito av", scale64=42)
+                close(zf, rzf, dtype, scale={64: 160, 32: 37}, what=f"random chain lfinito z_full ({ctx.last_kernel()})", scale64=25)
+                close(av, rav, dtype, scale={64: 190, 32: 50}, what="random chain lfinito av", scale64=41)
         finally:
             ctx.set_option("chain_max_batch", -1)
     ctx.synchronize()

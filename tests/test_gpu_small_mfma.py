@@ -36,7 +36,7 @@ def test_sweep_on_the_matrix_cores(ctx, ciao, dtype, loss, d):
             assert "rows_small_kernel" in kern, kern
             continue
         assert "rows_smallm_kernel" in kern, kern
-        close(av, O.full_pass(op, x0), dtype, scale={64: 540, 32: 810}, what=f"matrix-core sweep d={d} N={N}", scale64=260)
+        close(av, O.full_pass(op, x0), dtype, scale={64: 530, 32: 800}, what=f"matrix-core sweep d={d} N={N}", scale64=250)
         av0 = torch.empty_like(av)
         ctx.set_option("small_mfma", 0)
         try:
@@ -44,7 +44,7 @@ def test_sweep_on_the_matrix_cores(ctx, ciao, dtype, loss, d):
             assert "rows_small_kernel" in ctx.last_kernel(), ctx.last_kernel()
         finally:
             ctx.set_option("small_mfma", -1)
-        close(av, av0.cpu().numpy(), dtype, scale={64: 21, 32: 410}, what=f"matrix-core sweep vs the several-rows-per-wave kernel d={d} N={N}")
+        close(av, av0.cpu().numpy(), dtype, scale={64: 20, 32: 400}, what=f"matrix-core sweep vs the several-rows-per-wave kernel d={d} N={N}")
         av2 = torch.empty_like(av)
         ctx.full_gradient(dp, dev(x0), av2)
         assert torch.equal(av, av2), "not reproducible"
@@ -89,8 +89,8 @@ def test_row_dots_and_objective_ride_on_the_matrix_core_sweep(ctx, ciao, dtype):
         for _ in range(3):
             O.svrg_iterate(op, og, dtype(gamma), st.rand_indices(N, N), False, rav, rz, rzf, rw)
         # (a dependent chain's error grows about linearly in its steps: 3 x 3001 here)
-        close(zf, rzf, dtype, scale={64: 1600, 32: 99}, what=f"3 svrg epochs over matrix-core passes, z_full vs the oracle ({loss})", scale64=840)
-        close(zf, zf0.cpu().numpy(), dtype, scale={64: 39, 32: 12}, what=f"3 svrg epochs, z_full: matrix-core passes vs the several-rows-per-wave kernel ({loss})")
+        close(zf, rzf, dtype, scale={64: 1500, 32: 98}, what=f"3 svrg epochs over matrix-core passes, z_full vs the oracle ({loss})", scale64=840)
+        close(zf, zf0.cpu().numpy(), dtype, scale={64: 38, 32: 11}, what=f"3 svrg epochs, z_full: matrix-core passes vs the several-rows-per-wave kernel ({loss})")
         assert np.abs(av.cpu().numpy() - rav).max() <= 5000 * eps * scale_av
         assert np.abs(av.cpu().numpy() - av0.cpu().numpy()).max() <= 5000 * eps * scale_av
         obj = ctx.objective(dp, dg, zf)
@@ -154,15 +154,15 @@ def test_table_modes_on_the_matrix_core_kernel(ctx, ciao, dtype, loss):
             ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
             rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
             assert torch.isnan(big[N:]).all() and not torch.isnan(table).any(), (d, N)
-            close(table, rt, dtype, scale={64: 23, 32: 24}, what=f"saga_init table d={d} N={N}", scale64=20)
-            close(av, rav, dtype, scale={64: 99, 32: 66}, what=f"saga_init av d={d} N={N}", scale64=20)
+            close(table, rt, dtype, scale={64: 22, 32: 23}, what=f"saga_init table d={d} N={N}", scale64=19)
+            close(av, rav, dtype, scale={64: 98, 32: 65}, what=f"saga_init av d={d} N={N}", scale64=19)
             big.fill_(float("nan"))
             ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
             assert "rows_smallm_kernel" in ctx.last_kernel() and "mode3" in ctx.last_kernel(), ctx.last_kernel()
             rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
             assert torch.isnan(big[N:]).all() and not torch.isnan(table).any(), (d, N)
-            close(table, rt, dtype, scale=19, what=f"finito_init table d={d} N={N}", scale64=13)
-            close(av, rav, dtype, scale={64: 110, 32: 98}, what=f"finito_init av d={d} N={N}", scale64=11)
+            close(table, rt, dtype, scale=18, what=f"finito_init table d={d} N={N}", scale64=12)
+            close(av, rav, dtype, scale={64: 100, 32: 97}, what=f"finito_init av d={d} N={N}", scale64=10)
             if N < 1003:
                 continue
             # static blocks of 333 rows (the last one shorter), cyclic order, every block starting where 16-byte alignment allows or not
@@ -177,6 +177,6 @@ def test_table_modes_on_the_matrix_core_kernel(ctx, ciao, dtype, loss):
                 ctx.set_option("chain_max_batch", -1)
             O.finito_steps(op, og, gam, rhg, static, rt, rav, rz)
             assert torch.isnan(big[N:]).all() and not torch.isnan(table).any(), (d, N)
-            close(z, rz, dtype, scale={64: 310, 32: 520}, what=f"finito blocks z d={d} ({ctx.last_kernel()})", scale64=33)
-            close(table, rt, dtype, scale={64: 160, 32: 190}, what=f"finito blocks table d={d}", scale64=20)
+            close(z, rz, dtype, scale={64: 300, 32: 510}, what=f"finito blocks z d={d} ({ctx.last_kernel()})", scale64=32)
+            close(table, rt, dtype, scale={64: 150, 32: 180}, what=f"finito blocks table d={d}", scale64=19)
     ctx.synchronize()

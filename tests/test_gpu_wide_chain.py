@@ -36,8 +36,8 @@ def test_wide_chains_against_the_oracle(ctx, ciao, dtype, d):
         assert "chain_wide_kernel" in ctx.last_kernel() and f"grid={G} " in ctx.last_kernel(), ctx.last_kernel()
         rav, rz, rzf, rw = O.svrg_init(op, x0)
         O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
-        close(w, rw, dtype, scale={64: 57, 32: 44}, what=f"svrg_inner w, {G} workgroups, g={gk}", scale64=830)
-        close(z, rz, dtype, scale={64: 45, 32: 49}, what=f"svrg_inner z, {G} workgroups, g={gk}", scale64=440)
+        close(w, rw, dtype, scale={64: 56, 32: 43}, what=f"svrg_inner w, {G} workgroups, g={gk}", scale64=820)
+        close(z, rz, dtype, scale={64: 44, 32: 48}, what=f"svrg_inner z, {G} workgroups, g={gk}", scale64=430)
         # the one-workgroup kernel on the same chain: to rounding; itself again: bitwise
         av1, z1, zf1, w1 = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
         ctx.svrg_init(dp, dev(x0), av1, z1, zf1, w1)
@@ -47,7 +47,7 @@ def test_wide_chains_against_the_oracle(ctx, ciao, dtype, d):
             assert "chain_big_kernel" in ctx.last_kernel(), ctx.last_kernel()
         finally:
             ctx.set_option("chain_no_wide", 0)
-        close(w, w1.cpu().numpy(), dtype, scale=19, what="several workgroups vs one")
+        close(w, w1.cpu().numpy(), dtype, scale=18, what="several workgroups vs one")
         av2, z2, zf2, w2 = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(4))
         ctx.svrg_init(dp, dev(x0), av2, z2, zf2, w2)
         ctx.svrg_inner(dp, dg, gamma, idx, av2, z2, zf2, w2)
@@ -60,10 +60,10 @@ def test_wide_chains_against_the_oracle(ctx, ciao, dtype, d):
             assert "chain_wide_kernel" in ctx.last_kernel() and "alg1" in ctx.last_kernel(), ctx.last_kernel()
             rt, rsav, rsz = O.saga_init(op, og, dtype(gamma), x0)
             O.saga_steps(op, og, dtype(gamma), sag, idx, rt, rsav, rsz)
-            close(sz, rsz, dtype, scale={64: 51, 32: 73}, what=f"saga z sag={sag}, {G} workgroups, g={gk}", scale64=840)
-            close(sav, rsav, dtype, scale={64: 600, 32: 690}, what=f"saga av sag={sag}", scale64=640)
-            close(table, rt, dtype, scale={64: 890, 32: 800}, what="saga table", scale64=810)
-            close(sav, table.double().mean(dim=0).cpu().numpy(), dtype, scale={64: 160, 32: 170}, what="av invariant")
+            close(sz, rsz, dtype, scale={64: 50, 32: 72}, what=f"saga z sag={sag}, {G} workgroups, g={gk}", scale64=840)
+            close(sav, rsav, dtype, scale={64: 590, 32: 680}, what=f"saga av sag={sag}", scale64=630)
+            close(table, rt, dtype, scale={64: 880, 32: 790}, what="saga table", scale64=800)
+            close(sav, table.double().mean(dim=0).cpu().numpy(), dtype, scale={64: 150, 32: 160}, what="av invariant")
     ctx.synchronize()
 
 
@@ -98,9 +98,9 @@ def test_wide_finito_and_lfinito_chains(ctx, ciao, dtype, d):
         ctx.finito_steps(dp, dg, gam, hg, bptr, np.concatenate(batches), table, av, z)
         assert "chain_wide_kernel" in ctx.last_kernel() and "alg2" in ctx.last_kernel(), ctx.last_kernel()
         O.finito_steps(op, og, gamh, rhg, batches, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 250, 32: 220}, what=f"finito z, batches of {r}, several workgroups", scale64=140)
-        close(av, rav, dtype, scale={64: 240, 32: 210}, what=f"finito av, batches of {r}", scale64=130)
-        close(table, rt, dtype, scale={64: 210, 32: 180}, what=f"finito table, batches of {r}", scale64=110)
+        close(z, rz, dtype, scale={64: 240, 32: 210}, what=f"finito z, batches of {r}, several workgroups", scale64=130)
+        close(av, rav, dtype, scale={64: 230, 32: 200}, what=f"finito av, batches of {r}", scale64=120)
+        close(table, rt, dtype, scale={64: 200, 32: 170}, what=f"finito table, batches of {r}", scale64=100)
     lav, lz, lzf = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(3))
     rav, rz, rzf, rhg = O.lfinito_init(op, gamh, x0)
     ctx.lfinito_init(dp, hg, dev(x0), lav, lz, lzf)
@@ -110,8 +110,8 @@ def test_wide_finito_and_lfinito_chains(ctx, ciao, dtype, d):
         ctx.lfinito_iterate(dp, dg, gam, hg, bp, np.concatenate(blocks), lav, lz, lzf)
         assert "chain_wide_kernel" in ctx.last_kernel() and "alg3" in ctx.last_kernel(), ctx.last_kernel()
         O.lfinito_iterate(op, og, gamh, rhg, blocks, rav, rz, rzf)
-        close(lz, rz, dtype, scale=180, what=f"lfinito z it {it}, several workgroups", scale64=160)
-        close(lav, rav, dtype, scale={64: 170, 32: 180}, what=f"lfinito av it {it}", scale64=150)
+        close(lz, rz, dtype, scale=170, what=f"lfinito z it {it}, several workgroups", scale64=150)
+        close(lav, rav, dtype, scale={64: 160, 32: 170}, what=f"lfinito av it {it}", scale64=140)
     ctx.synchronize()
 
 
@@ -133,7 +133,7 @@ def test_wide_chain_epochs_through_the_solver(ctx, ciao):
         idx = st.rand_indices(N, 2 * N)
         ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w)
         O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
-        close(zf, rzf, dtype, scale={64: 47}, what=f"svrg epoch {ep} z_full on the several-workgroup chain")
+        close(zf, rzf, dtype, scale={64: 46}, what=f"svrg epoch {ep} z_full on the several-workgroup chain")
     ctx.synchronize()
 
 
@@ -176,8 +176,8 @@ def test_adaptive_finito_on_several_workgroups_is_repeatable(ctx, ciao, dtype):
     # (device against device, eps32: 3000 dependent backtracking steps whose every dot product is summed in another order -- 64 partial sums
     # against one running sum; the Float32 oracle stands as far from either.  Step-for-step against the oracle: test_adaptive_finito_on_rows_of_any_length)
     if outs[0][0] == outs[2][0]:   # (a backtracking test on the boundary may fall the other way with another summation order)
-        close(outs[0][1], outs[2][1].cpu().numpy(), dtype, scale={64: 8200, 32: 9800}, what="several workgroups vs one, z")
-        close(outs[0][2], outs[2][2].cpu().numpy(), dtype, scale={64: 8200, 32: 9800}, what="several workgroups vs one, av")
+        close(outs[0][1], outs[2][1].cpu().numpy(), dtype, scale={64: 8100, 32: 9700}, what="several workgroups vs one, z")
+        close(outs[0][2], outs[2][2].cpu().numpy(), dtype, scale={64: 8100, 32: 9700}, what="several workgroups vs one, av")
     assert abs(outs[0][0] - outs[2][0]) <= max(2, outs[2][0] // 50)
 
 
@@ -206,8 +206,8 @@ def test_adaptive_finito_on_several_workgroups_other_g(ctx, ciao, gk, loss):
     assert "afinito_wide_kernel" in ctx.last_kernel(), ctx.last_kernel()
     rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(0.999), dtype(1e-9), idx, rt, rg, rgam, rfi, rhg, rav, rz)
     assert done == rdone == len(idx) and trials == rtrials
-    close(z, rz, dtype, scale={64: 850}, what=f"adaptive z, g = {gk}")
-    close(av, rav, dtype, scale={64: 820}, what=f"adaptive av, g = {gk}")
-    close(table, rt, dtype, scale={64: 380}, what=f"adaptive table, g = {gk}")
-    close(meta[:, 0, 2], rgam, dtype, scale={64: 2500}, what=f"adaptive gamma_i, g = {gk}")
+    close(z, rz, dtype, scale={64: 840}, what=f"adaptive z, g = {gk}")
+    close(av, rav, dtype, scale={64: 810}, what=f"adaptive av, g = {gk}")
+    close(table, rt, dtype, scale={64: 370}, what=f"adaptive table, g = {gk}")
+    close(meta[:, 0, 2], rgam, dtype, scale={64: 2400}, what=f"adaptive gamma_i, g = {gk}")
     ctx.synchronize()
