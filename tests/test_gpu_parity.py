@@ -1896,7 +1896,7 @@ def test_chain_row_length_boundaries(ctx, ciao, dtype, d):
     rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
     ctx.saga_steps(dp, dg, gamma, False, idx, table, av, z)
     O.saga_steps(op, og, dtype(gamma), False, idx, rt, rav, rz)
-    close(z, rz, dtype, scale={64: 20, 32: 200}, what=f"saga z d={d} ({ctx.last_kernel()})")   # 20.4 eps observed at d = 2 (a two-element vector, scale64=480)
+    close(z, rz, dtype, scale={64: 20, 32: 200}, what=f"saga z d={d} ({ctx.last_kernel()})", scale64=480)   # 20.4 eps observed at d = 2 (a two-element vector)
     close(table, rt, dtype, scale={64: 91, 32: 120}, what="saga table", scale64=100)
     ctx.synchronize()
 

@@ -65,7 +65,8 @@ def retune(fname, log, write):
             if re.search(r"scale64=[^,)]+", out):
                 out = re.sub(r"scale64=[^,)]+", f"scale64={v}", out, count=1)
             else:
-                out = re.sub(r"\)(\s*(?:#.*)?)$", lambda m: f", scale64={v})" + m.group(1), out, count=1)
+                code, sep, comment = re.match(r"^(.*?\))(\s{2,}#.*)?()$", out).group(1, 2, 3) if re.match(r"^(.*?\))(\s{2,}#.*)?()$", out) else (out, None, "")
+                out = re.sub(r"\)\s*$", f", scale64={v})", code, count=1) + (sep or "")
         if out != src:
             changed += 1
             lines[ln - 1] = out
