@@ -16,7 +16,7 @@ using Printf
 using Random
 using ProximalOperators
 
-export solution
+export solution, solve_together
 
 const RealOrComplex{R} = Union{R,Complex{R}}      # CIAOAlgorithms.jl:3
 const Maybe{T} = Union{T,Nothing}                 # CIAOAlgorithms.jl:4
@@ -80,6 +80,23 @@ dptr(::Nothing) = C_NULL
 
 # complex T (CIAOAlgorithms.jl:3; test/test_lasso.jl:3 runs ComplexF32 / ComplexF64): every complex vector travels as its
 # interleaved (re, im) pairs -- reinterpret(R, x) -- and d counts reals.  LeastSquares rows pair with Zero / NormL1 only.
+# ---- feature padding (the Python mirror: solvers.py `_Iterable.__init__`, operators.pack_F(pad_to=...)) -------------------------------
+# The fast chain kernels stream rows of whole 16-byte chunks from 16-byte aligned addresses; a row of, say, 1001 Float64 is neither and
+# runs the register-ring chains at 2-3.7x the time per update.  A problem this wrapper packs ITSELF from host operators (not a PackedF
+# the caller laid out, not a complex problem, not adaptive Finito) is packed with dp - d zero columns, dp = d rounded up to whole
+# chunks: the extra coordinates multiply nothing and start at zero, so the d real ones evolve as without them (to rounding).  Every
+# state vector is a length-d contiguous view of a dp-long device buffer -- what the caller sees keeps the reference's shapes and
+# identities (`solution(state) === state.z`) -- and the library, told d = dp by the packed problem, reads and writes all dp entries.
+const PAD_FEATURES = Ref(true)
+padded_length(::Type{R}, d::Int) where {R} = (v = 16 ÷ sizeof(R); cld(d, v) * v)
+# a length-d view at the head of a zeroed buffer of dp entries (AMDGPU.jl: a contiguous view of a ROCArray is a ROCArray on the same memory)
+statevec(::Type{R}, d::Int, dp::Int) where {R} = view(AMDGPU.zeros(R, dp), 1:d)
+function statevec(x::Vector{R}, dp::Int) where {R}
+    buf = AMDGPU.zeros(R, dp)
+    copyto!(buf, 1, x, 1, length(x))
+    return view(buf, 1:length(x))
+end
+
 reals(::Type{R}, x::AbstractArray{<:Real}) where {R} = R.(vec(x))
 reals(::Type{R}, x::AbstractArray{<:Complex}) where {R} = collect(reinterpret(R, Complex{R}.(vec(x))))
 nreals(x0::AbstractArray) = eltype(x0) <: Complex ? 2 * length(x0) : length(x0)
@@ -114,6 +131,12 @@ function host_route(name::Symbol, ::Type{R}, cfg::NamedTuple, x0; kwargs...) whe
     return ref_solver(x0; kwargs...)
 end
 # iterator(solver, x0; ...) on the device, or `nothing` when the problem is unpackable and the caller allowed the host route
+# dp for a problem given as host operators: d itself for a PackedF the caller laid out, for complex problems and where the solver does
+# not pad (adaptive Finito, ProShI keep their d: solvers.py `_pads_features`)
+function padded_d(::Type{R}, F, d::Int, cplx::Bool; pads::Bool = true) where {R}
+    (PAD_FEATURES[] && pads && !cplx && !(F isa PackedF) && d >= 1) ? padded_length(R, d) : d
+end
+
 function device_iterator(solver, x0, fallback; kwargs...)
     try
         return iterator(solver, x0; kwargs...)
@@ -123,10 +146,11 @@ function device_iterator(solver, x0, fallback; kwargs...)
     end
 end
 
-function pack_F(::Type{R}, F, N::Int, d::Int; cplx::Bool = false) where {R}
+function pack_F(::Type{R}, F, N::Int, d::Int; cplx::Bool = false, pad_to::Int = d) where {R}
     F isa PackedF{R} && return F
+    dp = cplx ? d : pad_to           # rows of the packed matrix: d real columns + dp - d zero columns (feature padding, above)
     if F === nothing || all(f -> f isa ProximalOperators.Zero, F)
-        return PackedF{R}(LOSS_ZERO, nothing, nothing, 0.0, N, d)
+        return PackedF{R}(LOSS_ZERO, nothing, nothing, 0.0, N, dp)
     elseif cplx && all(f -> f isa ProximalOperators.LeastSquares, F)
         # complex x0: rows of d/2 complex entries (real rows are widened: real A times complex x is what LeastSquares computes)
         lam = F[1].lambda
@@ -143,32 +167,33 @@ function pack_F(::Type{R}, F, N::Int, d::Int; cplx::Bool = false) where {R}
     elseif all(f -> f isa ProximalOperators.LeastSquares, F)
         lam = F[1].lambda
         all(f -> f.lambda == lam && size(f.A) == (1, d), F) || throw(UnpackableOperator("unpackable LeastSquares terms"))
-        A = Matrix{R}(undef, d, N); b = Vector{R}(undef, N)
+        A = zeros(R, dp, N); b = Vector{R}(undef, N)
         for i in 1:N
-            A[:, i] .= vec(F[i].A); b[i] = F[i].b[1]
+            A[1:d, i] .= vec(F[i].A); b[i] = F[i].b[1]
         end
-        return PackedF{R}(LOSS_LS, ROCArray(A), ROCArray(b), Float64(lam), N, d)
+        return PackedF{R}(LOSS_LS, ROCArray(A), ROCArray(b), Float64(lam), N, dp)
     elseif all(f -> f isa ProximalOperators.Precompose && f.f isa ProximalOperators.LogisticLoss, F)
-        A = Matrix{R}(undef, d, N); y = Vector{R}(undef, N)
+        A = zeros(R, dp, N); y = Vector{R}(undef, N)
         for i in 1:N
             size(F[i].L) == (1, d) || throw(UnpackableOperator("unpackable Precompose term"))
-            A[:, i] .= vec(F[i].L); y[i] = F[i].f.y[1]
+            A[1:d, i] .= vec(F[i].L); y[i] = F[i].f.y[1]
         end
-        return PackedF{R}(LOSS_LOGISTIC, ROCArray(A), ROCArray(y), 1.0, N, d)
+        return PackedF{R}(LOSS_LOGISTIC, ROCArray(A), ROCArray(y), 1.0, N, dp)
     end
     throw(UnpackableOperator("F is not a family the device path can pack (LeastSquares rows, Precompose(LogisticLoss) rows, Zero)"))
 end
 cproblem(p::PackedF{R}) where {R} =
     CiaoProblem(p.loss, dtype_code(R), p.N, p.d, p.d, p.N, dptr(p.A), dptr(p.b), p.lam)
 
-function pack_g(::Type{R}, g, d::Int; cplx::Bool = false) where {R}
+function pack_g(::Type{R}, g, d::Int; cplx::Bool = false, pad_to::Int = d) where {R}
     g isa ProximalOperators.Zero && return (CiaoProxDesc(PROX_ZERO, 0, 0.0, -Inf, Inf, C_NULL, C_NULL), nothing)
     g isa ProximalOperators.NormL1 && g.lambda isa Real &&
         return (CiaoProxDesc(cplx ? PROX_L1_COMPLEX : PROX_L1, 0, Float64(g.lambda), -Inf, Inf, C_NULL, C_NULL), nothing)
     cplx && throw(UnpackableOperator("with a complex x0 g must be Zero or NormL1 (IndBox has no complex form)"))
     if g isa ProximalOperators.IndBox
-        lo = g.lb isa Real ? nothing : ROCArray(R.(vec(g.lb)))
-        hi = g.ub isa Real ? nothing : ROCArray(R.(vec(g.ub)))
+        # (per-coordinate bounds of a padded problem: the padding coordinates are unconstrained and stay at zero)
+        lo = g.lb isa Real ? nothing : ROCArray(vcat(R.(vec(g.lb)), fill(R(-Inf), pad_to - d)))
+        hi = g.ub isa Real ? nothing : ROCArray(vcat(R.(vec(g.ub)), fill(R(Inf), pad_to - d)))
         keep = (lo, hi)
         return (CiaoProxDesc(PROX_BOX, 0, 0.0, g.lb isa Real ? Float64(g.lb) : -Inf, g.ub isa Real ? Float64(g.ub) : Inf,
                              dptr(lo), dptr(hi)), keep)
@@ -323,8 +348,10 @@ function Base.iterate(iter::SVRG_basic_iterable{R}) where {R}          # SVRG_ba
     else
         γ = iter.γ
     end
-    x0d = ROCArray(reals(R, iter.x0))
-    av, z, z_full, w = (similar(x0d) for _ in 1:4)
+    xh = reals(R, iter.x0)
+    d, dp = length(xh), iter.F.d                                   # dp > d: a feature-padded problem (statevec: length-d views of dp-long buffers)
+    x0d = statevec(xh, dp)
+    av, z, z_full, w = (statevec(R, d, dp) for _ in 1:4)
     p = Ref(cproblem(iter.F))
     check(ccall((:ciao_svrg_init, libciao), Int32,
                 (Ptr{Cvoid}, Ref{CiaoProblem}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
@@ -404,8 +431,9 @@ function iterator(solver::SVRG{R}, x0::AbstractArray{C}; F = nothing, g = Proxim
                   μ = nothing, N) where {R,C<:RealOrComplex{R}}
     d = nreals(x0)                      # reals: twice the length of a complex x0
     m = solver.m === nothing ? N : solver.m
-    gd, keep = pack_g(R, g, d; cplx = C <: Complex)
-    return SVRG_basic_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex), gd, keep, x0, N, L, μ, solver.γ, m, solver.plus)
+    dp = padded_d(R, F, d, C <: Complex)
+    gd, keep = pack_g(R, g, d; cplx = C <: Complex, pad_to = dp)
+    return SVRG_basic_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex, pad_to = dp), gd, keep, x0, N, L, μ, solver.γ, m, solver.plus)
 end
 
 function (solver::SVRG{R})(x0::AbstractArray{C}; fallback = nothing, kwargs...) where {R,C<:RealOrComplex{R}}   # SVRG.jl:46-84
@@ -467,9 +495,11 @@ function Base.iterate(iter::SAGA_basic_iterable{R}) where {R}          # SAGA_ba
     else
         γ = iter.γ
     end
-    x0d = ROCArray(reals(R, iter.x0))
-    s = ROCArray{R}(undef, length(x0d), iter.N)
-    av, z = similar(x0d), similar(x0d)
+    xh = reals(R, iter.x0)
+    d, dp = length(xh), iter.F.d                                   # (feature padding: the table's rows are dp long, as the data rows)
+    x0d = statevec(xh, dp)
+    s = ROCArray{R}(undef, dp, iter.N)
+    av, z = statevec(R, d, dp), statevec(R, d, dp)
     p, g = Ref(cproblem(iter.F)), Ref(iter.g)
     check(ccall((:ciao_saga_init, libciao), Int32,
                 (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
@@ -499,8 +529,9 @@ solution(state::SAGA_basic_state) = state.z                                     
 function iterator(solver::SAGA{R}, x0::AbstractArray{C}; F = nothing, g = ProximalOperators.Zero(), L = nothing,
                   N) where {R,C<:RealOrComplex{R}}
     d = nreals(x0)                      # reals: twice the length of a complex x0
-    gd, keep = pack_g(R, g, d; cplx = C <: Complex)
-    return SAGA_basic_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex), gd, keep, x0, N, L, solver.γ, solver.SAG_flag)
+    dp = padded_d(R, F, d, C <: Complex)
+    gd, keep = pack_g(R, g, d; cplx = C <: Complex, pad_to = dp)
+    return SAGA_basic_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex, pad_to = dp), gd, keep, x0, N, L, solver.γ, solver.SAG_flag)
 end
 
 function (solver::SAGA{R})(x0::AbstractArray{C}; fallback = nothing, kwargs...) where {R,C<:RealOrComplex{R}}   # SAGA.jl:44-73
@@ -585,17 +616,19 @@ function Base.iterate(iter::FINITO_iterable{R}) where {R}    # Finito_basic.jl:4
     hg = Ref{Float64}(0.0)
     check(ccall((:ciao_hat_gamma, libciao), Int32, (Ptr{Cvoid}, Int32, Int64, Ptr{Cvoid}, Ref{Float64}),
                 context().h, dtype_code(R), N, dptr(γ), hg))
-    x0d = ROCArray(reals(R, iter.x0))
-    av, z = similar(x0d), similar(x0d)
+    xh = reals(R, iter.x0)
+    d, dp = length(xh), iter.F.d                                   # (feature padding: statevec)
+    x0d = statevec(xh, dp)
+    av, z = statevec(R, d, dp), statevec(R, d, dp)
     p, g = Ref(cproblem(iter.F)), Ref(iter.g)
     if iter.lfinito
-        z_full = similar(x0d)
+        z_full = statevec(R, d, dp)
         check(ccall((:ciao_lfinito_init, libciao), Int32,
                     (Ptr{Cvoid}, Ref{CiaoProblem}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
                     context().h, p, hg[], dptr(x0d), dptr(av), dptr(z), dptr(z_full)))
         state = FINITO_state{R}(nothing, γ, R(hg[]), av, z, z_full, ind, cld(N, r), 1, 0, collect(1:cld(N, r)))
     else
-        s = ROCArray{R}(undef, length(x0d), N)
+        s = ROCArray{R}(undef, dp, N)
         check(ccall((:ciao_finito_init, libciao), Int32,
                     (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
                     context().h, p, g, dptr(γ), hg[], dptr(x0d), dptr(s), dptr(av), dptr(z)))
@@ -656,6 +689,7 @@ function finito_steps!(iter::FINITO_iterable{R}, state::FINITO_state{R}, n::Int)
     batches = [copy(next_batch!(iter, state)) for _ in 1:n]
     bptr = Int64[0; cumsum(length.(batches))]
     bidx = to_dev_idx(reduce(vcat, batches))
+    BATCH_OPEN[] && push!(BATCH_KEEP, bidx)
     check(ccall((:ciao_finito_steps, libciao), Int32,
                 (Ptr{Cvoid}, Ref{CiaoProblem}, Ref{CiaoProxDesc}, Ptr{Cvoid}, Float64, Int64, Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
                 context().h, Ref(cproblem(iter.F)), Ref(iter.g), dptr(state.γ), Float64(state.hat_γ), n, bptr, dptr(bidx),
@@ -667,12 +701,14 @@ solution(state::FINITO_state) = state.z                            # Finito_basi
 function iterator(solver::Finito{R}, x0::AbstractArray{C}; F = nothing, g = ProximalOperators.Zero(), L = nothing,
                   N) where {R,C<:RealOrComplex{R}}
     d = nreals(x0)                      # reals: twice the length of a complex x0
-    gd, keep = pack_g(R, g, d; cplx = C <: Complex)
     if solver.adaptive && !solver.LFinito                          # Finito.jl:95-108: no minibatch in the adaptive mode
         solver.minibatch[1] && @warn "minibatch is not supported for adaptive Finito"
+        gd, keep = pack_g(R, g, d; cplx = C <: Complex)            # (adaptive Finito keeps its d: no feature padding)
         return FINITO_adaptive_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex), gd, keep, x0, N, solver.tol_b, solver.sweeping, solver.α)
     end
-    return FINITO_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex), gd, keep, x0, N, L, solver.γ, solver.sweeping,
+    dp = padded_d(R, F, d, C <: Complex)
+    gd, keep = pack_g(R, g, d; cplx = C <: Complex, pad_to = dp)
+    return FINITO_iterable{R,typeof(x0)}(pack_F(R, F, N, d; cplx = C <: Complex, pad_to = dp), gd, keep, x0, N, L, solver.γ, solver.sweeping,
                                          solver.minibatch[2], solver.α, solver.LFinito)
 end
 
@@ -704,6 +740,53 @@ function (solver::Finito{R})(x0::AbstractArray{C}; fallback = nothing, kwargs...
     solver.verbose && mod(num_iters, solver.freq) !== 0 && disp(num_iters, state)
     synchronize(context())
     return host_solution(solution(state), x0), num_iters
+end
+
+# ----------------------------------------------------------------------------------------------------------------------
+# solve_together(iters, maxit; one_pass = false): K independent SVRG, SAGA / SAG or small-batch (sweeping = 1) Finito solves over
+# device-resident rows advanced in LOCKSTEP, each reference iteration of all K as ONE launch of K chains (one workgroup, one compute
+# unit, per solve) -- the Python mirror's `solvers.solve_together`.  `iters` are what `iterator(solver, x0; ...)` returns, one kind per
+# call.  Returns the K final states (`solution(state)` each); every state ends bitwise as its own `Base.iterate` loop leaves it
+# (SVRG: with TRUST_SVRG_STATE[] = false; `one_pass = true`: to rounding -- the K full passes as one pass over the rows).
+# Not in the reference (one problem per call); a regularisation path, folds, restarts.
+# ----------------------------------------------------------------------------------------------------------------------
+function solve_together(iters::Vector, maxit::Int; one_pass::Bool = false, steps_per_launch::Int = 1000)
+    isempty(iters) && return Any[]
+    firsts = [Base.iterate(it) for it in iters]                     # the init state is iteration 1, as in the reference
+    any(f -> f === nothing, firsts) && throw(ArgumentError("an iterable ended before yielding a state (invalid configuration)"))
+    states = [f[1] for f in firsts]
+    done = 1
+    if iters[1] isa SVRG_basic_iterable
+        svrg_iters = convert(Vector{typeof(iters[1])}, iters); svrg_states = convert(Vector{typeof(states[1])}, states)
+        while done < maxit
+            iterate_together!(svrg_iters, svrg_states; one_pass = one_pass)
+            done += 1
+        end
+        return svrg_states
+    elseif iters[1] isa SAGA_basic_iterable
+        while done < maxit
+            n = min(steps_per_launch, maxit - done)
+            chain_batch() do
+                for (it, st) in zip(iters, states)
+                    saga_steps!(it, st, rand(1:it.N, n))                                    # SAGA_basic.jl:55, n draws
+                end
+            end
+            done += n
+        end
+        return states
+    elseif iters[1] isa FINITO_iterable && !iters[1].lfinito && iters[1].sweeping == 1
+        while done < maxit
+            n = min(steps_per_launch, maxit - done)
+            chain_batch() do
+                for (it, st) in zip(iters, states)
+                    finito_steps!(it, st, n)                                                # Finito_basic.jl:95-118, n iterations
+                end
+            end
+            done += n
+        end
+        return states
+    end
+    throw(ArgumentError("solve_together takes SVRG iterables, SAGA / SAG iterables or basic Finito iterables with sweeping = 1 (one kind)"))
 end
 
 # ======================================================================================================================

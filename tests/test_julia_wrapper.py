@@ -206,3 +206,147 @@ def test_the_wrapper_checks_the_abi_version_it_binds(ciao):
     hdr = open(os.path.join(ROOT, "include", "ciao_hip.h")).read()
     assert int(re.search(r"#define CIAO_ABI_VERSION (\d+)", hdr).group(1)) == ciao._lib.ABI_VERSION
     assert ":ciao_abi_version" in text and "CIAO_ABI_VERSION ||" in text.replace("== CIAO_ABI_VERSION ||", "CIAO_ABI_VERSION ||")
+
+
+# ======================================================================================================================
+# The Julia wrapper stays level with the Python mirror: every constructor keyword, every ABI call a solver's
+# iterable makes and every host-side feature of solvers.py has its counterpart in the .jl -- or is listed below with the reason.
+# The tables are the contract: a feature added on one side only fails here.
+# ======================================================================================================================
+SOLVERS_PY = os.path.join(ROOT, "ciaoalgorithms.jl_amd", "solvers.py")
+DEVICE_PY = os.path.join(ROOT, "ciaoalgorithms.jl_amd", "device.py")
+
+# the ABI entry points each solver's iterable reaches -- on BOTH sides (parsed from solvers.py + device.py, and from the .jl section)
+SOLVER_ABI = {
+    "SVRG": {"ciao_svrg_init", "ciao_svrg_iterate"},
+    "SAGA": {"ciao_saga_init", "ciao_saga_steps"},
+    "Finito": {"ciao_hat_gamma", "ciao_finito_init", "ciao_finito_steps", "ciao_finito_steps_blocks", "ciao_lfinito_init", "ciao_lfinito_iterate_blocks"},
+    "adaptive": {"ciao_afinito_init", "ciao_afinito_probe", "ciao_afinito_steps"},
+    "Proshi": {"ciao_proshi_init", "ciao_proshi_steps", "ciao_proshi_steps_blocks"},
+}
+# ... and what only ONE side calls there, with the reason
+JULIA_ONLY_ABI = {
+    "SVRG": {"ciao_svrg_inner", "ciao_svrg_epoch_tail", "ciao_svrg_epoch_tail_multi", "ciao_full_gradient_multi"},   # iterate_together!: in solvers.py these live in solve_together (below), outside the iterable's class
+    "Proshi": {"ciao_proshi_solution"},   # `solution(state)`: the Python mirror calls it from its state class
+}
+PYTHON_ONLY_ABI = {
+    "adaptive": {"ciao_ctx_synchronize"},   # the Python iterable reads the step counters back itself; the .jl does it in its generic `synchronize`
+}
+# constructor keywords: Julia spelling -> accepted Python spellings (the Python mirror takes the Greek names AND ascii aliases)
+KEYWORDS = {
+    "SVRG": ["γ", "maxit", "verbose", "freq", "m", "plus"],
+    "SAGA": ["γ", "maxit", "verbose", "freq", "SAG_flag"],
+    "Finito": ["γ", "sweeping", "LFinito", "adaptive", "minibatch", "maxit", "verbose", "freq", "α", "tol", "tol_b"],
+    "Proshi": ["γ", "sweeping", "minibatch", "maxit", "verbose", "freq", "α"],
+}
+# host-side features: (what, a pattern solvers.py / operators.py must contain, a pattern the .jl must contain)
+FEATURES = [
+    ("feature padding switch", r"PAD_FEATURES = True", r"const PAD_FEATURES = Ref\(true\)"),
+    ("padded packing of F", r"def pack_F\(.*pad_to", r"function pack_F\(.*pad_to::Int"),
+    ("padded box bounds of g", r"def pack_g\(.*pad_to", r"function pack_g\(.*pad_to::Int"),
+    ("state vectors as length-d views of padded buffers", r"base\[:self\.d\]", r"statevec\("),
+    ("adaptive Finito keeps its d", r"_pads_features", r"adaptive Finito keeps its d"),
+    ("K solves in lockstep", r"def solve_together\(iterables, maxit, one_pass=False\)", r"function solve_together\(iters::Vector, maxit::Int; one_pass::Bool = false"),
+    ("K full passes as one", r"svrg_epoch_tail_multi|full_gradient_multi", r"ciao_svrg_epoch_tail_multi"),
+    ("explicit host route", r"fallback", r"fallback = nothing"),
+    ("unpackable operators are an error", r"UnpackableOperator", r"struct UnpackableOperator"),
+    ("objective monitor", r"_monitor_on", r"set_monitor!"),
+    ("SVRG row-dot reuse only when the state is vouched for", r"reuse_rowdots", r"TRUST_SVRG_STATE"),
+    ("SVRG++ caps maxit at 25", r"maxit = 25|min\(.*25", r"maxit = 25"),
+    ("chain batches", r"chain_batch", r"function chain_batch\(f\)"),
+    ("shard table", r"set_shards", r"set_shards!"),
+    ("peer mailboxes", r"set_peers|PeerGroup", r"peer_mailbox_create"),
+    ("ABI version check", r"", r"CIAO_ABI_VERSION \|\|"),
+]
+# what the Python mirror has and the wrapper deliberately does not (and why)
+PYTHON_ONLY_FEATURES = {
+    "stream=": "explicit counter-based index streams: a Julia user keeps the reference's own RNG calls (rand / sample / randperm in the wrapper)",
+    "ctx=": "the wrapper has one default context per process (AMDGPU.jl's device and stream)",
+    "backend=": "test hook of the Python mirror (forces the host route)",
+    "stop=": "IterationTools.halt composes with the wrapper's iterables in Julia itself (SVRG.jl:70)",
+}
+
+
+def _py_method_abi():
+    """device.Context method -> the ABI symbols it reaches (through other methods too)"""
+    dev = open(DEVICE_PY).read()
+    meth = {}
+    for m in re.finditer(r"\n    def (\w+)\(self[^\n]*\n((?:(?!\n    def ).)*)", dev, re.S):
+        meth[m.group(1)] = (set(re.findall(r"self\.lib\.(ciao_\w+)", m.group(2))), set(re.findall(r"self\.(\w+)\(", m.group(2))))
+
+    def closure(name, seen):
+        if name in seen or name not in meth:
+            return set()
+        seen.add(name)
+        out = set(meth[name][0])
+        for c in meth[name][1]:
+            out |= closure(c, seen)
+        return out
+    return {k: closure(k, set()) for k in meth}
+
+
+def _py_solver_abi():
+    abi = _py_method_abi()
+    sol = open(SOLVERS_PY).read()
+    per_class = {}
+    for m in re.finditer(r"\nclass (\w+)\([^\n]*\n((?:(?!\nclass |\ndef ).)*)", sol, re.S):
+        calls = set(re.findall(r"(?:self\.ctx|ctx|it\.ctx|c)\.(\w+)\(", m.group(2)))
+        per_class[m.group(1)] = set().union(*[abi.get(c, set()) for c in calls]) if calls else set()
+    return {"SVRG": per_class["SVRG_basic_iterable"], "SAGA": per_class["SAGA_basic_iterable"],
+            "Finito": per_class["FINITO_basic_iterable"] | per_class["FINITO_LFinito_iterable"],
+            "adaptive": per_class["FINITO_adaptive_iterable"], "Proshi": per_class["Proshi_basic_iterable"]}
+
+
+def _jl_solver_abi():
+    jl = open(JL).read()
+    secs = re.split(r"\n# =+\n# ([^\n]+)\n# =+\n", jl)
+    out = {}
+    for i in range(1, len(secs), 2):
+        title, body = secs[i], secs[i + 1]
+        key = ("adaptive" if title.startswith("adaptive") else "SVRG" if title.startswith("SVRG") else "SAGA" if title.startswith("SAGA")
+               else "Finito" if title.startswith("Finito") else "Proshi" if title.startswith("ProShI") else None)
+        if key:
+            out[key] = set(re.findall(r"ccall\(\(:(ciao_\w+)", body))
+    return out
+
+
+def test_every_abi_call_of_a_python_solver_has_its_julia_counterpart():
+    py, jl = _py_solver_abi(), _jl_solver_abi()
+    for solver, both in SOLVER_ABI.items():
+        assert py[solver] - PYTHON_ONLY_ABI.get(solver, set()) == both, (solver, "solvers.py reaches", sorted(py[solver]), "the table says", sorted(both))
+        assert jl[solver] - JULIA_ONLY_ABI.get(solver, set()) == both, (solver, "the .jl calls", sorted(jl[solver]), "the table says", sorted(both))
+
+
+def test_every_constructor_keyword_exists_on_both_sides():
+    jl, py = open(JL).read(), open(SOLVERS_PY).read()
+    for solver, kws in KEYWORDS.items():
+        mj = re.search(r"function " + solver + r"\{R\}\(;(.*?)\) where", jl, re.S)
+        jkw = re.findall(r"(?:^\s*|[;,]\s*)(\w+)(?:::|\s*=)", mj.group(1).replace("\n", " "))
+        mp = re.search(r"class " + solver + r"\(_Solver\):.*?def __init__\(self, R=np\.float64, \*,(.*?)\):\n", py, re.S)
+        pkw = re.findall(r"(\w+)\s*=", mp.group(1))
+        assert set(kws) <= set(jkw), (solver, "Julia constructor lacks", sorted(set(kws) - set(jkw)))
+        assert set(kws) <= set(pkw), (solver, "Python constructor lacks", sorted(set(kws) - set(pkw)))
+        alias = {"gamma", "alpha"}   # ascii spellings of γ, α the Python mirror also takes
+        assert set(pkw) - alias == set(kws), (solver, "one-sided Python keywords", sorted(set(pkw) - alias - set(kws)))
+        assert set(jkw) == set(kws), (solver, "one-sided Julia keywords", sorted(set(jkw) - set(kws)))
+
+
+def test_every_host_side_feature_exists_on_both_sides():
+    jl = open(JL).read()
+    py = open(SOLVERS_PY).read() + open(os.path.join(ROOT, "ciaoalgorithms.jl_amd", "operators.py")).read() + open(DEVICE_PY).read()
+    missing = []
+    for what, ppat, jpat in FEATURES:
+        if ppat and not re.search(ppat, py):
+            missing.append(f"python lacks: {what}")
+        if not re.search(jpat, jl):
+            missing.append(f"julia lacks: {what}")
+    assert not missing, missing
+    # the call keywords of the Python functors: all but the documented Python-only ones appear in the wrapper's functors
+    for m in re.finditer(r"def _iterable\(self, x0,(.*?)\):", open(SOLVERS_PY).read(), re.S):
+        for kw in re.findall(r"(\w+)=", m.group(1)):
+            if kw + "=" in PYTHON_ONLY_FEATURES or kw in ("mu",):
+                continue
+            if kw == "shards":     # the wrapper sets a shard table on the context (set_shards!), not per call
+                assert "set_shards!" in jl
+                continue
+            assert re.search(r"\b" + kw + r"\b\s*=", jl), f"the wrapper's functors lack the keyword `{kw}`"
