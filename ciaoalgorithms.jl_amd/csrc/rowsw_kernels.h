@@ -15,7 +15,8 @@
 // loads (the row is wave-uniform): no vector register, no vmcnt.  Two rows are in flight per wave (ping-pong register sets), eight
 // waves per SIMD: 16 rows per SIMD, 16 K rows chip-wide.  Dot product: masked partial sums, one DPP wave sum.  The wave's accumulator is
 // combined across the block's waves through LDS in wave order; a block writes one partial d-vector (fixed order: bitwise reproducible).
-// Modes: RM_FINITO_BATCH (Finito_basic.jl:110-117).  Row blocks (idx == nullptr) run too -- the shapes the matrix-core kernel does not hold.
+// Modes: RM_FINITO_BATCH (Finito_basic.jl:110-117) and RM_GRAD2 (LFinito's batch sweep, Finito_LFinito.jl:93-98: two dot products per row, no
+// table).  Row blocks (idx == nullptr) run too -- the shapes the matrix-core kernel does not hold.
 #pragma once
 
 #include "rows_kernels.h"
@@ -36,11 +37,13 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (WrowWaves<sizeof(T), VEC, K>::val
 {
     (void)a_by_value;
     CIAO_KERNARG0(RowsArgs<T>, a);
-    static_assert(MODE == RM_FINITO_BATCH, "Finito batches");
+    static_assert(MODE == RM_FINITO_BATCH || MODE == RM_GRAD2, "the batch modes");
+    constexpr bool TWO = (MODE == RM_GRAD2);
     using V = typename ChunkOf<T, VEC>::type;
     constexpr int D = K * WAVE * VEC;   // elements a wave's lanes reach
 
     __shared__ __attribute__((aligned(16))) T red[D];
+    __shared__ T red_extra[ROWS_WAVES];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t nwaves = (int64_t)gridDim.x * ROWS_WAVES;
@@ -48,13 +51,15 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (WrowWaves<sizeof(T), VEC, K>::val
     const int64_t nchunks = d / VEC;
 
     bool ok[K];
-    V xv[K], acc[K];
+    V xv[K], x2v[K], acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         ok[k] = (k * WAVE + lane) < nchunks;
         xv[k] = ok[k] ? reinterpret_cast<const V *>(a.x1)[k * WAVE + lane] : V(T(0));
+        x2v[k] = (TWO && ok[k]) ? reinterpret_cast<const V *>(a.x2)[k * WAVE + lane] : V(T(0));
         acc[k] = V(T(0));
     }
+    T extra = T(0);
     // read-only for the kernel's lifetime and addressed wave-uniformly: constant address space, i.e. scalar loads
     typedef const __attribute__((address_space(4))) int64_t *cidx_t;
     typedef const __attribute__((address_space(4))) T *cval_t;
@@ -78,11 +83,11 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (WrowWaves<sizeof(T), VEC, K>::val
         }
         x.row = row;
         const V *ap = reinterpret_cast<const V *>(a.A + row * a.ld);
-        const V *sp = reinterpret_cast<const V *>(a.table + row * d);
+        const V *sp = TWO ? nullptr : reinterpret_cast<const V *>(a.table + row * d);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             x.ar[k] = ok[k] ? __builtin_nontemporal_load(&ap[k * WAVE + lane]) : V(T(0));
-            x.sr[k] = ok[k] ? __builtin_nontemporal_load(&sp[k * WAVE + lane]) : V(T(0));
+            if (!TWO) x.sr[k] = ok[k] ? __builtin_nontemporal_load(&sp[k * WAVE + lane]) : V(T(0));
         }
         x.bi = bc ? bc[row] : T(0);
         x.gi = gc ? gc[row] : gam_u;
@@ -95,6 +100,19 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (WrowWaves<sizeof(T), VEC, K>::val
             for (int v = 0; v < VEC; ++v) d1 += x.ar[k][v] * xv[k][v];
         d1 = wave_allsum(d1);
         const GradCoef<T> g1 = grad_coef(loss, d1, x.bi, lam);
+        if constexpr (TWO) {                 // Finito_LFinito.jl:93-98: acc += (c(a'z_full) - c(a'z)) a;  extra += hat_gamma / gamma_i
+            T d2 = T(0);
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) d2 += x.ar[k][v] * x2v[k][v];
+            d2 = wave_allsum(d2);
+            const T c = g1.coef() - grad_coef(loss, d2, x.bi, lam).coef();
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += c * x.ar[k];
+            extra += hat_gamma / x.gi;
+            return;
+        }
         const T cg = x.gi * invN;            // gamma_i / N
         const T rr = hat_gamma / x.gi;
         V *sp = reinterpret_cast<V *>(a.table + x.row * d);
@@ -146,7 +164,13 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (WrowWaves<sizeof(T), VEC, K>::val
     }
     T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
     for (int e = threadIdx.x; e < d; e += ROWS_BLOCK) pout[e] = red[e];
-    if (threadIdx.x == 0) a.pextra[blockIdx.x] = T(0);
+    if (lane == 0) red_extra[wib] = extra;   // (wave-uniform)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T ex = T(0);
+        for (int w = 0; w < ROWS_WAVES; ++w) ex += red_extra[w];
+        a.pextra[blockIdx.x] = ex;
+    }
 }
 
 }  // namespace ciao

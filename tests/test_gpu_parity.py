@@ -1087,7 +1087,7 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         lav2, lz2, lzf2 = lav.clone(), lz.clone(), lzf.clone()
         for it in range(2):
             ctx.lfinito_iterate(dp, dg, dgam, hg, bp, np.concatenate(blocks), lav, lz, lzf)
-            assert "rows_smallb_kernel" in ctx.last_kernel() and "mode1" in ctx.last_kernel(), ctx.last_kernel()
+            assert "rows_wrow_kernel" in ctx.last_kernel() and "mode1" in ctx.last_kernel(), ctx.last_kernel()   # (round 5: one wave per row)
             ctx.lfinito_iterate_blocks(dp, dg, dgam, hg, np.array([x[0] for x in blocks]), np.array([len(x) for x in blocks]), lav2, lz2, lzf2)
             O.lfinito_iterate(op, og, gam, rhg, blocks, rav, rz, rzf)
             if mfma and (r * d * np.dtype(dtype).itemsize) % 16 == 0:
