@@ -1330,8 +1330,6 @@ int32_t ciao_ctx_set_option(ciao_ctx *ctx, const char *key, int64_t value)
         ctx->proshi_chain_max_batch = value;
     } else if (!strcmp(key, "chain_four_waves")) {
         ctx->chain_four_waves = value;
-    } else if (!strcmp(key, "chain_one_wave")) {
-        ctx->chain_one_wave = value;
     } else if (!strcmp(key, "chain_big")) {
         ctx->chain_big = value != 0;
     } else if (!strcmp(key, "chain_no_dma")) {

@@ -75,36 +75,6 @@ __device__ __forceinline__ ChainArgsK<T> *chain_args_block()
     return k;
 }
 
-// A field of the argument block that the STEP LOOP reads: loaded once, and made opaque in its scalar register(s) so that hipcc
-// neither re-loads it from the block inside the loop (a scalar-cache round trip on the dependent path of every step -- what it did
-// with a.gamma, a.invN, a.lam once the block was read through a pointer) nor keeps it anywhere but in SGPRs.
-template <typename X>
-__device__ __forceinline__ X sgpr_pin(X v)
-{
-    asm volatile("" : "+s"(v));
-    return v;
-}
-// ... a value COMPUTED from such fields (the vector pipeline did the arithmetic): through v_readfirstlane, then pinned
-__device__ __forceinline__ float sgpr_pin_computed(float v)
-{
-    return sgpr_pin(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))));
-}
-__device__ __forceinline__ double sgpr_pin_computed(double v)
-{
-    const uint64_t u = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
-    return sgpr_pin(__builtin_bit_cast(double, ((uint64_t)hi << 32) | lo));
-}
-// ... a pointer field: the asm hides that it came from the argument block, so say again that it is global memory (generic
-// pointers make FLAT loads / stores, which count on both memory counters and break the hand-counted waits)
-template <typename P>
-__device__ __forceinline__ P *sgpr_pin_global(P *p)
-{
-    asm volatile("" : "+s"(p));
-    return (P *)(__attribute__((address_space(1))) P *)(uintptr_t)p;
-}
-
 // A batch of chains (ChainArgs::multi): workgroup k takes its own argument block.  Word by word through v_readfirstlane, so that
 // every field is in scalar registers exactly as a kernel argument would be (the inline asm of the chain kernels names SGPRs).
 template <typename T>

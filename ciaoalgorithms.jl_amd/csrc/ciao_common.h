@@ -19,11 +19,47 @@ constexpr int WAVE = 64;
 // The FIRST kernel argument (a struct passed by value), read through the kernel-argument segment, field by field WHERE IT IS USED:
 // hipcc loads every field of a by-value argument into scalar registers in the entry block, and the fields that only a prologue, a
 // staging phase or the final stores need then stay live through the hot loop -- 10 to 100 scalar registers pushed out to VGPR lanes
-// in the chain / long-row / small-row families (tools/kernel_meta.py).  The block is constant memory: scalar loads.  A field the hot
-// loop reads goes into a local first (chain_kernels.h sgpr_pin where hipcc would otherwise re-load it inside the loop).
+// in the chain / long-row / small-row families (tools/kernel_meta.py).  The block is constant memory: scalar loads.  A field a hot
+// LOOP reads is loaded once into a local through sgpr_pin (below): read in place hipcc re-loads it inside the loop, a scalar-cache
+// round trip behind a full wait on every iteration (profiles/r05_kernarg_ab.txt: up to 21 % of a sweep, 19 % of a chain step).
+#ifdef CIAO_KERNARG_BYVALUE   // same-box A/B only (tools/exp/kernarg_ab.sh): the by-value argument as it is
+#define CIAO_KERNARG0(Type, name) const Type &name = a_by_value
+#else
 #define CIAO_KERNARG0(Type, name)                                   \
     typedef const __attribute__((address_space(4))) Type name##_kernarg_t; \
     name##_kernarg_t &name = *(name##_kernarg_t *)__builtin_amdgcn_kernarg_segment_ptr()
+#endif
+
+// A field of the argument block that the STEP LOOP reads: loaded once, and made opaque in its scalar register(s) so that hipcc
+// neither re-loads it from the block inside the loop (a scalar-cache round trip on the dependent path of every step -- what it did
+// with a.gamma, a.invN, a.lam once the block was read through a pointer) nor keeps it anywhere but in SGPRs.
+template <typename X>
+__device__ __forceinline__ X sgpr_pin(X v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
+// ... a value COMPUTED from such fields (the vector pipeline did the arithmetic): through v_readfirstlane, then pinned
+__device__ __forceinline__ float sgpr_pin_computed(float v)
+{
+    return sgpr_pin(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))));
+}
+__device__ __forceinline__ double sgpr_pin_computed(double v)
+{
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return sgpr_pin(__builtin_bit_cast(double, ((uint64_t)hi << 32) | lo));
+}
+// ... a pointer field: the asm hides that it came from the argument block, so say again that it is global memory (generic
+// pointers make FLAT loads / stores, which count on both memory counters and break the hand-counted waits)
+template <typename P>
+__device__ __forceinline__ P *sgpr_pin_global(P *p)
+{
+    asm volatile("" : "+s"(p));
+    return (P *)(__attribute__((address_space(1))) P *)(uintptr_t)p;
+}
+
 
 // ------------------------------------------------------------------------------------------------------------------
 // DPP cross-lane moves (32-bit halves; 64-bit values move as two halves).  Controls used:

@@ -98,7 +98,6 @@ struct ciao_ctx {
     int64_t svrg_cache_rowdots = 1; // reuse a_i'z_full from the full pass inside the SVRG inner cycle (ciao_svrg_iterate)
     int64_t proshi_chain_max_batch = -1;   // ProShI batches up to this size run as one coordinate-parallel chain launch (-1 = automatic)
     int64_t chain_four_waves = 0;   // testing: short rows (<= 2 KiB) on the four-wave chain instead of the single-wave one
-    int64_t chain_one_wave = 0;     // experiment: 4 KiB rows on a single-wave chain (no cross-wave exchange)
     int64_t chain_no_wide = 0;      // testing: rows beyond 8192 elements on chain_big_kernel instead of the several-workgroup chain_wide_kernel
     void *wide_box = nullptr;       // chain_wide_kernel: the workgroups' mailbox
     size_t wide_box_bytes = 0;

@@ -325,7 +325,17 @@ template <typename T>
 __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a_by_value)
 {
     (void)a_by_value;
-    CIAO_KERNARG0(ProshiChainArgs<T>, a);
+    CIAO_KERNARG0(ProshiChainArgs<T>, ka);
+    // what a visit reads, loaded once and held in scalar registers (read in place hipcc re-loads fields inside the visit, a scalar-cache
+    // round trip on the dependent path: 0.338 -> 0.403 us per visit at d = 1024 fp64, profiles/r05_kernarg_ab.txt); staging and
+    // prologue fields are read where they are used
+    const struct {
+        const T *Q, *q;
+        T *table;
+        int64_t ld, d, batch, nvisits;
+        T lo, hi, eta, invN, hat_gamma;
+    } a = {sgpr_pin_global(ka.Q), sgpr_pin_global(ka.q), sgpr_pin_global(ka.table), sgpr_pin(ka.ld), sgpr_pin(ka.d), sgpr_pin(ka.batch),
+           sgpr_pin(ka.nvisits), sgpr_pin(ka.lo), sgpr_pin(ka.hi), sgpr_pin(ka.eta), sgpr_pin(ka.invN), sgpr_pin(ka.hat_gamma)};
     constexpr int CH = PROSHI_CH, PD = ProshiDepth<T>::value, NW = 4;
     constexpr int DW = sizeof(T) / 4;                 // dwords per value
     constexpr int OPS = 3 * DW + 1;                   // per visit and wave: 3 DW LDS-DMA loads + the table store (every wave that visits has a live lane)
@@ -357,13 +367,13 @@ __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a_
     // with the wave that owns it: the waves of this kernel are not synchronised inside a chunk); it only helps with the staging.
     const int64_t k = live ? k0 : a.d - 1;
     const bool wave_dead = ((int64_t)blockIdx.x * 256 + (int64_t)wib * WAVE) >= a.d;   // wave-uniform
-    T av = a.av[k], z = a.z[k];
+    T av = ka.av[k], z = ka.z[k];
     // g's parameters for coordinate k, fetched once
-    const T gl = (a.g.kind == CIAO_PROX_L1) ? a.hat_gamma * a.g.lam : T(0);
+    const T gl = (ka.g.kind == CIAO_PROX_L1) ? a.hat_gamma * ka.g.lam : T(0);
     T plo = -INFINITY, phi = INFINITY;
-    if (a.g.kind == CIAO_PROX_BOX) {
-        plo = a.g.lo_vec ? a.g.lo_vec[k] : a.g.lo;
-        phi = a.g.hi_vec ? a.g.hi_vec[k] : a.g.hi;
+    if (ka.g.kind == CIAO_PROX_BOX) {
+        plo = ka.g.lo_vec ? ka.g.lo_vec[k] : ka.g.lo;
+        phi = ka.g.hi_vec ? ka.g.hi_vec[k] : ka.g.hi;
     }
 #pragma unroll
     for (int u = 0; u < PD; ++u) hist[u * 256 + tid] = T(0);
@@ -398,13 +408,13 @@ __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a_
         for (int e = tid; e < nch + PD; e += 256) {
             int64_t v = base + e;
             if (v > a.nvisits - 1) v = a.nvisits - 1;          // look-ahead past the end repeats the last agent (harmless loads)
-            int64_t r = a.idx[v];
-            if ((uint64_t)r >= (uint64_t)a.N) {
-                *a.errflag = 1;
+            int64_t r = ka.idx[v];
+            if ((uint64_t)r >= (uint64_t)ka.N) {
+                *ka.errflag = 1;
                 r = 0;
             }
             s_row[PD + e] = r;
-            if (e < nch) s_gam[e] = a.gam[r];
+            if (e < nch) s_gam[e] = ka.gam[r];
         }
         __syncthreads();
         for (int e = tid; e < nch; e += 256) {
@@ -473,8 +483,8 @@ __global__ void __launch_bounds__(256) proshi_chain_kernel(ProshiChainArgs<T> a_
     }
     wait_vmcnt<0>();   // nothing may still be writing LDS when the workgroup retires
     if (live) {
-        a.av[k] = av;
-        a.z[k] = z;
+        ka.av[k] = av;
+        ka.z[k] = z;
     }
 }
 

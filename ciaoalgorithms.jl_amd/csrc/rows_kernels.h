@@ -54,6 +54,29 @@ struct RowsArgs {
     int small_nb;          // rows_smallm_kernel: tile buffers per wave
 };
 
+// What a rows kernel's LOOP reads of its argument block, loaded once and held in scalar registers (sgpr_pin, ciao_common.h): read in
+// place through CIAO_KERNARG0, hipcc re-loads the fields inside the loop, each behind a full scalar wait in front of a row's
+// requests (profiles/r05_kernarg_ab.txt).  The iterate(s), the partials' addresses and the one-off fields are read where they are used
+// and take no register in the loop; a field a kernel does not read costs one scalar load.
+template <typename T>
+struct RowsLoopArgs {
+    const T *A, *b, *gam;
+    T *table, *rowdot_out;
+    const int64_t *idx;
+    int *errflag;
+    int64_t ld, d, N, row0, nrows;
+    int loss, want_fval;
+    T lam, gam_uniform, invN, hat_gamma;
+};
+template <typename T, typename KA>
+__device__ __forceinline__ RowsLoopArgs<T> rows_loop_args(const KA &ka)
+{
+    return RowsLoopArgs<T>{sgpr_pin_global(ka.A), sgpr_pin_global(ka.b), sgpr_pin_global(ka.gam), sgpr_pin_global(ka.table),
+                           sgpr_pin_global(ka.rowdot_out), sgpr_pin_global(ka.idx), sgpr_pin_global(ka.errflag), sgpr_pin(ka.ld), sgpr_pin(ka.d),
+                           sgpr_pin(ka.N), sgpr_pin(ka.row0), sgpr_pin(ka.nrows), sgpr_pin(ka.loss), sgpr_pin(ka.want_fval), sgpr_pin(ka.lam),
+                           sgpr_pin(ka.gam_uniform), sgpr_pin(ka.invN), sgpr_pin(ka.hat_gamma)};
+}
+
 template <typename T>
 struct VecOf;
 template <>
@@ -538,7 +561,8 @@ template <typename T, int MODE, int SMALL_I, bool PADDED>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a_by_value)
 {
     (void)a_by_value;
-    CIAO_KERNARG0(RowsArgs<T>, a);
+    CIAO_KERNARG0(RowsArgs<T>, ka);
+    const RowsLoopArgs<T> a = rows_loop_args<T>(ka);
     constexpr int SMALL_GE = WAVE * SMALL_I;   // elements of one wave-iteration
     static_assert(MODE == RM_GRAD || MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT, "contiguous full sweeps only");
     extern __shared__ __attribute__((aligned(16))) unsigned char small_raw[];
@@ -578,7 +602,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a_by
         rrow[i] = live ? e / d : WAVE;
         const int c = live ? e - rrow[i] * d : 0;
         if (PADDED) aoff[i] = live ? rrow[i] * ld + c : 0;
-        xcol[i] = live ? a.x1[c] : T(0);
+        xcol[i] = live ? ka.x1[c] : T(0);
         acc[i] = T(0);
     }
     T ex = T(0);
@@ -714,7 +738,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a_by
     }
     if (lane == 0) red_extra_small[wib] = ex;
     __syncthreads();
-    T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
+    T *pout = ka.partial + (int64_t)blockIdx.x * ka.pstride;
     for (int c = threadIdx.x; c < d; c += ROWS_BLOCK) {
         T sacc = base[c];
         for (int w = 1; w < ROWS_WAVES; ++w) sacc += base[w * d + c];
@@ -723,7 +747,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_small_kernel(RowsArgs<T> a_by
     if (threadIdx.x == 0) {
         T e2 = T(0);
         for (int w = 0; w < ROWS_WAVES; ++w) e2 += red_extra_small[w];
-        a.pextra[blockIdx.x] = e2;
+        ka.pextra[blockIdx.x] = e2;
     }
 }
 
@@ -757,6 +781,7 @@ template <typename T, int MODE, int SMALL_I, bool GATHER>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallb_kernel(RowsArgs<T> a_by_value)
 {
     (void)a_by_value;
+    // (read in place: holding the fields costs 6-16 spilled registers here, and index lists run on rows_wrow_kernel by default)
     CIAO_KERNARG0(RowsArgs<T>, a);
     static_assert(MODE == RM_GRAD2 || MODE == RM_FINITO_BATCH, "the batch modes");
     constexpr bool TWO = (MODE == RM_GRAD2), TABLE = (MODE == RM_FINITO_BATCH);
@@ -1016,7 +1041,24 @@ template <typename T, int K, int R, int MODE>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_multi_kernel(RowsArgs<T> a_by_value)
 {
     (void)a_by_value;
-    CIAO_KERNARG0(RowsArgs<T>, a);
+    constexpr bool TWO_MODE = (MODE == RM_GRAD2);
+    CIAO_KERNARG0(RowsArgs<T>, ka);
+    // What the sweep loop reads, loaded ONCE into scalar registers (sgpr_pin).  Read in place, hipcc re-loaded the fields inside the loop,
+    // each behind an lgkmcnt(0) -- the one in front of the second row's address also waited for the first row's loads: the fp32
+    // d = 1024 sweep went from 5.90 to 7.15 ms (profiles/r05_kernarg_ab.txt).  Prologue and epilogue fields are read where they are used.
+    const struct {
+        const T *A, *b;
+        int64_t ld, row0, nrows, N;
+        const int64_t *idx;
+        int loss, want_fval;
+        T lam, gam_uniform, hat_gamma;
+        const T *gam;
+        T *rowdot_out;
+        int *errflag;
+    } a = {sgpr_pin_global(ka.A), sgpr_pin_global(ka.b), sgpr_pin(ka.ld), sgpr_pin(ka.row0), sgpr_pin(ka.nrows), sgpr_pin(ka.N),
+           sgpr_pin_global(ka.idx), sgpr_pin(ka.loss), sgpr_pin(ka.want_fval), sgpr_pin(ka.lam),
+           TWO_MODE ? sgpr_pin(ka.gam_uniform) : T(0), TWO_MODE ? sgpr_pin(ka.hat_gamma) : T(0),
+           TWO_MODE ? sgpr_pin_global(ka.gam) : nullptr, TWO_MODE ? nullptr : sgpr_pin_global(ka.rowdot_out), sgpr_pin_global(ka.errflag)};
     using V = typename VecOf<T>::type;
     constexpr int VEC = VecOf<T>::N;
     constexpr int D = K * WAVE * VEC;
@@ -1032,8 +1074,8 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_multi_kernel(RowsArgs<T> a_by
     const int64_t wave = (int64_t)blockIdx.x * ROWS_WAVES + wib;
 
     for (int e = threadIdx.x; e < D; e += ROWS_BLOCK) {
-        lds[e] = a.x1[e];
-        if (TWO) lds[D + e] = a.x2[e];
+        lds[e] = ka.x1[e];
+        if (TWO) lds[D + e] = ka.x2[e];
     }
     __syncthreads();
 
@@ -1046,7 +1088,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_multi_kernel(RowsArgs<T> a_by
     for (int64_t q0 = wave * R; q0 < a.nrows; q0 += nwaves * R) {
         V cur[R][K];
         int64_t row[R];
-        T bi[R];
+        T bi[R], gi[R];   // (gamma_i requested with the row: at the end of the group it was a dependent load, and kept row[] live)
         bool live[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -1067,6 +1109,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_multi_kernel(RowsArgs<T> a_by
                 for (int k = 0; k < K; ++k) cur[r][k] = V(T(0));
             }
             bi[r] = (a.b && live[r]) ? a.b[rr] : T(0);
+            gi[r] = (TWO && a.gam && live[r]) ? a.gam[rr] : a.gam_uniform;
         }
         int xl = lane;
         asm volatile("" : "+v"(xl));
@@ -1106,8 +1149,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_multi_kernel(RowsArgs<T> a_by
                     if (a.want_fval) extra += loss_value(a.loss, d1[r], bi[r], a.lam);
                     if (a.rowdot_out && lane == 0) a.rowdot_out[row[r]] = d1[r];
                 } else {
-                    const T gi = a.gam ? a.gam[row[r]] : a.gam_uniform;
-                    extra += a.hat_gamma / gi;
+                    extra += a.hat_gamma / gi[r];
                 }
             }
         }
@@ -1129,12 +1171,12 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_multi_kernel(RowsArgs<T> a_by
     }
     if (lane == 0) red_extra[wib] = extra;
     __syncthreads();
-    T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
+    T *pout = ka.partial + (int64_t)blockIdx.x * ka.pstride;
     for (int e = threadIdx.x; e < D; e += ROWS_BLOCK) pout[e] = lds[e];
     if (threadIdx.x == 0) {
         T ex = T(0);
         for (int w = 0; w < ROWS_WAVES; ++w) ex += red_extra[w];
-        a.pextra[blockIdx.x] = ex;
+        ka.pextra[blockIdx.x] = ex;
     }
 }
 

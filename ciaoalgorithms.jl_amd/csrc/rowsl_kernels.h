@@ -33,13 +33,31 @@ template <typename T, int J, int MODE>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_value, LongArgs la)
 {
     (void)a_by_value;
-    CIAO_KERNARG0(RowsArgs<T>, a);
+    CIAO_KERNARG0(RowsArgs<T>, ka);
     using V = typename VecOf<T>::type;
     using W = WideWord<T>;
     constexpr int VEC = VecOf<T>::N;
     constexpr bool TWO = (MODE == RM_GRAD2);
     constexpr bool TABLE = (MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH);
     constexpr bool TREAD = (MODE == RM_FINITO_BATCH);
+    constexpr bool GAMS = !(MODE == RM_GRAD || MODE == RM_SAGA_INIT);
+    // what the row loop reads, loaded once and held in scalar registers (read in place hipcc re-loads fields inside the loop, each
+    // load a scalar-cache round trip in front of the row's requests: d = 32 768 fp64 sweep 4.83 -> 4.27 TB/s, profiles/r05_kernarg_ab.txt);
+    // the iterate, the partials and the other modes' fields are read where they are used and hold no register in the loop
+    const struct {
+        const T *A, *b;
+        int64_t ld, d, row0, nrows, N;
+        const int64_t *idx;
+        int loss, want_fval;
+        T lam, gam_uniform, invN, hat_gamma;
+        const T *gam;
+        T *table, *rowdot_out;
+        int *errflag;
+    } a = {sgpr_pin_global(ka.A), sgpr_pin_global(ka.b), sgpr_pin(ka.ld), sgpr_pin(ka.d), sgpr_pin(ka.row0), sgpr_pin(ka.nrows), sgpr_pin(ka.N),
+           sgpr_pin_global(ka.idx), sgpr_pin(ka.loss), MODE == RM_GRAD ? sgpr_pin(ka.want_fval) : 0, sgpr_pin(ka.lam),
+           GAMS ? sgpr_pin(ka.gam_uniform) : T(0), (TABLE && MODE != RM_SAGA_INIT) ? sgpr_pin(ka.invN) : T(0),
+           (TWO || TREAD) ? sgpr_pin(ka.hat_gamma) : T(0), GAMS ? sgpr_pin_global(ka.gam) : nullptr,
+           TABLE ? sgpr_pin_global(ka.table) : nullptr, MODE == RM_GRAD ? sgpr_pin_global(ka.rowdot_out) : nullptr, sgpr_pin_global(ka.errflag)};
     constexpr int NWORD = (TWO ? 2 : 1) * W::N;
     static_assert(MODE != RM_AFINITO_INIT, "the adaptive init keeps to the wave-per-row kernels");
 
@@ -60,8 +78,8 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         ok[j] = coff + j * ROWS_BLOCK < nchunks;
-        x1[j] = ok[j] ? reinterpret_cast<const V *>(a.x1)[coff + j * ROWS_BLOCK] : V(T(0));
-        x2[j] = (TWO && ok[j]) ? reinterpret_cast<const V *>(a.x2)[coff + j * ROWS_BLOCK] : V(T(0));
+        x1[j] = ok[j] ? reinterpret_cast<const V *>(ka.x1)[coff + j * ROWS_BLOCK] : V(T(0));
+        x2[j] = (TWO && ok[j]) ? reinterpret_cast<const V *>(ka.x2)[coff + j * ROWS_BLOCK] : V(T(0));
         acc[j] = V(T(0));
     }
     T extra = T(0);
@@ -209,11 +227,11 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_
         q += C;
     }
 
-    V *pout = reinterpret_cast<V *>(a.partial + (int64_t)c * a.pstride) + coff;
+    V *pout = reinterpret_cast<V *>(ka.partial + (int64_t)c * ka.pstride) + coff;
 #pragma unroll
     for (int j = 0; j < J; ++j)
         if (ok[j]) PSTORE(acc[j], &pout[j * ROWS_BLOCK]);
-    if (s == 0 && tid == 0) a.pextra[c] = extra;   // extra is the same in every workgroup of the cluster
+    if (s == 0 && tid == 0) ka.pextra[c] = extra;   // extra is the same in every workgroup of the cluster
 }
 
 }  // namespace ciao

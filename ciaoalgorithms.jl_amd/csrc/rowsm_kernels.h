@@ -69,6 +69,8 @@ template <typename T, int NC2, int MODE>
 __global__ void __launch_bounds__(ROWS_BLOCK) rows_smallm_kernel(RowsArgs<T> a_by_value)
 {
     (void)a_by_value;
+    // (read in place: the tile loop is long, and holding the fields costs 15-21 spilled registers for nothing measurable --
+    // profiles/r05_kernarg_ab.txt, the small-row lines)
     CIAO_KERNARG0(RowsArgs<T>, a);
     constexpr bool TWO = (MODE == RM_GRAD2);
     constexpr bool TABLE = (MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH);

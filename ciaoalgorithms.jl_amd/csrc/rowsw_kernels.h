@@ -36,7 +36,20 @@ template <typename T, int VEC, int K, int MODE>
 __global__ void __launch_bounds__(ROWS_BLOCK, (WrowWaves<sizeof(T), VEC, K>::value)) rows_wrow_kernel(RowsArgs<T> a_by_value)
 {
     (void)a_by_value;
-    CIAO_KERNARG0(RowsArgs<T>, a);
+    CIAO_KERNARG0(RowsArgs<T>, ka);
+    // what the row loop reads: loaded once, held in scalar registers (read in place hipcc re-loaded a.idx, a.N, a.A, a.ld ... in front of
+    // every row's requests -- three scalar-cache round trips on the path list entry -> row address -> loads)
+    const struct {
+        const T *A, *b, *gam;
+        T *table;
+        const int64_t *idx;
+        int64_t ld, d, N, row0, nrows;
+        int *errflag;
+        T gam_uniform, invN, hat_gamma, lam;
+        int loss;
+    } a = {sgpr_pin_global(ka.A), sgpr_pin_global(ka.b), sgpr_pin_global(ka.gam), sgpr_pin_global(ka.table), sgpr_pin_global(ka.idx),
+           sgpr_pin(ka.ld), sgpr_pin(ka.d), sgpr_pin(ka.N), sgpr_pin(ka.row0), sgpr_pin(ka.nrows), sgpr_pin_global(ka.errflag),
+           sgpr_pin(ka.gam_uniform), sgpr_pin(ka.invN), sgpr_pin(ka.hat_gamma), sgpr_pin(ka.lam), sgpr_pin(ka.loss)};
     static_assert(MODE == RM_FINITO_BATCH || MODE == RM_GRAD2, "the batch modes");
     constexpr bool TWO = (MODE == RM_GRAD2);
     using V = typename ChunkOf<T, VEC>::type;
@@ -55,8 +68,8 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (WrowWaves<sizeof(T), VEC, K>::val
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         ok[k] = (k * WAVE + lane) < nchunks;
-        xv[k] = ok[k] ? reinterpret_cast<const V *>(a.x1)[k * WAVE + lane] : V(T(0));
-        x2v[k] = (TWO && ok[k]) ? reinterpret_cast<const V *>(a.x2)[k * WAVE + lane] : V(T(0));
+        xv[k] = ok[k] ? reinterpret_cast<const V *>(ka.x1)[k * WAVE + lane] : V(T(0));
+        x2v[k] = (TWO && ok[k]) ? reinterpret_cast<const V *>(ka.x2)[k * WAVE + lane] : V(T(0));
         acc[k] = V(T(0));
     }
     T extra = T(0);
@@ -162,14 +175,14 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (WrowWaves<sizeof(T), VEC, K>::val
         }
         __syncthreads();
     }
-    T *pout = a.partial + (int64_t)blockIdx.x * a.pstride;
+    T *pout = ka.partial + (int64_t)blockIdx.x * ka.pstride;
     for (int e = threadIdx.x; e < d; e += ROWS_BLOCK) pout[e] = red[e];
     if (lane == 0) red_extra[wib] = extra;   // (wave-uniform)
     __syncthreads();
     if (threadIdx.x == 0) {
         T ex = T(0);
         for (int w = 0; w < ROWS_WAVES; ++w) ex += red_extra[w];
-        a.pextra[blockIdx.x] = ex;
+        ka.pextra[blockIdx.x] = ex;
     }
 }
 

@@ -73,6 +73,13 @@ SGPR_EXCEPTIONS = {
     r"ciao::chain_dma_kernel<double, 2, 2, 1, true, 256, false>": 9,
     r"ciao::chain_dma_kernel<double, 4, 0, 1, true, 256, true>": 11,
     r"ciao::afinito_dma_kernel<double, 8, 1, true, 256, (true|false)>": 11,
+    # the sweep kernels hold the fields their row loop reads in scalar registers ON PURPOSE: read in place, hipcc re-loaded them inside
+    # the loop behind full waits (fp32 d = 1024 sweep 5.90 -> 7.15 ms, d = 32 768 fp64 cluster sweep 4.83 -> 4.27 TB/s; pinned: 5.68 ms and
+    # 5.47 TB/s, level with the by-value argument, profiles/r05_kernarg_ab.txt).  Where four rows' two fp64 dot products pass through
+    # scalar registers at once (the wave sum: 64 of them) the pinned fields are written to spill lanes in the prologue and read back
+    # by single v_readlane's, none in front of a memory instruction's address (tools/sgpr_vmem_hazard.py checks that)
+    r"ciao::rows_multi_kernel<double, 2, 4, 1>": 24,
+    r"ciao::rows_long_kernel<double, 8, (0|4)>": 10,
 }
 # VGPRs parked in AGPRs (vgpr_spill > 0 with no scratch: v_accvgpr moves).  One class: a thread that owns FOUR or more 16-byte chunks
 # of every state vector (rows of 16 KiB on four waves, adaptive Finito rows of 32 KiB) holds more state
