@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 F64, F32 = np.float64, np.float32
 ALGS = ("svrg", "svrg_cached", "saga", "sag", "finito", "lfinito")
-ALG_NO = {"svrg": 0, "saga": 1, "sag": 1, "finito": 2, "svrg_cached": 3, "lfinito": 4}   # chain_kernels.h CA_*
+ALG_NO = {"svrg": 0, "saga": 1, "sag": 1, "finito": 2, "lfinito": 3, "svrg_cached": 4}   # chain_kernels.h CA_*
 
 
 def _shard_table(L, dp, N, cuts, table=None):
@@ -65,14 +65,21 @@ def run_chain(ctx, ciao, alg, N, d, dtype, loss, gk, sharded=False, r=1):
             finally:
                 ctx.set_shards(None)
             O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
-            close(w, rw, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"dispatch sweep {tag} w ({name})")
-        else:
-            for ep in range(2):                        # (the second epoch of "svrg_cached" reuses the a_i'z_full of the first one's full pass)
-                ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w, reuse_rowdots=(alg == "svrg_cached"))
-                O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
+            close(w, rw, dtype, scale={64: 220, 32: 200}, scale64=250, what=f"dispatch sweep {tag} w ({name})")
+        elif alg == "svrg":
+            ctx.svrg_inner(dp, dg, gamma, idx, av, z, zf, w)
             name = ctx.last_kernel()
-            close(zf, rzf, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"dispatch sweep {tag} z_full ({name})")
-            close(av, rav, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"dispatch sweep {tag} av")
+            O.svrg_inner(op, og, dtype(gamma), idx, rav, rz, rzf, rw)
+            close(w, rw, dtype, scale={64: 220, 32: 200}, scale64=250, what=f"dispatch sweep {tag} w ({name})")
+        else:
+            # whole outer iterations: the inner cycle reuses the a_i'z_full of the full pass before it (CA_SVRGC); the launcher's last
+            # kernel is the full pass that closes the iteration, so no name here -- the kernel trace says what ran
+            for ep in range(2):
+                ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w, reuse_rowdots=True)
+                O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
+            name = None
+            close(zf, rzf, dtype, scale=160, scale64=230, what=f"dispatch sweep {tag} z_full")
+            close(av, rav, dtype, scale={64: 110, 32: 120}, scale64=160, what=f"dispatch sweep {tag} av")
     elif alg in ("saga", "sag"):
         gamma = 1.0 / ((16 if alg == "sag" else 3) * Li.max())
         table = torch.empty((N, d), dtype=tdt, device="cuda")
@@ -91,8 +98,8 @@ def run_chain(ctx, ciao, alg, N, d, dtype, loss, gk, sharded=False, r=1):
             if sharded:
                 ctx.set_shards(None)
         O.saga_steps(op, og, dtype(gamma), alg == "sag", idx, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"dispatch sweep {tag} z ({name})")
-        close(table, rt, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"dispatch sweep {tag} table")
+        close(z, rz, dtype, scale={64: 79, 32: 73}, scale64=360, what=f"dispatch sweep {tag} z ({name})")
+        close(table, rt, dtype, scale={64: 400, 32: 790}, scale64=450, what=f"dispatch sweep {tag} table")
     else:
         assert not sharded
         gam = (0.999 * N / Li).astype(dtype)
@@ -113,8 +120,8 @@ def run_chain(ctx, ciao, alg, N, d, dtype, loss, gk, sharded=False, r=1):
                 ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(batches), table, av, z)
                 name = ctx.last_kernel()
                 O.finito_steps(op, og, gam, rhg, batches, rt, rav, rz)
-                close(z, rz, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"dispatch sweep {tag} z ({name})")
-                close(table, rt, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"dispatch sweep {tag} table")
+                close(z, rz, dtype, scale={64: 110, 32: 160}, scale64=95, what=f"dispatch sweep {tag} z ({name})")
+                close(table, rt, dtype, scale={64: 110, 32: 140}, scale64=90, what=f"dispatch sweep {tag} table")
             else:
                 static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in range(nb)]
                 av, z, zf = new(), new(), new()
@@ -128,8 +135,8 @@ def run_chain(ctx, ciao, alg, N, d, dtype, loss, gk, sharded=False, r=1):
                     ctx.lfinito_iterate(dp, dg, dgam, hg, bptr, np.concatenate(batches), av, z, zf)
                     O.lfinito_iterate(op, og, gam, rhg, batches, rav, rz, rzf)
                 name = ctx.last_kernel()
-                close(zf, rzf, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"dispatch sweep {tag} z_full ({name})")
-                close(av, rav, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"dispatch sweep {tag} av")
+                close(zf, rzf, dtype, scale={64: 97, 32: 93}, scale64=68, what=f"dispatch sweep {tag} z_full ({name})")
+                close(av, rav, dtype, scale={64: 100, 32: 120}, scale64=100, what=f"dispatch sweep {tag} av")
         finally:
             ctx.set_option("chain_max_batch", -1)
     ctx.synchronize()
@@ -153,15 +160,15 @@ ROWB = [1024, 1008, 2048, 2000, 4096, 4080, 8192, 8176, 16384, 16000, 32768, 327
 
 
 def _dma_class(rowb):
-    """(J, waves, masked) of the default route"""
+    """(J as the launcher reports it = 4 KiB units of the row class, waves, masked) of the default route"""
     if rowb <= 1024:
         return 1, 1, rowb != 1024
     if rowb <= 2048:
-        return 2, 1, rowb != 2048
+        return 1, 1, rowb != 2048                      # (two chunks per lane of the one wave; reported by row class: J1)
     j = 1
     while j * 4096 < rowb:
         j *= 2
-    return min(j, 4), (8 if j == 8 else 4), rowb != j * 4096
+    return j, (8 if j == 8 else 4), rowb != j * 4096   # (32 KiB rows: reported as J8, eight waves of four chunks per thread)
 
 
 @pytest.mark.parametrize("dtype", [F64, F32], ids=["f64", "f32"])
@@ -175,6 +182,8 @@ def test_every_lds_dma_chain_class(ctx, ciao, dtype, loss, rowb):
     gk = "l1" if loss == "ls" else "boxvec"
     for alg in ALGS:
         name = run_chain(ctx, ciao, alg, N, d, dtype, loss, gk)
+        if name is None:
+            continue
         if alg in ("saga", "sag") and waves == 4 and J == 1:
             assert f"chain_ws_kernel<{ty},J1,alg1" in name and ("masked" in name) == masked, name
         else:
@@ -183,6 +192,8 @@ def test_every_lds_dma_chain_class(ctx, ciao, dtype, loss, rowb):
     if waves == 1:
         for alg in ALGS:
             name = _with(ctx, {"chain_four_waves": 1}, lambda: run_chain(ctx, ciao, alg, N, d, dtype, loss, gk))
+            if name is None:
+                continue
             want = "chain_ws_kernel" if alg in ("saga", "sag") else "chain_dma_kernel"
             assert want in name and "block=" in name and "block=64 " not in name, name
     if J == 1:
@@ -210,11 +221,11 @@ def test_every_register_ring_chain_class(ctx, ciao, dtype, loss, d):
     ty = "f64" if dtype == F64 else "f32"
     for alg in ALGS:
         name = _with(ctx, {"chain_no_dma": 1}, lambda: run_chain(ctx, ciao, alg, N, d, dtype, loss, "l1"))
-        assert f"chain_kernel<{ty}" in name, name
+        assert name is None or f"chain_kernel<{ty}" in name, name
         # the same shape through the any-length kernel (state in the caller's vectors)
         if d in (256, 999):
             name = _with(ctx, {"chain_big": 1}, lambda: run_chain(ctx, ciao, alg, N, d, dtype, loss, "box"))
-            assert "chain_big_kernel" in name, name
+            assert name is None or "chain_big_kernel" in name, name
 
 
 # ---- adaptive Finito: afinito_dma_kernel (one wave / four waves, J = 1 ... 8, masked, over a shard table), afinito_chain_kernel ------
@@ -281,11 +292,13 @@ def run_afinito(ctx, ciao, N, d, dtype, loss, sharded=False):
     rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(alpha), x0)
     rdone, rhg, rtrials = O.afinito_steps(op, og, dtype(alpha), dtype(tol_b), idx, rt, rg, rgam, rfi, rhg, rav, rz)
     assert done == rdone == len(idx)
-    assert abs(trials - rtrials) <= max(1, rtrials // 50), (trials, rtrials)
-    if trials == rtrials:   # (Float32: a backtracking test on its boundary may be decided differently -- test_adaptive_finito_steps says how rarely)
-        close(z, rz, dtype, scale={64: 3000, 32: 800}, what=f"dispatch sweep adaptive z N={N} d={d} {loss} ({name})")
-        close(table, rt, dtype, scale={64: 3000, 32: 800}, what=f"dispatch sweep adaptive table d={d} {loss}")
-        close(hg, [rhg], dtype, scale={64: 3000, 32: 800}, what=f"dispatch sweep adaptive hat_gamma d={d} {loss}")
+    # Float32: a backtracking test f_i(z) <= model + tol that sits on its boundary to within the rounding of the dot products may be
+    # decided differently, and every later decision of these 39 steps with it (test_adaptive_finito_steps: how rarely); Float64: never
+    assert abs(trials - rtrials) <= (0 if dtype == F64 else max(2, rtrials // 10)), (trials, rtrials)
+    if trials == rtrials:
+        close(z, rz, dtype, scale={64: 360, 32: 340}, what=f"dispatch sweep adaptive z N={N} d={d} {loss} ({name})")
+        close(table, rt, dtype, scale=300, what=f"dispatch sweep adaptive table d={d} {loss}")
+        close(hg, [rhg], dtype, scale={64: 160, 32: 130}, what=f"dispatch sweep adaptive hat_gamma d={d} {loss}")
     return name
 
 
@@ -337,21 +350,21 @@ def run_modes(ctx, ciao, N, d, dtype, loss, r, pad=0):
         av = new()
         ctx.full_gradient(dp, dev(x0), av)
         names["grad"] = ctx.last_kernel()
-        close(av, O.full_pass(op, x0), dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: full gradient ({names['grad']})")
+        close(av, O.full_pass(op, x0), dtype, scale={64: 150, 32: 110}, scale64=16, what=f"every mode {tag}: full gradient ({names['grad']})")
         table = torch.empty((N, d), dtype=tdt, device="cuda")
         sav, sz = new(), new()
         g0 = 0.1 / max(Li.max(), 1.0)
         ctx.saga_init(dp, dg, g0, dev(x0), table, sav, sz)
         names["saga_init"] = ctx.last_kernel()
         rt, rav, rz = O.saga_init(op, og, dtype(g0), x0)
-        close(table, rt, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: saga_init table")
-        close(sav, rav, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: saga_init av")
+        close(table, rt, dtype, scale={64: 87, 32: 160}, scale64=15, what=f"every mode {tag}: saga_init table")
+        close(sav, rav, dtype, scale={64: 67, 32: 100}, scale64=15, what=f"every mode {tag}: saga_init av")
         z = new()
         rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
         ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
         names["finito_init"] = ctx.last_kernel()
-        close(table, rt, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: finito_init table")
-        close(av, rav, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: finito_init av")
+        close(table, rt, dtype, scale={64: 13, 32: 17}, scale64=11, what=f"every mode {tag}: finito_init table")
+        close(av, rav, dtype, scale={64: 110, 32: 80}, scale64=12, what=f"every mode {tag}: finito_init av")
         # Finito batches: random lists, then static blocks (the last one short) as row blocks
         st = ciao.IndexStream(d)
         rnd = [st.sample_without_replacement(N, r) for _ in range(3)] + [st.sample_without_replacement(N, max(1, r // 3))]
@@ -360,15 +373,15 @@ def run_modes(ctx, ciao, N, d, dtype, loss, r, pad=0):
         ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(rnd), table, av, z)
         names["finito_lists"] = ctx.last_kernel()
         O.finito_steps(op, og, gam, rhg, rnd, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: finito z, lists ({names['finito_lists']})")
-        close(table, rt, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: finito table, lists")
+        close(z, rz, dtype, scale={64: 220, 32: 470}, scale64=30, what=f"every mode {tag}: finito z, lists ({names['finito_lists']})")
+        close(table, rt, dtype, scale={64: 170, 32: 390}, scale64=31, what=f"every mode {tag}: finito table, lists")
         nb = -(-N // r)
         blocks = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in range(nb)]
         ctx.finito_steps_blocks(dp, dg, dgam, hg, np.array([x[0] for x in blocks]), np.array([len(x) for x in blocks]), table, av, z)
         names["finito_blocks"] = ctx.last_kernel()
         O.finito_steps(op, og, gam, rhg, blocks, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: finito z, blocks ({names['finito_blocks']})")
-        close(table, rt, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: finito table, blocks")
+        close(z, rz, dtype, scale={64: 490, 32: 1500}, scale64=64, what=f"every mode {tag}: finito z, blocks ({names['finito_blocks']})")
+        close(table, rt, dtype, scale={64: 390, 32: 1300}, scale64=55, what=f"every mode {tag}: finito table, blocks")
         # LFinito: the full pass + the batch sweep with two dot products per row, lists then blocks
         lav, lz, lzf = new(), new(), new()
         rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
@@ -381,16 +394,16 @@ def run_modes(ctx, ciao, N, d, dtype, loss, r, pad=0):
         ctx.lfinito_iterate_blocks(dp, dg, dgam, hg, np.array([x[0] for x in blocks]), np.array([len(x) for x in blocks]), lav, lz, lzf)
         names["lfinito_blocks"] = ctx.last_kernel()
         O.lfinito_iterate(op, og, gam, rhg, blocks, rav, rz, rzf)
-        close(lz, rz, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: lfinito z ({names['lfinito_blocks']})")
-        close(lav, rav, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: lfinito av")
+        close(lz, rz, dtype, scale={64: 1000, 32: 6100}, scale64=100, what=f"every mode {tag}: lfinito z ({names['lfinito_blocks']})")
+        close(lav, rav, dtype, scale={64: 1000, 32: 6600}, scale64=86, what=f"every mode {tag}: lfinito av")
         # the adaptive init (Finito_adaptive.jl:59-93)
         meta4 = torch.empty((N, 4, 4), dtype=tdt, device="cuda")
         hgd = torch.empty(1, dtype=tdt, device="cuda")
         ctx.afinito_init(dp, dg, 0.999, dev(x0), table, meta4, av, z, hgd)
         names["afinito_init"] = ctx.last_kernel()
         rt, rg, rgam, rfi, rav, rz, rhg = O.afinito_init(op, og, dtype(0.999), x0)
-        close(av, rav, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: adaptive init av ({names['afinito_init']})")
-        close(meta4[:, 0, 1], rfi, dtype, scale={64: 3000, 32: 3000}, scale64=840, what=f"every mode {tag}: adaptive init f_i(x0)")
+        close(av, rav, dtype, scale={64: 100, 32: 96}, scale64=20, what=f"every mode {tag}: adaptive init av ({names['afinito_init']})")
+        close(meta4[:, 0, 1], rfi, dtype, scale={64: 150, 32: 190}, scale64=18, what=f"every mode {tag}: adaptive init f_i(x0)")
     finally:
         ctx.set_option("chain_max_batch", -1)
     ctx.synchronize()
@@ -408,7 +421,8 @@ def test_every_wave_per_row_and_workgroup_per_row_class(ctx, ciao, dtype, K):
     loss = "logistic" if K in (2, 8) else "ls"
     n = run_modes(ctx, ciao, N, d, dtype, loss, r)
     assert "rows_fast_kernel" in n["grad"] or "rows_multi_kernel" in n["grad"], n
-    assert "rows_split_kernel" in n["finito_lists"] or K == 16, n
+    # (batches up to 16 384 rows of exactly J x 256 chunks take a workgroup per row; 64 and 128 chunks stay one wave per row)
+    assert ("rows_split_kernel" if K >= 4 else "rows_fast_kernel") in n["finito_lists"], n
     for opts in ({"sweep_prefetch": 1}, {"sweep_multi": 0, "split_max_rows": 0}, {"sweep_multi": 0, "sweep_prefetch": 1, "split_max_rows": 0}):
         try:
             n = _with(ctx, opts, lambda: run_modes(ctx, ciao, N, d, dtype, loss, r))
@@ -443,3 +457,111 @@ def test_every_masked_workgroup_per_row_class(ctx, ciao, dtype, J, kind):
     n = run_modes(ctx, ciao, N, d, dtype, "ls" if J % 4 else "logistic", r, pad=pad)
     assert "rows_split_kernel" in n["grad"] and "rows_split_kernel" in n["finito_lists"] and "rows_split_kernel" in n["lfinito_blocks"], n
     assert ("scalar" in n["grad"]) == (kind != "chunks"), n
+
+
+@pytest.mark.parametrize("dtype", [F64, F32], ids=["f64", "f32"])
+def test_remaining_rows_classes(ctx, ciao, dtype):
+    """What the two sweeps above leave: exact J x 256 chunks beyond the wave-per-row shapes (J = 8, 16: 32 and 64 x 64 chunks), 256 single
+    elements (J = 1 of the element form), the wave-per-row kernels without the prefetch and the two-row form on the batch sweep, the
+    any-shape kernel with one wave per workgroup (rows of 24-48 KiB with no 16-byte structure), padded short rows at 16 elements
+    per lane, the several-rows-per-wave batch kernel that rows_wrow_kernel replaced as the default (small_wrow = 0)."""
+    vec = 16 // np.dtype(dtype).itemsize
+    ty = "f64" if dtype == F64 else "f32"
+    for J in (8, 16):
+        n = run_modes(ctx, ciao, 120, J * 256 * vec, dtype, "ls", 30)
+        assert f"rows_split_kernel<{ty},J{J}," in n["grad"] and f"rows_split_kernel<{ty},J{J}," in n["finito_lists"], n
+    n = run_modes(ctx, ciao, 260, 256, dtype, "logistic", 50, pad=3)
+    assert f"rows_split_kernel<{ty},J1," in n["grad"] and "scalar" in n["grad"], n
+    d2 = 2 * 64 * vec
+    for opts in ({"sweep_multi": 0, "sweep_prefetch": 0}, {"split_max_rows": 0}):
+        try:
+            n = _with(ctx, opts, lambda: run_modes(ctx, ciao, 700, d2 * (2 if "split_max_rows" in opts else 1), dtype, "ls", 90))
+        finally:
+            ctx.set_option("sweep_multi", 1), ctx.set_option("split_max_rows", -1), ctx.set_option("sweep_prefetch", -1)
+        assert ("rows_fast_kernel" in n["grad"]) == ("sweep_multi" in opts), (opts, n)
+    d_nw1 = 5001 if dtype == F64 else 9001
+    n = run_modes(ctx, ciao, 40, d_nw1, dtype, "ls", 7)
+    assert "rows_generic_kernel" in n["grad"] and "NW1" in n["lfinito_lists"], n
+    n = _with(ctx, {"small_i": 16}, lambda: run_modes(ctx, ciao, 500, 50, dtype, "ls", 60, pad=3))
+    assert "rows_small_kernel" in n["grad"] and "I16" in n["grad"], n
+    for pad in (0, 3):
+        try:
+            n = _with(ctx, {"small_wrow": 0}, lambda: run_modes(ctx, ciao, 900, 50, dtype, "logistic", 130, pad=pad))
+        finally:
+            ctx.set_option("small_wrow", -1)
+        assert "rows_smallb_kernel" in n["finito_lists"] and ("rows_smallb_kernel" in n["lfinito_lists"] or "rows_smallm_kernel" in n["lfinito_lists"]), n
+    try:   # ... and on dense blocks of rows too short for the matrix-core tiles
+        n = _with(ctx, {"small_wrow": 0}, lambda: run_modes(ctx, ciao, 900, 5, dtype, "ls", 130))
+    finally:
+        ctx.set_option("small_wrow", -1)
+    assert "rows_smallb_kernel" in n["finito_blocks"] and "rows_smallb_kernel" in n["lfinito_blocks"], n
+
+
+@pytest.mark.parametrize("dtype", [F64, F32], ids=["f64", "f32"])
+@pytest.mark.parametrize("nc2", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_every_matrix_core_tile_class(ctx, ciao, dtype, nc2):
+    """rows_smallm_kernel: dense rows of 32 (nc2 - 1) < d <= 32 nc2 elements, every mode (fp64 tiles reach 144 elements)."""
+    d = 32 * nc2 - 3 if nc2 > 1 else 20
+    if dtype == F64 and nc2 > 5:
+        pytest.skip("fp64 rows beyond 144 elements do not fit LDS with two tile buffers per wave")
+    # the longest rows whose Finito batches still run here (three tile buffers per wave: d <= 98 fp64 / 196 fp32, plan_rows), and the
+    # longest fp64 rows at all
+    d = {(F64, 4): 98, (F64, 5): 141, (F32, 7): 196}.get((dtype, nc2), d)   # (141: whole chunks of 64 and more would be the workgroup-per-row kernel's)
+    # (N a multiple of the batch and the batch of 16: every block starts on a 16-byte boundary whatever d)
+    n = run_modes(ctx, ciao, 1600, d, dtype, "ls" if nc2 % 2 else "logistic", 160)
+    assert "rows_smallm_kernel" in n["grad"] and "rows_smallm_kernel" in n["lfinito_blocks"], n
+
+
+def test_the_other_files_cases_on_the_classes_they_leave(ctx, ciao):
+    """Complex chains (chain_cdma_kernel J = 1 / 2 / 4 exact and masked, chain_cplx_reg_kernel with 1 ... 8 entries per thread for the
+    Finito chains), the complex workgroup-per-row kernel's J = 4 / 8 / 16 classes, ProShI's vector kernel at J = 4 / 8 and its scalar kernel
+    with one wave per workgroup: the test bodies of tests/test_gpu_complex.py and tests/test_gpu_parity.py, run on the shapes those
+    files' own parameter lists do not hold."""
+    import test_gpu_complex as TC
+    import test_gpu_parity as TP
+    C128, C64 = np.complex128, np.complex64
+    for ctype, n in ((C128, 256), (C128, 1024), (C64, 1024), (C64, 1500)):
+        TC.test_complex_lds_dma_chain_is_dispatched_and_bitwise_the_register_ring(ctx, ciao, ctype, n)
+    for ctype, n in ((C128, 256), (C128, 400), (C128, 1024), (C64, 1024), (C64, 1500), (C64, 2048)):
+        TC.test_complex_finito_and_lfinito(ctx, ciao, ctype, (14, n), 1, "chain")
+    for ctype in (C128, C64):
+        for n in (200, 500, 1000, 2000):
+            _with(ctx, {"chain_no_dma": 1}, lambda: TC.test_complex_finito_and_lfinito(ctx, ciao, ctype, (14, n), 1, "chain"))
+    for ctype, n in ((C128, 2000), (C64, 1500), (C64, 5000)):
+        TC.test_complex_finito_and_lfinito(ctx, ciao, ctype, (60, n), 20, "rows")
+    TC.test_complex_full_pass_and_proxgrad(ctx, C64, (60, 5000))
+    TC.test_complex_saga_steps(ctx, ciao, C64, False, (60, 5000))
+    for dtype, shape, r, generic in ((F64, (600, 4096), 500, 0), (F32, (600, 3000), 500, 0), (F32, (300, 8192), 200, 0), (F32, (60, 8001), 50, 1)):
+        TP.test_proshi_steps(ctx, ciao, dtype, shape, r, generic)
+
+
+def test_the_all_reduce_hook_path_in_one_process(ctx, ciao):
+    """finalize -> hook -> epilogue_kernel: the native-collective path of config #4 (tests/test_gpu_multirank.py runs it in child
+    processes, which a kernel trace of the suite does not see).  A hook that adds nothing -- a world of one rank -- is called once per
+    step with the d + 1 raw sums and leaves the fused path's result."""
+    import torch
+    from oracle import twin as O
+    for dtype in (F64, F32):
+        N, d = 500, 1024
+        A, b, x0 = P.synthetic("ls", N, d, dtype, seed=5)
+        op, dp = make("ls", A, b, float(N), dtype)
+        og, dg = make_g("l1", dtype, d, lam=0.01)
+        tdt = dev(x0).dtype
+        av0, y0 = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+        ctx.proxgrad_step(dp, dg, 0.3, dev(x0), av0, y0)
+        calls = []
+
+        def hook(ptr, count, dt, stream):
+            calls.append(count)
+            return 0
+        ctx.set_allreduce(hook)
+        try:
+            av1, y1 = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
+            ctx.proxgrad_step(dp, dg, 0.3, dev(x0), av1, y1)
+            ctx.synchronize()
+        finally:
+            ctx.set_allreduce(None)
+        assert calls == [d + 1], calls
+        close(av1, av0.cpu().numpy(), dtype, scale=8, what="hook path against the fused finalize: av")
+        close(y1, y0.cpu().numpy(), dtype, scale=8, what="hook path against the fused finalize: y")
+        close(av1, O.full_pass(op, x0), dtype, scale={64: 67, 32: 57}, scale64=10, what="hook path: full gradient")

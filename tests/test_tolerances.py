@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 FILES = ("test_gpu_parity.py", "test_gpu_complex.py", "test_gpu_wide_chain.py", "test_gpu_long_rows.py", "test_gpu_small_mfma.py",
-         "test_gpu_feature_padding.py", "test_gpu_multi_rhs.py")
+         "test_gpu_feature_padding.py", "test_gpu_multi_rhs.py", "test_gpu_every_kernel.py")
 F64_MAX = 1e-10 / np.finfo(np.float64).eps      # 450 359 eps64
 F32_MAX = 1e-4 / np.finfo(np.float32).eps       # 838.9 eps32
 

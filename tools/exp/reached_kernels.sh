@@ -5,7 +5,7 @@
 #   gpurun --timeout 1100 -- 'bash tools/exp/reached_kernels.sh'   ->  gpurun_out/reached/launched.tsv, reached.txt
 R="${GRAFT_REPO_ROOT:-/root/repo}"; O="$R/gpurun_out/reached"; T=/tmp/reached_trace; mkdir -p "$O" "$T"; cd /tmp; export TMPDIR=/tmp
 cd "$R"
-timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d "$T" -o t -- python3 -m pytest tests -m gpu -q -x -p no:cacheprovider > "$O/pytest.log" 2>&1
+timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d "$T" -o t -- python3 -m pytest tests -m gpu -q -p no:cacheprovider > "$O/pytest.log" 2>&1
 rc=$?; echo "pytest under rocprofv3 rc=$rc"; tail -2 "$O/pytest.log"
 python3 - "$T" "$O/launched.tsv" <<'PY'
 import collections, csv, glob, sys

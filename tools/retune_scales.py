@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ("test_gpu_parity.py", "test_gpu_complex.py", "test_gpu_wide_chain.py", "test_gpu_long_rows.py", "test_gpu_small_mfma.py",
-         "test_gpu_feature_padding.py", "test_gpu_multi_rhs.py")
+         "test_gpu_feature_padding.py", "test_gpu_multi_rhs.py", "test_gpu_every_kernel.py")
 
 
 def nice(x):
