@@ -1,7 +1,7 @@
 // chain_wide_kernels.h -- the sequential chains (SVRG, SAGA / SAG, small-batch Finito and LFinito) on rows LONGER than one workgroup's
 // registers hold (more than 8192 elements): several workgroups share ONE chain.
 //
-// Why.  chain_big_kernel (chain_kernels.h) keeps the whole state in the caller's vectors and streams row and state through one CU:
+// Why.  chain_big_kernel (chain_reg_kernels.h) keeps the whole state in the caller's vectors and streams row and state through one CU:
 // 12-40 us per update at d = 9000 ... 32 768, a 10-30x cliff behind the register-resident chains (0.25-1.9 us).  A chain step is a
 // dot product over the row and an element-wise update: both split by COLUMNS.  Workgroup g of G owns columns [g S, (g + 1) S) of
 // every vector -- its slice of the state lives in registers for the whole launch, its slices of the next two rows are in flight while

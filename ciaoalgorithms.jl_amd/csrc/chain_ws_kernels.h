@@ -1,6 +1,6 @@
 // chain_ws_kernels.h -- the sequential inner loops as a WAVE-SPECIALISED workgroup.
 //
-// chain_dma_kernel (chain_kernels.h) runs a step on four waves that each do everything: address arithmetic and LDS-DMA issue
+// chain_dma_kernel (chain_dma_kernels.h) runs a step on four waves that each do everything: address arithmetic and LDS-DMA issue
 // for the rows DEPTH steps ahead, the arithmetic of the step, and a cross-wave exchange of the four partial dot products made
 // of two serialized LDS round trips around an s_barrier (write, lgkmcnt(0), barrier, read).  One wave per SIMD executes that
 // as one dependent instruction stream, so every instruction that is not arithmetic is time (profiles/r02_chain_pmc_instructions).
@@ -183,7 +183,7 @@ __device__ __forceinline__ unsigned int ws_poll_wait(unsigned int &c, V (&rv)[4]
 }
 
 // the table-row DMA with agent scope (sc1): never served from a line the CU's vector L1 cached before a consumer's store.
-// (The memory instruction reads a scalar COPY of the base made inside the asm: glds16s in chain_kernels.h, and why.)
+// (The memory instruction reads a scalar COPY of the base made inside the asm: glds16s in chain_dma_kernels.h, and why.)
 __device__ __forceinline__ void glds16s_sc1(const void *sbase, uint32_t voff, uint32_t lds_dst)
 {
     uint64_t base_copy;

@@ -45,7 +45,7 @@ struct RowsArgs {
     T *meta;               // AFINITO_INIT: N x 4 copies x 4 per-sample scalars {c_i, f_i, gam_i, a_i's_i}
     T alpha;               // AFINITO_INIT: the solver's α
     double Nd;             // AFINITO_INIT: N_total as a double (the reference divides a Float64 by the Int N, :88)
-    T *rowdot_out;         // GRAD only: if non-null, rowdot_out[row] = a_row'x1 (feeds the SVRG chain, chain_kernels.h CA_SVRGC)
+    T *rowdot_out;         // GRAD only: if non-null, rowdot_out[row] = a_row'x1 (feeds the SVRG chain, chain_common.h CA_SVRGC)
     T *partial;            // [gridDim.x][pstride]
     int64_t pstride;
     T *pextra;             // [gridDim.x]
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (RowsWaves<sizeof(T), K, MODE, PF>
                 for (int v = 0; v < VEC; ++v) acc[k][v] += xv[v] * rinv - cn * cur[k][v];
             }
             extra += rinv;
-            if (lane < 4) {   // four identical copies, one per wave of the step kernel (chain_kernels.h)
+            if (lane < 4) {   // four identical copies, one per wave of the step kernel (afinito_kernels.h)
                 T *mp = a.meta + (row * 4 + lane) * 4;
                 mp[0] = c0;
                 mp[1] = loss_value(a.loss, d1, bi, a.lam);
@@ -1286,7 +1286,7 @@ __global__ void __launch_bounds__(NW *WAVE) rows_generic_kernel(RowsArgs<T> a)
                 acc[e] += xv * rinv - cn * (ap ? ap[e] : T(0));
             }
             extra += rinv;
-            if (lane < 4) {   // four identical copies, one per wave of the step kernel (chain_kernels.h)
+            if (lane < 4) {   // four identical copies, one per wave of the step kernel (afinito_kernels.h)
                 T *mp = a.meta + (row * 4 + lane) * 4;
                 mp[0] = c0;
                 mp[1] = loss_value(a.loss, d1, bi, a.lam);

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 F64, F32 = np.float64, np.float32
 ALGS = ("svrg", "svrg_cached", "saga", "sag", "finito", "lfinito")
-ALG_NO = {"svrg": 0, "saga": 1, "sag": 1, "finito": 2, "lfinito": 3, "svrg_cached": 4}   # chain_kernels.h CA_*
+ALG_NO = {"svrg": 0, "saga": 1, "sag": 1, "finito": 2, "lfinito": 3, "svrg_cached": 4}   # chain_common.h CA_*
 
 
 def _shard_table(L, dp, N, cuts, table=None):
