@@ -1964,7 +1964,7 @@ def _random_cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _random_cases(int(os.environ.get("CIAO_FUZZ_SHAPES", "48")), int(os.environ.get("CIAO_FUZZ_SEED", "2024"))), ids=lambda c: f"N{c[0]}-d{c[1]}-pad{c[2]}-{'f64' if c[3] == np.float64 else 'f32'}-{c[4]}")
+@pytest.mark.parametrize("case", _random_cases(int(os.environ.get("CIAO_FUZZ_SHAPES", "300")), int(os.environ.get("CIAO_FUZZ_SEED", "2024"))), ids=lambda c: f"N{c[0]}-d{c[1]}-pad{c[2]}-{'f64' if c[3] == np.float64 else 'f32'}-{c[4]}")
 def test_random_shapes(ctx, ciao, case):
     """Sweep, both table inits, a Finito batch (batch-parallel) and a short SAGA chain on seeded random (N, d, row stride,
     type, loss): every combination lands on some kernel, and that kernel agrees with the oracle."""
@@ -1979,22 +1979,22 @@ def test_random_shapes(ctx, ciao, case):
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
     table = torch.empty((N, d), dtype=tdt, device="cuda")
     ctx.full_gradient(dp, dev(x0), av)
-    close(av, O.full_pass(op, x0), dtype, scale=100, what=f"sweep ({ctx.last_kernel()})", scale64=17)
+    close(av, O.full_pass(op, x0), dtype, scale={64: 120, 32: 370}, what=f"sweep ({ctx.last_kernel()})", scale64=25)
     gamma = 0.5 / max(lam_f, 1.0)
     ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
     rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
-    close(table, rt, dtype, scale=100, what=f"saga_init table ({ctx.last_kernel()})", scale64=16)
+    close(table, rt, dtype, scale={64: 100, 32: 370}, what=f"saga_init table ({ctx.last_kernel()})", scale64=25)
     idx = ciao.IndexStream(N + d).rand_indices(N, 25)
     ctx.saga_steps(dp, dg, gamma, False, idx, table, av, z)
     O.saga_steps(op, og, dtype(gamma), False, idx, rt, rav, rz)
-    close(z, rz, dtype, scale={64: 49, 32: 86}, what=f"saga z ({ctx.last_kernel()})", scale64=140)
+    close(z, rz, dtype, scale=86, what=f"saga z ({ctx.last_kernel()})", scale64=140)
     Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1) + 1e-12
     gam = (0.999 * N / Li).astype(dtype)
     dgam = dev(gam)
     hg = ctx.hat_gamma(dgam)
     rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
     ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
-    close(table, rt, dtype, scale={64: 12, 32: 18}, what=f"finito_init table ({ctx.last_kernel()})", scale64=12)
+    close(table, rt, dtype, scale={64: 13, 32: 19}, what=f"finito_init table ({ctx.last_kernel()})", scale64=13)
     r = min(N, 9)
     batch = ciao.IndexStream(d).sample_without_replacement(N, r)
     ctx.set_option("chain_max_batch", 0)
@@ -2003,8 +2003,8 @@ def test_random_shapes(ctx, ciao, case):
     finally:
         ctx.set_option("chain_max_batch", -1)
     O.finito_steps(op, og, gam, rhg, [batch], rt, rav, rz)
-    close(table, rt, dtype, scale={64: 69, 32: 59}, what=f"finito batch table ({ctx.last_kernel()})", scale64=12)
-    close(z, rz, dtype, scale={64: 87, 32: 97}, what="finito batch z", scale64=18)
+    close(table, rt, dtype, scale={64: 86, 32: 77}, what=f"finito batch table ({ctx.last_kernel()})", scale64=15)
+    close(z, rz, dtype, scale={64: 100, 32: 97}, what="finito batch z", scale64=28)
     ctx.synchronize()
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -2077,8 +2077,8 @@ def _random_chain_cases(n, seed):
     return out
 
 
-# CIAO_FUZZ_CASES / CIAO_FUZZ_SEED: a longer one-off hunt with other seeds (the default 160 cases with seed 77 are the suite's)
-@pytest.mark.parametrize("case", _random_chain_cases(int(os.environ.get("CIAO_FUZZ_CASES", "160")), int(os.environ.get("CIAO_FUZZ_SEED", "77"))),
+# CIAO_FUZZ_CASES / CIAO_FUZZ_SEED: a longer one-off hunt with other seeds (the default 1000 cases with seed 77 are the suite's: the stated scales are 10 x the largest error over all of them)
+@pytest.mark.parametrize("case", _random_chain_cases(int(os.environ.get("CIAO_FUZZ_CASES", "1000")), int(os.environ.get("CIAO_FUZZ_SEED", "77"))),
                          ids=lambda c: f"{c[0]}-N{c[1]}-d{c[2]}-{'f64' if c[3] == np.float64 else 'f32'}-{c[4]}-{c[5]}-r{c[6]}")
 def test_random_chain_configurations(ctx, ciao, case):
     """Seeded random (algorithm, N, d, type, loss, g, batch) through the chain kernels -- every prox family (the IndBox clamp is its
@@ -2105,8 +2105,8 @@ def test_random_chain_configurations(ctx, ciao, case):
             idx = st.rand_indices(N, 3 * N + 5)
             ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w, reuse_rowdots=(alg == "svrg_cached"))
             O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
-        close(zf, rzf, dtype, scale=830, what=f"random chain {alg} z_full ({ctx.last_kernel()})", scale64=810)
-        close(av, rav, dtype, scale={64: 360, 32: 410}, what=f"random chain {alg} av", scale64=420)
+        close(zf, rzf, dtype, scale={64: 1200, 32: 1100}, what=f"random chain {alg} z_full ({ctx.last_kernel()})", scale64=840)
+        close(av, rav, dtype, scale={64: 400, 32: 410}, what=f"random chain {alg} av", scale64=520)
     elif alg in ("saga", "sag"):
         gamma = 1.0 / ((16 if alg == "sag" else 3) * Li.max())
         table = torch.empty((N, d), dtype=tdt, device="cuda")
@@ -2116,8 +2116,8 @@ def test_random_chain_configurations(ctx, ciao, case):
         idx = st.rand_indices(N, 6 * N + 3)
         ctx.saga_steps(dp, dg, gamma, alg == "sag", idx, table, av, z)
         O.saga_steps(op, og, dtype(gamma), alg == "sag", idx, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 430, 32: 89}, what=f"random chain {alg} z ({ctx.last_kernel()})", scale64=840)
-        close(table, rt, dtype, scale={64: 400, 32: 290}, what=f"random chain {alg} table", scale64=800)
+        close(z, rz, dtype, scale={64: 430, 32: 230}, what=f"random chain {alg} z ({ctx.last_kernel()})", scale64=840)
+        close(table, rt, dtype, scale={64: 710, 32: 1400}, what=f"random chain {alg} table", scale64=840)
     else:
         gam = (0.999 * N / Li).astype(dtype)
         dgam = dev(gam)
@@ -2136,8 +2136,8 @@ def test_random_chain_configurations(ctx, ciao, case):
                 np.cumsum([len(x) for x in batches], out=bptr[1:])
                 ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(batches), table, av, z)
                 O.finito_steps(op, og, gam, rhg, batches, rt, rav, rz)
-                close(z, rz, dtype, scale={64: 160, 32: 150}, what=f"random chain finito z ({ctx.last_kernel()})", scale64=140)
-                close(table, rt, dtype, scale={64: 65, 32: 110}, what="random chain finito table", scale64=86)
+                close(z, rz, dtype, scale={64: 280, 32: 220}, what=f"random chain finito z ({ctx.last_kernel()})", scale64=240)
+                close(table, rt, dtype, scale={64: 200, 32: 130}, what="random chain finito table", scale64=130)
             else:
                 av, z, zf = new(), new(), new()
                 rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
@@ -2149,8 +2149,8 @@ def test_random_chain_configurations(ctx, ciao, case):
                     np.cumsum([len(x) for x in batches], out=bptr[1:])
                     ctx.lfinito_iterate(dp, dg, dgam, hg, bptr, np.concatenate(batches), av, z, zf)
                     O.lfinito_iterate(op, og, gam, rhg, batches, rav, rz, rzf)
-                close(zf, rzf, dtype, scale={64: 160, 32: 37}, what=f"random chain lfinito z_full ({ctx.last_kernel()})", scale64=25)
-                close(av, rav, dtype, scale={64: 190, 32: 50}, what="random chain lfinito av", scale64=41)
+                close(zf, rzf, dtype, scale={64: 170, 32: 280}, what=f"random chain lfinito z_full ({ctx.last_kernel()})", scale64=230)
+                close(av, rav, dtype, scale={64: 230, 32: 380}, what="random chain lfinito av", scale64=250)
         finally:
             ctx.set_option("chain_max_batch", -1)
     ctx.synchronize()
