@@ -23,9 +23,10 @@
 namespace ciao {
 
 constexpr int LONG_SMAX = 64;   // segments per row (the exchange's fixed tree is one wave wide)
+constexpr int LONG_NBUF = 4;    // mailbox buffers (a row's total is collected one row late: rowsl_kernels.h, reduce_publish)
 
 struct LongArgs {
-    unsigned long long *box;   // [2 parities][C][S][words]
+    unsigned long long *box;   // [LONG_NBUF][C][S][words]
     int S, C;
 };
 
@@ -40,6 +41,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_
     constexpr bool TWO = (MODE == RM_GRAD2);
     constexpr bool TABLE = (MODE == RM_SAGA_INIT || MODE == RM_FINITO_INIT || MODE == RM_FINITO_BATCH);
     constexpr bool TREAD = (MODE == RM_FINITO_BATCH);
+    constexpr bool LATE = (J == 4);   // the row's total one iteration late (below)
     constexpr bool GAMS = !(MODE == RM_GRAD || MODE == RM_SAGA_INIT);
     // what the row loop reads, loaded once and held in scalar registers (read in place hipcc re-loads fields inside the loop, each
     // load a scalar-cache round trip in front of the row's requests: d = 32 768 fp64 sweep 4.83 -> 4.27 TB/s, profiles/r05_kernarg_ab.txt);
@@ -61,8 +63,8 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_
     constexpr int NWORD = (TWO ? 2 : 1) * W::N;
     static_assert(MODE != RM_AFINITO_INIT, "the adaptive init keeps to the wave-per-row kernels");
 
-    __shared__ T red[2][ROWS_WAVES][2];
-    __shared__ T tot[2][2];
+    __shared__ T red[2][ROWS_WAVES][2];   // by row parity: iteration 0 has no second barrier
+    __shared__ T tot[2];
     __shared__ int s_fail;
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -83,8 +85,6 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_
         acc[j] = V(T(0));
     }
     T extra = T(0);
-    int par = 0;
-    unsigned int seq = 0;
     __syncthreads();
 
     struct RowIn {
@@ -117,8 +117,17 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_
         x.bi = a.b ? a.b[row] : T(0);
         x.gi = (MODE == RM_GRAD || MODE == RM_SAGA_INIT) ? T(1) : (a.gam ? a.gam[row] : a.gam_uniform);
     };
-    // false: the cluster's exchange timed out
-    auto process = [&](RowIn &x) -> bool {
+    // LATE (the 16 KiB segments, J = 4 -- the Finito batches): row t's partial dot product(s) leave through the mailbox in iteration t and
+    // its total is collected in iteration t + 1, behind row t + 1's dot product and publication: the mailbox round trip -- a microsecond
+    // across the chip's dies -- is off the path of an iteration.  Three register sets: row t (sum outstanding), row t + 1 (being
+    // reduced), row t + 2 (in flight).  Measured (profiles/r05_long_rows_late.txt, d = 32 768 fp64): Finito batches of 256 / 4096 rows
+    // 59.9 -> 52.3 / 660 -> 554 us, the J = 4 sweep 3.53 -> 4.22 TB/s.  NOT for the 32 KiB segments (J = 8): a third set of 32 KiB rows
+    // leaves one workgroup per CU instead of two (326 registers; forced under 256 it spills 300 B per lane) and the sweep falls from
+    // 5.4 to 3.75 TB/s -- there the total is collected in the same iteration, as before.  The mailbox has LONG_NBUF = 4 buffers: a
+    // workgroup publishes row t + 4 only after it has collected row t + 2, which every sibling published after collecting row t -- so
+    // nobody still polls a word when it is reused.
+    unsigned int seq = 0;   // rows published so far (the next row's sequence number is seq + 1)
+    auto reduce_publish = [&](RowIn &x) {
         T d1 = T(0), d2 = T(0);
 #pragma unroll
         for (int j = 0; j < J; ++j)
@@ -129,26 +138,29 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_
             }
         d1 = wave_sum_lane63(d1);
         if (TWO) d2 = wave_sum_lane63(d2);
+        const int par = (int)(seq & 1u);
         if (lane == WAVE - 1) {
             red[par][wib][0] = d1;
             if (TWO) red[par][wib][1] = d2;
         }
         __syncthreads();
         ++seq;
-        if (wib == 0) {
-            // the workgroup's partial(s) out, the cluster's in: lane q polls segment q's word(s), the S values are added in one fixed
-            // tree (lanes beyond S hold zeros)
+        if (wib == 0 && lane == 0) {
             const T p1 = (red[par][0][0] + red[par][1][0]) + (red[par][2][0] + red[par][3][0]);
-            const T p2 = TWO ? (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]) : T(0);
-            unsigned long long *slot = la.box + (((size_t)par * C + c) * S) * NWORD;
-            if (lane == 0) {
-                W::put(slot + (size_t)s * NWORD, p1, seq);
-                if (TWO) W::put(slot + (size_t)s * NWORD + W::N, p2, seq);
-            }
+            unsigned long long *slot = la.box + ((((size_t)(seq & (LONG_NBUF - 1))) * C + c) * S + s) * NWORD;
+            W::put(slot, p1, seq);
+            if (TWO) W::put(slot + W::N, (red[par][0][1] + red[par][1][1]) + (red[par][2][1] + red[par][3][1]), seq);
+        }
+    };
+    // false: the cluster's exchange timed out.  `want` = the sequence number of the row whose total is collected (the row of x)
+    auto collect_apply = [&](RowIn &x, unsigned int want) -> bool {
+        if (wib == 0) {
+            // lane q polls segment q's word(s); the S values are added in one fixed tree (lanes beyond S hold zeros)
+            const unsigned long long *slot = la.box + (((size_t)(want & (LONG_NBUF - 1))) * C + c) * S * NWORD;
             T g1 = T(0), g2 = T(0);
             if (lane < S) {
                 unsigned int pw[NWORD];
-                if (!wide_get_run(slot + (size_t)lane * NWORD, seq, pw)) {
+                if (!wide_get_run(slot + (size_t)lane * NWORD, want, pw)) {
 #pragma unroll
                     for (int i = 0; i < NWORD; ++i) pw[i] = 0;
                     s_fail = 1;
@@ -159,8 +171,8 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_
             g1 = wave_sum_lane63(g1);
             if (TWO) g2 = wave_sum_lane63(g2);
             if (lane == WAVE - 1) {
-                tot[par][0] = g1;
-                if (TWO) tot[par][1] = g2;
+                tot[0] = g1;
+                if (TWO) tot[1] = g2;
             }
         }
         __syncthreads();
@@ -168,9 +180,8 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_
             if (tid == 0) *a.errflag = 6;
             return false;
         }
-        d1 = tot[par][0];
-        if (TWO) d2 = tot[par][1];
-        par ^= 1;
+        const T d1 = tot[0];
+        const T d2 = TWO ? tot[1] : T(0);
 
         const GradCoef<T> g1 = grad_coef(a.loss, d1, x.bi, a.lam);
         if (MODE == RM_GRAD) {                        // SVRG_basic.jl:58-63, :87-92
@@ -213,18 +224,49 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_
         return true;
     };
 
-    // cluster c takes rows c, c + C, ...; the next row's slice is requested before this one is reduced (two register sets)
-    RowIn r0, r1;
-    int64_t q = c;
-    if (q < a.nrows) issue(r0, q);
-    while (q < a.nrows) {
-        if (q + C < a.nrows) issue(r1, q + C);
-        if (!process(r0)) return;
-        q += C;
-        if (q >= a.nrows) break;
-        if (q + C < a.nrows) issue(r0, q + C);
-        if (!process(r1)) return;
-        q += C;
+    // cluster c takes rows c, c + C, ...: n of them
+    const int64_t n = a.nrows > c ? (a.nrows - c + C - 1) / C : 0;
+    int64_t k = 0;
+    if constexpr (LATE) {
+        // iteration k: request row k + 1, reduce and publish row k, collect and apply row k - 1 (three register sets, rotating)
+        RowIn r0, r1, r2;
+        if (n > 0) issue(r0, c);
+#define CIAO_LONG_ITER(CUR, PREV, NEXT)                              \
+    {                                                                \
+        if (k + 1 < n) issue(NEXT, c + (k + 1) * C);                 \
+        reduce_publish(CUR);                                         \
+        if (k > 0 && !collect_apply(PREV, seq - 1)) return;          \
+        ++k;                                                         \
+        if (k >= n) break;                                           \
+    }
+        int last = -1;   // which set holds the last row (its total is still outstanding)
+        while (k < n) {
+            last = 0;
+            CIAO_LONG_ITER(r0, r2, r1)
+            last = 1;
+            CIAO_LONG_ITER(r1, r0, r2)
+            last = 2;
+            CIAO_LONG_ITER(r2, r1, r0)
+        }
+#undef CIAO_LONG_ITER
+        if (n > 0) {
+            const bool okk = last == 0 ? collect_apply(r0, seq) : (last == 1 ? collect_apply(r1, seq) : collect_apply(r2, seq));
+            if (!okk) return;
+        }
+    } else {
+        // the next row's slice is requested before this one is reduced; its total is collected at once (two register sets)
+        RowIn r0, r1;
+        if (n > 0) issue(r0, c);
+        while (k < n) {
+            if (k + 1 < n) issue(r1, c + (k + 1) * C);
+            reduce_publish(r0);
+            if (!collect_apply(r0, seq)) return;
+            if (++k >= n) break;
+            if (k + 1 < n) issue(r0, c + (k + 1) * C);
+            reduce_publish(r1);
+            if (!collect_apply(r1, seq)) return;
+            ++k;
+        }
     }
 
     V *pout = reinterpret_cast<V *>(ka.partial + (int64_t)c * ka.pstride) + coff;
