@@ -100,6 +100,8 @@ template <typename T>
 bool wrow_plan(int mode, const RowsArgs<T> &a, int *vec, int *k);
 template <typename T>
 int32_t launch_wrow(ciao_ctx *ctx, int mode, int vec, int k, int grid, RowsArgs<T> &a);
+template <typename T>
+int wrow_block_waves(int vec, int k);
 
 // sweeps / batch steps over rows beyond 64 KiB: a cluster of S workgroups per row (rowsl_kernels.h).  Specialised in rowsl_f32.hip /
 // rowsl_f64.hip.  long_plan: CIAO_ERR_UNSUPPORTED (no error text) when the shape is not for this kernel.

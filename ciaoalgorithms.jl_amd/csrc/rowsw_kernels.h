@@ -30,11 +30,18 @@ struct WrowWaves {
     static constexpr int budget = 6 * K * (VEC * ES / 4) + (ES == 8 ? 56 : 40);
     static constexpr int raw = 512 / ((budget + 7) / 8 * 8);
     static constexpr int value = raw < 1 ? 1 : (raw > 8 ? 8 : raw);
+    // waves of a workgroup: TWO workgroups fill a CU's four SIMDs at `value` waves each -- at most 2 x 256 partial d-vectors for
+    // finalize to add, whose time is set by their number (with 256-thread workgroups, 6-8 per CU, 1536-2048 partials: finalize 13 us
+    // of a 42 us batch of 65 536 rows of 50 Float64; now 512: profiles/r05_wrow_blocks.txt)
+    static constexpr int block_waves = 2 * value;
 };
 
 template <typename T, int VEC, int K, int MODE>
-__global__ void __launch_bounds__(ROWS_BLOCK, (WrowWaves<sizeof(T), VEC, K>::value)) rows_wrow_kernel(RowsArgs<T> a_by_value)
+__global__ void __launch_bounds__((WAVE * WrowWaves<sizeof(T), VEC, K>::block_waves), (WrowWaves<sizeof(T), VEC, K>::value))
+    rows_wrow_kernel(RowsArgs<T> a_by_value)
 {
+    constexpr int NWAVES = WrowWaves<sizeof(T), VEC, K>::block_waves;   // waves of this workgroup
+    constexpr int BLOCK = NWAVES * WAVE;
     (void)a_by_value;
     CIAO_KERNARG0(RowsArgs<T>, ka);
     // what the row loop reads: loaded once, held in scalar registers (read in place hipcc re-loaded a.idx, a.N, a.A, a.ld ... in front of
@@ -55,11 +62,11 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (WrowWaves<sizeof(T), VEC, K>::val
     using V = typename ChunkOf<T, VEC>::type;
     constexpr int D = K * WAVE * VEC;   // elements a wave's lanes reach
 
-    __shared__ __attribute__((aligned(16))) T red[D];
-    __shared__ T red_extra[ROWS_WAVES];
+    __shared__ __attribute__((aligned(16))) T red[NWAVES][D];   // (at most 16 waves x 256 elements x 8 bytes = 32 KiB)
+    __shared__ T red_extra[NWAVES];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t nwaves = (int64_t)gridDim.x * ROWS_WAVES;
+    const int64_t nwaves = (int64_t)gridDim.x * NWAVES;
     const int64_t d = a.d;
     const int64_t nchunks = d / VEC;
 
@@ -141,7 +148,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (WrowWaves<sizeof(T), VEC, K>::val
         }
     };
 
-    int64_t q = (int64_t)blockIdx.x * ROWS_WAVES + wib;
+    int64_t q = (int64_t)blockIdx.x * NWAVES + wib;
     if (q < a.nrows) {
         RowIn A0, B0;
         issue(A0, q);
@@ -161,27 +168,21 @@ __global__ void __launch_bounds__(ROWS_BLOCK, (WrowWaves<sizeof(T), VEC, K>::val
         }
     }
 
-    // the block's waves in wave order through LDS, then one partial per block
-    for (int w = 0; w < ROWS_WAVES; ++w) {
-        if (wib == w) {
+    // every wave's accumulator into its own LDS row, then element e summed over the waves in wave order: one partial per block
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                V *rp = reinterpret_cast<V *>(red) + k * WAVE + lane;
-                if (w == 0)
-                    *rp = acc[k];
-                else
-                    *rp += acc[k];
-            }
-        }
-        __syncthreads();
-    }
-    T *pout = ka.partial + (int64_t)blockIdx.x * ka.pstride;
-    for (int e = threadIdx.x; e < d; e += ROWS_BLOCK) pout[e] = red[e];
+    for (int k = 0; k < K; ++k) reinterpret_cast<V *>(red[wib])[k * WAVE + lane] = acc[k];
     if (lane == 0) red_extra[wib] = extra;   // (wave-uniform)
     __syncthreads();
+    T *pout = ka.partial + (int64_t)blockIdx.x * ka.pstride;
+    for (int e = threadIdx.x; e < d; e += BLOCK) {
+        T t = red[0][e];
+#pragma unroll
+        for (int w = 1; w < NWAVES; ++w) t += red[w][e];
+        pout[e] = t;
+    }
     if (threadIdx.x == 0) {
         T ex = T(0);
-        for (int w = 0; w < ROWS_WAVES; ++w) ex += red_extra[w];
+        for (int w = 0; w < NWAVES; ++w) ex += red_extra[w];
         ka.pextra[blockIdx.x] = ex;
     }
 }

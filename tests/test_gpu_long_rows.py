@@ -65,7 +65,7 @@ def test_long_rows_in_all_five_modes(ctx, ciao, dtype, d, loss, opts):
         ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
         assert "rows_long_kernel" in ctx.last_kernel() and "mode3" in ctx.last_kernel(), ctx.last_kernel()
         close(table, rt, dtype, scale={64: 9.200000000000001, 32: 8.8}, what="long rows finito_init table", scale64=8)
-        close(av, rav, dtype, scale={64: 92, 32: 67}, what="long rows finito_init av", scale64=13)
+        close(av, rav, dtype, scale={64: 92, 32: 67}, what="long rows finito_init av", scale64=14)
         # Finito batches: random index lists, then static blocks as index lists AND as row blocks (bitwise the same)
         st = ciao.IndexStream(d)
         rnd = [st.sample_without_replacement(N, r) for _ in range(3)]
@@ -73,8 +73,8 @@ def test_long_rows_in_all_five_modes(ctx, ciao, dtype, d, loss, opts):
         ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(rnd), table, av, z)
         assert "rows_long_kernel" in ctx.last_kernel() and f"J{opts.get('long_j', 4)},mode4" in ctx.last_kernel(), ctx.last_kernel()
         O.finito_steps(op, og, gam, rhg, rnd, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 140, 32: 290}, what=f"long rows finito z, index lists ({ctx.last_kernel()})", scale64=34)
-        close(table, rt, dtype, scale={64: 110, 32: 210}, what="long rows finito table, index lists", scale64=28)
+        close(z, rz, dtype, scale={64: 150, 32: 290}, what=f"long rows finito z, index lists ({ctx.last_kernel()})", scale64=34)
+        close(table, rt, dtype, scale={64: 120, 32: 210}, what="long rows finito table, index lists", scale64=28)
         nb = -(-N // r)
         static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in [(t + 1) % nb for t in range(nb + 1)]]
         t2, a2, z2 = table.clone(), av.clone(), z.clone()
@@ -84,8 +84,8 @@ def test_long_rows_in_all_five_modes(ctx, ciao, dtype, d, loss, opts):
         ctx.finito_steps_blocks(dp, dg, dgam, hg, np.array([x[0] for x in static]), np.array([len(x) for x in static]), t2, a2, z2)
         assert torch.equal(z, z2) and torch.equal(av, a2) and torch.equal(table, t2), "row blocks and the same batches as index lists differ"
         O.finito_steps(op, og, gam, rhg, static, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 390, 32: 1400}, what="long rows finito z, row blocks", scale64=69)
-        close(table, rt, dtype, scale={64: 360, 32: 1300}, what="long rows finito table, row blocks", scale64=59)
+        close(z, rz, dtype, scale={64: 400, 32: 1400}, what="long rows finito z, row blocks", scale64=69)
+        close(table, rt, dtype, scale={64: 370, 32: 1300}, what="long rows finito table, row blocks", scale64=59)
         inv = (table.double() / dgam.double()[:, None]).sum(dim=0).cpu().numpy() * hg
         close(av, inv, dtype, scale=26, what="long rows finito av invariant")
         # LFinito: the full pass + the batch sweep with two dot products per row

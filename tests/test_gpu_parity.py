@@ -1045,7 +1045,7 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         assert ("chunks" in ctx.last_kernel()) == (pad == 0 and (d * es) % 16 == 0), ctx.last_kernel()   # 16 bytes per lane where rows allow
         O.finito_steps(op, og, gam, rhg, rnd, rt, rav, rz)
         close(z, rz, dtype, scale={64: 200, 32: 1300}, what=f"small rows finito z, index lists ({ctx.last_kernel()})", scale64=17)
-        close(table, rt, dtype, scale={64: 120, 32: 800}, what="small rows finito table, index lists", scale64=13)
+        close(table, rt, dtype, scale={64: 130, 32: 800}, what="small rows finito table, index lists", scale64=13)
         ctx.set_option("small_wrow", 0)   # ... and the same lists on the several-rows-per-wave kernel: another order of summation
         try:
             ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(rnd), t3, av3, z3)
@@ -1061,9 +1061,15 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         bp = np.zeros(len(static) + 1, np.int64)
         np.cumsum([len(x) for x in static], out=bp[1:])
         ctx.finito_steps(dp, dg, dgam, hg, bp, np.concatenate(static), table, av, z)
-        ctx.finito_steps_blocks(dp, dg, dgam, hg, np.array([x[0] for x in static]), np.array([len(x) for x in static]), t2, av2, z2)
+        on_tiles = mfma_tab and (r * d * np.dtype(dtype).itemsize) % 16 == 0
+        if on_tiles:   # (blocks of up to 8192 rows take the one-wave-per-row kernel by default since round 5: the tiles by option)
+            ctx.set_option("small_wrow", 0)
+        try:
+            ctx.finito_steps_blocks(dp, dg, dgam, hg, np.array([x[0] for x in static]), np.array([len(x) for x in static]), t2, av2, z2)
+        finally:
+            ctx.set_option("small_wrow", -1)
         O.finito_steps(op, og, gam, rhg, static, rt, rav, rz)
-        if mfma_tab and (r * d * np.dtype(dtype).itemsize) % 16 == 0:
+        if on_tiles:
             # dense row blocks of such rows: the batch on the matrix-core kernel (row tile and table tile by LDS-DMA) -- another order
             # of summation than the index-list form: each against the oracle
             assert "rows_smallm_kernel" in ctx.last_kernel() and "mode4" in ctx.last_kernel(), ctx.last_kernel()
@@ -1076,7 +1082,7 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         close(z, rz, dtype, scale={64: 1100, 32: 6900}, what="small rows finito z, row blocks", scale64=180)
         close(table, rt, dtype, scale={64: 520, 32: 2200}, what="small rows finito table, row blocks", scale64=32)
         inv = (table.double() / dgam.double()[:, None]).sum(dim=0).cpu().numpy() * hg
-        close(av, inv, dtype, scale={64: 33, 32: 27}, what="small rows finito av invariant")
+        close(av, inv, dtype, scale={64: 26, 32: 27}, what="small rows finito av invariant")
         # ---- mode 1: LFinito iterations (full pass + the batch sweep with two dot products per row), lists and blocks
         lav, lz, lzf = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(3))
         rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
@@ -1094,13 +1100,13 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
                 # dense row blocks of such rows run the batch sweep on the matrix cores (both dots from one MFMA pass): another order of
                 # summation than the index-list form, so equal to rounding; each is held against the oracle below
                 assert "rows_smallm_kernel" in ctx.last_kernel() and "mode1" in ctx.last_kernel(), ctx.last_kernel()
-                close(lz2, rz, dtype, scale={64: 930, 32: 2100}, what=f"small rows lfinito z it {it}, row blocks ({ctx.last_kernel()})", scale64=73)
-                close(lav2, rav, dtype, scale={64: 960, 32: 1800}, what=f"small rows lfinito av it {it}, row blocks", scale64=58)
+                close(lz2, rz, dtype, scale={64: 930, 32: 2100}, what=f"small rows lfinito z it {it}, row blocks ({ctx.last_kernel()})", scale64=79)
+                close(lav2, rav, dtype, scale={64: 940, 32: 1800}, what=f"small rows lfinito av it {it}, row blocks", scale64=89)
                 lz2.copy_(lz), lav2.copy_(lav), lzf2.copy_(lzf)       # (so that the two forms start the next iteration from the same state)
             else:
                 assert torch.equal(lz, lz2) and torch.equal(lav, lav2) and torch.equal(lzf, lzf2)
-            close(lz, rz, dtype, scale={64: 2400, 32: 2100}, what=f"small rows lfinito z it {it} ({ctx.last_kernel()})", scale64=140)
-            close(lav, rav, dtype, scale={64: 2100, 32: 1800}, what=f"small rows lfinito av it {it}", scale64=58)
+            close(lz, rz, dtype, scale={64: 2400, 32: 2100}, what=f"small rows lfinito z it {it} ({ctx.last_kernel()})", scale64=79)
+            close(lav, rav, dtype, scale={64: 2100, 32: 1800}, what=f"small rows lfinito av it {it}", scale64=89)
     finally:
         ctx.set_option("chain_max_batch", -1)
     ctx.synchronize()
