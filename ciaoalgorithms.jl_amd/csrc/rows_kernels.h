@@ -1610,19 +1610,25 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_csplit_kernel(RowsArgs<T> a)
 constexpr int FIN_THREADS = 256;
 constexpr int FIN_BYTES = 128;   // bytes of one partial row that a finalize block covers (one L2 line)
 
-template <typename T>
-__global__ void __launch_bounds__(FIN_THREADS)
+// NT = FIN_THREADS (up to 256 partials in one round) or FIN_THREADS_MANY = 1024 (up to 1024 per round: the kernels that fill the chip with
+// several small workgroups per CU write 512-2048 partials, and every further round is a memory round trip -- 1536 partials of 50 Float64
+// took 13 us on 256 threads, profiles/r05_wrow_blocks.txt).  Same tree, four times as wide; the launcher picks by the number of partials.
+constexpr int FIN_THREADS_MANY = 1024;
+
+template <typename T, int NT = FIN_THREADS>
+__global__ void __launch_bounds__(NT)
     finalize_kernel(const T *__restrict__ partial, int64_t pstride, int nparts, const T *__restrict__ pextra,
                     int64_t d, T *raw_out, Epilogue<T> ep, PeerDev peers)
 {
     constexpr int VEC = 16 / sizeof(T);
     using V = typename ChunkOf<T, VEC>::type;
     constexpr int LANES = FIN_BYTES / 16;         // 16-byte chunks of the line
-    constexpr int SLICES = FIN_THREADS / LANES;        // 32
+    constexpr int SLICES = NT / LANES;                 // 32 (128)
+    constexpr int GROUPS = SLICES / 8;                 // 4 (16)
     constexpr int COLS = FIN_BYTES / sizeof(T);
     constexpr int U = 8;                               // loads in flight per thread and round
     __shared__ V lds[SLICES][LANES];
-    __shared__ V lds2[4][LANES];
+    __shared__ V lds2[GROUPS][LANES];
     __shared__ T lds_extra;
     const int tx = threadIdx.x % LANES;
     const int ty = threadIdx.x / LANES;
@@ -1656,7 +1662,7 @@ __global__ void __launch_bounds__(FIN_THREADS)
         }
     }
     lds[ty][tx] = s;
-    if (threadIdx.x >= FIN_THREADS - WAVE) {   // last wave: the extra scalar (all 64 lanes active)
+    if (threadIdx.x >= NT - WAVE) {   // last wave: the extra scalar (all 64 lanes active)
         const int l = threadIdx.x & (WAVE - 1);
         T ex = T(0);
         for (int p = l; p < nparts; p += WAVE) ex += pextra[p];
@@ -1664,7 +1670,7 @@ __global__ void __launch_bounds__(FIN_THREADS)
         if (l == 0) lds_extra = ex;
     }
     __syncthreads();
-    if (ty < 4) {
+    if (ty < GROUPS) {
         V g = lds[ty * 8][tx];
 #pragma unroll
         for (int j = 1; j < 8; ++j) g += lds[ty * 8 + j][tx];
@@ -1672,7 +1678,10 @@ __global__ void __launch_bounds__(FIN_THREADS)
     }
     __syncthreads();
     if (ty == 0) {
-        const V tot = (lds2[0][tx] + lds2[1][tx]) + (lds2[2][tx] + lds2[3][tx]);
+        V tot = (lds2[0][tx] + lds2[1][tx]) + (lds2[2][tx] + lds2[3][tx]);
+        if constexpr (GROUPS == 16)
+            tot = (tot + ((lds2[4][tx] + lds2[5][tx]) + (lds2[6][tx] + lds2[7][tx]))) +
+                  (((lds2[8][tx] + lds2[9][tx]) + (lds2[10][tx] + lds2[11][tx])) + ((lds2[12][tx] + lds2[13][tx]) + (lds2[14][tx] + lds2[15][tx])));
         const T extra = lds_extra;
         const bool cpairs = !raw_out && ep.z_out && ep.g.kind == CIAO_PROX_L1_COMPLEX;   // (re, im) pairs: d even, col even
 #pragma unroll

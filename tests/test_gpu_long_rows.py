@@ -51,7 +51,7 @@ def test_long_rows_in_all_five_modes(ctx, ciao, dtype, d, loss, opts):
         ctx.full_gradient(dp, dev(x0), av2)
         assert "rows_long_kernel" not in ctx.last_kernel()
         ctx.set_option("long_rows", 1)
-        close(av2, ref, dtype, scale={64: 170, 32: 240}, what="the generic kernel on the same rows", scale64=32)
+        close(av2, ref, dtype, scale={64: 170, 32: 240}, what="the generic kernel on the same rows", scale64=34)
         # SAGA init, Finito init
         table = torch.empty((N, d), dtype=tdt, device="cuda")
         sav, sz = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")

@@ -1023,13 +1023,13 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         assert ("rows_smallm_kernel" if mfma else "rows_small_kernel") in ctx.last_kernel() or "prox" in ctx.last_kernel(), ctx.last_kernel()
         rt, rav, rz = O.saga_init(op, og, dtype(0.1 / max(Li.max(), 1.0)), x0)
         close(table, rt, dtype, scale={64: 16, 32: 19}, what="small rows saga_init table", scale64=9.4)
-        close(sav, rav, dtype, scale={64: 19, 32: 23}, what="small rows saga_init av", scale64=8)
+        close(sav, rav, dtype, scale={64: 22, 32: 23}, what="small rows saga_init av", scale64=8)
         z = torch.empty(d, dtype=tdt, device="cuda")
         rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
         ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
         assert ("rows_smallm_kernel" if mfma else "rows_small_kernel") in ctx.last_kernel(), ctx.last_kernel()
         close(table, rt, dtype, scale={64: 13, 32: 16}, what="small rows finito_init table", scale64=11)
-        close(av, rav, dtype, scale={64: 41, 32: 25}, what="small rows finito_init av", scale64=9)
+        close(av, rav, dtype, scale={64: 41, 32: 25}, what="small rows finito_init av", scale64=8.5)
         # ---- mode 4: Finito batches -- random index lists, then static blocks given BOTH as index lists and as row blocks
         st = ciao.IndexStream(d)
         rnd = [st.sample_without_replacement(N, r) for _ in range(4)]
@@ -1044,16 +1044,16 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         assert "rows_wrow_kernel" in ctx.last_kernel() and "mode4" in ctx.last_kernel(), ctx.last_kernel()
         assert ("chunks" in ctx.last_kernel()) == (pad == 0 and (d * es) % 16 == 0), ctx.last_kernel()   # 16 bytes per lane where rows allow
         O.finito_steps(op, og, gam, rhg, rnd, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 200, 32: 1300}, what=f"small rows finito z, index lists ({ctx.last_kernel()})", scale64=17)
-        close(table, rt, dtype, scale={64: 130, 32: 800}, what="small rows finito table, index lists", scale64=13)
+        close(z, rz, dtype, scale={64: 200, 32: 1300}, what=f"small rows finito z, index lists ({ctx.last_kernel()})", scale64=21)
+        close(table, rt, dtype, scale={64: 130, 32: 800}, what="small rows finito table, index lists", scale64=14)
         ctx.set_option("small_wrow", 0)   # ... and the same lists on the several-rows-per-wave kernel: another order of summation
         try:
             ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(rnd), t3, av3, z3)
             assert "rows_smallb_kernel" in ctx.last_kernel() and "mode4" in ctx.last_kernel(), ctx.last_kernel()
         finally:
             ctx.set_option("small_wrow", -1)
-        close(z3, rz, dtype, scale={64: 200, 32: 1300}, what="small rows finito z, index lists on rows_smallb_kernel", scale64=17)
-        close(t3, rt, dtype, scale={64: 130, 32: 800}, what="small rows finito table, index lists on rows_smallb_kernel", scale64=13)
+        close(z3, rz, dtype, scale={64: 200, 32: 1300}, what="small rows finito z, index lists on rows_smallb_kernel", scale64=21)
+        close(t3, rt, dtype, scale={64: 130, 32: 800}, what="small rows finito table, index lists on rows_smallb_kernel", scale64=14)
         nb = -(-N // r)
         order = [(t + 1) % nb for t in range(nb + 2)]                     # cyclic: the first step uses batch 2 (Finito_basic.jl:99)
         static = [np.arange(r * j, min(r * j + r, N), dtype=np.int64) for j in order]   # the last block is short (6000 = 8 * 700 + 400)
@@ -1080,9 +1080,9 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
             assert "rows_wrow_kernel" in ctx.last_kernel(), ctx.last_kernel()
             assert torch.equal(z, z2) and torch.equal(av, av2) and torch.equal(table, t2), "row blocks and the same batches as index lists differ"
         close(z, rz, dtype, scale={64: 1100, 32: 6900}, what="small rows finito z, row blocks", scale64=180)
-        close(table, rt, dtype, scale={64: 520, 32: 2200}, what="small rows finito table, row blocks", scale64=32)
+        close(table, rt, dtype, scale={64: 520, 32: 2200}, what="small rows finito table, row blocks", scale64=34)
         inv = (table.double() / dgam.double()[:, None]).sum(dim=0).cpu().numpy() * hg
-        close(av, inv, dtype, scale={64: 26, 32: 27}, what="small rows finito av invariant")
+        close(av, inv, dtype, scale={64: 30, 32: 27}, what="small rows finito av invariant")
         # ---- mode 1: LFinito iterations (full pass + the batch sweep with two dot products per row), lists and blocks
         lav, lz, lzf = (torch.empty(d, dtype=tdt, device="cuda") for _ in range(3))
         rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
@@ -1638,7 +1638,7 @@ def test_proshi_dense_quadratic(ctx, ciao, dtype, shape, r):
         Q.astype(np.float64) @ x0.astype(np.float64) + q + eta * (x0 - np.clip(x0, lo, hi)).astype(np.float64))
     close(table, want, dtype, scale=8, what="dense proshi init table vs numpy")
     close(table, rt, dtype, scale=8, what="dense proshi init table", scale64=8)
-    close(av, rav, dtype, scale={64: 26, 32: 35}, what="dense proshi init av", scale64=8)
+    close(av, rav, dtype, scale={64: 29, 32: 35}, what="dense proshi init av", scale64=8)
     close(z, rz, dtype, scale={64: 22, 32: 63}, what="dense proshi init z", size=np.abs(rav).max() / abs(float(rhg)), scale64=12)
     st = ciao.IndexStream(2)
     batches = [st.sample_without_replacement(N, r) if 2 * r <= N else np.sort(st.randperm(N)[:r]) for _ in range(10)]
