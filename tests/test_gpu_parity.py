@@ -1094,9 +1094,15 @@ def test_small_rows_in_all_five_modes(ctx, ciao, dtype, d, pad):
         for it in range(2):
             ctx.lfinito_iterate(dp, dg, dgam, hg, bp, np.concatenate(blocks), lav, lz, lzf)
             assert "rows_wrow_kernel" in ctx.last_kernel() and "mode1" in ctx.last_kernel(), ctx.last_kernel()   # (round 5: one wave per row)
-            ctx.lfinito_iterate_blocks(dp, dg, dgam, hg, np.array([x[0] for x in blocks]), np.array([len(x) for x in blocks]), lav2, lz2, lzf2)
+            lf_tiles = mfma and (r * d * np.dtype(dtype).itemsize) % 16 == 0
+            if lf_tiles:   # (row blocks of up to 8192 rows take the one-wave-per-row kernel by default since round 5: the tiles by option)
+                ctx.set_option("small_wrow", 0)
+            try:
+                ctx.lfinito_iterate_blocks(dp, dg, dgam, hg, np.array([x[0] for x in blocks]), np.array([len(x) for x in blocks]), lav2, lz2, lzf2)
+            finally:
+                ctx.set_option("small_wrow", -1)
             O.lfinito_iterate(op, og, gam, rhg, blocks, rav, rz, rzf)
-            if mfma and (r * d * np.dtype(dtype).itemsize) % 16 == 0:
+            if lf_tiles:
                 # dense row blocks of such rows run the batch sweep on the matrix cores (both dots from one MFMA pass): another order of
                 # summation than the index-list form, so equal to rounding; each is held against the oracle below
                 assert "rows_smallm_kernel" in ctx.last_kernel() and "mode1" in ctx.last_kernel(), ctx.last_kernel()

@@ -56,7 +56,7 @@ for d in DS:
             ctx.set_option("force_generic", 0)
             print(" | ".join(row) + f"  [{kern}]", flush=True)
         # LFinito: one iteration = full pass + batch sweep over all rows in static batches of 65536
-        r = 65536
+        r = int(os.environ.get("CIAO_LFINITO_R", "65536"))   # (CIAO_LFINITO_R=4096: the mid-size batches)
         nb = N // r
         first = np.arange(nb, dtype=np.int64) * r
         ln = np.full(nb, r, np.int64)
