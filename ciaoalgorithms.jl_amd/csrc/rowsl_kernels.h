@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_
     const int64_t nchunks = a.d / VEC;
     const int64_t coff = (int64_t)s * J * ROWS_BLOCK + tid;   // this thread's first chunk
     if (tid == 0) s_fail = 0;
+    const bool full = ((int64_t)(s + 1) * J * ROWS_BLOCK <= nchunks);   // (workgroup-uniform)
 
     bool ok[J];
     V x1[J], x2[J], acc[J];
@@ -102,17 +103,26 @@ __global__ void __launch_bounds__(ROWS_BLOCK) rows_long_kernel(RowsArgs<T> a_by_
         }
         x.row = row;
         x.sp = TABLE ? reinterpret_cast<V *>(a.table + row * a.d) + coff : nullptr;
-        if (a.A) {
+        if (!a.A) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) x.ar[j] = V(T(0));
+        } else if (full) {   // every thread's J chunks lie inside the row (all segments but possibly the last): no predication
+            const V *ap = reinterpret_cast<const V *>(a.A + row * a.ld) + coff;
+#pragma unroll
+            for (int j = 0; j < J; ++j) x.ar[j] = __builtin_nontemporal_load(&ap[j * ROWS_BLOCK]);
+        } else {
             const V *ap = reinterpret_cast<const V *>(a.A + row * a.ld) + coff;
 #pragma unroll
             for (int j = 0; j < J; ++j) x.ar[j] = ok[j] ? __builtin_nontemporal_load(&ap[j * ROWS_BLOCK]) : V(T(0));
-        } else {
-#pragma unroll
-            for (int j = 0; j < J; ++j) x.ar[j] = V(T(0));
         }
         if (TREAD) {
+            if (full) {
 #pragma unroll
-            for (int j = 0; j < J; ++j) x.sr[j] = ok[j] ? __builtin_nontemporal_load(&x.sp[j * ROWS_BLOCK]) : V(T(0));
+                for (int j = 0; j < J; ++j) x.sr[j] = __builtin_nontemporal_load(&x.sp[j * ROWS_BLOCK]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < J; ++j) x.sr[j] = ok[j] ? __builtin_nontemporal_load(&x.sp[j * ROWS_BLOCK]) : V(T(0));
+            }
         }
         x.bi = a.b ? a.b[row] : T(0);
         x.gi = (MODE == RM_GRAD || MODE == RM_SAGA_INIT) ? T(1) : (a.gam ? a.gam[row] : a.gam_uniform);
