@@ -5,9 +5,9 @@
 #   gpurun --timeout 1100 -- 'bash tools/exp/reached_kernels.sh'   ->  gpurun_out/reached/launched.tsv, reached.txt;  then
 #   grep 'ciao::\|sample_uniform_kernel' gpurun_out/reached/launched.tsv > profiles/r05_launched_kernels.tsv  (tests/test_kernel_reach_record.py holds the
 #   built library against it on every CPU test run)
-R="${GRAFT_REPO_ROOT:-/root/repo}"; O="$R/gpurun_out/reached"; T=/tmp/reached_trace; mkdir -p "$O" "$T"; cd /tmp; export TMPDIR=/tmp
+R="${GRAFT_REPO_ROOT:-/root/repo}"; O="$R/gpurun_out/reached"; T=/tmp/reached_trace; rm -rf "$T"; mkdir -p "$O" "$T"; cd /tmp; export TMPDIR=/tmp
 cd "$R"
-timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d "$T" -o t -- python3 -m pytest tests -m gpu -q -p no:cacheprovider > "$O/pytest.log" 2>&1
+timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d "$T" -o "t_%pid%" -- python3 -m pytest tests -m gpu -q -p no:cacheprovider > "$O/pytest.log" 2>&1
 rc=$?; echo "pytest under rocprofv3 rc=$rc"; tail -2 "$O/pytest.log"
 python3 - "$T" "$O/launched.tsv" <<'PY'
 import collections, csv, glob, sys
