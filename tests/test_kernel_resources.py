@@ -80,6 +80,7 @@ SGPR_EXCEPTIONS = {
     # by single v_readlane's, none in front of a memory instruction's address (tools/sgpr_vmem_hazard.py checks that)
     r"ciao::rows_multi_kernel<double, 2, 4, 1>": 24,
     r"ciao::rows_long_kernel<double, (4|8), 0>": 20,
+    r"ciao::rows_long_kernel<double, 8, 4>": 10,
 }
 # VGPRs parked in AGPRs (vgpr_spill > 0 with no scratch: v_accvgpr moves).  One class: a thread that owns FOUR or more 16-byte chunks
 # of every state vector (rows of 16 KiB on four waves, adaptive Finito rows of 32 KiB) holds more state
