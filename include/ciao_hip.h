@@ -143,6 +143,9 @@ CIAO_API int32_t ciao_ctx_set_monitor(ciao_ctx *ctx, const ciao_prox_desc *g, do
  *   "small_mfma"           0: dense rows of 17 .. 256 elements do not take the matrix-core tile kernel (rows_smallm_kernel)
  *   "small_mfma_table"     0: ... its table modes (SAGA / Finito init, Finito batches over row blocks) are off, the sweeps stay
  *   "small_nb"             ... tile buffers per wave, 2 .. 4 (0 = automatic: 2)
+ *   "small_wrow"           0: Finito / LFinito batches on rows of up to 256 elements do not take the one-wave-per-row kernel
+ *                          (rows_wrow_kernel: index lists, and row blocks of up to 8192 rows) but rows_smallb_kernel / the tiles
+ *   "wrow_rows_per_wave"   rows_wrow_kernel: rows a wave takes in a small batch before more workgroups are used (0 = 4)
  *   "multi_rhs_off"        1: ciao_full_gradient_multi / ciao_svrg_epoch_tail_multi run K single sweeps (testing)
  *   "peer_timeout_s"       wall-clock bound of a peer-mailbox wait, seconds (default 30)
  *   "chain_no_dma"         the register-ring chain instead of the LDS-DMA one;  "chain_big": the any-length kernels at any d
