@@ -1990,23 +1990,26 @@ def test_random_shapes(ctx, ciao, case):
     tdt = dev(x0).dtype
     av, z = torch.empty(d, dtype=tdt, device="cuda"), torch.empty(d, dtype=tdt, device="cuda")
     table = torch.empty((N, d), dtype=tdt, device="cuda")
+    # Iterates and Finito table rows are x - gamma (...): on rows of one or two elements the result can be orders of magnitude smaller than
+    # its operands, and its rounding is theirs -- one rounding unit is taken at the size of the operands (`size=`, as close() says)
+    osz = lambda ref: max(float(np.abs(np.asarray(ref)).max(initial=0.0)), float(np.abs(x0).max(initial=0.0)))
     ctx.full_gradient(dp, dev(x0), av)
-    close(av, O.full_pass(op, x0), dtype, scale={64: 120, 32: 370}, what=f"sweep ({ctx.last_kernel()})", scale64=25)
+    close(av, O.full_pass(op, x0), dtype, scale={64: 140, 32: 400}, what=f"sweep ({ctx.last_kernel()})", scale64=120)
     gamma = 0.5 / max(lam_f, 1.0)
     ctx.saga_init(dp, dg, gamma, dev(x0), table, av, z)
     rt, rav, rz = O.saga_init(op, og, dtype(gamma), x0)
-    close(table, rt, dtype, scale={64: 100, 32: 370}, what=f"saga_init table ({ctx.last_kernel()})", scale64=25)
+    close(table, rt, dtype, scale={64: 190, 32: 400}, what=f"saga_init table ({ctx.last_kernel()})", scale64=120)
     idx = ciao.IndexStream(N + d).rand_indices(N, 25)
     ctx.saga_steps(dp, dg, gamma, False, idx, table, av, z)
     O.saga_steps(op, og, dtype(gamma), False, idx, rt, rav, rz)
-    close(z, rz, dtype, scale=86, what=f"saga z ({ctx.last_kernel()})", scale64=140)
+    close(z, rz, dtype, scale={64: 94, 32: 82}, what=f"saga z ({ctx.last_kernel()})", scale64=130, size=osz(rz))
     Li = (lam_f if loss == "ls" else 0.25) * np.sum(A.astype(np.float64) ** 2, axis=1) + 1e-12
     gam = (0.999 * N / Li).astype(dtype)
     dgam = dev(gam)
     hg = ctx.hat_gamma(dgam)
     rt, rav, rz, rhg = O.finito_init(op, og, gam, x0)
     ctx.finito_init(dp, dg, dgam, hg, dev(x0), table, av, z)
-    close(table, rt, dtype, scale={64: 13, 32: 19}, what=f"finito_init table ({ctx.last_kernel()})", scale64=13)
+    close(table, rt, dtype, scale={64: 24, 32: 23}, what=f"finito_init table ({ctx.last_kernel()})", scale64=16, size=osz(rt))
     r = min(N, 9)
     batch = ciao.IndexStream(d).sample_without_replacement(N, r)
     ctx.set_option("chain_max_batch", 0)
@@ -2015,8 +2018,8 @@ def test_random_shapes(ctx, ciao, case):
     finally:
         ctx.set_option("chain_max_batch", -1)
     O.finito_steps(op, og, gam, rhg, [batch], rt, rav, rz)
-    close(table, rt, dtype, scale={64: 86, 32: 77}, what=f"finito batch table ({ctx.last_kernel()})", scale64=15)
-    close(z, rz, dtype, scale={64: 100, 32: 97}, what="finito batch z", scale64=28)
+    close(table, rt, dtype, scale={64: 110, 32: 100}, what=f"finito batch table ({ctx.last_kernel()})", scale64=20, size=osz(rt))
+    close(z, rz, dtype, scale={64: 150, 32: 130}, what="finito batch z", scale64=31, size=osz(rz))
     ctx.synchronize()
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -2108,6 +2111,8 @@ def test_random_chain_configurations(ctx, ciao, case):
     st = ciao.IndexStream(N * 1000 + d)
     new = lambda: torch.empty(d, dtype=tdt, device="cuda")
     S = 5000
+    # (iterates and Finito table rows: one rounding unit at the size of the operands -- test_random_shapes says why)
+    osz = lambda ref: max(float(np.abs(np.asarray(ref)).max(initial=0.0)), float(np.abs(x0).max(initial=0.0)))
     if alg in ("svrg", "svrg_cached"):
         gamma = 1.0 / (7 * Li.max())
         av, z, zf, w = new(), new(), new(), new()
@@ -2117,8 +2122,8 @@ def test_random_chain_configurations(ctx, ciao, case):
             idx = st.rand_indices(N, 3 * N + 5)
             ctx.svrg_iterate(dp, dg, gamma, idx, False, av, z, zf, w, reuse_rowdots=(alg == "svrg_cached"))
             O.svrg_iterate(op, og, dtype(gamma), idx, False, rav, rz, rzf, rw)
-        close(zf, rzf, dtype, scale={64: 1200, 32: 1100}, what=f"random chain {alg} z_full ({ctx.last_kernel()})", scale64=840)
-        close(av, rav, dtype, scale={64: 400, 32: 410}, what=f"random chain {alg} av", scale64=520)
+        close(zf, rzf, dtype, scale={64: 1100, 32: 1000}, what=f"random chain {alg} z_full ({ctx.last_kernel()})", scale64=840, size=osz(rzf))
+        close(av, rav, dtype, scale={64: 1200, 32: 430}, what=f"random chain {alg} av", scale64=840)
     elif alg in ("saga", "sag"):
         gamma = 1.0 / ((16 if alg == "sag" else 3) * Li.max())
         table = torch.empty((N, d), dtype=tdt, device="cuda")
@@ -2128,8 +2133,8 @@ def test_random_chain_configurations(ctx, ciao, case):
         idx = st.rand_indices(N, 6 * N + 3)
         ctx.saga_steps(dp, dg, gamma, alg == "sag", idx, table, av, z)
         O.saga_steps(op, og, dtype(gamma), alg == "sag", idx, rt, rav, rz)
-        close(z, rz, dtype, scale={64: 430, 32: 230}, what=f"random chain {alg} z ({ctx.last_kernel()})", scale64=840)
-        close(table, rt, dtype, scale={64: 710, 32: 1400}, what=f"random chain {alg} table", scale64=840)
+        close(z, rz, dtype, scale={64: 120, 32: 110}, what=f"random chain {alg} z ({ctx.last_kernel()})", scale64=840, size=osz(rz))
+        close(table, rt, dtype, scale={64: 1100, 32: 1900}, what=f"random chain {alg} table", scale64=840)
     else:
         gam = (0.999 * N / Li).astype(dtype)
         dgam = dev(gam)
@@ -2148,8 +2153,8 @@ def test_random_chain_configurations(ctx, ciao, case):
                 np.cumsum([len(x) for x in batches], out=bptr[1:])
                 ctx.finito_steps(dp, dg, dgam, hg, bptr, np.concatenate(batches), table, av, z)
                 O.finito_steps(op, og, gam, rhg, batches, rt, rav, rz)
-                close(z, rz, dtype, scale={64: 280, 32: 220}, what=f"random chain finito z ({ctx.last_kernel()})", scale64=240)
-                close(table, rt, dtype, scale={64: 200, 32: 130}, what="random chain finito table", scale64=130)
+                close(z, rz, dtype, scale={64: 230, 32: 220}, what=f"random chain finito z ({ctx.last_kernel()})", scale64=210, size=osz(rz))
+                close(table, rt, dtype, scale={64: 220, 32: 210}, what="random chain finito table", scale64=200, size=osz(rt))
             else:
                 av, z, zf = new(), new(), new()
                 rav, rz, rzf, rhg = O.lfinito_init(op, gam, x0)
@@ -2161,8 +2166,8 @@ def test_random_chain_configurations(ctx, ciao, case):
                     np.cumsum([len(x) for x in batches], out=bptr[1:])
                     ctx.lfinito_iterate(dp, dg, dgam, hg, bptr, np.concatenate(batches), av, z, zf)
                     O.lfinito_iterate(op, og, gam, rhg, batches, rav, rz, rzf)
-                close(zf, rzf, dtype, scale={64: 170, 32: 280}, what=f"random chain lfinito z_full ({ctx.last_kernel()})", scale64=230)
-                close(av, rav, dtype, scale={64: 230, 32: 380}, what="random chain lfinito av", scale64=250)
+                close(zf, rzf, dtype, scale={64: 310, 32: 250}, what=f"random chain lfinito z_full ({ctx.last_kernel()})", scale64=270, size=osz(rzf))
+                close(av, rav, dtype, scale={64: 450, 32: 490}, what="random chain lfinito av", scale64=350)
         finally:
             ctx.set_option("chain_max_batch", -1)
     ctx.synchronize()
