@@ -7,9 +7,8 @@ launcher distinguishes -- row bytes (the J / wave-count classes), exact or maske
 shard table, and the options that force a fallback route (chain_four_waves, chain_no_ws, chain_no_dma, chain_big) -- one small
 problem, the same index stream through the device and the oracle (SVRG_basic.jl:73-82, SAGA_basic.jl:53-68, Finito_basic.jl:97-117,
 Finito_LFinito.jl:77-100, Finito_adaptive.jl:120-152 restated in oracle/), and the kernel the launcher reports is checked against
-the class.  tools/exp/reached_kernels.sh re-runs the trace (every process, the child ranks of the multi-process tests too): with this file the suite
-launches every kernel of the library (profiles/r05_reached_kernels.txt), and tests/test_kernel_reach_record.py holds the built library against
-that record on the CPU."""
+the class.  tools/exp/reached_kernels.sh re-runs the trace (every process, child ranks too): with this file the suite launches every kernel of the
+library (profiles/r05_reached_kernels.txt); tests/test_kernel_reach_record.py holds the built library against that record on the CPU."""
 import numpy as np
 import pytest
 
